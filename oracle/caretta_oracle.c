@@ -1,0 +1,706 @@
+/*
+ * ORACLE -- TEST INFRASTRUCTURE ONLY (see caretta_oracle.h).  Not part of the product.
+ *
+ * Reference-shaped CPU restatement of caretta's pairwise alignment path.  Every function
+ * cites the reference lines it follows (paths relative to the reference root).  Arrays are
+ * materialised exactly as the reference does (dense f64 DP matrices, int64 backtrack), loops
+ * run in the reference's order, all arithmetic is FP64 without contraction.
+ *
+ * Build: gcc -O2 -ffp-contract=off -mfma -fopenmp -shared -fPIC (oracle/Makefile).
+ * -mfma only turns the explicit fma() calls of cro_exp into instructions; -ffp-contract=off
+ * forbids any implicit fusion.
+ */
+#include "caretta_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static int g_sum_mode = 0;
+
+void cro_set_sum_mode(int mode) { g_sum_mode = mode; }
+
+int cro_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Summation: numba's np.sum / np.mean accumulate sequentially; numpy (which produced the golden
+ * vectors under CPython) uses pairwise summation with 8 accumulators in blocks of <=128.
+ * ---------------------------------------------------------------------------------------- */
+static double sum_pairwise(const double *a, int64_t n, int64_t stride) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int64_t i = 0; i < n; i++) res += a[i * stride];
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; j++) r[j] = a[j * stride];
+        int64_t i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[(i + j) * stride];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i * stride];
+        return res;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return sum_pairwise(a, n2, stride) + sum_pairwise(a + n2 * stride, n - n2, stride);
+}
+
+static double sum_strided(const double *a, int64_t n, int64_t stride) {
+    if (g_sum_mode == 1) return sum_pairwise(a, n, stride);
+    double res = 0.0;
+    for (int64_t i = 0; i < n; i++) res += a[i * stride];
+    return res;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * exp.  k = RN(x*16/ln2), r = x - k*ln2/16, exp(x) = 2^(k/16) * (1 + p(r)), |r| <= ln2/32.
+ * Restated identically (same constants, same operation order) in caretta_amd/csrc/cr_math.h.
+ * Constants: tools/gen_exp_constants.py.
+ * ---------------------------------------------------------------------------------------- */
+static const double EXP_TAB[16][2] = {
+    {0x1.0000000000000p+0, 0x0.0p+0},
+    {0x1.0b5586cf9890fp+0, 0x1.8a62e4adc610bp-54},
+    {0x1.172b83c7d517bp+0, -0x1.19041b9d78a76p-55},
+    {0x1.2387a6e756238p+0, 0x1.9b07eb6c70573p-54},
+    {0x1.306fe0a31b715p+0, 0x1.6f46ad23182e4p-55},
+    {0x1.3dea64c123422p+0, 0x1.ada0911f09ebcp-55},
+    {0x1.4bfdad5362a27p+0, 0x1.d4397afec42e2p-56},
+    {0x1.5ab07dd485429p+0, 0x1.6324c054647adp-54},
+    {0x1.6a09e667f3bcdp+0, -0x1.bdd3413b26456p-54},
+    {0x1.7a11473eb0187p+0, -0x1.41577ee04992fp-55},
+    {0x1.8ace5422aa0dbp+0, 0x1.6e9f156864b27p-54},
+    {0x1.9c49182a3f090p+0, 0x1.c7c46b071f2bep-56},
+    {0x1.ae89f995ad3adp+0, 0x1.7a1cd345dcc81p-54},
+    {0x1.c199bdd85529cp+0, 0x1.11065895048ddp-55},
+    {0x1.d5818dcfba487p+0, 0x1.2ed02d75b3707p-55},
+    {0x1.ea4afa2a490dap+0, -0x1.e9c23179c2893p-54},
+};
+
+static inline double pow2i(int e) { /* 2^e for -1022 <= e <= 1023 */
+    uint64_t bits = (uint64_t)(e + 1023) << 52;
+    double v;
+    memcpy(&v, &bits, 8);
+    return v;
+}
+
+double cro_exp(double x) {
+#ifdef CRO_LIBM_EXP
+    return exp(x);
+#else
+    const double INV_LN2_16 = 0x1.71547652b82fep+4;
+    const double LN2_16_HI = 0x1.62e42fefa39efp-5;
+    const double LN2_16_LO = 0x1.abc9e3b39803fp-60;
+    const double SHIFT = 0x1.8p52;
+    const double C2 = 0x1.0000000000000p-1, C3 = 0x1.5555555555555p-3, C4 = 0x1.5555555555555p-5;
+    const double C5 = 0x1.1111111111111p-7, C6 = 0x1.6c16c16c16c17p-10, C7 = 0x1.a01a01a01a01ap-13;
+    if (x > 710.0) x = 710.0;      /* -> +inf through the scaling below */
+    if (x < -746.0) x = -746.0;    /* -> 0 */
+    double z = fma(x, INV_LN2_16, SHIFT);
+    uint64_t zb;
+    memcpy(&zb, &z, 8);
+    int32_t ki = (int32_t)(uint32_t)zb;
+    double kd = z - SHIFT;
+    double r = fma(kd, -LN2_16_HI, x);
+    r = fma(kd, -LN2_16_LO, r);
+    int j = ki & 15;
+    int e = (ki - j) / 16;
+    double r2 = r * r;
+    double q = fma(r, C7, C6);
+    q = fma(r, q, C5);
+    q = fma(r, q, C4);
+    q = fma(r, q, C3);
+    q = fma(r, q, C2);
+    double p = fma(r2, q, r);
+    double th = EXP_TAB[j][0], tl = EXP_TAB[j][1];
+    double y = th + fma(th, p, tl);
+    int e1 = (e - (e & 1)) / 2;
+    int e2 = e - e1;
+    return (y * pow2i(e1)) * pow2i(e2);
+#endif
+}
+
+/* ------------------------------------------------------------------------------------------
+ * score_functions.py:7-11  get_gaussian_score = exp(-gamma * sum((c1-c2)**2))
+ * score_functions.py:23-51 make_score_matrix (normalized=False; no caller passes True)
+ * ---------------------------------------------------------------------------------------- */
+static inline double gaussian_score(const double *c1, const double *c2, int64_t k, double gamma) {
+    double d;
+    if (g_sum_mode == 1 && k >= 8) {
+        double tmp[k];
+        for (int64_t x = 0; x < k; x++) {
+            double df = c1[x] - c2[x];
+            tmp[x] = df * df;
+        }
+        d = sum_pairwise(tmp, k, 1);
+    } else {
+        d = 0.0;
+        for (int64_t x = 0; x < k; x++) {
+            double df = c1[x] - c2[x];
+            d += df * df;
+        }
+    }
+    return cro_exp(-gamma * d);
+}
+
+void cro_make_score_matrix(const double *a, int64_t n, const double *b, int64_t m, int64_t k,
+                           double gamma, double *S) {
+    for (int64_t i = 0; i < n; i++)
+        for (int64_t j = 0; j < m; j++)
+            S[i * m + j] = gaussian_score(a + i * k, b + j * k, k, gamma);
+}
+
+/* score_functions.py:15-19 */
+double cro_get_rmsd(const double *x1, const double *x2, int64_t k) {
+    double s;
+    int64_t n = 3 * k;
+    if (g_sum_mode == 1) {
+        double *tmp = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+        for (int64_t i = 0; i < n; i++) {
+            double df = x1[i] - x2[i];
+            tmp[i] = df * df;
+        }
+        s = sum_pairwise(tmp, n, 1);
+        free(tmp);
+    } else {
+        s = 0.0;
+        for (int64_t i = 0; i < n; i++) {
+            double df = x1[i] - x2[i];
+            s += df * df;
+        }
+    }
+    return sqrt(s / (double)k);
+}
+
+/* multiple_alignment.py:59-70.  `1.24 * (l - 15) ** 1 / 3 - 1.8` parses as ((1.24*(l-15))/3)-1.8
+ * and the per-residue term uses the SIGNED sum of the three coordinate differences. */
+double cro_tm_score(const double *x1, const double *x2, int64_t k, int64_t l1, int64_t l2) {
+    double d1 = 1.24 * (double)(l1 - 15) / 3.0 - 1.8;
+    double d2 = 1.24 * (double)(l2 - 15) / 3.0 - 1.8;
+    double sum1 = 0.0, sum2 = 0.0;
+    for (int64_t i = 0; i < k; i++) {
+        double s = ((x1[3 * i] - x2[3 * i]) + (x1[3 * i + 1] - x2[3 * i + 1])) + (x1[3 * i + 2] - x2[3 * i + 2]);
+        double q1 = s / d1, q2 = s / d2;
+        sum1 += 1.0 / (1.0 + q1 * q1);
+        sum2 += 1.0 / (1.0 + q2 * q2);
+    }
+    double t1 = (1.0 / (double)l1) * sum1;
+    double t2 = (1.0 / (double)l2) * sum2;
+    return t1 > t2 ? t1 : t2; /* max(t1, t2): first maximal */
+}
+
+/* ------------------------------------------------------------------------------------------
+ * dynamic_time_warping.py:8-86  _make_dtw_matrix
+ * ---------------------------------------------------------------------------------------- */
+#define MIN_FLOAT64 (-DBL_MAX) /* dynamic_time_warping.py:4 */
+#define IX3(i, j, l) ((((size_t)(i)) * (size_t)(m + 1) + (size_t)(j)) * 3 + (size_t)(l))
+
+static void make_dtw_matrix(const int64_t *seq1, int64_t n, const int64_t *seq2, int64_t m,
+                            const double *S, int64_t s_cols, double gap_open, double gap_extend,
+                            double *M, int64_t *B) {
+    size_t total = (size_t)(n + 1) * (size_t)(m + 1) * 3;
+    memset(M, 0, total * sizeof(double));                   /* :37 */
+    memset(B, 0, total * sizeof(int64_t));                  /* :41 */
+    for (int64_t i = 0; i <= n; i++)
+        for (int l = 0; l < 3; l++) M[IX3(i, 0, l)] = MIN_FLOAT64; /* :38 */
+    for (int64_t j = 0; j <= m; j++)
+        for (int l = 0; l < 3; l++) M[IX3(0, j, l)] = MIN_FLOAT64; /* :39 */
+    for (int l = 0; l < 3; l++) M[IX3(0, 0, l)] = 0.0;             /* :40 */
+    for (int64_t i = 1; i <= n; i++) {                             /* :42-46 */
+        M[IX3(i, 0, 0)] = 0.0;
+        M[IX3(i, 0, 1)] = 0.0;
+        M[IX3(i, 0, 2)] = MIN_FLOAT64 - gap_open;
+        for (int l = 0; l < 3; l++) B[IX3(i, 0, l)] = 0;
+    }
+    for (int64_t j = 1; j <= m; j++) {                             /* :48-52 */
+        M[IX3(0, j, 0)] = MIN_FLOAT64 - gap_open;
+        M[IX3(0, j, 1)] = 0.0;
+        M[IX3(0, j, 2)] = 0.0;
+        for (int l = 0; l < 3; l++) B[IX3(0, j, l)] = 1;
+    }
+    for (int64_t i = 1; i <= n; i++) {
+        for (int64_t j = 1; j <= m; j++) {
+            double lo0 = M[IX3(i - 1, j, 0)] - gap_extend;         /* :56-64 */
+            double lo1 = M[IX3(i - 1, j, 1)] - gap_open;
+            int il = lo1 > lo0 ? 1 : 0;                            /* np.argmax: first maximum */
+            M[IX3(i, j, 0)] = il ? lo1 : lo0;
+            B[IX3(i, j, 0)] = il;
+            double up0 = M[IX3(i, j - 1, 1)] - gap_open;           /* :66-74 */
+            double up1 = M[IX3(i, j - 1, 2)] - gap_extend;
+            int iu = up1 > up0 ? 1 : 0;
+            M[IX3(i, j, 2)] = iu ? up1 : up0;
+            B[IX3(i, j, 2)] = iu + 1;
+            double c0 = M[IX3(i, j, 0)];                           /* :76-85 */
+            double c1 = M[IX3(i - 1, j - 1, 1)] + S[seq1[i - 1] * s_cols + seq2[j - 1]];
+            double c2 = M[IX3(i, j, 2)];
+            int idx = 0;
+            double best = c0;
+            if (c1 > best) { best = c1; idx = 1; }
+            if (c2 > best) { best = c2; idx = 2; }
+            M[IX3(i, j, 1)] = best;
+            B[IX3(i, j, 1)] = idx;
+        }
+    }
+}
+
+/* dynamic_time_warping.py:90-144 _get_dtw_alignment; returns length, arrays already reversed */
+static int64_t get_dtw_alignment(int start, const int64_t *B, int64_t n1, int64_t m1,
+                                 int64_t *aln1, int64_t *aln2) {
+    int64_t m = m1; /* for IX3 */
+    int64_t index = 0, n = n1, mm = m1;
+    int64_t direction = start;
+    while (!(n == 0 && mm == 0)) {
+        if (mm == 0) {
+            n -= 1; aln1[index] = n; aln2[index] = -1; index++;
+        } else if (n == 0) {
+            mm -= 1; aln1[index] = -1; aln2[index] = mm; index++;
+        } else if (direction == 0) {
+            direction = B[IX3(n, mm, 0)];
+            n -= 1; aln1[index] = n; aln2[index] = -1; index++;
+        } else if (direction == 1) {
+            direction = B[IX3(n, mm, 1)];
+            if (direction == 1) {
+                n -= 1; mm -= 1; aln1[index] = n; aln2[index] = mm; index++;
+            }
+        } else { /* direction == 2 */
+            direction = B[IX3(n, mm, 2)];
+            mm -= 1; aln1[index] = -1; aln2[index] = mm; index++;
+        }
+    }
+    for (int64_t a = 0, b = index - 1; a < b; a++, b--) { /* [::-1], :144 */
+        int64_t t = aln1[a]; aln1[a] = aln1[b]; aln1[b] = t;
+        t = aln2[a]; aln2[a] = aln2[b]; aln2[b] = t;
+    }
+    return index;
+}
+
+/* dynamic_time_warping.py:148-184 dtw_align (and :188-201 dtw_align_score when aln1==NULL) */
+int cro_dtw_align(const int64_t *seq1, int64_t n, const int64_t *seq2, int64_t m,
+                  const double *S, int64_t s_cols, double gap_open, double gap_extend,
+                  int64_t *aln1, int64_t *aln2, int64_t *aln_len, double *score,
+                  double *matrix_out, int64_t *backtrack_out) {
+    size_t total = (size_t)(n + 1) * (size_t)(m + 1) * 3;
+    double *M = matrix_out ? matrix_out : (double *)malloc(total * sizeof(double));
+    int64_t *B = backtrack_out ? backtrack_out : (int64_t *)malloc(total * sizeof(int64_t));
+    if (!M || !B) return -1;
+    make_dtw_matrix(seq1, n, seq2, m, S, s_cols, gap_open, gap_extend, M, B);
+    double sc[3] = {M[IX3(n, m, 0)], M[IX3(n, m, 1)], M[IX3(n, m, 2)]}; /* :181 */
+    int idx = 0;
+    if (sc[1] > sc[idx]) idx = 1;
+    if (sc[2] > sc[idx]) idx = 2;
+    if (score) *score = sc[idx];
+    if (aln1 && aln2) {
+        int64_t len = get_dtw_alignment(idx, B, n, m, aln1, aln2);
+        if (aln_len) *aln_len = len;
+    }
+    if (!matrix_out) free(M);
+    if (!backtrack_out) free(B);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * dynamic_time_warping.py:205-222 smith_waterman_score
+ * ---------------------------------------------------------------------------------------- */
+#define IXH(i, j) ((size_t)(i) * (size_t)(m + 1) + (size_t)(j))
+
+static inline double max4_first(double a, double b, double c, double d) {
+    /* Python max(a, b, c, d): keep the first maximal argument */
+    double r = a;
+    if (b > r) r = b;
+    if (c > r) r = c;
+    if (d > r) r = d;
+    return r;
+}
+
+double cro_smith_waterman_score(const int64_t *seq1, int64_t n, const int64_t *seq2, int64_t m,
+                                const double *S, int64_t s_cols, double gap) {
+    double *H = (double *)calloc((size_t)(n + 1) * (size_t)(m + 1), sizeof(double)); /* :209 */
+    for (int64_t i = 1; i <= n; i++) {
+        for (int64_t j = 1; j <= m; j++) {
+            if (seq2[j - 1] == -1) break;                                            /* :214-215 */
+            double dg = H[IXH(i - 1, j - 1)] + S[seq1[i - 1] * s_cols + seq2[j - 1]];
+            double lf = H[IXH(i, j - 1)] - gap;
+            double up = H[IXH(i - 1, j)] - gap;
+            H[IXH(i, j)] = max4_first(0.0, dg, lf, up);
+        }
+    }
+    double best = H[0];                                                              /* np.max */
+    size_t total = (size_t)(n + 1) * (size_t)(m + 1);
+    for (size_t x = 1; x < total; x++)
+        if (H[x] > best) best = H[x];
+    free(H);
+    return best;
+}
+
+/* dynamic_time_warping.py:226-278 smith_waterman */
+int cro_smith_waterman(const int64_t *seq1, int64_t n, const int64_t *seq2, int64_t m,
+                       const double *S, int64_t s_cols, double gap,
+                       int64_t *aln1, int64_t *aln2, int64_t *aln_len, double *score) {
+    double *H = (double *)calloc((size_t)(n + 1) * (size_t)(m + 1), sizeof(double)); /* :229 */
+    for (int64_t i = 1; i <= n; i++) {
+        for (int64_t j = 1; j <= m; j++) {
+            double dg = H[IXH(i - 1, j - 1)] + S[seq1[i - 1] * s_cols + seq2[j - 1]];
+            double lf = H[IXH(i, j - 1)] - gap;
+            double up = H[IXH(i - 1, j)] - gap;
+            H[IXH(i, j)] = max4_first(0.0, dg, lf, up);
+        }
+    }
+    double max_score = 0.0;                                                          /* :241-247 */
+    int64_t pi = -1, pj = -1;
+    for (int64_t i = 1; i <= n; i++)
+        for (int64_t j = 1; j <= m; j++)
+            if (H[IXH(i, j)] > max_score) { max_score = H[IXH(i, j)]; pi = i; pj = j; }
+    *score = max_score;
+    *aln_len = 0;
+    if (pi < 0) { free(H); return 1; } /* max_pos is None: the reference raises TypeError here */
+    int64_t i = pi, j = pj, index = 0;
+    while (i > 0 && j > 0) {                                                         /* :255-277 */
+        double sc = H[IXH(i, j)];
+        double dg = H[IXH(i - 1, j - 1)], lf = H[IXH(i, j - 1)], up = H[IXH(i - 1, j)];
+        if (sc == 0.0) break;
+        else if (sc == dg + S[seq1[i - 1] * s_cols + seq2[j - 1]]) {
+            i--; j--; aln1[index] = i; aln2[index] = j; index++;
+        } else if (sc == lf - gap) {
+            j--; aln1[index] = -1; aln2[index] = j; index++;
+        } else if (sc == up - gap) {
+            i--; aln1[index] = i; aln2[index] = -1; index++;
+        } else break; /* cannot happen: sc is one of the four candidates */
+    }
+    for (int64_t a = 0, b = index - 1; a < b; a++, b--) {
+        int64_t t = aln1[a]; aln1[a] = aln1[b]; aln1[b] = t;
+        t = aln2[a]; aln2[a] = aln2[b]; aln2[b] = t;
+    }
+    *aln_len = index;
+    free(H);
+    return 0;
+}
+
+/* helper.py:13-42 */
+int64_t cro_get_common_positions(const int64_t *a1, const int64_t *a2, int64_t len,
+                                 int64_t *p1, int64_t *p2) {
+    int64_t k = 0;
+    for (int64_t i = 0; i < len; i++)
+        if (a1[i] != -1 && a2[i] != -1) { p1[k] = a1[i]; p2[k] = a2[i]; k++; }
+    return k;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * 3x3 SVD (stands in for LAPACK dgesdd at superposition_functions.py:28).
+ * One-sided Jacobi on the columns of C; singular values sorted descending; the vector of a
+ * (numerically) vanishing third singular value is the cross product of the other two.
+ * Restated identically in caretta_amd/csrc/cr_math.h.
+ * ---------------------------------------------------------------------------------------- */
+static inline double det3(const double *A) {
+    return (A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6])) +
+           A[2] * (A[3] * A[7] - A[4] * A[6]);
+}
+
+void cro_svd3(const double C[9], double U[9], double Sg[3], double Vt[9]) {
+    double A[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    memcpy(A, C, sizeof(A));
+    static const int PQ[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+    for (int sweep = 0; sweep < 30; sweep++) {
+        int rotated = 0;
+        for (int x = 0; x < 3; x++) {
+            int p = PQ[x][0], q = PQ[x][1];
+            double alpha = (A[p] * A[p] + A[3 + p] * A[3 + p]) + A[6 + p] * A[6 + p];
+            double beta = (A[q] * A[q] + A[3 + q] * A[3 + q]) + A[6 + q] * A[6 + q];
+            double gam = (A[p] * A[q] + A[3 + p] * A[3 + q]) + A[6 + p] * A[6 + q];
+            if (gam == 0.0) continue;
+            if (fabs(gam) <= 1e-15 * sqrt(alpha * beta)) continue;
+            double zeta = (beta - alpha) / (2.0 * gam);
+            double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            double c = 1.0 / sqrt(1.0 + tt * tt);
+            double s = c * tt;
+            for (int r = 0; r < 3; r++) {
+                double ap = A[3 * r + p], aq = A[3 * r + q];
+                A[3 * r + p] = c * ap - s * aq;
+                A[3 * r + q] = s * ap + c * aq;
+                double vp = V[3 * r + p], vq = V[3 * r + q];
+                V[3 * r + p] = c * vp - s * vq;
+                V[3 * r + q] = s * vp + c * vq;
+            }
+            rotated = 1;
+        }
+        if (!rotated) break;
+    }
+    double sg[3];
+    int ord[3] = {0, 1, 2};
+    for (int j = 0; j < 3; j++) sg[j] = sqrt((A[j] * A[j] + A[3 + j] * A[3 + j]) + A[6 + j] * A[6 + j]);
+    /* descending, stable: three compare-exchanges */
+    if (sg[ord[1]] > sg[ord[0]]) { int t = ord[0]; ord[0] = ord[1]; ord[1] = t; }
+    if (sg[ord[2]] > sg[ord[1]]) { int t = ord[1]; ord[1] = ord[2]; ord[2] = t; }
+    if (sg[ord[1]] > sg[ord[0]]) { int t = ord[0]; ord[0] = ord[1]; ord[1] = t; }
+    double Um[9], Vm[9];
+    for (int j = 0; j < 3; j++) {
+        int o = ord[j];
+        Sg[j] = sg[o];
+        for (int r = 0; r < 3; r++) Vm[3 * r + j] = V[3 * r + o];
+        if (sg[o] > 0.0)
+            for (int r = 0; r < 3; r++) Um[3 * r + j] = A[3 * r + o] / sg[o];
+        else
+            for (int r = 0; r < 3; r++) Um[3 * r + j] = (r == j) ? 1.0 : 0.0;
+    }
+    if (!(Sg[2] > 1e-12 * Sg[0])) { /* rank <= 2: complete the basis */
+        Um[2] = Um[3] * Um[7] - Um[6] * Um[4];
+        Um[5] = Um[6] * Um[1] - Um[0] * Um[7];
+        Um[8] = Um[0] * Um[4] - Um[3] * Um[1];
+    }
+    memcpy(U, Um, sizeof(Um));
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) Vt[3 * r + c] = Vm[3 * c + r];
+}
+
+/* helper.py:46-53 nb_mean_axis_0 on a (k,3) array */
+static void mean_axis0(const double *x, int64_t k, double c[3]) {
+    for (int a = 0; a < 3; a++) c[a] = sum_strided(x + a, k, 3) / (double)k;
+}
+
+/* superposition_functions.py:7-35.  Convention: x2 @ R + t ~ x1. */
+void cro_paired_svd_superpose(const double *x1, const double *x2, int64_t k, double R[9], double t[3]) {
+    double c1[3], c2[3];
+    mean_axis0(x1, k, c1);                                   /* :22-25 */
+    mean_axis0(x2, k, c2);
+    double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};               /* :27 coords_2_c.T @ coords_1_c */
+    for (int64_t i = 0; i < k; i++) {
+        double a[3] = {x2[3 * i] - c2[0], x2[3 * i + 1] - c2[1], x2[3 * i + 2] - c2[2]};
+        double b[3] = {x1[3 * i] - c1[0], x1[3 * i + 1] - c1[1], x1[3 * i + 2] - c1[2]};
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) C[3 * r + c] += a[r] * b[c];
+    }
+    double U[9], S[3], Vt[9];
+    cro_svd3(C, U, S, Vt);                                   /* :28 */
+    if (det3(U) * det3(Vt) < 0.0) {                          /* :29-32 */
+        U[2] = -U[2]; U[5] = -U[5]; U[8] = -U[8];
+    }
+    for (int r = 0; r < 3; r++)                              /* :33 */
+        for (int c = 0; c < 3; c++)
+            R[3 * r + c] = (U[3 * r] * Vt[c] + U[3 * r + 1] * Vt[3 + c]) + U[3 * r + 2] * Vt[6 + c];
+    for (int c = 0; c < 3; c++)                              /* :34 */
+        t[c] = c1[c] - ((c2[0] * R[c] + c2[1] * R[3 + c]) + c2[2] * R[6 + c]);
+}
+
+/* superposition_functions.py:64-80 */
+void cro_apply_rotran(const double *x, int64_t k, const double R[9], const double t[3], double *out) {
+    for (int64_t i = 0; i < k; i++)
+        for (int c = 0; c < 3; c++)
+            out[3 * i + c] = ((x[3 * i] * R[c] + x[3 * i + 1] * R[3 + c]) + x[3 * i + 2] * R[6 + c]) + t[c];
+}
+
+/* superposition_functions.py:39-60 */
+void cro_paired_svd_superpose_with_subset(const double *c1, int64_t n, const double *c2, int64_t m,
+                                          const double *s1, const double *s2, int64_t k,
+                                          double *o1, double *o2, double *o3) {
+    double R[9], t[3], m1[3], m2[3];
+    cro_paired_svd_superpose(s1, s2, k, R, t);               /* :56 */
+    mean_axis0(s1, k, m1);
+    mean_axis0(s2, k, m2);
+    for (int64_t i = 0; i < n; i++)                          /* :57 */
+        for (int c = 0; c < 3; c++) o1[3 * i + c] = c1[3 * i + c] - m1[c];
+    for (int64_t i = 0; i < m; i++) {                        /* :58 */
+        double v[3] = {c2[3 * i] - m2[0], c2[3 * i + 1] - m2[1], c2[3 * i + 2] - m2[2]};
+        for (int c = 0; c < 3; c++) o2[3 * i + c] = (v[0] * R[c] + v[1] * R[3 + c]) + v[2] * R[6 + c];
+    }
+    if (o3) cro_apply_rotran(s2, k, R, t, o3);               /* :59 */
+}
+
+/* ------------------------------------------------------------------------------------------
+ * multiple_alignment.py:321-349 Protein.score_function (flexible=False)
+ * ---------------------------------------------------------------------------------------- */
+static int64_t *arange64(int64_t n) {
+    int64_t *a = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));
+    for (int64_t i = 0; i < n; i++) a[i] = i;
+    return a;
+}
+
+uint32_t cro_protein_score_function(const double *Xi, const double *Ti, int64_t n,
+                                    const double *Xj, const double *Tj, int64_t m, int64_t d,
+                                    double gamma_tensor, double gamma_coords, double sw_gap,
+                                    double *S, int64_t *seed1, int64_t *seed2, int64_t *seed_len,
+                                    double *seed_score) {
+    uint32_t flags = 0;
+    int64_t *s1 = arange64(n), *s2 = arange64(m);
+    double *St = (double *)malloc(sizeof(double) * (size_t)n * (size_t)m);
+    cro_make_score_matrix(Ti, n, Tj, m, d, gamma_tensor, St);                 /* :328-331 */
+    int64_t *a1 = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n + m + 1));
+    int64_t *a2 = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n + m + 1));
+    int64_t len = 0;
+    double sc = 0.0;
+    if (cro_smith_waterman(s1, n, s2, m, St, m, sw_gap, a1, a2, &len, &sc)) flags |= 4; /* :332-335 */
+    int64_t *p1 = (int64_t *)malloc(sizeof(int64_t) * (size_t)(len + 1));
+    int64_t *p2 = (int64_t *)malloc(sizeof(int64_t) * (size_t)(len + 1));
+    int64_t k = cro_get_common_positions(a1, a2, len, p1, p2);                /* :336 */
+    if (seed1 && seed2) { memcpy(seed1, a1, sizeof(int64_t) * (size_t)len); memcpy(seed2, a2, sizeof(int64_t) * (size_t)len); }
+    if (seed_len) *seed_len = len;
+    if (seed_score) *seed_score = sc;
+    if (k <= 3) {                                                             /* :337-342 */
+        flags |= 1;
+        cro_make_score_matrix(Xi, n, Xj, m, 3, gamma_coords, S);
+    } else {
+        double *sub1 = (double *)malloc(sizeof(double) * 3 * (size_t)k);
+        double *sub2 = (double *)malloc(sizeof(double) * 3 * (size_t)k);
+        for (int64_t x = 0; x < k; x++)
+            for (int c = 0; c < 3; c++) {
+                sub1[3 * x + c] = Xi[3 * p1[x] + c];
+                sub2[3 * x + c] = Xj[3 * p2[x] + c];
+            }
+        double *o1 = (double *)malloc(sizeof(double) * 3 * (size_t)n);
+        double *o2 = (double *)malloc(sizeof(double) * 3 * (size_t)m);
+        cro_paired_svd_superpose_with_subset(Xi, n, Xj, m, sub1, sub2, k, o1, o2, NULL); /* :344-346 */
+        cro_make_score_matrix(o1, n, o2, m, 3, gamma_coords, S);              /* :347-349 */
+        free(sub1); free(sub2); free(o1); free(o2);
+    }
+    free(s1); free(s2); free(St); free(a1); free(a2); free(p1); free(p2);
+    return flags;
+}
+
+/* pipeline H: score_function -> smith_waterman_score (-> NJ matrix,
+ * multiple_alignment.py:164) and dtw_align (:263-275) -> metrics (:1033-1054, superpose_first=False) */
+void cro_pipeline_pair(const double *Xi, const double *Ti, int64_t n,
+                       const double *Xj, const double *Tj, int64_t m, int64_t d,
+                       const cro_params *prm, cro_pair_out *out,
+                       int64_t *aln1, int64_t *aln2, int64_t *seed1, int64_t *seed2) {
+    memset(out, 0, sizeof(*out));
+    double *S = (double *)malloc(sizeof(double) * (size_t)n * (size_t)m);
+    out->flags = cro_protein_score_function(Xi, Ti, n, Xj, Tj, m, d, prm->gamma_tensor, prm->gamma_coords,
+                                            prm->sw_gap, S, seed1, seed2, &out->seed_len, &out->seed_score);
+    int64_t *s1 = arange64(n), *s2 = arange64(m);
+    out->sw = cro_smith_waterman_score(s1, n, s2, m, S, m, prm->sw_gap);      /* :164 (gap default 0.) */
+    int64_t *a1 = aln1 ? aln1 : (int64_t *)malloc(sizeof(int64_t) * (size_t)(n + m + 1));
+    int64_t *a2 = aln2 ? aln2 : (int64_t *)malloc(sizeof(int64_t) * (size_t)(n + m + 1));
+    cro_dtw_align(s1, n, s2, m, S, m, prm->gap_open, prm->gap_extend, a1, a2, &out->aln_len,
+                  &out->dtw_score, NULL, NULL);
+    int64_t len = out->aln_len;
+    int64_t *p1 = (int64_t *)malloc(sizeof(int64_t) * (size_t)(len + 1));
+    int64_t *p2 = (int64_t *)malloc(sizeof(int64_t) * (size_t)(len + 1));
+    int64_t k = cro_get_common_positions(a1, a2, len, p1, p2);                /* :1033 */
+    if (k >= 3) {                                                             /* assert at :1034 */
+        double *x1 = (double *)malloc(sizeof(double) * 3 * (size_t)k);
+        double *x2 = (double *)malloc(sizeof(double) * 3 * (size_t)k);
+        double *x2m = (double *)malloc(sizeof(double) * 3 * (size_t)k);
+        for (int64_t x = 0; x < k; x++)
+            for (int c = 0; c < 3; c++) {
+                x1[3 * x + c] = Xi[3 * p1[x] + c];
+                x2[3 * x + c] = Xj[3 * p2[x] + c];
+            }
+        cro_paired_svd_superpose(x1, x2, k, out->R, out->t);                  /* :1037-1039 */
+        cro_apply_rotran(x2, k, out->R, out->t, x2m);                         /* :1040-1042 */
+        out->rmsd = cro_get_rmsd(x1, x2m, k);                                 /* :1043-1045 */
+        out->coverage = (double)k / (double)len;                              /* :1046-1048 */
+        out->tm = cro_tm_score(x1, x2m, k, n, m);                             /* :1049-1054 */
+        free(x1); free(x2); free(x2m);
+    } else {
+        out->flags |= 2;
+    }
+    if (!aln1) free(a1);
+    if (!aln2) free(a2);
+    free(p1); free(p2); free(s1); free(s2); free(S);
+}
+
+int cro_pairwise_batch(const double *coords, const double *tensors, const int64_t *offsets,
+                       int64_t d, const int32_t *pairs, int64_t npairs, const cro_params *prm,
+                       cro_pair_out *outs, int64_t *aln, int64_t aln_stride, int nthreads) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 1 ? nthreads : 1)
+#endif
+    for (int64_t p = 0; p < npairs; p++) {
+        int64_t i = pairs[2 * p], j = pairs[2 * p + 1];
+        int64_t n = offsets[i + 1] - offsets[i], m = offsets[j + 1] - offsets[j];
+        int64_t *a1 = NULL, *a2 = NULL;
+        if (aln) {
+            a1 = aln + (size_t)p * 2 * (size_t)aln_stride;
+            a2 = a1 + aln_stride;
+            for (int64_t x = 0; x < 2 * aln_stride; x++) a1[x] = -2; /* padding marker */
+        }
+        cro_pipeline_pair(coords + 3 * offsets[i], tensors + d * offsets[i], n,
+                          coords + 3 * offsets[j], tensors + d * offsets[j], m, d, prm, &outs[p],
+                          a1, a2, NULL, NULL);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * neighbor_joining.py:19-157
+ * ---------------------------------------------------------------------------------------- */
+static void find_join_nodes(const double *D, int64_t n, int hoist, const double *rs, int64_t *mi, int64_t *mj) {
+    double min_q = INFINITY;                                  /* :113-117 */
+    *mi = 0; *mj = 0;
+    for (int64_t i = 0; i < n; i++)
+        for (int64_t j = 0; j < n; j++)
+            if (i != j) {
+                double si = hoist ? rs[i] : sum_strided(D + i * n, n, 1);
+                double sj = hoist ? rs[j] : sum_strided(D + j * n, n, 1);
+                double q = ((double)(n - 2) * D[i * n + j] - si) - sj; /* :121-125 */
+                if (q < min_q) { *mi = i; *mj = j; min_q = q; }        /* :127-129 */
+            }
+}
+
+static void find_branch_length(const double *D, int64_t n, int64_t i, int64_t j, double out[2]) {
+    double si = sum_strided(D + i * n, n, 1), sj = sum_strided(D + j * n, n, 1);
+    out[0] = 0.5 * D[i * n + j] + (0.5 / (double)(n - 2)) * (si - sj); /* :152-154 */
+    out[1] = D[i * n + j] - out[0];                                    /* :156 */
+}
+
+int cro_neighbor_joining(const double *D0, int64_t P, int hoist, uint64_t *tree, double *bl) {
+    if (P < 3) return -1;
+    int64_t n = P, index = 0, nint = 0;
+    double *D = (double *)malloc(sizeof(double) * (size_t)P * (size_t)P);
+    double *N = (double *)malloc(sizeof(double) * (size_t)P * (size_t)P);
+    double *rs = (double *)malloc(sizeof(double) * (size_t)P);
+    int64_t *true_idx = (int64_t *)malloc(sizeof(int64_t) * (size_t)P);
+    int64_t *idx = (int64_t *)malloc(sizeof(int64_t) * (size_t)P);
+    memcpy(D, D0, sizeof(double) * (size_t)P * (size_t)P);
+    for (int64_t i = 0; i < P; i++) true_idx[i] = i;
+    while (n > 3) {                                           /* :40 */
+        int64_t mi, mj;
+        if (hoist)
+            for (int64_t i = 0; i < n; i++) rs[i] = sum_strided(D + i * n, n, 1);
+        find_join_nodes(D, n, hoist, rs, &mi, &mj);           /* :42 */
+        double dl[2];
+        find_branch_length(D, n, mi, mj, dl);                 /* :44 */
+        int64_t node = nint + P;                              /* :47-48 */
+        nint++;
+        tree[2 * index] = (uint64_t)true_idx[mi]; tree[2 * index + 1] = (uint64_t)node; bl[index] = dl[0]; index++;
+        tree[2 * index] = (uint64_t)true_idx[mj]; tree[2 * index + 1] = (uint64_t)node; bl[index] = dl[1]; index++;
+        int64_t cnt = 0;                                      /* :59 */
+        for (int64_t i = 0; i < n; i++)
+            if (i != mi && i != mj) idx[cnt++] = i;
+        int64_t nn = n - 1;
+        memset(N, 0, sizeof(double) * (size_t)nn * (size_t)nn);
+        for (int64_t a = 0; a < cnt; a++)                     /* :61 */
+            for (int64_t b = 0; b < cnt; b++) N[(a + 1) * nn + (b + 1)] = D[idx[a] * n + idx[b]];
+        for (int64_t a = 0; a < cnt; a++) {                   /* :62-67 */
+            double v = 0.5 * ((D[mi * n + idx[a]] + D[mj * n + idx[a]]) - D[mi * n + mj]);
+            N[a + 1] = v;
+            N[(a + 1) * nn] = v;
+        }
+        int64_t *nt = (int64_t *)malloc(sizeof(int64_t) * (size_t)nn); /* :72-74 */
+        nt[0] = node;
+        for (int64_t a = 0; a < cnt; a++) nt[a + 1] = true_idx[idx[a]];
+        memcpy(true_idx, nt, sizeof(int64_t) * (size_t)nn);
+        free(nt);
+        double *tmp = D; D = N; N = tmp;
+        n = nn;
+    }
+    double dl[2];                                             /* :77-93 */
+    find_branch_length(D, n, 1, 2, dl);
+    int64_t node = nint + P;
+    tree[2 * index] = (uint64_t)true_idx[1]; tree[2 * index + 1] = (uint64_t)node; bl[index] = dl[0]; index++;
+    tree[2 * index] = (uint64_t)true_idx[2]; tree[2 * index + 1] = (uint64_t)node; bl[index] = dl[1]; index++;
+    tree[2 * index] = (uint64_t)true_idx[0]; tree[2 * index + 1] = (uint64_t)node;
+    bl[index] = 0.5 * ((D[1 * n + 0] + D[2 * n + 0]) - D[1 * n + 2]);
+    index++;
+    free(D); free(N); free(rs); free(true_idx); free(idx);
+    return (int)index;
+}

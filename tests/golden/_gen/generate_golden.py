@@ -1,0 +1,375 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE's own source.
+
+Run only in the build container (the reference tree does not travel to the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/_gen/generate_golden.py
+
+How the reference is executed: ``/root/reference/caretta`` is imported with the
+name-only stand-ins in ``_gen/stubs`` first on ``sys.path`` (``numba.njit`` -> identity,
+empty ``prody``/``Bio``/``geometricus`` names).  The hot-path modules are plain numpy code
+under ``@nb.njit``, so CPython runs the reference's statements unchanged.  Only inputs
+and outputs are written; no reference source text is stored.
+
+Deltas of this CPython execution against a real numba run:
+``np.exp`` is numpy's SIMD exp instead of libm's (<=1 ulp apart), ``np.sum``/``np.mean`` use
+numpy's pairwise order instead of numba's sequential order, BLAS/LAPACK builds differ.
+Integer semantics (argmax tie-breaks, loop order, traceback) are the reference's own.
+"""
+import os
+import sys
+import time
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parents[2]
+sys.dont_write_bytecode = True
+sys.path.insert(0, str(HERE / "stubs"))
+sys.path.insert(1, os.environ.get("CARETTA_REFERENCE", "/root/reference"))
+sys.path.insert(2, str(REPO))
+
+import numpy as np  # noqa: E402
+
+from caretta import dynamic_time_warping as dtw  # noqa: E402
+from caretta import helper, multiple_alignment, neighbor_joining, score_functions  # noqa: E402
+from caretta import superposition_functions as sup  # noqa: E402
+
+from caretta_amd import synthetic  # noqa: E402
+
+OUT = HERE.parent
+SF_PARAMS = dict(flexible=False, gamma_tensor=7.0, gamma_coords=0.03)
+
+
+def save(name, arrays):
+    arrays = dict(arrays)
+    arrays["_numpy_version"] = np.array(np.__version__)
+    path = OUT / name
+    np.savez_compressed(path, **arrays)
+    print(f"  wrote {path.name}: {len(arrays)} arrays, {path.stat().st_size / 1024:.0f} KiB")
+
+
+# --------------------------------------------------------------------------- F1
+def gen_score_matrix(rng):
+    out = {}
+    cases = [(1, 1, 3, 0.03), (2, 3, 3, 0.03), (5, 17, 3, 0.03), (37, 64, 3, 0.03), (65, 100, 3, 0.03),
+             (17, 5, 10, 7.0), (64, 65, 10, 7.0), (100, 37, 10, 7.0), (3, 2, 1, 1.0), (64, 17, 1, 1.0),
+             (40, 40, 16, 2.5), (150, 150, 3, 0.03)]
+    for c, (n, m, k, gamma) in enumerate(cases):
+        if k == 3:
+            a = rng.normal(scale=15.0, size=(n, k))
+            b = rng.normal(scale=15.0, size=(m, k))
+        else:
+            a = rng.uniform(size=(n, k))
+            b = rng.uniform(size=(m, k))
+        s = score_functions.make_score_matrix(a, b, score_functions.get_gaussian_score, gamma)
+        out[f"c{c}_a"], out[f"c{c}_b"], out[f"c{c}_gamma"], out[f"c{c}_S"] = a, b, np.float64(gamma), s
+    # far-apart chains: RBF underflows to subnormals / exact zero
+    a = rng.normal(scale=5.0, size=(20, 3))
+    b = rng.normal(scale=5.0, size=(23, 3)) + np.array([150.0, 20.0, 0.0])
+    c = len(cases)
+    out[f"c{c}_a"], out[f"c{c}_b"], out[f"c{c}_gamma"] = a, b, np.float64(0.03)
+    out[f"c{c}_S"] = score_functions.make_score_matrix(a, b, score_functions.get_gaussian_score, 0.03)
+    out["ncases"] = np.int64(c + 1)
+    save("f1_score_matrix.npz", out)
+
+
+def rbf_pair(rng, n, m, noise=1.5):
+    """A related pair of C-alpha traces already roughly superposed."""
+    base = synthetic._walk(rng, max(n, m) + 8)
+    a = base[2:2 + n] + rng.normal(scale=noise, size=(n, 3))
+    b = base[5:5 + m] + rng.normal(scale=noise, size=(m, 3))
+    return score_functions.make_score_matrix(a, b, score_functions.get_gaussian_score, 0.03)
+
+
+def dp_inputs(rng):
+    """Score matrices shared by the dtw_align and smith_waterman fixtures."""
+    mats = []
+    for n, m in [(1, 1), (1, 5), (5, 1), (2, 3), (3, 3), (5, 17), (17, 5), (17, 17), (37, 64), (64, 37),
+                 (64, 65), (65, 64), (100, 100), (100, 65), (150, 150), (129, 150)]:
+        mats.append(("rbf", rbf_pair(rng, n, m)))
+    mats.append(("ones", np.ones((7, 9))))
+    mats.append(("ones", np.ones((16, 16))))
+    mats.append(("identity", np.eye(12)))
+    mats.append(("identity", np.eye(9, 14)))
+    mats.append(("checker", (np.add.outer(np.arange(13), np.arange(11)) % 2).astype(np.float64)))
+    mats.append(("small_ints", rng.integers(0, 3, size=(15, 14)).astype(np.float64)))
+    mats.append(("small_ints", rng.integers(0, 2, size=(33, 70)).astype(np.float64)))
+    far_a = rng.normal(scale=5.0, size=(20, 3))
+    far_b = rng.normal(scale=5.0, size=(23, 3)) + np.array([148.0, 20.0, 0.0])
+    mats.append(("underflow", score_functions.make_score_matrix(far_a, far_b, score_functions.get_gaussian_score, 0.03)))
+    mats.append(("uniform", rng.uniform(size=(70, 66))))
+    mats.append(("negative", rng.normal(size=(24, 31))))
+    return mats
+
+
+def gen_dtw(rng, mats):
+    out = {}
+    penalties = [(0.0, 0.0), (1.0, 0.01), (0.5, 0.5), (3.0, 0.1)]
+    c = 0
+    for kind, s in mats:
+        n, m = s.shape
+        for (go, ge) in penalties:
+            a1, a2, score = dtw.dtw_align(np.arange(n), np.arange(m), s, go, ge)
+            out[f"c{c}_S"], out[f"c{c}_open"], out[f"c{c}_extend"] = s, np.float64(go), np.float64(ge)
+            out[f"c{c}_aln1"], out[f"c{c}_aln2"], out[f"c{c}_score"] = a1.astype(np.int64), a2.astype(np.int64), np.float64(score)
+            out[f"c{c}_score2"] = np.float64(dtw.dtw_align_score(np.arange(n), np.arange(m), s, go, ge))
+            if n <= 17 and m <= 17:
+                mat, bt = dtw._make_dtw_matrix(np.arange(n), np.arange(m), s, go, ge)
+                out[f"c{c}_matrix"], out[f"c{c}_backtrack"] = mat, bt
+            c += 1
+    # alphabet mode: score matrix over an alphabet, sequences are index strings
+    for (la, n, m) in [(4, 11, 14), (20, 40, 33)]:
+        s = rng.normal(size=(la, la))
+        s = s + s.T + 2.0 * np.eye(la)
+        s1 = rng.integers(0, la, size=n).astype(np.int64)
+        s2 = rng.integers(0, la, size=m).astype(np.int64)
+        for (go, ge) in penalties[1:3]:
+            a1, a2, score = dtw.dtw_align(s1, s2, s, go, ge)
+            out[f"c{c}_S"], out[f"c{c}_open"], out[f"c{c}_extend"] = s, np.float64(go), np.float64(ge)
+            out[f"c{c}_seq1"], out[f"c{c}_seq2"] = s1, s2
+            out[f"c{c}_aln1"], out[f"c{c}_aln2"], out[f"c{c}_score"] = a1.astype(np.int64), a2.astype(np.int64), np.float64(score)
+            out[f"c{c}_score2"] = np.float64(dtw.dtw_align_score(s1, s2, s, go, ge))
+            c += 1
+    out["ncases"] = np.int64(c)
+    save("f1_dtw.npz", out)
+
+
+def gen_sw(rng, mats):
+    out = {}
+    c = 0
+    for kind, s in mats:
+        n, m = s.shape
+        for gap in (0.0, 0.25):
+            if not (s > 0).any():
+                continue
+            try:
+                a1, a2, score = dtw.smith_waterman(np.arange(n), np.arange(m), s, gap)
+            except TypeError:
+                continue  # all-zero H: the reference crashes (max_pos None)
+            score2 = dtw.smith_waterman_score(np.arange(n), np.arange(m), s, gap)
+            out[f"c{c}_S"], out[f"c{c}_gap"] = s, np.float64(gap)
+            out[f"c{c}_aln1"], out[f"c{c}_aln2"] = a1.astype(np.int64), a2.astype(np.int64)
+            out[f"c{c}_score"], out[f"c{c}_score_only"] = np.float64(score), np.float64(score2)
+            c += 1
+    out["ncases"] = np.int64(c)
+    save("f1_sw.npz", out)
+
+
+def gen_kabsch(rng):
+    out = {}
+    c = 0
+
+    def add(x1, x2, tag):
+        nonlocal c
+        rot, tran = sup.paired_svd_superpose(x1, x2)
+        moved = sup.apply_rotran(x2, rot, tran)
+        out[f"c{c}_x1"], out[f"c{c}_x2"], out[f"c{c}_R"], out[f"c{c}_t"] = x1, x2, rot, tran
+        out[f"c{c}_moved"] = moved
+        out[f"c{c}_rmsd"] = np.float64(score_functions.get_rmsd(x1, moved))
+        out[f"c{c}_tag"] = np.array(tag)
+        c += 1
+
+    for k in (4, 5, 17, 64, 150, 300):
+        x1 = synthetic._walk(rng, k)
+        x2 = (x1 + rng.normal(scale=1.0, size=x1.shape)) @ synthetic._random_rotation(rng) + rng.uniform(-50, 50, 3)
+        add(x1, x2, "noisy")
+    x1 = synthetic._walk(rng, 40)
+    add(x1, x1 @ synthetic._random_rotation(rng) + np.array([3.0, -7.0, 11.0]), "rigid")
+    add(x1, x1 * np.array([1.0, 1.0, -1.0]), "mirror")
+    add(x1, rng.normal(scale=20.0, size=x1.shape), "unrelated")
+    add(x1[:3], x1[:3] @ synthetic._random_rotation(rng), "three_points")
+    out["ncases"] = np.int64(c)
+    # with_subset
+    for s, (n, m, k) in enumerate([(30, 34, 12), (150, 150, 90)]):
+        a = synthetic._walk(rng, n)
+        b = synthetic._walk(rng, m) @ synthetic._random_rotation(rng) + 9.0
+        p1 = np.sort(rng.choice(n, size=k, replace=False))
+        p2 = np.sort(rng.choice(m, size=k, replace=False))
+        o1, o2, o3 = sup.paired_svd_superpose_with_subset(a, b, a[p1], b[p2])
+        out[f"s{s}_a"], out[f"s{s}_b"], out[f"s{s}_p1"], out[f"s{s}_p2"] = a, b, p1.astype(np.int64), p2.astype(np.int64)
+        out[f"s{s}_o1"], out[f"s{s}_o2"], out[f"s{s}_o3"] = o1, o2, o3
+    out["nsubset"] = np.int64(2)
+    save("f1_kabsch.npz", out)
+
+
+def gen_misc(rng):
+    out = {}
+    # get_common_positions
+    alns = [(np.array([0, -1, 1]), np.array([0, 1, -1])),
+            (np.array([-1, -1, 0, 1, 2, -1, 3]), np.array([0, 1, 2, -1, 3, 4, 5])),
+            (np.array([-1, -1]), np.array([0, 1])),
+            (np.arange(10), np.arange(10))]
+    for c, (a1, a2) in enumerate(alns):
+        p1, p2 = helper.get_common_positions(a1, a2)
+        out[f"cp{c}_a1"], out[f"cp{c}_a2"] = a1.astype(np.int64), a2.astype(np.int64)
+        out[f"cp{c}_p1"], out[f"cp{c}_p2"] = np.asarray(p1, dtype=np.int64), np.asarray(p2, dtype=np.int64)
+    out["ncp"] = np.int64(len(alns))
+    # tm_score and get_rmsd
+    c = 0
+    for k, l1, l2 in [(3, 10, 12), (5, 14, 16), (20, 15, 30), (50, 60, 80), (100, 100, 100), (140, 150, 300)]:
+        x1 = rng.normal(scale=10.0, size=(k, 3))
+        x2 = x1 + rng.normal(scale=1.5, size=(k, 3))
+        out[f"tm{c}_x1"], out[f"tm{c}_x2"], out[f"tm{c}_l1"], out[f"tm{c}_l2"] = x1, x2, np.int64(l1), np.int64(l2)
+        out[f"tm{c}_tm"] = np.float64(multiple_alignment.tm_score(x1, x2, l1, l2))
+        out[f"tm{c}_rmsd"] = np.float64(score_functions.get_rmsd(x1, x2))
+        c += 1
+    out["ntm"] = np.int64(c)
+    # apply_rotran
+    x = rng.normal(size=(9, 3))
+    rot = synthetic._random_rotation(rng)
+    tr = rng.normal(size=3)
+    out["ar_x"], out["ar_R"], out["ar_t"], out["ar_out"] = x, rot, tr, sup.apply_rotran(x, rot, tr)
+    save("f1_misc.npz", out)
+
+
+# --------------------------------------------------------------------------- F2
+def to_proteins(family):
+    return [multiple_alignment.Protein(s.name, s.tensors, s.coordinates, s.sequence) for s in family]
+
+
+def pipeline_h(pi, pj, out, key):
+    """One pair through pipeline H using only reference functions."""
+    n, m = len(pi), len(pj)
+    s_t = score_functions.make_score_matrix(pi.tensors, pj.tensors, score_functions.get_gaussian_score, 7.0)
+    flags = 0
+    if (s_t > 0).any():
+        sa1, sa2, sw_t = dtw.smith_waterman(np.arange(n), np.arange(m), s_t, 0.0)
+        pos1, pos2 = helper.get_common_positions(sa1, sa2)
+    else:
+        flags |= 4
+        sa1 = sa2 = pos1 = pos2 = np.zeros(0, dtype=np.int64)
+        sw_t = 0.0
+    if flags & 4:
+        s_c = None
+    else:
+        s_c = pi.score_function(pj, verbose=False, **SF_PARAMS)
+        if len(pos1) <= 3:
+            flags |= 1
+            chk = score_functions.make_score_matrix(np.array(pi.coordinates), np.array(pj.coordinates),
+                                                    score_functions.get_gaussian_score, 0.03)
+        else:
+            c1, c2, _ = sup.paired_svd_superpose_with_subset(pi.coordinates, pj.coordinates,
+                                                             pi.coordinates[pos1], pj.coordinates[pos2])
+            chk = score_functions.make_score_matrix(c1, c2, score_functions.get_gaussian_score, 0.03)
+        assert np.array_equal(chk, s_c), "step-by-step pipeline differs from Protein.score_function"
+    out[f"{key}_seed_aln1"], out[f"{key}_seed_aln2"] = np.asarray(sa1, np.int64), np.asarray(sa2, np.int64)
+    out[f"{key}_seed_score"] = np.float64(sw_t)
+    if s_c is None:
+        out[f"{key}_flags"] = np.int64(flags)
+        return
+    sw = dtw.smith_waterman_score(np.arange(n), np.arange(m), s_c, 0.0)
+    a1, a2, dscore = dtw.dtw_align(np.arange(n), np.arange(m), s_c, 1.0, 0.01)
+    q1, q2 = helper.get_common_positions(a1, a2)
+    out[f"{key}_sw"], out[f"{key}_dtw_score"] = np.float64(sw), np.float64(dscore)
+    out[f"{key}_aln1"], out[f"{key}_aln2"] = np.asarray(a1, np.int64), np.asarray(a2, np.int64)
+    if len(q1) >= 3:
+        x1, x2 = pi.coordinates[q1], pj.coordinates[q2]
+        rot, tran = sup.paired_svd_superpose(x1, x2)
+        x2m = sup.apply_rotran(x2, rot, tran)
+        out[f"{key}_R"], out[f"{key}_t"] = rot, tran
+        out[f"{key}_rmsd"] = np.float64(score_functions.get_rmsd(x1, x2m))
+        out[f"{key}_coverage"] = np.float64(x1.shape[0] / len(a1))
+        out[f"{key}_tm"] = np.float64(multiple_alignment.tm_score(x1, x2m, n, m))
+    else:
+        flags |= 2
+    out[f"{key}_flags"] = np.int64(flags)
+
+
+def store_family(out, prefix, family):
+    coords, tensors, offsets = synthetic.pack(family)
+    out[f"{prefix}_coords"], out[f"{prefix}_tensors"], out[f"{prefix}_offsets"] = coords, tensors, offsets
+
+
+def gen_pipeline():
+    out = {}
+    fams = {
+        "A": synthetic.make_family(8, 60, seed=20231, ragged=True),
+        "B": synthetic.make_family(6, 150, seed=20232),
+        "C": synthetic.make_family(2, 300, seed=20233, clades=1),
+        "D": synthetic.make_family(3, 310, seed=20234, ragged=True, clades=1),
+    }
+    # family E: includes a 3-residue member (k<=3 branch) and a 5-residue one
+    e = synthetic.make_family(4, 40, seed=20235, clades=1)
+    e[1] = synthetic.Structure("tiny3", e[1].tensors[:3].copy(), e[1].coordinates[:3].copy(), "AAA")
+    e[3] = synthetic.Structure("tiny5", e[3].tensors[10:15].copy(), e[3].coordinates[10:15].copy(), "AAAAA")
+    fams["E"] = e
+    for tag, fam in fams.items():
+        t0 = time.time()
+        store_family(out, f"fam{tag}", fam)
+        prots = to_proteins(fam)
+        pairs = [(i, j) for i in range(len(prots)) for j in range(i + 1, len(prots))]
+        out[f"fam{tag}_pairs"] = np.array(pairs, dtype=np.int32)
+        for p, (i, j) in enumerate(pairs):
+            pipeline_h(prots[i], prots[j], out, f"fam{tag}_p{p}")
+        print(f"  family {tag}: {len(pairs)} pairs in {time.time() - t0:.1f}s")
+    out["families"] = np.array(list(fams.keys()))
+    save("f2_pipeline.npz", out)
+
+
+def gen_pipeline_long():
+    out = {}
+    fam = synthetic.make_family(2, 1200, seed=20236, clades=1)
+    store_family(out, "famL", fam)
+    prots = to_proteins(fam)
+    out["famL_pairs"] = np.array([(0, 1)], dtype=np.int32)
+    t0 = time.time()
+    pipeline_h(prots[0], prots[1], out, "famL_p0")
+    print(f"  family L (1200 residues): {time.time() - t0:.1f}s")
+    out["families"] = np.array(["L"])
+    save("f2_pipeline_long.npz", out)
+
+
+# --------------------------------------------------------------------------- F3 / F4
+def gen_tree(rng):
+    out = {}
+    for tag, fam in (("T8", synthetic.make_family(8, 60, seed=20231, ragged=True)),
+                     ("T16", synthetic.make_family(16, 80, seed=20237, ragged=True))):
+        store_family(out, f"fam{tag}", fam)
+        msa = multiple_alignment.MultipleAlignment(to_proteins(fam))
+        m = msa.make_pairwise_matrix(score_function_params=dict(SF_PARAMS, verbose=False))
+        d = m.max() - m
+        tree, bl = neighbor_joining.neighbor_joining(d.copy())
+        out[f"fam{tag}_M"], out[f"fam{tag}_D"] = m, d
+        out[f"fam{tag}_tree"], out[f"fam{tag}_branch_lengths"] = tree, bl
+        if tag == "T8":
+            aln = msa.multiple_align(d, gap_open_penalty=1.0, gap_extend_penalty=0.01, consensus_weight=1.0,
+                                     gamma_weight=1.0, score_function_params=dict(SF_PARAMS, verbose=False),
+                                     mean_function_params=dict(flexible=False, verbose=False))
+            out["famT8_msa"] = np.array([aln[s.name] for s in fam], dtype=np.int64)
+    c = 0
+    for p in (3, 4, 5, 8, 16, 40, 64):
+        for rep in range(2 if p >= 8 else 1):
+            x = rng.uniform(0.5, 10.0, size=(p, p))
+            d = (x + x.T) / 2
+            np.fill_diagonal(d, rng.uniform(0.0, 3.0))  # non-zero diagonal, as on the real path
+            tree, bl = neighbor_joining.neighbor_joining(d.copy())
+            out[f"nj{c}_D"], out[f"nj{c}_tree"], out[f"nj{c}_branch_lengths"] = d, tree, bl
+            c += 1
+    out["nnj"] = np.int64(c)
+    save("f3_tree.npz", out)
+
+
+def main():
+    only = set(sys.argv[1:])
+    rng = np.random.default_rng(20230)
+    print("generating golden vectors from", sys.modules["caretta"].__path__)
+    steps = [("score", lambda: gen_score_matrix(rng))]
+    mats = dp_inputs(np.random.default_rng(20229))
+    steps += [("dtw", lambda: gen_dtw(np.random.default_rng(20228), mats)),
+              ("sw", lambda: gen_sw(np.random.default_rng(20227), mats)),
+              ("kabsch", lambda: gen_kabsch(np.random.default_rng(20226))),
+              ("misc", lambda: gen_misc(np.random.default_rng(20225))),
+              ("pipeline", gen_pipeline),
+              ("long", gen_pipeline_long),
+              ("tree", lambda: gen_tree(np.random.default_rng(20224)))]
+    for name, fn in steps:
+        if only and name not in only:
+            continue
+        t0 = time.time()
+        print(f"[{name}]")
+        fn()
+        print(f"  {time.time() - t0:.1f}s")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,222 @@
+"""Pin the C oracle against golden vectors produced by the reference's own source.
+
+Golden vectors: tests/golden/*.npz (generator: tests/golden/_gen/generate_golden.py).
+Bar: integers exact; floats within the tolerances of SURVEY.md section 8(c).
+"""
+import numpy as np
+import pytest
+
+from oracle.pyoracle import tree_bipartitions
+
+RTOL_S = 1e-12      # exp differs from numpy's by <= 1 ulp, d^2 summation order by a few ulp
+
+
+def test_exp_accuracy(oracle, oracle_libm):
+    rng = np.random.default_rng(7)
+    x = np.concatenate([-rng.uniform(0, 750, 20000), rng.uniform(0, 709, 2000), -10 ** rng.uniform(-20, 0, 2000),
+                        [0.0, -0.0, -745.2, -745.13, -745.14, -708.4, -708.39, 709.78, 709.79, -1e-300, 1e-300]])
+    ours = oracle.exp(x)
+    libm = oracle_libm.exp(x)
+    with np.errstate(over="ignore"):
+        ref = np.exp(x.astype(np.longdouble)).astype(np.float64)  # 64-bit mantissa reference, rounded
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isinf(ours), ~fin) and np.array_equal(np.isinf(libm), ~fin)
+    ours, libm, ref = ours[fin], libm[fin], ref[fin]
+    ulp = np.spacing(np.maximum(np.abs(ref), 5e-324))
+    assert np.all(np.abs(ours - ref) <= ulp), "own exp is more than 1 ulp off"
+    assert np.all(np.abs(ours - libm) <= ulp)
+    frac = np.mean(ours != libm)
+    assert frac < 0.02, f"own exp differs from libm on {frac:.3%} of arguments"
+    assert oracle.exp(np.array([-746.0, -1000.0, -1e308]))[0] == 0.0
+    assert np.isinf(oracle.exp(np.array([710.0]))[0]) and np.isnan(oracle.exp(np.array([np.nan]))[0])
+    assert oracle.exp(np.array([0.0]))[0] == 1.0
+
+
+def test_make_score_matrix(oracle, golden):
+    g = golden("f1_score_matrix.npz")
+    for c in range(int(g["ncases"])):
+        for mode in (0, 1):
+            oracle.set_sum_mode(mode)
+            s = oracle.make_score_matrix(g[f"c{c}_a"], g[f"c{c}_b"], float(g[f"c{c}_gamma"]))
+            ref = g[f"c{c}_S"]
+            assert s.shape == ref.shape
+            np.testing.assert_allclose(s, ref, rtol=RTOL_S, atol=5e-324 * 4)
+            assert np.array_equal(s == 0, ref == 0) or np.max(np.abs(s - ref)) < 1e-320
+    oracle.set_sum_mode(0)
+
+
+def _dtw_case(g, c):
+    s = g[f"c{c}_S"]
+    if f"c{c}_seq1" in g:
+        return g[f"c{c}_seq1"], g[f"c{c}_seq2"], s
+    return np.arange(s.shape[0]), np.arange(s.shape[1]), s
+
+
+def test_dtw_align(oracle, golden):
+    g = golden("f1_dtw.npz")
+    n = int(g["ncases"])
+    assert n > 100
+    for c in range(n):
+        s1, s2, s = _dtw_case(g, c)
+        go, ge = float(g[f"c{c}_open"]), float(g[f"c{c}_extend"])
+        small = f"c{c}_matrix" in g
+        res = oracle.dtw_align(s1, s2, s, go, ge, want_matrices=small)
+        assert np.array_equal(res[0], g[f"c{c}_aln1"]), c
+        assert np.array_equal(res[1], g[f"c{c}_aln2"]), c
+        assert res[2] == float(g[f"c{c}_score"]), c          # same S in, same adds: bit-exact
+        assert oracle.dtw_align_score(s1, s2, s, go, ge) == float(g[f"c{c}_score2"])
+        if small:
+            assert np.array_equal(res[4], g[f"c{c}_backtrack"]), c
+            assert np.array_equal(res[3], g[f"c{c}_matrix"]), c
+
+
+def test_smith_waterman(oracle, golden):
+    g = golden("f1_sw.npz")
+    n = int(g["ncases"])
+    assert n > 30
+    for c in range(n):
+        s = g[f"c{c}_S"]
+        a, b = np.arange(s.shape[0]), np.arange(s.shape[1])
+        gap = float(g[f"c{c}_gap"])
+        a1, a2, sc, rc = oracle.smith_waterman(a, b, s, gap)
+        assert rc == 0
+        assert np.array_equal(a1, g[f"c{c}_aln1"]) and np.array_equal(a2, g[f"c{c}_aln2"]), c
+        assert sc == float(g[f"c{c}_score"])
+        assert oracle.smith_waterman_score(a, b, s, gap) == float(g[f"c{c}_score_only"])
+
+
+def test_smith_waterman_all_zero_flag(oracle):
+    a1, a2, sc, rc = oracle.smith_waterman(np.arange(4), np.arange(5), np.zeros((4, 5)), 0.0)
+    assert rc == 1 and len(a1) == 0 and sc == 0.0
+
+
+def test_kabsch(oracle, golden):
+    g = golden("f1_kabsch.npz")
+    for c in range(int(g["ncases"])):
+        x1, x2 = g[f"c{c}_x1"], g[f"c{c}_x2"]
+        r, t = oracle.paired_svd_superpose(x1, x2)
+        tag = str(g[f"c{c}_tag"])
+        assert abs(np.linalg.det(r) - 1.0) < 1e-12
+        np.testing.assert_allclose(r @ r.T, np.eye(3), atol=1e-12)
+        np.testing.assert_allclose(r, g[f"c{c}_R"], atol=1e-9, err_msg=tag)
+        np.testing.assert_allclose(t, g[f"c{c}_t"], atol=1e-8, err_msg=tag)
+        moved = oracle.apply_rotran(x2, r, t)
+        np.testing.assert_allclose(moved, g[f"c{c}_moved"], atol=1e-8)
+        assert abs(oracle.get_rmsd(x1, moved) - float(g[f"c{c}_rmsd"])) < 1e-9
+    for s in range(int(g["nsubset"])):
+        a, b = g[f"s{s}_a"], g[f"s{s}_b"]
+        o1, o2, o3 = oracle.paired_svd_superpose_with_subset(a, b, a[g[f"s{s}_p1"]], b[g[f"s{s}_p2"]])
+        np.testing.assert_allclose(o1, g[f"s{s}_o1"], atol=1e-9)
+        np.testing.assert_allclose(o2, g[f"s{s}_o2"], atol=1e-8)
+        np.testing.assert_allclose(o3, g[f"s{s}_o3"], atol=1e-8)
+
+
+def test_svd3_properties(oracle):
+    rng = np.random.default_rng(3)
+    mats = [rng.normal(size=(3, 3)) * 10 ** rng.uniform(-3, 3) for _ in range(200)]
+    mats += [np.outer(rng.normal(size=3), rng.normal(size=3)), np.zeros((3, 3)), np.eye(3), np.diag([3.0, 3.0, 1.0]),
+             np.diag([2.0, 1.0, 0.0])]
+    for c in mats:
+        u, s, vt = oracle.svd3(c)
+        scale = max(np.abs(c).max(), 1e-300)
+        np.testing.assert_allclose(u @ np.diag(s) @ vt, c, atol=1e-13 * scale)
+        assert s[0] >= s[1] >= s[2] >= 0
+        np.testing.assert_allclose(s, np.linalg.svd(c, compute_uv=False), atol=1e-13 * scale)
+        if s[1] > 1e-9 * max(s[0], 1e-300):
+            np.testing.assert_allclose(u.T @ u, np.eye(3), atol=1e-12)
+            np.testing.assert_allclose(vt @ vt.T, np.eye(3), atol=1e-12)
+
+
+def test_misc(oracle, golden):
+    g = golden("f1_misc.npz")
+    for c in range(int(g["ncp"])):
+        p1, p2 = oracle.get_common_positions(g[f"cp{c}_a1"], g[f"cp{c}_a2"])
+        assert np.array_equal(p1, g[f"cp{c}_p1"]) and np.array_equal(p2, g[f"cp{c}_p2"])
+    for c in range(int(g["ntm"])):
+        x1, x2 = g[f"tm{c}_x1"], g[f"tm{c}_x2"]
+        tm = oracle.tm_score(x1, x2, int(g[f"tm{c}_l1"]), int(g[f"tm{c}_l2"]))
+        assert abs(tm - float(g[f"tm{c}_tm"])) <= 1e-13 * max(1.0, abs(tm))
+        assert abs(oracle.get_rmsd(x1, x2) - float(g[f"tm{c}_rmsd"])) < 1e-13
+        oracle.set_sum_mode(1)
+        assert oracle.get_rmsd(x1, x2) == float(g[f"tm{c}_rmsd"])  # numpy summation order: bit-exact
+        oracle.set_sum_mode(0)
+    np.testing.assert_allclose(oracle.apply_rotran(g["ar_x"], g["ar_R"], g["ar_t"]), g["ar_out"], atol=1e-14)
+
+
+def _check_pipeline(orc, g, fam):
+    coords, tensors, offsets = g[f"fam{fam}_coords"], g[f"fam{fam}_tensors"], g[f"fam{fam}_offsets"]
+    pairs = g[f"fam{fam}_pairs"]
+    outs, aln = orc.pairwise_batch(coords, tensors, offsets, pairs)
+    for p in range(len(pairs)):
+        key = f"fam{fam}_p{p}"
+        o = outs[p]
+        assert int(o["flags"]) == int(g[key + "_flags"]), key
+        assert int(o["seed_len"]) == len(g[key + "_seed_aln1"]), key
+        assert abs(o["seed_score"] - float(g[key + "_seed_score"])) <= 1e-11 * max(1.0, abs(o["seed_score"]))
+        ln = int(o["aln_len"])
+        assert np.array_equal(aln[p, 0, :ln], g[key + "_aln1"]), key
+        assert np.array_equal(aln[p, 1, :ln], g[key + "_aln2"]), key
+        assert np.all(aln[p, :, ln:] == -2)
+        sw_ref = float(g[key + "_sw"])
+        assert abs(o["sw"] - sw_ref) <= 1e-9 * max(1.0, abs(sw_ref)), key
+        d_ref = float(g[key + "_dtw_score"])
+        assert abs(o["dtw_score"] - d_ref) <= 1e-9 * max(1.0, abs(d_ref)), key
+        if not int(o["flags"]) & 2:
+            np.testing.assert_allclose(o["R"].reshape(3, 3), g[key + "_R"], atol=1e-9)
+            np.testing.assert_allclose(o["t"], g[key + "_t"], atol=1e-7)
+            assert abs(o["rmsd"] - float(g[key + "_rmsd"])) < 1e-9
+            assert o["coverage"] == float(g[key + "_coverage"])
+            assert abs(o["tm"] - float(g[key + "_tm"])) < 1e-9
+    return outs
+
+
+@pytest.mark.parametrize("fam", ["A", "B", "C", "D", "E"])
+def test_pipeline_h(oracle, golden, fam):
+    _check_pipeline(oracle, golden("f2_pipeline.npz"), fam)
+
+
+def test_pipeline_h_libm_exp_same_integers(oracle, oracle_libm, golden):
+    """libm exp (what numba calls) and the shared exp give the same integer outputs."""
+    g = golden("f2_pipeline.npz")
+    for fam in ("A", "E"):
+        a = _check_pipeline(oracle_libm, g, fam)
+        b = _check_pipeline(oracle, g, fam)
+        assert np.array_equal(a["aln_len"], b["aln_len"])
+        np.testing.assert_allclose(a["sw"], b["sw"], rtol=1e-13)
+
+
+def test_pipeline_h_long(oracle, golden):
+    _check_pipeline(oracle, golden("f2_pipeline_long.npz"), "L")
+
+
+def test_pairwise_matrix_and_tree(oracle, golden):
+    g = golden("f3_tree.npz")
+    for fam in ("T8", "T16"):
+        offsets = g[f"fam{fam}_offsets"]
+        p = len(offsets) - 1
+        pairs = np.array([(i, j) for i in range(p) for j in range(i + 1, p)], dtype=np.int32)
+        outs, _ = oracle.pairwise_batch(g[f"fam{fam}_coords"], g[f"fam{fam}_tensors"], offsets, pairs, want_aln=False,
+                                        nthreads=4)
+        m = np.zeros((p, p))
+        m[pairs[:, 0], pairs[:, 1]] = outs["sw"]
+        m[pairs[:, 1], pairs[:, 0]] = outs["sw"]
+        np.testing.assert_allclose(m, g[f"fam{fam}_M"], rtol=1e-9)
+        d = m.max() - m                                   # multiple_alignment.py:501
+        tree, bl = oracle.neighbor_joining(d)
+        assert tree_bipartitions(tree, p) == tree_bipartitions(g[f"fam{fam}_tree"], p)
+        np.testing.assert_allclose(np.sort(bl.ravel()), np.sort(g[f"fam{fam}_branch_lengths"].ravel()), atol=1e-7)
+
+
+def test_neighbor_joining(oracle, golden):
+    g = golden("f3_tree.npz")
+    for c in range(int(g["nnj"])):
+        d = g[f"nj{c}_D"]
+        p = d.shape[0]
+        oracle.set_sum_mode(1)                            # numpy's summation order -> byte-exact tree
+        for hoist in (False, True) if p <= 40 else (True,):
+            tree, bl = oracle.neighbor_joining(d, hoist=hoist)
+            assert np.array_equal(tree, g[f"nj{c}_tree"]), (c, hoist)
+            np.testing.assert_allclose(bl, g[f"nj{c}_branch_lengths"], rtol=0, atol=1e-12)
+        oracle.set_sum_mode(0)                            # numba's order: same topology
+        tree, bl = oracle.neighbor_joining(d)
+        assert tree_bipartitions(tree, p) == tree_bipartitions(g[f"nj{c}_tree"], p)
