@@ -1,0 +1,117 @@
+"""ctypes binding of libcaretta_hip (include/caretta_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).  There is no CPU
+fallback: a missing library or a missing GPU raises, loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libcaretta_hip.so"
+
+CR_NUM_STAGES = 4
+FLAG_SEED_SKIPPED, FLAG_METRICS_SKIPPED, FLAG_SEED_ALL_ZERO = 1, 2, 4
+
+
+class CarettaHipError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    _fields_ = [("gamma_tensor", C.c_double), ("gamma_coords", C.c_double), ("gap_open", C.c_double),
+                ("gap_extend", C.c_double), ("sw_gap", C.c_double)]
+
+
+PAIR_RESULT_DTYPE = np.dtype([("sw", "f8"), ("dtw_score", "f8"), ("R", "f8", (9,)), ("t", "f8", (3,)),
+                              ("rmsd", "f8"), ("coverage", "f8"), ("tm", "f8"), ("seed_score", "f8"),
+                              ("aln_len", "i4"), ("aln_start", "i4"), ("seed_len", "i4"), ("flags", "u4")])
+assert PAIR_RESULT_DTYPE.itemsize == 160
+
+_vp, _i64, _i32, _f64 = C.c_void_p, C.c_int64, C.c_int, C.c_double
+_pp = C.POINTER(C.c_void_p)
+
+# name -> argtypes; every entry point returns int (cr_status) except cr_last_error
+SIGNATURES = {
+    "cr_abi_version": [],
+    "cr_device_count": [C.POINTER(C.c_int)],
+    "cr_context_create": [_i32, _vp, _pp],
+    "cr_context_destroy": [_vp],
+    "cr_context_synchronize": [_vp],
+    "cr_context_stream": [_vp, _pp],
+    "cr_context_set_profiling": [_vp, _i32],
+    "cr_batch_create": [_vp, _vp, _vp, _vp, _i64, _i64, _pp],
+    "cr_batch_set_pairs": [_vp, _vp, _i64],
+    "cr_batch_run": [_vp, C.POINTER(Params), _vp],
+    "cr_batch_fetch": [_vp, _vp, _vp, _i64],
+    "cr_batch_max_aln_len": [_vp, C.POINTER(C.c_int64)],
+    "cr_batch_stage_ms": [_vp, C.POINTER(C.c_float * CR_NUM_STAGES)],
+    "cr_batch_work": [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)],
+    "cr_batch_destroy": [_vp],
+    "cr_make_score_matrix": [_vp, _vp, _i64, _vp, _i64, _i64, _f64, _vp],
+    "cr_protein_score_function": [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _f64, _f64, _vp, C.POINTER(C.c_uint32)],
+    "cr_dtw_align": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _f64, _f64, _vp, _vp, C.POINTER(C.c_int64),
+                     C.POINTER(C.c_double)],
+    "cr_smith_waterman_score": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _f64, C.POINTER(C.c_double)],
+    "cr_smith_waterman": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _f64, _vp, _vp, C.POINTER(C.c_int64),
+                          C.POINTER(C.c_double), C.POINTER(C.c_int)],
+    "cr_paired_svd_superpose": [_vp, _vp, _vp, _i64, _vp, _vp],
+    "cr_paired_svd_superpose_with_subset": [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp],
+    "cr_apply_rotran": [_vp, _vp, _i64, _vp, _vp, _vp],
+    "cr_get_rmsd": [_vp, _vp, _vp, _i64, C.POINTER(C.c_double)],
+    "cr_tm_score": [_vp, _vp, _vp, _i64, _i64, _i64, C.POINTER(C.c_double)],
+    "cr_get_common_positions": [_vp, _vp, _i64, _vp, _vp, C.POINTER(C.c_int64)],
+    "cr_neighbor_joining": [_vp, _i64, _vp, _vp],
+    "cr_assemble_matrix": [_vp, _vp, _i64, _i64, _vp],
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("CARETTA_HIP_LIB", LIB_PATH))
+    if not path.exists():
+        raise CarettaHipError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  caretta_amd has no CPU fallback.")
+    lib = C.CDLL(str(path))
+    lib.cr_last_error.restype = C.c_char_p
+    lib.cr_last_error.argtypes = []
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = argtypes
+    if lib.cr_abi_version() != 1:
+        raise CarettaHipError("libcaretta_hip ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc == 0:
+        return
+    msg = load().cr_last_error().decode("utf-8", "replace")
+    if rc == -1:
+        raise ValueError(msg)
+    if rc == -3:
+        raise MemoryError(msg)
+    raise CarettaHipError(msg)
+
+
+def ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def f64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.int64)

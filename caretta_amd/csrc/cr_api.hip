@@ -1,0 +1,460 @@
+// libcaretta_hip: C ABI (include/caretta_hip.h) over the gfx950 kernels in cr_kernels.h.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see __graft_entry__.build()).
+#include "../../include/caretta_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "cr_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define CR_HIP(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess)                                                                          \
+            return fail(_e == hipErrorOutOfMemory ? CR_ERR_MEMORY : CR_ERR_HIP,                        \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                            \
+    } while (0)
+
+#define CR_REQUIRE(cond, msg)                                 \
+    do {                                                      \
+        if (!(cond)) return fail(CR_ERR_ARGUMENT, (msg));     \
+    } while (0)
+
+// device buffer that frees itself
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t ensure(size_t count) {
+        if (count <= n && p) return hipSuccess;
+        release();
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+};
+
+}  // namespace
+
+struct cr_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool profiling = false;
+    hipEvent_t ev[CR_NUM_STAGES + 1] = {};
+    bool have_events = false;
+};
+
+struct cr_batch {
+    cr_context* ctx = nullptr;
+    int64_t P = 0, d = 0, total = 0;
+    std::vector<int64_t> offsets;
+    DevBuf<double> coords, tensors;
+    // pair list
+    int64_t npairs = 0;
+    int r_seed = 5, r_align = 5, d_pad = 0;
+    int n_max = 0, m_max = 0;
+    int64_t max_aln = 0;
+    std::vector<cr::PairDesc> h_pairs;
+    DevBuf<cr::PairDesc> pairs;
+    DevBuf<uint32_t> dirs, bits;
+    DevBuf<int32_t> pos, aln;
+    DevBuf<cr::SeedMax> seed;
+    DevBuf<cr::Transform> xf;
+    DevBuf<cr::AlignEnd> ends;
+    DevBuf<double> seed_score;
+    DevBuf<cr::PairResult> res;
+    int64_t aln_elems = 0;
+    double alg_bytes = 0.0, cells = 0.0;
+    bool ran = false;
+    float stage_ms[CR_NUM_STAGES] = {0, 0, 0, 0};
+};
+
+static_assert(sizeof(cr::PairResult) == sizeof(cr_pair_result), "device/host result layouts differ");
+
+namespace {
+
+int set_device(cr_context* ctx) {
+    CR_REQUIRE(ctx != nullptr, "null context");
+    CR_HIP(hipSetDevice(ctx->device));
+    return CR_OK;
+}
+
+template <class K>
+int allow_lds(K kernel, size_t bytes) {
+    if (bytes > 160 * 1024) return fail(CR_ERR_ARGUMENT, "sequence too long: strip hand-off rows exceed the 160 KiB LDS");
+    if (bytes > 48 * 1024)
+        CR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)bytes));
+    return CR_OK;
+}
+
+template <int R, int D>
+int launch_seed(cr_batch* b, const cr_params& prm) {
+    using Src = cr::RbfTensor<R, D>;
+    size_t lds = cr::sweep_lds_doubles<R, cr::kSwTrace, Src>(b->n_max, b->m_max) * sizeof(double);
+    int rc = allow_lds(cr::k_seed_fill<R, D>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((cr::k_seed_fill<R, D>), dim3((unsigned)b->npairs), dim3(cr::kWave), lds, b->ctx->stream,
+                       b->pairs.p, b->tensors.p, (int)b->d, prm.gamma_tensor, prm.sw_gap, b->dirs.p, b->seed.p);
+    CR_HIP(hipGetLastError());
+    return CR_OK;
+}
+
+template <int R>
+int launch_seed_d(cr_batch* b, const cr_params& prm) {
+    switch (b->d_pad) {
+        case 4: return launch_seed<R, 4>(b, prm);
+        case 8: return launch_seed<R, 8>(b, prm);
+        case 10: return launch_seed<R, 10>(b, prm);
+        case 16: return launch_seed<R, 16>(b, prm);
+        default: return fail(CR_ERR_ARGUMENT, "unsupported tensor width");
+    }
+}
+
+template <int R>
+int launch_align(cr_batch* b, const cr_params& prm) {
+    using Src = cr::RbfCoords<R>;
+    size_t lds = cr::sweep_lds_doubles<R, cr::kSwScore | cr::kDtw, Src>(b->n_max, b->m_max) * sizeof(double);
+    int rc = allow_lds(cr::k_align_fill<R>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((cr::k_align_fill<R>), dim3((unsigned)b->npairs), dim3(cr::kWave), lds, b->ctx->stream,
+                       b->pairs.p, b->coords.p, b->xf.p, prm.gamma_coords, prm.sw_gap, prm.gap_open, prm.gap_extend,
+                       b->bits.p, b->ends.p);
+    CR_HIP(hipGetLastError());
+    return CR_OK;
+}
+
+// widths the seed-fill kernel is instantiated for; narrower tensors are zero-padded in registers
+int padded_width(int64_t d) {
+    if (d <= 4) return 4;
+    if (d <= 8) return 8;
+    if (d <= 10) return 10;
+    if (d <= 16) return 16;
+    if (d <= 32) return 32;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* cr_last_error(void) { return g_err.c_str(); }
+int cr_abi_version(void) { return CR_ABI_VERSION; }
+
+int cr_device_count(int* count) {
+    CR_REQUIRE(count != nullptr, "null count");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(CR_ERR_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *count = n;
+    return CR_OK;
+}
+
+int cr_context_create(int device, void* stream, cr_context** out) {
+    CR_REQUIRE(out != nullptr, "null out");
+    *out = nullptr;
+    int n = 0;
+    CR_HIP(hipGetDeviceCount(&n));
+    if (n <= 0) return fail(CR_ERR_HIP, "no HIP device visible: libcaretta_hip has no CPU fallback");
+    CR_REQUIRE(device >= 0 && device < n, "device index out of range");
+    CR_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    CR_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(CR_ERR_HIP, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    cr_context* ctx = new (std::nothrow) cr_context();
+    if (!ctx) return fail(CR_ERR_MEMORY, "out of host memory");
+    ctx->device = device;
+    if (stream) {
+        ctx->stream = reinterpret_cast<hipStream_t>(stream);
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete ctx;
+            return fail(CR_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+        }
+        ctx->own_stream = true;
+    }
+    *out = ctx;
+    return CR_OK;
+}
+
+int cr_context_destroy(cr_context* ctx) {
+    if (!ctx) return CR_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->have_events)
+        for (auto& e : ctx->ev) (void)hipEventDestroy(e);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return CR_OK;
+}
+
+int cr_context_synchronize(cr_context* ctx) {
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    CR_HIP(hipStreamSynchronize(ctx->stream));
+    return CR_OK;
+}
+
+int cr_context_stream(cr_context* ctx, void** stream_out) {
+    CR_REQUIRE(ctx && stream_out, "null argument");
+    *stream_out = reinterpret_cast<void*>(ctx->stream);
+    return CR_OK;
+}
+
+int cr_context_set_profiling(cr_context* ctx, int enabled) {
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    if (enabled && !ctx->have_events) {
+        for (auto& e : ctx->ev) CR_HIP(hipEventCreate(&e));
+        ctx->have_events = true;
+    }
+    ctx->profiling = enabled != 0;
+    return CR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// batch
+// ---------------------------------------------------------------------------------------------
+int cr_batch_create(cr_context* ctx, const double* coords, const double* tensors, const int64_t* offsets,
+                    int64_t num_structures, int64_t d, cr_batch** out) {
+    CR_REQUIRE(out != nullptr, "null out");
+    *out = nullptr;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    CR_REQUIRE(coords && tensors && offsets, "null input array");
+    CR_REQUIRE(num_structures >= 1, "need at least one structure");
+    CR_REQUIRE(d >= 1, "tensor width must be >= 1");
+    CR_REQUIRE(padded_width(d) != 0 && padded_width(d) <= 16, "tensor width > 16 is not supported by this build");
+    CR_REQUIRE(offsets[0] == 0, "offsets[0] must be 0");
+    for (int64_t s = 0; s < num_structures; s++) {
+        CR_REQUIRE(offsets[s + 1] > offsets[s], "every structure needs at least one residue");
+        CR_REQUIRE(offsets[s + 1] - offsets[s] < (1 << 24), "structure too long");
+    }
+    cr_batch* b = new (std::nothrow) cr_batch();
+    if (!b) return fail(CR_ERR_MEMORY, "out of host memory");
+    b->ctx = ctx;
+    b->P = num_structures;
+    b->d = d;
+    b->d_pad = padded_width(d);
+    b->total = offsets[num_structures];
+    b->offsets.assign(offsets, offsets + num_structures + 1);
+    hipError_t e = b->coords.ensure((size_t)b->total * 3);
+    if (e == hipSuccess) e = b->tensors.ensure((size_t)b->total * d);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(b->coords.p, coords, sizeof(double) * b->total * 3, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(b->tensors.p, tensors, sizeof(double) * b->total * d, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        delete b;
+        return fail(e == hipErrorOutOfMemory ? CR_ERR_MEMORY : CR_ERR_HIP,
+                    std::string("uploading structures: ") + hipGetErrorString(e));
+    }
+    *out = b;
+    return CR_OK;
+}
+
+int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
+    CR_REQUIRE(b != nullptr, "null batch");
+    int rc = set_device(b->ctx);
+    if (rc) return rc;
+    CR_REQUIRE(npairs >= 0 && (npairs == 0 || pairs != nullptr), "bad pair list");
+    CR_REQUIRE(npairs < (int64_t)std::numeric_limits<int32_t>::max(), "too many pairs for one batch");
+    b->h_pairs.resize((size_t)npairs);
+    b->npairs = npairs;
+    b->ran = false;
+    b->n_max = b->m_max = 0;
+    for (int64_t p = 0; p < npairs; p++) {
+        int64_t i = pairs[2 * p], j = pairs[2 * p + 1];
+        CR_REQUIRE(i >= 0 && i < b->P && j >= 0 && j < b->P, "pair index out of range");
+        int n = (int)(b->offsets[i + 1] - b->offsets[i]), m = (int)(b->offsets[j + 1] - b->offsets[j]);
+        b->n_max = std::max(b->n_max, n);
+        b->m_max = std::max(b->m_max, m);
+    }
+    // rows per lane: 3 covers 192 rows in one strip, 5 covers 320
+    b->r_seed = b->r_align = (b->n_max <= 3 * cr::kWave) ? 3 : 5;
+    int64_t dirs_off = 0, bt_off = 0, aln_off = 0, pos_off = 0, max_aln = 0;
+    double bytes = 0.0, cells = 0.0;
+    for (int64_t p = 0; p < npairs; p++) {
+        int64_t i = pairs[2 * p], j = pairs[2 * p + 1];
+        cr::PairDesc& pd = b->h_pairs[(size_t)p];
+        pd.n = (int)(b->offsets[i + 1] - b->offsets[i]);
+        pd.m = (int)(b->offsets[j + 1] - b->offsets[j]);
+        pd.off_i = b->offsets[i];
+        pd.off_j = b->offsets[j];
+        pd.dirs_off = dirs_off;
+        pd.bt_off = bt_off;
+        pd.aln_off = aln_off;
+        pd.pos_off = pos_off;
+        dirs_off += (int64_t)cr::strips_of(pd.n, b->r_seed) * cr::tblocks(pd.m, 16) * b->r_seed * cr::kWave;
+        bt_off += (int64_t)cr::strips_of(pd.n, b->r_align) * cr::tblocks(pd.m, 8) * b->r_align * cr::kWave;
+        aln_off += 2 * (int64_t)(pd.n + pd.m);
+        pos_off += std::min(pd.n, pd.m);
+        max_aln = std::max<int64_t>(max_aln, pd.n + pd.m);
+        const double nm = (double)pd.n * pd.m, npm = (double)pd.n + pd.m;
+        bytes += 8.0 * (3 + b->d) * npm + nm / 4 + nm / 2 + 16.0 * npm + 136.0;   // SURVEY.md 8(d) B_alg
+        cells += nm;
+    }
+    b->max_aln = max_aln;
+    b->aln_elems = aln_off;
+    b->alg_bytes = bytes;
+    b->cells = cells;
+    hipError_t e = b->pairs.ensure((size_t)npairs);
+    if (e == hipSuccess) e = b->dirs.ensure((size_t)dirs_off);
+    if (e == hipSuccess) e = b->bits.ensure((size_t)bt_off);
+    if (e == hipSuccess) e = b->pos.ensure((size_t)pos_off * 2);
+    if (e == hipSuccess) e = b->aln.ensure((size_t)aln_off);
+    if (e == hipSuccess) e = b->seed.ensure((size_t)npairs);
+    if (e == hipSuccess) e = b->xf.ensure((size_t)npairs);
+    if (e == hipSuccess) e = b->ends.ensure((size_t)npairs);
+    if (e == hipSuccess) e = b->seed_score.ensure((size_t)npairs);
+    if (e == hipSuccess) e = b->res.ensure((size_t)npairs);
+    if (e == hipSuccess && npairs)
+        e = hipMemcpyAsync(b->pairs.p, b->h_pairs.data(), sizeof(cr::PairDesc) * (size_t)npairs, hipMemcpyHostToDevice,
+                           b->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(b->ctx->stream);
+    if (e != hipSuccess)
+        return fail(e == hipErrorOutOfMemory ? CR_ERR_MEMORY : CR_ERR_HIP,
+                    std::string("allocating pair scratch: ") + hipGetErrorString(e));
+    return CR_OK;
+}
+
+int cr_batch_run(cr_batch* b, const cr_params* params, double* d_sw_out) {
+    CR_REQUIRE(b != nullptr && params != nullptr, "null argument");
+    int rc = set_device(b->ctx);
+    if (rc) return rc;
+    if (b->npairs == 0) {
+        b->ran = true;
+        return CR_OK;
+    }
+    cr_context* ctx = b->ctx;
+    const cr_params prm = *params;
+    const bool prof = ctx->profiling && ctx->have_events;
+    const int threads = 64;
+    const unsigned tblocks = (unsigned)((b->npairs + threads - 1) / threads);
+    if (prof) CR_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    rc = (b->r_seed == 3) ? launch_seed_d<3>(b, prm) : launch_seed_d<5>(b, prm);
+    if (rc) return rc;
+    if (prof) CR_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    hipLaunchKernelGGL(cr::k_seed_trace, dim3(tblocks), dim3(threads), 0, ctx->stream, b->pairs.p, (int)b->npairs,
+                       b->r_seed, b->coords.p, b->dirs.p, b->seed.p, b->pos.p, b->xf.p, b->seed_score.p);
+    CR_HIP(hipGetLastError());
+    if (prof) CR_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+    rc = (b->r_align == 3) ? launch_align<3>(b, prm) : launch_align<5>(b, prm);
+    if (rc) return rc;
+    if (prof) CR_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+    hipLaunchKernelGGL(cr::k_align_trace, dim3(tblocks), dim3(threads), 0, ctx->stream, b->pairs.p, (int)b->npairs,
+                       b->r_align, b->coords.p, b->bits.p, b->ends.p, b->xf.p, b->seed_score.p, b->aln.p, b->res.p);
+    CR_HIP(hipGetLastError());
+    if (prof) CR_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
+    if (d_sw_out) {
+        // strided device-to-device copy of the first field of every PairResult
+        CR_HIP(hipMemcpy2DAsync(d_sw_out, sizeof(double), b->res.p, sizeof(cr::PairResult), sizeof(double),
+                                (size_t)b->npairs, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    b->ran = true;
+    return CR_OK;
+}
+
+int cr_batch_stage_ms(cr_batch* b, float ms[CR_NUM_STAGES]) {
+    CR_REQUIRE(b != nullptr && ms != nullptr, "null argument");
+    cr_context* ctx = b->ctx;
+    if (!(ctx->profiling && ctx->have_events) || !b->ran) return fail(CR_ERR_STATE, "profiling not enabled or batch not run");
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    CR_HIP(hipEventSynchronize(ctx->ev[CR_NUM_STAGES]));
+    for (int s = 0; s < CR_NUM_STAGES; s++) CR_HIP(hipEventElapsedTime(&ms[s], ctx->ev[s], ctx->ev[s + 1]));
+    return CR_OK;
+}
+
+int cr_batch_work(cr_batch* b, double* alg_bytes, double* cells) {
+    CR_REQUIRE(b != nullptr, "null batch");
+    if (alg_bytes) *alg_bytes = b->alg_bytes;
+    if (cells) *cells = b->cells;
+    return CR_OK;
+}
+
+int cr_batch_max_aln_len(cr_batch* b, int64_t* out) {
+    CR_REQUIRE(b != nullptr && out != nullptr, "null argument");
+    *out = b->max_aln;
+    return CR_OK;
+}
+
+int cr_batch_fetch(cr_batch* b, cr_pair_result* results, int64_t* aln, int64_t aln_stride) {
+    CR_REQUIRE(b != nullptr, "null batch");
+    if (!b->ran) return fail(CR_ERR_STATE, "cr_batch_fetch before cr_batch_run");
+    int rc = set_device(b->ctx);
+    if (rc) return rc;
+    CR_HIP(hipStreamSynchronize(b->ctx->stream));
+    if (b->npairs == 0) return CR_OK;
+    std::vector<cr_pair_result> local;
+    cr_pair_result* res = results;
+    if (!res && aln) {
+        local.resize((size_t)b->npairs);
+        res = local.data();
+    }
+    if (res) CR_HIP(hipMemcpy(res, b->res.p, sizeof(cr_pair_result) * (size_t)b->npairs, hipMemcpyDeviceToHost));
+    if (aln) {
+        CR_REQUIRE(aln_stride >= b->max_aln, "aln_stride smaller than the longest possible alignment");
+        std::vector<int32_t> h((size_t)b->aln_elems);
+        CR_HIP(hipMemcpy(h.data(), b->aln.p, sizeof(int32_t) * (size_t)b->aln_elems, hipMemcpyDeviceToHost));
+        for (int64_t p = 0; p < b->npairs; p++) {
+            const cr::PairDesc& pd = b->h_pairs[(size_t)p];
+            const int cap = pd.n + pd.m;
+            const int32_t* a1 = h.data() + pd.aln_off + res[p].aln_start;
+            const int32_t* a2 = a1 + cap;
+            int64_t* o1 = aln + (size_t)p * 2 * (size_t)aln_stride;
+            int64_t* o2 = o1 + aln_stride;
+            const int len = res[p].aln_len;
+            for (int x = 0; x < len; x++) {
+                o1[x] = a1[x];
+                o2[x] = a2[x];
+            }
+            for (int64_t x = len; x < aln_stride; x++) o1[x] = o2[x] = -2;
+        }
+    }
+    return CR_OK;
+}
+
+int cr_batch_destroy(cr_batch* b) {
+    if (!b) return CR_OK;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    delete b;
+    return CR_OK;
+}
+
+}  // extern "C"
+
+#include "cr_dropins.h"

@@ -1,0 +1,558 @@
+// Single-call drop-ins of the reference's njit functions (host buffers in/out, device compute) and
+// the host-side integer / tree work.  Included at the end of cr_api.hip.
+#pragma once
+
+namespace cr {
+
+// make_score_matrix (score_functions.py:23-51): one thread per cell, coalesced along j.
+__global__ void k_score_matrix(const double* __restrict__ a, int n, const double* __restrict__ b, int m, int k,
+                               double neg_gamma, double* __restrict__ S) {
+    __shared__ ExpEntry tab[16];
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    if (tid < 16) tab[tid] = kExpTable[tid];
+    __syncthreads();
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= n || j >= m) return;
+    const double* ai = a + (int64_t)i * k;
+    const double* bj = b + (int64_t)j * k;
+    double df = ai[0] - bj[0];
+    double acc = df * df;
+    for (int x = 1; x < k; x++) {
+        df = ai[x] - bj[x];
+        acc = acc + df * df;
+    }
+    S[(int64_t)i * m + j] = exp_tab(neg_gamma * acc, tab);
+}
+
+// coordinate score matrix on the seed-superposed frames (multiple_alignment.py:344-349)
+__global__ void k_score_matrix_xf(const double* __restrict__ xi, int n, const double* __restrict__ xj, int m,
+                                  const Transform* __restrict__ xf, double neg_gamma, double* __restrict__ S) {
+    __shared__ ExpEntry tab[16];
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    if (tid < 16) tab[tid] = kExpTable[tid];
+    __syncthreads();
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= n || j >= m) return;
+    double a[3], o[3];
+    const bool raw = xf->flags & kFlagSeedSkipped;
+    for (int x = 0; x < 3; x++) {
+        const double v = xi[(int64_t)i * 3 + x];
+        a[x] = raw ? v : v - xf->c1[x];
+    }
+    if (raw) {
+        for (int x = 0; x < 3; x++) o[x] = xj[(int64_t)j * 3 + x];
+    } else {
+        double w[3];
+        for (int x = 0; x < 3; x++) w[x] = xj[(int64_t)j * 3 + x] - xf->c2[x];
+        rot3(w, xf->R, o);
+    }
+    const double dx = a[0] - o[0], dy = a[1] - o[1], dz = a[2] - o[2];
+    const double acc = (dx * dx + dy * dy) + dz * dz;
+    S[(int64_t)i * m + j] = exp_tab(neg_gamma * acc, tab);
+}
+
+// DP on an explicit score matrix (dtw_align / smith_waterman(_score) drop-ins).  One wave.
+template <int R, int MODE>
+__global__ __launch_bounds__(kWave) void k_explicit(const int32_t* __restrict__ seq1, int n,
+                                                   const int32_t* __restrict__ seq2, int m,
+                                                   const double* __restrict__ S, int64_t s_cols, SweepParams prm,
+                                                   uint32_t* __restrict__ dirs, uint32_t* __restrict__ bits,
+                                                   SeedMax* __restrict__ seed, AlignEnd* __restrict__ end) {
+    extern __shared__ double lds[];
+    Explicit<R> src;
+    src.S = S;
+    src.seq1 = seq1;
+    src.seq2 = seq2;
+    src.s_cols = s_cols;
+    sweep<R, MODE>(src, n, m, prm, lds, dirs, bits, seed, end);
+}
+
+struct TraceOut {
+    int32_t len, start;
+};
+
+__global__ void k_dtw_trace_full(int n, int m, int R, const uint32_t* __restrict__ bits,
+                                 const AlignEnd* __restrict__ end, int32_t* __restrict__ aln, TraceOut* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int cap = n + m;
+    const int len = dtw_traceback(bits, R, tblocks(m, 8), n, m, end->start_layer, aln, aln + cap, cap);
+    out->len = len;
+    out->start = cap - len;
+}
+
+__global__ void k_sw_trace_full(int n, int m, int R, const uint32_t* __restrict__ dirs,
+                                const SeedMax* __restrict__ seed, int32_t* __restrict__ aln, TraceOut* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int cap = n + m;
+    int len = 0;
+    if (seed->i > 0) len = sw_traceback(dirs, R, tblocks(m, 16), seed->i, seed->j, aln, aln + cap, cap);
+    out->len = len;
+    out->start = cap - len;
+}
+
+// paired_svd_superpose (superposition_functions.py:7-35), sequential sums as under numba.
+CR_D void kabsch_seq(const double* __restrict__ x1, const double* __restrict__ x2, int k, double* R, double* t,
+                     double* c1, double* c2) {
+    for (int a = 0; a < 3; a++) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int i = 0; i < k; i++) {
+            s1 += x1[(int64_t)i * 3 + a];
+            s2 += x2[(int64_t)i * 3 + a];
+        }
+        c1[a] = s1 / (double)k;
+        c2[a] = s2 / (double)k;
+    }
+    double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < k; i++) {
+        const double a[3] = {x2[(int64_t)i * 3] - c2[0], x2[(int64_t)i * 3 + 1] - c2[1], x2[(int64_t)i * 3 + 2] - c2[2]};
+        const double b[3] = {x1[(int64_t)i * 3] - c1[0], x1[(int64_t)i * 3 + 1] - c1[1], x1[(int64_t)i * 3 + 2] - c1[2]};
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) C[3 * r + c] += a[r] * b[c];
+    }
+    kabsch_from_correlation(C, c1, c2, R, t);
+}
+
+// out layout: R[9], t[3], c1[3], c2[3]
+__global__ void k_kabsch(const double* __restrict__ x1, const double* __restrict__ x2, int k, double* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    kabsch_seq(x1, x2, k, out, out + 9, out + 12, out + 15);
+}
+
+// apply_rotran (superposition_functions.py:64-80); with center != nullptr computes (x - center) @ R
+// and with R == nullptr just x - center (the two lines superposition_functions.py:57-58).
+__global__ void k_transform(const double* __restrict__ x, int k, const double* __restrict__ R,
+                            const double* __restrict__ t, const double* __restrict__ center, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    double v[3] = {x[(int64_t)i * 3], x[(int64_t)i * 3 + 1], x[(int64_t)i * 3 + 2]};
+    if (center)
+        for (int a = 0; a < 3; a++) v[a] = v[a] - center[a];
+    double o[3] = {v[0], v[1], v[2]};
+    if (R) rot3(v, R, o);
+    if (t)
+        for (int a = 0; a < 3; a++) o[a] = o[a] + t[a];
+    for (int a = 0; a < 3; a++) out[(int64_t)i * 3 + a] = o[a];
+}
+
+// get_rmsd (score_functions.py:15-19) and tm_score (multiple_alignment.py:59-70); out[0]=rmsd, out[1]=tm
+__global__ void k_rmsd_tm(const double* __restrict__ x1, const double* __restrict__ x2, int k, int64_t l1, int64_t l2,
+                          double* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double d1 = 1.24 * (double)(l1 - 15) / 3.0 - 1.8;
+    const double d2 = 1.24 * (double)(l2 - 15) / 3.0 - 1.8;
+    double ss = 0.0, sum1 = 0.0, sum2 = 0.0;
+    for (int i = 0; i < k; i++) {
+        const double e0 = x1[(int64_t)i * 3] - x2[(int64_t)i * 3];
+        const double e1 = x1[(int64_t)i * 3 + 1] - x2[(int64_t)i * 3 + 1];
+        const double e2 = x1[(int64_t)i * 3 + 2] - x2[(int64_t)i * 3 + 2];
+        ss += e0 * e0;
+        ss += e1 * e1;
+        ss += e2 * e2;
+        const double sg = (e0 + e1) + e2;
+        const double q1 = sg / d1, q2 = sg / d2;
+        sum1 += 1.0 / (1.0 + q1 * q1);
+        sum2 += 1.0 / (1.0 + q2 * q2);
+    }
+    out[0] = sqrt(ss / (double)k);
+    const double t1 = (1.0 / (double)l1) * sum1;
+    const double t2 = (1.0 / (double)l2) * sum2;
+    out[1] = t1 > t2 ? t1 : t2;
+}
+
+}  // namespace cr
+
+namespace {
+
+template <class T>
+int upload(DevBuf<T>& buf, const T* host, size_t count, hipStream_t stream) {
+    hipError_t e = buf.ensure(count);
+    if (e == hipSuccess && count) e = hipMemcpyAsync(buf.p, host, sizeof(T) * count, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess)
+        return fail(e == hipErrorOutOfMemory ? CR_ERR_MEMORY : CR_ERR_HIP, std::string("upload: ") + hipGetErrorString(e));
+    return CR_OK;
+}
+
+int to_i32(const int64_t* seq, int64_t len, int64_t bound, std::vector<int32_t>& out, const char* what) {
+    out.resize((size_t)len);
+    for (int64_t x = 0; x < len; x++) {
+        if (seq[x] < 0 || seq[x] >= bound) return fail(CR_ERR_ARGUMENT, std::string(what) + ": index outside the score matrix");
+        out[(size_t)x] = (int32_t)seq[x];
+    }
+    return CR_OK;
+}
+
+struct ExplicitRun {
+    DevBuf<double> S;
+    DevBuf<int32_t> s1, s2, aln;
+    DevBuf<uint32_t> dirs, bits;
+    DevBuf<cr::SeedMax> seed;
+    DevBuf<cr::AlignEnd> end;
+    DevBuf<cr::TraceOut> tout;
+};
+
+constexpr int kExplicitR = 5;
+
+// shared body of the three explicit-matrix drop-ins
+template <int MODE>
+int run_explicit(cr_context* ctx, const int64_t* seq1, int64_t n, const int64_t* seq2, int64_t m, const double* S,
+                 int64_t s_rows, int64_t s_cols, cr::SweepParams prm, ExplicitRun& r) {
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    CR_REQUIRE(seq1 && seq2 && S, "null input array");
+    CR_REQUIRE(n >= 1 && m >= 1 && s_rows >= 1 && s_cols >= 1, "empty sequence or score matrix");
+    CR_REQUIRE(n < (1 << 24) && m < (1 << 24), "sequence too long");
+    std::vector<int32_t> h1, h2;
+    if ((rc = to_i32(seq1, n, s_rows, h1, "seq1"))) return rc;
+    if ((rc = to_i32(seq2, m, s_cols, h2, "seq2"))) return rc;
+    if ((rc = upload(r.S, S, (size_t)s_rows * s_cols, ctx->stream))) return rc;
+    if ((rc = upload(r.s1, h1.data(), (size_t)n, ctx->stream))) return rc;
+    if ((rc = upload(r.s2, h2.data(), (size_t)m, ctx->stream))) return rc;
+    constexpr int R = kExplicitR;
+    const size_t nd = (size_t)cr::strips_of((int)n, R) * cr::tblocks((int)m, 16) * R * cr::kWave;
+    const size_t nb = (size_t)cr::strips_of((int)n, R) * cr::tblocks((int)m, 8) * R * cr::kWave;
+    CR_HIP(r.dirs.ensure((MODE & cr::kSwTrace) ? nd : 1));
+    CR_HIP(r.bits.ensure((MODE & cr::kDtw) ? nb : 1));
+    CR_HIP(r.seed.ensure(1));
+    CR_HIP(r.end.ensure(1));
+    CR_HIP(r.tout.ensure(1));
+    CR_HIP(r.aln.ensure(2 * (size_t)(n + m)));
+    const size_t lds = cr::sweep_lds_doubles<R, MODE, cr::Explicit<R>>((int)n, (int)m) * sizeof(double);
+    if ((rc = allow_lds(cr::k_explicit<R, MODE>, lds))) return rc;
+    hipLaunchKernelGGL((cr::k_explicit<R, MODE>), dim3(1), dim3(cr::kWave), lds, ctx->stream, r.s1.p, (int)n, r.s2.p,
+                       (int)m, r.S.p, s_cols, prm, r.dirs.p, r.bits.p, r.seed.p, r.end.p);
+    CR_HIP(hipGetLastError());
+    return CR_OK;
+}
+
+int fetch_alignment(cr_context* ctx, ExplicitRun& r, int64_t n, int64_t m, int64_t* aln1, int64_t* aln2,
+                    int64_t* aln_len) {
+    cr::TraceOut to;
+    CR_HIP(hipMemcpyAsync(&to, r.tout.p, sizeof(to), hipMemcpyDeviceToHost, ctx->stream));
+    CR_HIP(hipStreamSynchronize(ctx->stream));
+    const int64_t cap = n + m;
+    std::vector<int32_t> h((size_t)(2 * cap));
+    CR_HIP(hipMemcpy(h.data(), r.aln.p, sizeof(int32_t) * (size_t)(2 * cap), hipMemcpyDeviceToHost));
+    for (int x = 0; x < to.len; x++) {
+        aln1[x] = h[(size_t)(to.start + x)];
+        aln2[x] = h[(size_t)(cap + to.start + x)];
+    }
+    if (aln_len) *aln_len = to.len;
+    return CR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cr_make_score_matrix(cr_context* ctx, const double* a, int64_t n, const double* b, int64_t m, int64_t k,
+                         double gamma, double* S) {
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    CR_REQUIRE(n >= 0 && m >= 0 && k >= 1, "bad shape");
+    if (n == 0 || m == 0) return CR_OK;
+    CR_REQUIRE(a && b && S, "null array");
+    CR_REQUIRE(n < (1 << 24) && m < (1 << 24), "matrix too large");
+    DevBuf<double> da, db, ds;
+    if ((rc = upload(da, a, (size_t)n * k, ctx->stream))) return rc;
+    if ((rc = upload(db, b, (size_t)m * k, ctx->stream))) return rc;
+    CR_HIP(ds.ensure((size_t)n * m));
+    dim3 block(64, 4), grid((unsigned)((m + 63) / 64), (unsigned)((n + 3) / 4));
+    hipLaunchKernelGGL(cr::k_score_matrix, grid, block, 0, ctx->stream, da.p, (int)n, db.p, (int)m, (int)k, -gamma, ds.p);
+    CR_HIP(hipGetLastError());
+    CR_HIP(hipMemcpyAsync(S, ds.p, sizeof(double) * (size_t)n * m, hipMemcpyDeviceToHost, ctx->stream));
+    CR_HIP(hipStreamSynchronize(ctx->stream));
+    return CR_OK;
+}
+
+int cr_protein_score_function(cr_context* ctx, const double* coords_i, const double* tensors_i, int64_t n,
+                              const double* coords_j, const double* tensors_j, int64_t m, int64_t d,
+                              double gamma_tensor, double gamma_coords, double* S, uint32_t* flags) {
+    CR_REQUIRE(coords_i && tensors_i && coords_j && tensors_j && S, "null array");
+    CR_REQUIRE(n >= 1 && m >= 1, "empty structure");
+    // a two-structure batch driven through stages 1-2, then the explicit matrix
+    std::vector<double> coords((size_t)(n + m) * 3), tensors((size_t)(n + m) * d);
+    std::memcpy(coords.data(), coords_i, sizeof(double) * (size_t)n * 3);
+    std::memcpy(coords.data() + n * 3, coords_j, sizeof(double) * (size_t)m * 3);
+    std::memcpy(tensors.data(), tensors_i, sizeof(double) * (size_t)n * d);
+    std::memcpy(tensors.data() + n * d, tensors_j, sizeof(double) * (size_t)m * d);
+    const int64_t offsets[3] = {0, n, n + m};
+    const int32_t pair[2] = {0, 1};
+    cr_batch* b = nullptr;
+    int rc = cr_batch_create(ctx, coords.data(), tensors.data(), offsets, 2, d, &b);
+    if (rc) return rc;
+    rc = cr_batch_set_pairs(b, pair, 1);
+    if (rc == CR_OK) {
+        cr_params prm{gamma_tensor, gamma_coords, 1.0, 0.01, 0.0};
+        rc = (b->r_seed == 3) ? launch_seed_d<3>(b, prm) : launch_seed_d<5>(b, prm);
+    }
+    if (rc == CR_OK) {
+        hipLaunchKernelGGL(cr::k_seed_trace, dim3(1), dim3(64), 0, ctx->stream, b->pairs.p, 1, b->r_seed, b->coords.p,
+                           b->dirs.p, b->seed.p, b->pos.p, b->xf.p, b->seed_score.p);
+        DevBuf<double> ds;
+        hipError_t e = ds.ensure((size_t)n * m);
+        if (e == hipSuccess) {
+            dim3 block(64, 4), grid((unsigned)((m + 63) / 64), (unsigned)((n + 3) / 4));
+            hipLaunchKernelGGL(cr::k_score_matrix_xf, grid, block, 0, ctx->stream, b->coords.p, (int)n,
+                               b->coords.p + n * 3, (int)m, b->xf.p, -gamma_coords, ds.p);
+            e = hipGetLastError();
+        }
+        cr::Transform tr;
+        if (e == hipSuccess) e = hipMemcpyAsync(S, ds.p, sizeof(double) * (size_t)n * m, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&tr, b->xf.p, sizeof(tr), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = fail(CR_ERR_HIP, std::string("score_function: ") + hipGetErrorString(e));
+        else if (flags) *flags = tr.flags;
+    }
+    cr_batch_destroy(b);
+    return rc;
+}
+
+int cr_dtw_align(cr_context* ctx, const int64_t* seq1, int64_t n, const int64_t* seq2, int64_t m, const double* S,
+                 int64_t s_rows, int64_t s_cols, double gap_open, double gap_extend, int64_t* aln1, int64_t* aln2,
+                 int64_t* aln_len, double* score) {
+    ExplicitRun r;
+    cr::SweepParams prm{0.0, gap_open, gap_extend};
+    int rc = run_explicit<cr::kDtw>(ctx, seq1, n, seq2, m, S, s_rows, s_cols, prm, r);
+    if (rc) return rc;
+    cr::AlignEnd e;
+    if (aln1 && aln2) {
+        hipLaunchKernelGGL(cr::k_dtw_trace_full, dim3(1), dim3(1), 0, ctx->stream, (int)n, (int)m, kExplicitR, r.bits.p,
+                           r.end.p, r.aln.p, r.tout.p);
+        CR_HIP(hipGetLastError());
+    }
+    CR_HIP(hipMemcpyAsync(&e, r.end.p, sizeof(e), hipMemcpyDeviceToHost, ctx->stream));
+    CR_HIP(hipStreamSynchronize(ctx->stream));
+    if (score) *score = e.dtw_score;
+    if (aln1 && aln2) return fetch_alignment(ctx, r, n, m, aln1, aln2, aln_len);
+    return CR_OK;
+}
+
+int cr_smith_waterman_score(cr_context* ctx, const int64_t* seq1, int64_t n, const int64_t* seq2, int64_t m,
+                            const double* S, int64_t s_rows, int64_t s_cols, double gap, double* score) {
+    CR_REQUIRE(score != nullptr && seq2 != nullptr, "null argument");
+    // dynamic_time_warping.py:214-215: a row stops at the first -1 of seq2; later columns stay 0
+    int64_t m_eff = m;
+    for (int64_t x = 0; x < m; x++)
+        if (seq2[x] == -1) { m_eff = x; break; }
+    if (m_eff == 0 || n == 0) { *score = 0.0; return CR_OK; }
+    ExplicitRun r;
+    cr::SweepParams prm{gap, 0.0, 0.0};
+    int rc = run_explicit<cr::kSwScore>(ctx, seq1, n, seq2, m_eff, S, s_rows, s_cols, prm, r);
+    if (rc) return rc;
+    cr::AlignEnd e;
+    CR_HIP(hipMemcpyAsync(&e, r.end.p, sizeof(e), hipMemcpyDeviceToHost, ctx->stream));
+    CR_HIP(hipStreamSynchronize(ctx->stream));
+    *score = e.sw;
+    return CR_OK;
+}
+
+int cr_smith_waterman(cr_context* ctx, const int64_t* seq1, int64_t n, const int64_t* seq2, int64_t m, const double* S,
+                      int64_t s_rows, int64_t s_cols, double gap, int64_t* aln1, int64_t* aln2, int64_t* aln_len,
+                      double* score, int* all_zero) {
+    CR_REQUIRE(aln1 && aln2 && aln_len && score, "null output");
+    ExplicitRun r;
+    cr::SweepParams prm{gap, 0.0, 0.0};
+    int rc = run_explicit<cr::kSwTrace>(ctx, seq1, n, seq2, m, S, s_rows, s_cols, prm, r);
+    if (rc) return rc;
+    hipLaunchKernelGGL(cr::k_sw_trace_full, dim3(1), dim3(1), 0, ctx->stream, (int)n, (int)m, kExplicitR, r.dirs.p,
+                       r.seed.p, r.aln.p, r.tout.p);
+    CR_HIP(hipGetLastError());
+    cr::SeedMax sm;
+    CR_HIP(hipMemcpyAsync(&sm, r.seed.p, sizeof(sm), hipMemcpyDeviceToHost, ctx->stream));
+    CR_HIP(hipStreamSynchronize(ctx->stream));
+    *score = sm.score;
+    if (all_zero) *all_zero = (sm.i == 0) ? 1 : 0;
+    return fetch_alignment(ctx, r, n, m, aln1, aln2, aln_len);
+}
+
+int cr_paired_svd_superpose(cr_context* ctx, const double* x1, const double* x2, int64_t k, double* R, double* t) {
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    CR_REQUIRE(x1 && x2 && R && t && k >= 1 && k < (1 << 28), "bad argument");
+    DevBuf<double> d1, d2, out;
+    if ((rc = upload(d1, x1, (size_t)k * 3, ctx->stream))) return rc;
+    if ((rc = upload(d2, x2, (size_t)k * 3, ctx->stream))) return rc;
+    CR_HIP(out.ensure(18));
+    hipLaunchKernelGGL(cr::k_kabsch, dim3(1), dim3(1), 0, ctx->stream, d1.p, d2.p, (int)k, out.p);
+    CR_HIP(hipGetLastError());
+    double h[18];
+    CR_HIP(hipMemcpyAsync(h, out.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    CR_HIP(hipStreamSynchronize(ctx->stream));
+    std::memcpy(R, h, sizeof(double) * 9);
+    std::memcpy(t, h + 9, sizeof(double) * 3);
+    return CR_OK;
+}
+
+int cr_paired_svd_superpose_with_subset(cr_context* ctx, const double* c1, int64_t n, const double* c2, int64_t m,
+                                        const double* s1, const double* s2, int64_t k, double* o1, double* o2,
+                                        double* o3) {
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    CR_REQUIRE(c1 && c2 && s1 && s2 && o1 && o2 && k >= 1 && n >= 1 && m >= 1, "bad argument");
+    DevBuf<double> dc1, dc2, ds1, ds2, kab, r1, r2, r3;
+    if ((rc = upload(dc1, c1, (size_t)n * 3, ctx->stream))) return rc;
+    if ((rc = upload(dc2, c2, (size_t)m * 3, ctx->stream))) return rc;
+    if ((rc = upload(ds1, s1, (size_t)k * 3, ctx->stream))) return rc;
+    if ((rc = upload(ds2, s2, (size_t)k * 3, ctx->stream))) return rc;
+    CR_HIP(kab.ensure(18));
+    CR_HIP(r1.ensure((size_t)n * 3));
+    CR_HIP(r2.ensure((size_t)m * 3));
+    CR_HIP(r3.ensure((size_t)k * 3));
+    hipLaunchKernelGGL(cr::k_kabsch, dim3(1), dim3(1), 0, ctx->stream, ds1.p, ds2.p, (int)k, kab.p);
+    const int th = 256;
+    hipLaunchKernelGGL(cr::k_transform, dim3((unsigned)((n + th - 1) / th)), dim3(th), 0, ctx->stream, dc1.p, (int)n,
+                       (const double*)nullptr, (const double*)nullptr, kab.p + 12, r1.p);
+    hipLaunchKernelGGL(cr::k_transform, dim3((unsigned)((m + th - 1) / th)), dim3(th), 0, ctx->stream, dc2.p, (int)m,
+                       kab.p, (const double*)nullptr, kab.p + 15, r2.p);
+    hipLaunchKernelGGL(cr::k_transform, dim3((unsigned)((k + th - 1) / th)), dim3(th), 0, ctx->stream, ds2.p, (int)k,
+                       kab.p, kab.p + 9, (const double*)nullptr, r3.p);
+    CR_HIP(hipGetLastError());
+    CR_HIP(hipMemcpyAsync(o1, r1.p, sizeof(double) * (size_t)n * 3, hipMemcpyDeviceToHost, ctx->stream));
+    CR_HIP(hipMemcpyAsync(o2, r2.p, sizeof(double) * (size_t)m * 3, hipMemcpyDeviceToHost, ctx->stream));
+    if (o3) CR_HIP(hipMemcpyAsync(o3, r3.p, sizeof(double) * (size_t)k * 3, hipMemcpyDeviceToHost, ctx->stream));
+    CR_HIP(hipStreamSynchronize(ctx->stream));
+    return CR_OK;
+}
+
+int cr_apply_rotran(cr_context* ctx, const double* x, int64_t k, const double* R, const double* t, double* out) {
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    CR_REQUIRE(x && R && t && out && k >= 0, "bad argument");
+    if (k == 0) return CR_OK;
+    DevBuf<double> dx, dr, dout;
+    double rt[12];
+    std::memcpy(rt, R, sizeof(double) * 9);
+    std::memcpy(rt + 9, t, sizeof(double) * 3);
+    if ((rc = upload(dx, x, (size_t)k * 3, ctx->stream))) return rc;
+    if ((rc = upload(dr, rt, 12, ctx->stream))) return rc;
+    CR_HIP(dout.ensure((size_t)k * 3));
+    const int th = 256;
+    hipLaunchKernelGGL(cr::k_transform, dim3((unsigned)((k + th - 1) / th)), dim3(th), 0, ctx->stream, dx.p, (int)k, dr.p,
+                       dr.p + 9, (const double*)nullptr, dout.p);
+    CR_HIP(hipGetLastError());
+    CR_HIP(hipMemcpyAsync(out, dout.p, sizeof(double) * (size_t)k * 3, hipMemcpyDeviceToHost, ctx->stream));
+    CR_HIP(hipStreamSynchronize(ctx->stream));
+    return CR_OK;
+}
+
+static int rmsd_tm(cr_context* ctx, const double* x1, const double* x2, int64_t k, int64_t l1, int64_t l2, double* h) {
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    CR_REQUIRE(x1 && x2 && k >= 1, "bad argument");
+    DevBuf<double> d1, d2, out;
+    if ((rc = upload(d1, x1, (size_t)k * 3, ctx->stream))) return rc;
+    if ((rc = upload(d2, x2, (size_t)k * 3, ctx->stream))) return rc;
+    CR_HIP(out.ensure(2));
+    hipLaunchKernelGGL(cr::k_rmsd_tm, dim3(1), dim3(1), 0, ctx->stream, d1.p, d2.p, (int)k, l1, l2, out.p);
+    CR_HIP(hipGetLastError());
+    CR_HIP(hipMemcpyAsync(h, out.p, sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->stream));
+    CR_HIP(hipStreamSynchronize(ctx->stream));
+    return CR_OK;
+}
+
+int cr_get_rmsd(cr_context* ctx, const double* x1, const double* x2, int64_t k, double* out) {
+    CR_REQUIRE(out != nullptr, "null output");
+    double h[2];
+    int rc = rmsd_tm(ctx, x1, x2, k, 100, 100, h);
+    if (rc == CR_OK) *out = h[0];
+    return rc;
+}
+
+int cr_tm_score(cr_context* ctx, const double* x1, const double* x2, int64_t k, int64_t l1, int64_t l2, double* out) {
+    CR_REQUIRE(out != nullptr, "null output");
+    double h[2];
+    int rc = rmsd_tm(ctx, x1, x2, k, l1, l2, h);
+    if (rc == CR_OK) *out = h[1];
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side integer / tree work
+// ---------------------------------------------------------------------------------------------
+int cr_get_common_positions(const int64_t* a1, const int64_t* a2, int64_t len, int64_t* p1, int64_t* p2, int64_t* k) {
+    CR_REQUIRE(len >= 0 && (len == 0 || (a1 && a2 && p1 && p2)) && k, "bad argument");
+    int64_t c = 0;
+    for (int64_t x = 0; x < len; x++)
+        if (a1[x] != -1 && a2[x] != -1) {
+            p1[c] = a1[x];
+            p2[c] = a2[x];
+            c++;
+        }
+    *k = c;
+    return CR_OK;
+}
+
+int cr_assemble_matrix(const int32_t* pairs, const double* scores, int64_t npairs, int64_t P, double* M) {
+    CR_REQUIRE(pairs && scores && M && P >= 1 && npairs >= 0, "bad argument");
+    std::fill(M, M + P * P, 0.0);
+    for (int64_t p = 0; p < npairs; p++) {
+        int64_t i = pairs[2 * p], j = pairs[2 * p + 1];
+        CR_REQUIRE(i >= 0 && i < P && j >= 0 && j < P, "pair index out of range");
+        M[i * P + j] = M[j * P + i] = scores[p];
+    }
+    return CR_OK;
+}
+
+// neighbor_joining.py:19-157.  The reference recomputes both row sums for every (i, j) (O(P^4));
+// here each row sum is formed once per iteration with the same sequential left-to-right order
+// (numba's np.sum), so every Q value, hence every decision, is bit-identical to the reference's.
+int cr_neighbor_joining(const double* D0, int64_t P, uint64_t* tree, double* bl) {
+    CR_REQUIRE(D0 && tree && bl, "null argument");
+    CR_REQUIRE(P >= 3, "neighbor joining needs at least 3 taxa");
+    std::vector<double> D(D0, D0 + P * P), N((size_t)(P * P)), rs((size_t)P);
+    std::vector<int64_t> true_idx((size_t)P), idx((size_t)P), nt((size_t)P);
+    for (int64_t i = 0; i < P; i++) true_idx[(size_t)i] = i;
+    auto rowsum = [](const double* row, int64_t n) {
+        double s = 0.0;
+        for (int64_t k = 0; k < n; k++) s += row[k];
+        return s;
+    };
+    int64_t n = P, index = 0, nint = 0;
+    while (n > 3) {
+        for (int64_t i = 0; i < n; i++) rs[(size_t)i] = rowsum(&D[(size_t)(i * n)], n);
+        double min_q = std::numeric_limits<double>::infinity();
+        int64_t mi = 0, mj = 0;
+        for (int64_t i = 0; i < n; i++)
+            for (int64_t j = 0; j < n; j++)
+                if (i != j) {
+                    const double q = ((double)(n - 2) * D[(size_t)(i * n + j)] - rs[(size_t)i]) - rs[(size_t)j];
+                    if (q < min_q) { mi = i; mj = j; min_q = q; }
+                }
+        const double dij = D[(size_t)(mi * n + mj)];
+        const double di = 0.5 * dij + (0.5 / (double)(n - 2)) * (rs[(size_t)mi] - rs[(size_t)mj]);
+        const double dj = dij - di;
+        const int64_t node = nint + P;
+        nint++;
+        tree[2 * index] = (uint64_t)true_idx[(size_t)mi]; tree[2 * index + 1] = (uint64_t)node; bl[index++] = di;
+        tree[2 * index] = (uint64_t)true_idx[(size_t)mj]; tree[2 * index + 1] = (uint64_t)node; bl[index++] = dj;
+        int64_t cnt = 0;
+        for (int64_t i = 0; i < n; i++)
+            if (i != mi && i != mj) idx[(size_t)cnt++] = i;
+        const int64_t nn = n - 1;
+        N[0] = 0.0;
+        for (int64_t a = 0; a < cnt; a++) {
+            for (int64_t b = 0; b < cnt; b++) N[(size_t)((a + 1) * nn + b + 1)] = D[(size_t)(idx[(size_t)a] * n + idx[(size_t)b])];
+            const double v = 0.5 * ((D[(size_t)(mi * n + idx[(size_t)a])] + D[(size_t)(mj * n + idx[(size_t)a])]) - dij);
+            N[(size_t)(a + 1)] = v;
+            N[(size_t)((a + 1) * nn)] = v;
+        }
+        nt[0] = node;
+        for (int64_t a = 0; a < cnt; a++) nt[(size_t)(a + 1)] = true_idx[(size_t)idx[(size_t)a]];
+        std::copy(nt.begin(), nt.begin() + nn, true_idx.begin());
+        D.swap(N);
+        n = nn;
+    }
+    const double s1 = rowsum(&D[(size_t)(1 * n)], n), s2 = rowsum(&D[(size_t)(2 * n)], n);
+    const double d12 = D[(size_t)(1 * n + 2)];
+    const double di = 0.5 * d12 + (0.5 / (double)(n - 2)) * (s1 - s2);
+    const int64_t node = nint + P;
+    tree[2 * index] = (uint64_t)true_idx[1]; tree[2 * index + 1] = (uint64_t)node; bl[index++] = di;
+    tree[2 * index] = (uint64_t)true_idx[2]; tree[2 * index + 1] = (uint64_t)node; bl[index++] = d12 - di;
+    tree[2 * index] = (uint64_t)true_idx[0]; tree[2 * index + 1] = (uint64_t)node;
+    bl[index++] = 0.5 * ((D[(size_t)(1 * n + 0)] + D[(size_t)(2 * n + 0)]) - d12);
+    return CR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,153 @@
+"""Host-side handles over the C ABI: a device context and a resident batch of structures.
+
+``Context``  = device + HIP stream (optionally borrowed from torch) + per-stage profiling events.
+``PairBatch`` = packed structures resident in HBM plus the scratch of one pair list; ``run()`` enqueues
+the four stages of the pairwise pipeline, ``fetch()`` brings results to the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _capi
+from ._capi import Params, check, f64, i64, ptr
+
+DEFAULT_PARAMS = dict(gamma_tensor=7.0, gamma_coords=0.03, gap_open=1.0, gap_extend=0.01, sw_gap=0.0)
+
+
+def make_params(**kw) -> Params:
+    p = dict(DEFAULT_PARAMS)
+    for k, v in kw.items():
+        if k not in p:
+            raise TypeError(f"unknown parameter {k!r}")
+        p[k] = float(v)
+    return Params(**p)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = _capi.load().cr_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+class Context:
+    def __init__(self, device: int = 0, stream: Optional[int] = None, profiling: bool = False):
+        self._lib = _capi.load()
+        self._h = C.c_void_p()
+        check(self._lib.cr_context_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        self.device = int(device)
+        if profiling:
+            self.set_profiling(True)
+
+    def set_profiling(self, enabled: bool):
+        check(self._lib.cr_context_set_profiling(self._h, 1 if enabled else 0))
+
+    def synchronize(self):
+        check(self._lib.cr_context_synchronize(self._h))
+
+    @property
+    def stream(self) -> int:
+        s = C.c_void_p()
+        check(self._lib.cr_context_stream(self._h, C.byref(s)))
+        return s.value or 0
+
+    def close(self):
+        if self._h:
+            self._lib.cr_context_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device: int = 0) -> Context:
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+def all_pairs(num: int) -> np.ndarray:
+    """(i, j), i < j in the row-major order of multiple_alignment.py:162-163."""
+    i, j = np.triu_indices(num, k=1)
+    return np.ascontiguousarray(np.stack([i, j], axis=1), dtype=np.int32)
+
+
+class PairBatch:
+    def __init__(self, ctx: Context, coords, tensors, offsets):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        self.coords, self.tensors, self.offsets = f64(coords), f64(tensors), i64(offsets)
+        if self.coords.ndim != 2 or self.coords.shape[1] != 3:
+            raise ValueError("coords must have shape (total, 3)")
+        if self.tensors.ndim != 2 or self.tensors.shape[0] != self.coords.shape[0]:
+            raise ValueError("tensors must have shape (total, d)")
+        if self.offsets.ndim != 1 or self.offsets[-1] != self.coords.shape[0]:
+            raise ValueError("offsets must end at the total residue count")
+        self.num_structures = len(self.offsets) - 1
+        self._h = C.c_void_p()
+        check(self._lib.cr_batch_create(ctx._h, ptr(self.coords), ptr(self.tensors), ptr(self.offsets),
+                                        self.num_structures, self.tensors.shape[1], C.byref(self._h)))
+        self.pairs = np.zeros((0, 2), np.int32)
+
+    def set_pairs(self, pairs: Sequence) -> "PairBatch":
+        self.pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        check(self._lib.cr_batch_set_pairs(self._h, ptr(self.pairs), len(self.pairs)))
+        return self
+
+    def run(self, params: Optional[Params] = None, sw_out_device_ptr: Optional[int] = None):
+        params = params or make_params()
+        check(self._lib.cr_batch_run(self._h, C.byref(params),
+                                     C.c_void_p(sw_out_device_ptr) if sw_out_device_ptr else None))
+
+    def fetch(self, want_alignments: bool = True):
+        """-> (structured array of per-pair results, aln int64 [npairs, 2, stride] or None)."""
+        n = len(self.pairs)
+        res = np.zeros(n, dtype=_capi.PAIR_RESULT_DTYPE)
+        aln = None
+        stride = 0
+        if want_alignments:
+            mx = C.c_int64(0)
+            check(self._lib.cr_batch_max_aln_len(self._h, C.byref(mx)))
+            stride = max(int(mx.value), 1)
+            aln = np.empty((n, 2, stride), dtype=np.int64)
+        check(self._lib.cr_batch_fetch(self._h, ptr(res), ptr(aln) if aln is not None else None, stride))
+        return res, aln
+
+    def stage_ms(self) -> np.ndarray:
+        buf = (C.c_float * _capi.CR_NUM_STAGES)()
+        check(self._lib.cr_batch_stage_ms(self._h, C.byref(buf)))
+        return np.array(list(buf), dtype=np.float64)
+
+    def work(self):
+        """(algorithmic HBM bytes, DP cells per pass) of one run of the current pair list."""
+        b, c = C.c_double(0), C.c_double(0)
+        check(self._lib.cr_batch_work(self._h, C.byref(b), C.byref(c)))
+        return b.value, c.value
+
+    def close(self):
+        if self._h:
+            self._lib.cr_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def assemble_matrix(pairs, scores, num: int) -> np.ndarray:
+    """Symmetric P x P score matrix with a zero diagonal (multiple_alignment.py:161-169)."""
+    pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+    scores = f64(scores)
+    out = np.zeros((num, num))
+    check(_capi.load().cr_assemble_matrix(ptr(pairs), ptr(scores), len(pairs), num, ptr(out)))
+    return out

@@ -1,0 +1,317 @@
+"""Host-side mirror of the pairwise-alignment surface of the reference's
+``caretta/multiple_alignment.py``: ``SequenceBase`` (:109-127), ``Protein`` (:312-387),
+``MultipleAlignment`` (:148-309), ``tm_score`` (:59-70), ``make_rmsd_coverage_tm_matrix`` (:1000-1055).
+
+The O(P^2) pair loop of ``make_pairwise_matrix`` (:158-170) runs as one batched launch sequence on
+the GPU (``engine.PairBatch``); everything numeric goes through the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import typing
+from abc import ABC, abstractmethod
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _capi
+from . import dynamic_time_warping as dtw
+from . import helper
+from . import neighbor_joining as nj
+from . import score_functions, superposition_functions
+from ._capi import check, f64, ptr
+from .engine import Context, PairBatch, all_pairs, assemble_matrix, default_context, make_params
+
+
+def tm_score(coords_1, coords_2, l1, l2):
+    """The reference's own TM-like score (multiple_alignment.py:59-70)."""
+    x1, x2 = f64(coords_1), f64(coords_2)
+    out = C.c_double(0.0)
+    check(_capi.load().cr_tm_score(default_context()._h, ptr(x1), ptr(x2), x1.shape[0], int(l1), int(l2),
+                                   C.byref(out)))
+    return out.value
+
+
+def get_mean_weights(weights_1, weights_2, aln_1, aln_2) -> np.ndarray:
+    """multiple_alignment.py:73-82"""
+    mean_weights = np.zeros((aln_1.shape[0], 1))
+    for i, (x, y) in enumerate(zip(aln_1, aln_2)):
+        if not x == -1:
+            mean_weights[i] += weights_1[x]
+        if not y == -1:
+            mean_weights[i] += weights_2[y]
+    return mean_weights
+
+
+class SequenceBase(ABC):
+    """Plugin interface of the reference (multiple_alignment.py:109-127)."""
+    name: str
+
+    @abstractmethod
+    def score_function(self, other: "SequenceBase", **kwargs) -> np.ndarray:
+        pass
+
+    def mean_function(self, other: "SequenceBase", aln_1: np.ndarray, aln_2: np.ndarray, name_int: str,
+                      **kwargs) -> "SequenceBase":
+        pass
+
+    @abstractmethod
+    def __len__(self) -> int:
+        pass
+
+    @abstractmethod
+    def __str__(self) -> str:
+        pass
+
+
+@dataclass
+class Protein(SequenceBase):
+    name: str
+    tensors: np.ndarray
+    coordinates: np.ndarray = None
+    sequence: str = ""
+
+    def score_function(self, other: "Protein", flexible=False, gamma_tensor=0.03, gamma_coords=0.03,
+                       verbose=True) -> np.ndarray:
+        """multiple_alignment.py:321-349"""
+        if flexible:
+            return score_functions.make_score_matrix(self.tensors, other.tensors, score_functions.get_gaussian_score,
+                                                     gamma_tensor)
+        xi, ti, xj, tj = f64(self.coordinates), f64(self.tensors), f64(other.coordinates), f64(other.tensors)
+        if ti.shape[1] != tj.shape[1]:
+            raise ValueError("tensor widths differ")
+        s = np.empty((xi.shape[0], xj.shape[0]))
+        flags = C.c_uint32(0)
+        check(_capi.load().cr_protein_score_function(default_context()._h, ptr(xi), ptr(ti), xi.shape[0], ptr(xj),
+                                                     ptr(tj), xj.shape[0], ti.shape[1], float(gamma_tensor),
+                                                     float(gamma_coords), ptr(s), C.byref(flags)))
+        if flags.value & _capi.FLAG_SEED_ALL_ZERO:
+            raise TypeError("tensor score matrix has no positive local alignment (reference: max_pos is None)")
+        if (flags.value & _capi.FLAG_SEED_SKIPPED) and verbose:
+            print(f"Too few aligning positions for {self.name} and {other.name}, continuing without superposition")
+        return s
+
+    def mean_function(self, other: "Protein", aln_1: np.ndarray, aln_2: np.ndarray, name_int: str, flexible=False,
+                      verbose=True) -> "Protein":
+        """multiple_alignment.py:351-381"""
+        tensors_mean = np.zeros((len(aln_1), self.tensors.shape[1]))
+        for i, (x, y) in enumerate(zip(aln_1, aln_2)):
+            if x == -1:
+                tensors_mean[i] = other.tensors[y]
+            elif y == -1:
+                tensors_mean[i] = self.tensors[x]
+            else:
+                tensors_mean[i] = (self.tensors[x] + other.tensors[y]) / 2
+        if flexible:
+            return Protein(name_int, tensors_mean)
+        pos_1, pos_2 = helper.get_common_positions(aln_1, aln_2)
+        if len(pos_1) <= 3:
+            if verbose:
+                print(f"Too few aligning positions for {self.name} and {other.name}, continuing without superposition")
+            coords_1, coords_2 = np.array(self.coordinates), np.array(other.coordinates)
+        else:
+            coords_1, coords_2, _ = superposition_functions.paired_svd_superpose_with_subset(
+                self.coordinates, other.coordinates, self.coordinates[pos_1], other.coordinates[pos_2])
+        coordinates_mean = np.zeros((len(aln_1), self.coordinates.shape[1]))
+        for i, (x, y) in enumerate(zip(aln_1, aln_2)):
+            if x == -1:
+                coordinates_mean[i] = coords_2[y]
+            elif y == -1:
+                coordinates_mean[i] = coords_1[x]
+            else:
+                coordinates_mean[i] = (coords_1[x] + coords_2[y]) / 2
+        return Protein(name_int, tensors_mean, coordinates_mean)
+
+    def __len__(self) -> int:
+        return self.tensors.shape[0]
+
+    def __str__(self):
+        return self.sequence
+
+
+def pack_proteins(proteins: typing.Sequence[Protein]):
+    lens = [len(p) for p in proteins]
+    offsets = np.zeros(len(proteins) + 1, dtype=np.int64)
+    offsets[1:] = np.cumsum(lens)
+    coords = np.ascontiguousarray(np.vstack([f64(p.coordinates) for p in proteins]))
+    tensors = np.ascontiguousarray(np.vstack([f64(p.tensors) for p in proteins]))
+    return coords, tensors, offsets
+
+
+@dataclass
+class PairwiseResults:
+    """Everything pipeline H produces for a pair list (one entry per pair, in pair order)."""
+    pairs: np.ndarray           # (npairs, 2) int32
+    results: np.ndarray         # structured, _capi.PAIR_RESULT_DTYPE
+    alignments: typing.Optional[np.ndarray]  # (npairs, 2, stride) int64, padded with -2
+
+    def alignment(self, p: int):
+        ln = int(self.results["aln_len"][p])
+        return self.alignments[p, 0, :ln], self.alignments[p, 1, :ln]
+
+
+@dataclass
+class MultipleAlignment:
+    sequences: typing.List[SequenceBase]
+    tree: typing.Optional[np.ndarray] = None
+    branch_lengths: typing.Optional[np.ndarray] = None
+    alignment: typing.Optional[typing.Dict[str, np.ndarray]] = None
+    final_sequences: typing.Optional[typing.List[SequenceBase]] = None
+    final_consensus_weights: typing.Optional[typing.List[np.ndarray]] = None
+    final_alignments: typing.Optional[typing.Dict[str, typing.Dict[str, np.ndarray]]] = None
+
+    # -- batched GPU path ---------------------------------------------------------------------
+    def _all_proteins(self) -> bool:
+        return all(type(s) is Protein and s.coordinates is not None for s in self.sequences)
+
+    def pairwise(self, score_function_params=None, gap_open_penalty=1.0, gap_extend_penalty=0.01, pairs=None,
+                 want_alignments=True, context: typing.Optional[Context] = None) -> PairwiseResults:
+        """Pipeline H over a pair list (default: all i<j): the P x P score entry, the pairwise
+        dtw_align alignment and its RMSD / coverage / TM, in one batched launch sequence."""
+        prm = dict(score_function_params or {})
+        if prm.pop("flexible", False):
+            raise ValueError("flexible=True bypasses the pairwise path; not supported by the batched engine")
+        prm.pop("verbose", None)
+        params = make_params(gamma_tensor=prm.pop("gamma_tensor", 0.03), gamma_coords=prm.pop("gamma_coords", 0.03),
+                             gap_open=gap_open_penalty, gap_extend=gap_extend_penalty)
+        if prm:
+            raise TypeError(f"unknown score_function parameters {sorted(prm)}")
+        ctx = context or default_context()
+        coords, tensors, offsets = pack_proteins(self.sequences)
+        batch = PairBatch(ctx, coords, tensors, offsets)
+        try:
+            pairs = all_pairs(len(self.sequences)) if pairs is None else np.asarray(pairs, np.int32).reshape(-1, 2)
+            batch.set_pairs(pairs)
+            batch.run(params)
+            res, aln = batch.fetch(want_alignments)
+        finally:
+            batch.close()
+        if np.any(res["flags"] & _capi.FLAG_SEED_ALL_ZERO):
+            bad = pairs[np.nonzero(res["flags"] & _capi.FLAG_SEED_ALL_ZERO)[0][0]]
+            raise TypeError(f"tensor score matrix of pair {tuple(bad)} has no positive local alignment "
+                            "(reference: max_pos is None)")
+        return PairwiseResults(pairs, res, aln)
+
+    def make_pairwise_matrix(self, score_function_params=None):
+        """multiple_alignment.py:158-170"""
+        if score_function_params is None:
+            score_function_params = {}
+        num = len(self.sequences)
+        if num < 2:
+            return np.zeros((num, num))
+        if self._all_proteins() and not score_function_params.get("flexible", False):
+            out = self.pairwise(score_function_params, want_alignments=False)
+            return assemble_matrix(out.pairs, out.results["sw"], num)
+        # third-party SequenceBase plugins: their own score_function, our smith_waterman_score
+        matrix = np.zeros((num, num))
+        for i in range(num - 1):
+            for j in range(i + 1, num):
+                matrix[i, j] = matrix[j, i] = dtw.smith_waterman_score(
+                    np.arange(len(self.sequences[i])), np.arange(len(self.sequences[j])),
+                    self.sequences[i].score_function(self.sequences[j], **score_function_params))
+        return matrix
+
+    # -- guide tree + progressive alignment ---------------------------------------------------
+    def progressive_align(self, tree, gap_open_penalty, gap_extend_penalty, consensus_weight, gamma_weight,
+                          score_function_params=None, mean_function_params=None) -> typing.Dict[str, np.ndarray]:
+        """multiple_alignment.py:172-253"""
+        mean_function_params = mean_function_params or {}
+        score_function_params = score_function_params or {}
+        final_sequences = [s for s in self.sequences]
+        final_alignments = {s.name: {s.name: np.arange(len(s))} for s in final_sequences}
+        final_consensus_weights = [np.full((len(s), 1), consensus_weight, dtype=np.float64) for s in final_sequences]
+
+        def make_intermediate_node(n1, n2, n_int):
+            name_1, name_2 = final_sequences[n1].name, final_sequences[n2].name
+            n1_weights, n2_weights = final_consensus_weights[n1], final_consensus_weights[n2]
+            total = len(final_alignments[name_1]) + len(final_alignments[name_2])
+            multiplier_n1 = len(final_alignments[name_2]) / (2 * total)
+            multiplier_n2 = len(final_alignments[name_1]) / (2 * total)
+            name_int = f"int-{n_int}"
+            score_matrix = final_sequences[n1].score_function(final_sequences[n2], **score_function_params)
+            score_matrix += score_functions.make_score_matrix(n1_weights * multiplier_n1, n2_weights * multiplier_n2,
+                                                              score_functions.get_gaussian_score, gamma_weight)
+            aln_1, aln_2, _ = dtw.dtw_align(np.arange(score_matrix.shape[0]), np.arange(score_matrix.shape[1]),
+                                            score_matrix, gap_open_penalty=gap_open_penalty,
+                                            gap_extend_penalty=gap_extend_penalty)
+            intermediate = final_sequences[n1].mean_function(final_sequences[n2], aln_1, aln_2, name_int,
+                                                             **mean_function_params)
+            weights = get_mean_weights(n1_weights, n2_weights, aln_1, aln_2)
+            final_alignments[name_1] = {name: np.array([seq[i] if i != -1 else -1 for i in aln_1])
+                                        for name, seq in final_alignments[name_1].items()}
+            final_alignments[name_2] = {name: np.array([seq[i] if i != -1 else -1 for i in aln_2])
+                                        for name, seq in final_alignments[name_2].items()}
+            final_alignments[name_int] = {**final_alignments[name_1], **final_alignments[name_2]}
+            final_sequences.append(intermediate)
+            final_consensus_weights.append(weights)
+
+        for x in range(0, tree.shape[0] - 1, 2):
+            node_1, node_2, node_int = int(tree[x, 0]), int(tree[x + 1, 0]), int(tree[x, 1])
+            assert int(tree[x + 1, 1]) == node_int
+            make_intermediate_node(node_1, node_2, node_int)
+        node_1, node_2 = int(tree[-1, 0]), int(tree[-1, 1])
+        make_intermediate_node(node_1, node_2, "final")
+        alignment = {**final_alignments[final_sequences[node_1].name], **final_alignments[final_sequences[node_2].name]}
+        self.final_consensus_weights = final_consensus_weights
+        self.final_alignments = final_alignments
+        self.final_sequences = final_sequences
+        return alignment
+
+    def multiple_align(self, pairwise_distance_matrix, gap_open_penalty, gap_extend_penalty, consensus_weight,
+                       gamma_weight, score_function_params=None, mean_function_params=None):
+        """multiple_alignment.py:255-285"""
+        mean_function_params = mean_function_params or {}
+        score_function_params = score_function_params or {}
+        if len(self.sequences) == 2:
+            score_matrix = self.sequences[0].score_function(self.sequences[1], **score_function_params)
+            aln_1, aln_2, _ = dtw.dtw_align(np.arange(score_matrix.shape[0]), np.arange(score_matrix.shape[1]),
+                                            score_matrix, gap_open_penalty=gap_open_penalty,
+                                            gap_extend_penalty=gap_extend_penalty)
+            self.alignment = {self.sequences[0].name: aln_1, self.sequences[1].name: aln_2}
+            return self.alignment
+        self.tree, self.branch_lengths = nj.neighbor_joining(pairwise_distance_matrix)
+        self.alignment = self.progressive_align(self.tree, gap_open_penalty, gap_extend_penalty, consensus_weight,
+                                                gamma_weight, score_function_params, mean_function_params)
+        return self.alignment
+
+    def to_sequence_alignment(self, alignment=None):
+        """multiple_alignment.py:287-297"""
+        alignment = self.alignment if alignment is None else alignment
+        out = {}
+        for p in self.sequences:
+            sequence = str(p)
+            out[p.name] = "".join(sequence[i] if i != -1 else "-" for i in alignment[p.name])
+        return out
+
+    def write_alignment(self, fasta_file, alignment=None):
+        """multiple_alignment.py:299-309"""
+        alignment = self.alignment if alignment is None else alignment
+        with open(fasta_file, "w") as f:
+            for p in self.sequences:
+                sequence = str(p)
+                aligned = "".join(sequence[i] if i != -1 else "-" for i in alignment[p.name])
+                f.write(f">{p.name}\n{aligned}\n")
+
+
+def make_rmsd_coverage_tm_matrix(alignment, proteins, superpose_first: bool = False):
+    """multiple_alignment.py:1000-1055 with per-pair superposition (``superpose_first=False`` is what
+    the reference's CLI uses, :571; the in-place ``superpose()`` variant is outside this path)."""
+    if superpose_first:
+        raise NotImplementedError("superpose_first=True (in-place superpose()) is outside the pairwise path")
+    num = len(alignment)
+    rmsd = np.zeros((num, num))
+    coverage = np.ones((num, num))
+    tm = np.ones((num, num))
+    names = [p.name for p in proteins]
+    for i in range(num - 1):
+        for j in range(i + 1, num):
+            aln_1, aln_2 = alignment[names[i]], alignment[names[j]]
+            pos_1, pos_2 = helper.get_common_positions(aln_1, aln_2)
+            assert len(pos_1) >= 3
+            c1, c2 = proteins[i].coordinates[pos_1], proteins[j].coordinates[pos_2]
+            rot, tran = superposition_functions.paired_svd_superpose(c1, c2)
+            c2 = superposition_functions.apply_rotran(c2, rot, tran)
+            rmsd[i, j] = rmsd[j, i] = score_functions.get_rmsd(c1, c2)
+            coverage[i, j] = coverage[j, i] = c1.shape[0] / len(aln_1)
+            tm[i, j] = tm[j, i] = tm_score(c1, c2, len(proteins[i]), len(proteins[j]))
+    return rmsd, coverage, tm

@@ -1,0 +1,43 @@
+"""Drop-ins for the reference's ``caretta/score_functions.py`` (score_functions.py:7-51)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import check, f64, ptr
+from .engine import default_context
+
+
+def get_gaussian_score(coord_1, coord_2, gamma: float = 0.03):
+    """exp(-gamma * sum((c1 - c2)**2)) for one pair of feature vectors (score_functions.py:7-11)."""
+    a = f64(coord_1).reshape(1, -1)
+    b = f64(coord_2).reshape(1, -1)
+    return float(make_score_matrix(a, b, get_gaussian_score, gamma)[0, 0])
+
+
+def get_rmsd(coords_1, coords_2) -> float:
+    x1, x2 = f64(coords_1), f64(coords_2)
+    out = C.c_double(0.0)
+    check(_capi.load().cr_get_rmsd(default_context()._h, ptr(x1), ptr(x2), x1.shape[0], C.byref(out)))
+    return out.value
+
+
+def make_score_matrix(coords_1, coords_2, score_function, gamma, normalized: bool = False) -> np.ndarray:
+    """(n, m) matrix of ``score_function`` between all rows (score_functions.py:23-51).
+
+    Only ``get_gaussian_score`` is ever passed by the reference (and is the only function the
+    kernels implement); ``normalized=True`` has no caller in the reference and is rejected.
+    """
+    if score_function is not get_gaussian_score:
+        raise ValueError("only caretta_amd.score_functions.get_gaussian_score is supported")
+    if normalized:
+        raise ValueError("normalized=True is not supported (no caller in the reference)")
+    a, b = f64(coords_1), f64(coords_2)
+    if a.ndim != 2 or b.ndim != 2 or a.shape[1] != b.shape[1]:
+        raise ValueError("coords_1 and coords_2 must be 2-D with equal width")
+    s = np.zeros((a.shape[0], b.shape[0]))
+    check(_capi.load().cr_make_score_matrix(default_context()._h, ptr(a), a.shape[0], ptr(b), b.shape[0], a.shape[1],
+                                            float(gamma), ptr(s)))
+    return s

@@ -1,0 +1,156 @@
+/*
+ * libcaretta_hip -- C ABI of the MI355X-native pairwise structural-alignment path.
+ *
+ * Drop-in boundary for the numba-compiled functions of TurtleTools/caretta v0.2.0 that form the
+ * all-vs-all pairwise alignment path.  The reference has no FFI (it is pure Python + @nb.njit), so
+ * each entry point names the reference function it replaces (paths relative to the reference
+ * root).  Plain pointers and sizes only; every array is C-contiguous; all floating point is FP64.
+ * Unless a parameter is documented as a device pointer, buffers are host memory owned by the
+ * caller, never retained after the call returns.
+ *
+ * Every function returns 0 on success or a negative cr_status; cr_last_error() gives the message
+ * (thread-local).  Per-pair soft conditions are reported in `flags`, not as errors.
+ * All compute entry points need a gfx950 device: there is no CPU fallback.
+ */
+#ifndef CARETTA_HIP_H
+#define CARETTA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CR_ABI_VERSION 1
+
+typedef enum {
+    CR_OK = 0,
+    CR_ERR_ARGUMENT = -1,     /* bad pointer / size / unsupported width   -> ValueError  */
+    CR_ERR_HIP = -2,          /* HIP runtime failure (incl. no device)    -> RuntimeError */
+    CR_ERR_MEMORY = -3,       /* host or device allocation failed         -> MemoryError */
+    CR_ERR_STATE = -4         /* call order violated (e.g. fetch before run) */
+} cr_status;
+
+/* per-pair flag bits */
+#define CR_FLAG_SEED_SKIPPED 1u     /* <=3 seed positions: superposition skipped (multiple_alignment.py:337-342) */
+#define CR_FLAG_METRICS_SKIPPED 2u  /* <3 aligned positions: RMSD/coverage/TM not computed (assert at :1034)     */
+#define CR_FLAG_SEED_ALL_ZERO 4u    /* tensor Smith-Waterman matrix all zero (the reference raises TypeError)    */
+
+typedef struct cr_context cr_context;   /* device + stream + profiling events */
+typedef struct cr_batch cr_batch;       /* structures resident in HBM + per-pair scratch */
+
+/* Score/alignment parameters; defaults are the reference's hard-coded values
+ * (multiple_alignment.py:490-492, bin/caretta-cli:39-44, dynamic_time_warping.py:205,226). */
+typedef struct {
+    double gamma_tensor;   /* 7.0  */
+    double gamma_coords;   /* 0.03 */
+    double gap_open;       /* 1.0  */
+    double gap_extend;     /* 0.01 */
+    double sw_gap;         /* 0.0  */
+} cr_params;
+
+/* Per-pair scalar results of the batched pipeline (host layout == device layout). */
+typedef struct {
+    double sw;             /* smith_waterman_score of the coordinate score matrix: the P x P matrix entry
+                              (multiple_alignment.py:164) */
+    double dtw_score;      /* score returned by dtw_align (dynamic_time_warping.py:184) */
+    double R[9];           /* rotation, row-major; X_j @ R + t ~ X_i on the aligned positions
+                              (superposition_functions.py:33) */
+    double t[3];           /* translation (superposition_functions.py:34) */
+    double rmsd;           /* score_functions.py:15-19 */
+    double coverage;       /* multiple_alignment.py:1046-1048 */
+    double tm;             /* multiple_alignment.py:59-70 (the reference's own formula) */
+    double seed_score;     /* smith_waterman score on the tensor score matrix (multiple_alignment.py:332) */
+    int32_t aln_len;       /* length of the dtw_align alignment rows */
+    int32_t aln_start;     /* internal: first valid element in the device alignment rows */
+    int32_t seed_len;      /* length of the seed smith_waterman alignment */
+    uint32_t flags;        /* CR_FLAG_* */
+} cr_pair_result;
+
+#define CR_NUM_STAGES 4    /* seed fill, seed traceback+Kabsch, alignment fill, alignment traceback+metrics */
+
+const char *cr_last_error(void);
+int cr_abi_version(void);
+int cr_device_count(int *count);
+
+/* ---- context ---------------------------------------------------------------------------- */
+/* `stream` is a hipStream_t to launch on (e.g. torch.cuda.current_stream().cuda_stream) or NULL to
+ * create a private stream. */
+int cr_context_create(int device, void *stream, cr_context **out);
+int cr_context_destroy(cr_context *ctx);
+int cr_context_synchronize(cr_context *ctx);
+int cr_context_stream(cr_context *ctx, void **stream_out);
+int cr_context_set_profiling(cr_context *ctx, int enabled);   /* record per-stage HIP events */
+
+/* ---- batched all-vs-all pipeline -------------------------------------------------------- */
+/* Replaces the pair loop MultipleAlignment.make_pairwise_matrix (multiple_alignment.py:158-170)
+ * together with Protein.score_function (:321-349), the 2-sequence dtw_align (:263-275) and the
+ * per-pair body of make_rmsd_coverage_tm_matrix (:1028-1054, superpose_first=False).
+ *
+ * coords  f64[total, 3], tensors f64[total, d], offsets i64[P+1] (structure s = rows
+ * offsets[s]..offsets[s+1]).  Uploads the structures to HBM. */
+int cr_batch_create(cr_context *ctx, const double *coords, const double *tensors, const int64_t *offsets,
+                    int64_t num_structures, int64_t d, cr_batch **out);
+/* pairs i32[npairs, 2]: ordered (i, j) = (rows, columns); structure j is superposed onto i. */
+int cr_batch_set_pairs(cr_batch *b, const int32_t *pairs, int64_t npairs);
+/* Enqueue the four stages on the context's stream (asynchronous).  `d_sw_out`, if not NULL, is a
+ * DEVICE pointer to f64[npairs] that also receives the `sw` scores (e.g. a torch tensor that is
+ * then all-gathered over RCCL). */
+int cr_batch_run(cr_batch *b, const cr_params *params, double *d_sw_out);
+/* Synchronise and copy results to host.  Any pointer may be NULL.  results[npairs];
+ * aln i64[npairs, 2, aln_stride] (rows padded with -2 after aln_len; aln_stride >= max(n+m)). */
+int cr_batch_fetch(cr_batch *b, cr_pair_result *results, int64_t *aln, int64_t aln_stride);
+int cr_batch_max_aln_len(cr_batch *b, int64_t *out);
+/* per-stage device time of the last run in ms (needs cr_context_set_profiling(ctx, 1)) */
+int cr_batch_stage_ms(cr_batch *b, float ms[CR_NUM_STAGES]);
+/* algorithmic HBM bytes of one run of the current pair list (SURVEY.md 8(d) B_alg) and DP cells */
+int cr_batch_work(cr_batch *b, double *alg_bytes, double *cells);
+int cr_batch_destroy(cr_batch *b);
+
+/* ---- single-call drop-ins (host buffers in, host buffers out) --------------------------- */
+/* score_functions.make_score_matrix(a, b, get_gaussian_score, gamma)   score_functions.py:23-51 */
+int cr_make_score_matrix(cr_context *ctx, const double *a, int64_t n, const double *b, int64_t m, int64_t k,
+                         double gamma, double *S);
+/* Protein.score_function(other, flexible=False, ...)                   multiple_alignment.py:321-349 */
+int cr_protein_score_function(cr_context *ctx, const double *coords_i, const double *tensors_i, int64_t n,
+                              const double *coords_j, const double *tensors_j, int64_t m, int64_t d,
+                              double gamma_tensor, double gamma_coords, double *S, uint32_t *flags);
+/* dynamic_time_warping.dtw_align / dtw_align_score (aln1 == NULL)      dynamic_time_warping.py:148-201
+ * S f64[s_rows, s_cols] indexed S[seq1[i], seq2[j]]; aln1/aln2 need n+m entries. */
+int cr_dtw_align(cr_context *ctx, const int64_t *seq1, int64_t n, const int64_t *seq2, int64_t m,
+                 const double *S, int64_t s_rows, int64_t s_cols, double gap_open, double gap_extend,
+                 int64_t *aln1, int64_t *aln2, int64_t *aln_len, double *score);
+/* dynamic_time_warping.smith_waterman_score                            dynamic_time_warping.py:205-222 */
+int cr_smith_waterman_score(cr_context *ctx, const int64_t *seq1, int64_t n, const int64_t *seq2, int64_t m,
+                            const double *S, int64_t s_rows, int64_t s_cols, double gap, double *score);
+/* dynamic_time_warping.smith_waterman; *all_zero = 1 where the reference raises (no maximum)
+ *                                                                      dynamic_time_warping.py:226-278 */
+int cr_smith_waterman(cr_context *ctx, const int64_t *seq1, int64_t n, const int64_t *seq2, int64_t m,
+                      const double *S, int64_t s_rows, int64_t s_cols, double gap,
+                      int64_t *aln1, int64_t *aln2, int64_t *aln_len, double *score, int *all_zero);
+/* superposition_functions.paired_svd_superpose                         superposition_functions.py:7-35 */
+int cr_paired_svd_superpose(cr_context *ctx, const double *x1, const double *x2, int64_t k, double *R, double *t);
+/* superposition_functions.paired_svd_superpose_with_subset             superposition_functions.py:39-60 */
+int cr_paired_svd_superpose_with_subset(cr_context *ctx, const double *c1, int64_t n, const double *c2, int64_t m,
+                                        const double *s1, const double *s2, int64_t k,
+                                        double *o1, double *o2, double *o3);
+/* superposition_functions.apply_rotran                                 superposition_functions.py:64-80 */
+int cr_apply_rotran(cr_context *ctx, const double *x, int64_t k, const double *R, const double *t, double *out);
+/* score_functions.get_rmsd                                             score_functions.py:15-19 */
+int cr_get_rmsd(cr_context *ctx, const double *x1, const double *x2, int64_t k, double *out);
+/* multiple_alignment.tm_score                                          multiple_alignment.py:59-70 */
+int cr_tm_score(cr_context *ctx, const double *x1, const double *x2, int64_t k, int64_t l1, int64_t l2, double *out);
+
+/* ---- host-side integer / tree work ------------------------------------------------------ */
+/* helper.get_common_positions                                          helper.py:13-42 */
+int cr_get_common_positions(const int64_t *a1, const int64_t *a2, int64_t len, int64_t *p1, int64_t *p2, int64_t *k);
+/* neighbor_joining.neighbor_joining; tree u64[2P-3, 2], branch_lengths f64[2P-3]
+ *                                                                      neighbor_joining.py:19-157 */
+int cr_neighbor_joining(const double *D, int64_t P, uint64_t *tree, double *branch_lengths);
+/* scatter per-pair scores into the symmetric P x P matrix (multiple_alignment.py:161-169) */
+int cr_assemble_matrix(const int32_t *pairs, const double *scores, int64_t npairs, int64_t P, double *M);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,313 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X): the HIP path, called through the C ABI
+(``caretta_amd`` -> ctypes -> libcaretta_hip.so), against
+  * the golden vectors produced by the reference's own source (integers exact, floats to tolerance),
+  * the C oracle on fresh seeded inputs (bit-identical: same FP64 operation order on both sides),
+  * size-independent properties at BASELINE.json's full sizes.
+"""
+import numpy as np
+import pytest
+
+from caretta_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from caretta_amd import engine
+    c = engine.Context(0)
+    yield c
+    c.close()
+
+
+def run_batch(ctx, coords, tensors, offsets, pairs, **params):
+    from caretta_amd import engine
+    b = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
+    b.run(engine.make_params(**params) if params else None)
+    res, aln = b.fetch()
+    b.close()
+    return res, aln
+
+
+def assert_bit_identical(res, aln, ref, ref_aln):
+    assert np.array_equal(res["flags"], ref["flags"])
+    assert np.array_equal(res["aln_len"], ref["aln_len"])
+    assert np.array_equal(res["seed_len"], ref["seed_len"])
+    for p in range(len(res)):
+        ln = int(ref["aln_len"][p])
+        assert np.array_equal(aln[p, :, :ln], ref_aln[p, :, :ln]), f"pair {p}: alignment differs"
+        assert np.all(aln[p, :, ln:] == -2)
+    for key in ("sw", "dtw_score", "seed_score", "rmsd", "coverage", "tm", "R", "t"):
+        assert np.array_equal(res[key], ref[key]), f"{key}: not bit-identical to the oracle"
+
+
+# ------------------------------------------------------------------------------- device math
+def test_exp_bit_identical_to_oracle(oracle):
+    from caretta_amd import score_functions as sf
+    rng = np.random.default_rng(11)
+    x = np.concatenate([rng.uniform(0, 27.4, 4000), 10 ** rng.uniform(-12, 0, 1000), [0.0, 27.29, 27.3, 26.6, 26.61]])
+    a = x.reshape(-1, 1)
+    b = np.zeros((3, 1))
+    for gamma in (1.0, 0.03, 7.0, -0.9):          # exp(-gamma * x^2): covers [-746, 0] and positive arguments
+        s = sf.make_score_matrix(a, b, sf.get_gaussian_score, gamma)
+        assert np.array_equal(s, oracle.make_score_matrix(a, b, gamma))
+    assert sf.get_gaussian_score(np.zeros(3), np.zeros(3)) == 1.0
+
+
+def test_make_score_matrix_golden(oracle, golden):
+    from caretta_amd import score_functions as sf
+    g = golden("f1_score_matrix.npz")
+    for c in range(int(g["ncases"])):
+        a, b, gamma = g[f"c{c}_a"], g[f"c{c}_b"], float(g[f"c{c}_gamma"])
+        s = sf.make_score_matrix(a, b, sf.get_gaussian_score, gamma)
+        assert np.array_equal(s, oracle.make_score_matrix(a, b, gamma)), c
+        np.testing.assert_allclose(s, g[f"c{c}_S"], rtol=1e-12, atol=2e-323)
+
+
+# ------------------------------------------------------------------------------- DP drop-ins
+def test_dtw_align_golden(golden):
+    from caretta_amd import dynamic_time_warping as dtw
+    g = golden("f1_dtw.npz")
+    for c in range(int(g["ncases"])):
+        s = g[f"c{c}_S"]
+        if f"c{c}_seq1" in g:
+            s1, s2 = g[f"c{c}_seq1"], g[f"c{c}_seq2"]
+        else:
+            s1, s2 = np.arange(s.shape[0]), np.arange(s.shape[1])
+        go, ge = float(g[f"c{c}_open"]), float(g[f"c{c}_extend"])
+        a1, a2, score = dtw.dtw_align(s1, s2, s, go, ge)
+        assert np.array_equal(a1, g[f"c{c}_aln1"]) and np.array_equal(a2, g[f"c{c}_aln2"]), c
+        assert score == float(g[f"c{c}_score"]), c
+        assert dtw.dtw_align_score(s1, s2, s, go, ge) == float(g[f"c{c}_score2"])
+
+
+def test_smith_waterman_golden(golden):
+    from caretta_amd import dynamic_time_warping as dtw
+    g = golden("f1_sw.npz")
+    for c in range(int(g["ncases"])):
+        s = g[f"c{c}_S"]
+        s1, s2 = np.arange(s.shape[0]), np.arange(s.shape[1])
+        gap = float(g[f"c{c}_gap"])
+        a1, a2, score = dtw.smith_waterman(s1, s2, s, gap)
+        assert np.array_equal(a1, g[f"c{c}_aln1"]) and np.array_equal(a2, g[f"c{c}_aln2"]), c
+        assert score == float(g[f"c{c}_score"])
+        assert dtw.smith_waterman_score(s1, s2, s, gap) == float(g[f"c{c}_score_only"])
+
+
+def test_smith_waterman_edge_cases():
+    from caretta_amd import dynamic_time_warping as dtw
+    with pytest.raises(TypeError):
+        dtw.smith_waterman(np.arange(4), np.arange(5), np.zeros((4, 5)))
+    assert dtw.smith_waterman_score(np.arange(4), np.arange(5), np.zeros((4, 5))) == 0.0
+    # a row stops at the first -1 of seq2 (dynamic_time_warping.py:214-215)
+    s = np.ones((3, 6))
+    seq2 = np.array([0, 1, 2, -1, 4, 5])
+    assert dtw.smith_waterman_score(np.arange(3), seq2, s) == 3.0
+    with pytest.raises(ValueError):
+        dtw.dtw_align(np.array([0, 7]), np.arange(3), np.ones((2, 3)))
+
+
+def test_dp_multistrip_vs_oracle(oracle):
+    """n > 320 rows: strips hand their last row over through LDS."""
+    from caretta_amd import dynamic_time_warping as dtw
+    rng = np.random.default_rng(5)
+    for n, m in [(321, 50), (700, 333), (1000, 64), (64, 1000)]:
+        s = rng.uniform(size=(n, m)) ** 3
+        a, b = np.arange(n), np.arange(m)
+        r1 = dtw.dtw_align(a, b, s, 1.0, 0.01)
+        o1 = oracle.dtw_align(a, b, s, 1.0, 0.01)
+        assert np.array_equal(r1[0], o1[0]) and np.array_equal(r1[1], o1[1]) and r1[2] == o1[2]
+        r2 = dtw.smith_waterman(a, b, s - 0.3, 0.1)
+        o2 = oracle.smith_waterman(a, b, s - 0.3, 0.1)
+        assert np.array_equal(r2[0], o2[0]) and np.array_equal(r2[1], o2[1]) and r2[2] == o2[2]
+        assert dtw.smith_waterman_score(a, b, s - 0.3, 0.1) == oracle.smith_waterman_score(a, b, s - 0.3, 0.1)
+
+
+# ------------------------------------------------------------------------------- Kabsch & metrics
+def test_kabsch_golden(oracle, golden):
+    from caretta_amd import score_functions as sf
+    from caretta_amd import superposition_functions as sup
+    g = golden("f1_kabsch.npz")
+    for c in range(int(g["ncases"])):
+        x1, x2 = g[f"c{c}_x1"], g[f"c{c}_x2"]
+        r, t = sup.paired_svd_superpose(x1, x2)
+        ro, to = oracle.paired_svd_superpose(x1, x2)
+        assert np.array_equal(r, ro) and np.array_equal(t, to), "SVD/div/sqrt differ between GPU and CPU"
+        np.testing.assert_allclose(r, g[f"c{c}_R"], atol=1e-9)
+        np.testing.assert_allclose(t, g[f"c{c}_t"], atol=1e-8)
+        moved = sup.apply_rotran(x2, r, t)
+        assert np.array_equal(moved, oracle.apply_rotran(x2, r, t))
+        assert abs(sf.get_rmsd(x1, moved) - float(g[f"c{c}_rmsd"])) < 1e-5
+        assert sf.get_rmsd(x1, moved) == oracle.get_rmsd(x1, moved)
+    for s in range(int(g["nsubset"])):
+        a, b = g[f"s{s}_a"], g[f"s{s}_b"]
+        o = sup.paired_svd_superpose_with_subset(a, b, a[g[f"s{s}_p1"]], b[g[f"s{s}_p2"]])
+        ref = oracle.paired_svd_superpose_with_subset(a, b, a[g[f"s{s}_p1"]], b[g[f"s{s}_p2"]])
+        for x, y, key in zip(o, ref, ("o1", "o2", "o3")):
+            assert np.array_equal(x, y)
+            np.testing.assert_allclose(x, g[f"s{s}_{key}"], atol=1e-8)
+
+
+def test_misc_golden(oracle, golden):
+    from caretta_amd import helper, multiple_alignment as ma, score_functions as sf
+    g = golden("f1_misc.npz")
+    for c in range(int(g["ncp"])):
+        p1, p2 = helper.get_common_positions(g[f"cp{c}_a1"], g[f"cp{c}_a2"])
+        assert np.array_equal(p1, g[f"cp{c}_p1"]) and np.array_equal(p2, g[f"cp{c}_p2"])
+    for c in range(int(g["ntm"])):
+        x1, x2, l1, l2 = g[f"tm{c}_x1"], g[f"tm{c}_x2"], int(g[f"tm{c}_l1"]), int(g[f"tm{c}_l2"])
+        assert abs(ma.tm_score(x1, x2, l1, l2) - float(g[f"tm{c}_tm"])) < 1e-5
+        assert ma.tm_score(x1, x2, l1, l2) == oracle.tm_score(x1, x2, l1, l2)
+        assert abs(sf.get_rmsd(x1, x2) - float(g[f"tm{c}_rmsd"])) < 1e-5
+
+
+# ------------------------------------------------------------------------------- pipeline H
+def check_against_golden(g, fam, res, aln):
+    pairs = g[f"fam{fam}_pairs"]
+    for p in range(len(pairs)):
+        key = f"fam{fam}_p{p}"
+        assert int(res["flags"][p]) == int(g[key + "_flags"]), key
+        assert int(res["seed_len"][p]) == len(g[key + "_seed_aln1"]), key
+        ln = int(res["aln_len"][p])
+        assert np.array_equal(aln[p, 0, :ln], g[key + "_aln1"]), key       # bit-exact DTW traceback indices
+        assert np.array_equal(aln[p, 1, :ln], g[key + "_aln2"]), key
+        assert abs(res["sw"][p] - float(g[key + "_sw"])) <= 1e-9 * max(1.0, abs(res["sw"][p]))
+        assert abs(res["dtw_score"][p] - float(g[key + "_dtw_score"])) <= 1e-9 * max(1.0, abs(res["dtw_score"][p]))
+        if not int(res["flags"][p]) & 2:
+            assert abs(res["rmsd"][p] - float(g[key + "_rmsd"])) < 1e-5     # north-star tolerance
+            assert abs(res["tm"][p] - float(g[key + "_tm"])) < 1e-5
+            assert abs(res["coverage"][p] - float(g[key + "_coverage"])) < 1e-12
+            np.testing.assert_allclose(res["R"][p].reshape(3, 3), g[key + "_R"], atol=1e-8)
+
+
+@pytest.mark.parametrize("fam", ["A", "B", "C", "D", "E"])
+def test_pipeline_golden(ctx, oracle, golden, fam):
+    g = golden("f2_pipeline.npz")
+    coords, tensors, offsets = g[f"fam{fam}_coords"], g[f"fam{fam}_tensors"], g[f"fam{fam}_offsets"]
+    pairs = g[f"fam{fam}_pairs"]
+    res, aln = run_batch(ctx, coords, tensors, offsets, pairs)
+    check_against_golden(g, fam, res, aln)
+    ref, ref_aln = oracle.pairwise_batch(coords, tensors, offsets, pairs)
+    assert_bit_identical(res, aln, ref, ref_aln)
+
+
+def test_pipeline_golden_long(ctx, oracle, golden):
+    g = golden("f2_pipeline_long.npz")
+    coords, tensors, offsets, pairs = g["famL_coords"], g["famL_tensors"], g["famL_offsets"], g["famL_pairs"]
+    res, aln = run_batch(ctx, coords, tensors, offsets, pairs)
+    check_against_golden(g, "L", res, aln)
+    ref, ref_aln = oracle.pairwise_batch(coords, tensors, offsets, pairs)
+    assert_bit_identical(res, aln, ref, ref_aln)
+
+
+@pytest.mark.parametrize("num,length,dim,ragged,seed", [
+    (32, 150, 10, False, 20241),      # BASELINE config 2, all 496 pairs
+    (12, 200, 10, True, 31),          # ragged, 160..200 rows: R=3/R=5 boundary
+    (6, 330, 10, True, 32),           # spills into a second strip for some pairs
+    (5, 90, 3, True, 33), (5, 90, 4, False, 34), (5, 90, 7, True, 35), (5, 90, 16, False, 36), (4, 70, 1, True, 37),
+])
+def test_pipeline_vs_oracle(ctx, oracle, num, length, dim, ragged, seed):
+    from caretta_amd import engine
+    fam = synthetic.make_family(num, length, dim=dim, seed=seed, ragged=ragged)
+    coords, tensors, offsets = synthetic.pack(fam)
+    pairs = engine.all_pairs(num)
+    res, aln = run_batch(ctx, coords, tensors, offsets, pairs)
+    ref, ref_aln = oracle.pairwise_batch(coords, tensors, offsets, pairs, nthreads=8)
+    assert_bit_identical(res, aln, ref, ref_aln)
+
+
+def test_pipeline_other_parameters_and_orientation(ctx, oracle):
+    from caretta_amd import engine
+    fam = synthetic.make_family(6, 80, seed=77, ragged=True)
+    coords, tensors, offsets = synthetic.pack(fam)
+    pairs = np.array([(i, j) for i in range(6) for j in range(6) if i != j], dtype=np.int32)  # both orientations
+    prm = dict(gamma_tensor=3.0, gamma_coords=0.05, gap_open=0.5, gap_extend=0.5, sw_gap=0.2)
+    res, aln = run_batch(ctx, coords, tensors, offsets, pairs, **prm)
+    from oracle.pyoracle import default_params
+    ref, ref_aln = oracle.pairwise_batch(coords, tensors, offsets, pairs, default_params(**prm))
+    assert_bit_identical(res, aln, ref, ref_aln)
+
+
+def test_headline_config_sample_and_properties(ctx, oracle):
+    """BASELINE config 3 (128 x 300, all 8128 pairs) on the GPU; a 2% sample re-done by the oracle,
+    and size-independent properties on every pair."""
+    from caretta_amd import engine
+    fam = synthetic.make_family(128, 300, seed=20242)
+    coords, tensors, offsets = synthetic.pack(fam)
+    pairs = engine.all_pairs(128)
+    res, aln = run_batch(ctx, coords, tensors, offsets, pairs)
+    n = m = 300
+    ln = res["aln_len"]
+    assert np.all((ln >= 300) & (ln <= 600)) and np.all(res["flags"] == 0)
+    for row in (0, 1):
+        a = aln[:, row, :]
+        # every residue index appears exactly once, in increasing order
+        present = np.sort(np.where(a >= 0, a, 10 ** 6), axis=1)[:, :n]
+        assert np.array_equal(present, np.tile(np.arange(n), (len(pairs), 1)))
+        srt = np.where(a >= 0, a, -1)
+        for p in range(0, len(pairs), 97):
+            x = srt[p][srt[p] >= 0]
+            assert np.all(np.diff(x) == 1)
+    matched = ((aln[:, 0, :] >= 0) & (aln[:, 1, :] >= 0)).sum(axis=1)
+    np.testing.assert_allclose(res["coverage"], matched / ln, rtol=0, atol=0)
+    assert np.all(ln == 2 * n - matched)
+    assert np.all(res["sw"] > 0) and np.all(np.isfinite(res["dtw_score"])) and np.all(res["rmsd"] >= 0)
+    dets = np.linalg.det(res["R"].reshape(-1, 3, 3))
+    np.testing.assert_allclose(dets, 1.0, atol=1e-12)
+    # oracle on a deterministic sample
+    sample = np.arange(0, len(pairs), 50)
+    ref, ref_aln = oracle.pairwise_batch(coords, tensors, offsets, pairs[sample], nthreads=8)
+    assert_bit_identical(res[sample], aln[sample], ref, ref_aln)
+
+
+def test_guide_tree_from_gpu_matrix(ctx, oracle, golden):
+    """P x P matrix -> max - M -> neighbor joining: identical topology to the golden tree and to the oracle."""
+    from caretta_amd import engine, multiple_alignment as ma, neighbor_joining as nj
+    g = golden("f3_tree.npz")
+    for fam in ("T8", "T16"):
+        coords, tensors, offsets = g[f"fam{fam}_coords"], g[f"fam{fam}_tensors"], g[f"fam{fam}_offsets"]
+        p = len(offsets) - 1
+        prots = [ma.Protein(f"s{i}", tensors[offsets[i]:offsets[i + 1]], coords[offsets[i]:offsets[i + 1]], "")
+                 for i in range(p)]
+        msa = ma.MultipleAlignment(prots)
+        m = msa.make_pairwise_matrix(dict(flexible=False, gamma_tensor=7.0, gamma_coords=0.03))
+        np.testing.assert_allclose(m, g[f"fam{fam}_M"], rtol=1e-9)
+        d = m.max() - m
+        tree, bl = nj.neighbor_joining(d)
+        assert nj.bipartitions(tree, p) == nj.bipartitions(g[f"fam{fam}_tree"], p)
+        otree, obl = oracle.neighbor_joining(d)
+        assert np.array_equal(tree, otree) and np.array_equal(bl, obl)
+
+
+def test_multiple_align_golden(golden):
+    """Progressive alignment on the same kernels (a 'next' row): the 8-structure family's MSA."""
+    from caretta_amd import multiple_alignment as ma
+    g = golden("f3_tree.npz")
+    coords, tensors, offsets = g["famT8_coords"], g["famT8_tensors"], g["famT8_offsets"]
+    p = len(offsets) - 1
+    prots = [ma.Protein(f"s{i:04d}", tensors[offsets[i]:offsets[i + 1]], coords[offsets[i]:offsets[i + 1]], "")
+             for i in range(p)]
+    msa = ma.MultipleAlignment(prots)
+    prm = dict(flexible=False, gamma_tensor=7.0, gamma_coords=0.03)
+    m = msa.make_pairwise_matrix(prm)
+    aln = msa.multiple_align(m.max() - m, gap_open_penalty=1.0, gap_extend_penalty=0.01, consensus_weight=1.0,
+                             gamma_weight=1.0, score_function_params=dict(prm, verbose=False),
+                             mean_function_params=dict(flexible=False, verbose=False))
+    got = np.array([aln[q.name] for q in prots], dtype=np.int64)
+    assert np.array_equal(got, g["famT8_msa"])
+
+
+def test_two_sequence_alignment_and_metrics(ctx, golden):
+    """multiple_align's 2-sequence branch and make_rmsd_coverage_tm_matrix through the drop-ins."""
+    from caretta_amd import multiple_alignment as ma
+    g = golden("f2_pipeline.npz")
+    coords, tensors, offsets = g["famB_coords"], g["famB_tensors"], g["famB_offsets"]
+    prots = [ma.Protein(f"s{i}", tensors[offsets[i]:offsets[i + 1]], coords[offsets[i]:offsets[i + 1]], "A" * 150)
+             for i in (0, 1)]
+    msa = ma.MultipleAlignment(prots)
+    aln = msa.multiple_align(None, 1.0, 0.01, 1.0, 1.0,
+                             score_function_params=dict(flexible=False, gamma_tensor=7.0, gamma_coords=0.03))
+    assert np.array_equal(aln["s0"], g["famB_p0_aln1"]) and np.array_equal(aln["s1"], g["famB_p0_aln2"])
+    rmsd, cov, tm = ma.make_rmsd_coverage_tm_matrix(aln, prots)
+    assert abs(rmsd[0, 1] - float(g["famB_p0_rmsd"])) < 1e-5 and abs(tm[0, 1] - float(g["famB_p0_tm"])) < 1e-5
+    assert cov[0, 1] == float(g["famB_p0_coverage"])
