@@ -48,7 +48,7 @@ SIGNATURES = {
     "cr_batch_run": [_vp, C.POINTER(Params), _vp],
     "cr_batch_fetch": [_vp, _vp, _vp, _i64],
     "cr_batch_max_aln_len": [_vp, C.POINTER(C.c_int64)],
-    "cr_batch_stage_ms": [_vp, C.POINTER(C.c_float * CR_NUM_STAGES)],
+    "cr_batch_stage_ms": [_vp, C.POINTER(C.c_float * CR_NUM_STAGES), C.POINTER(C.c_int)],
     "cr_batch_work": [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "cr_batch_destroy": [_vp],
     "cr_make_score_matrix": [_vp, _vp, _i64, _vp, _i64, _i64, _f64, _vp],

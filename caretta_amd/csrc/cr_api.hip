@@ -66,9 +66,10 @@ struct cr_context {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    bool profiling = false;
-    hipEvent_t ev[CR_NUM_STAGES + 1] = {};
-    bool have_events = false;
+    // profiling: a ring of event sets, one set (CR_NUM_STAGES + 1 events) per recorded run
+    std::vector<hipEvent_t> ev;
+    int slots = 0;
+    int64_t runs_recorded = 0;
 };
 
 struct cr_batch {
@@ -93,7 +94,6 @@ struct cr_batch {
     int64_t aln_elems = 0;
     double alg_bytes = 0.0, cells = 0.0;
     bool ran = false;
-    float stage_ms[CR_NUM_STAGES] = {0, 0, 0, 0};
 };
 
 static_assert(sizeof(cr::PairResult) == sizeof(cr_pair_result), "device/host result layouts differ");
@@ -212,8 +212,7 @@ int cr_context_create(int device, void* stream, cr_context** out) {
 int cr_context_destroy(cr_context* ctx) {
     if (!ctx) return CR_OK;
     (void)hipSetDevice(ctx->device);
-    if (ctx->have_events)
-        for (auto& e : ctx->ev) (void)hipEventDestroy(e);
+    for (auto& e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return CR_OK;
@@ -232,14 +231,18 @@ int cr_context_stream(cr_context* ctx, void** stream_out) {
     return CR_OK;
 }
 
-int cr_context_set_profiling(cr_context* ctx, int enabled) {
+int cr_context_set_profiling(cr_context* ctx, int slots) {
     int rc = set_device(ctx);
     if (rc) return rc;
-    if (enabled && !ctx->have_events) {
-        for (auto& e : ctx->ev) CR_HIP(hipEventCreate(&e));
-        ctx->have_events = true;
-    }
-    ctx->profiling = enabled != 0;
+    CR_REQUIRE(slots >= 0 && slots <= 4096, "profiling slots must be in [0, 4096]");
+    CR_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto& e : ctx->ev) (void)hipEventDestroy(e);
+    ctx->ev.clear();
+    ctx->slots = 0;
+    ctx->runs_recorded = 0;
+    ctx->ev.resize((size_t)slots * (CR_NUM_STAGES + 1));
+    for (auto& e : ctx->ev) CR_HIP(hipEventCreate(&e));
+    ctx->slots = slots;
     return CR_OK;
 }
 
@@ -360,41 +363,54 @@ int cr_batch_run(cr_batch* b, const cr_params* params, double* d_sw_out) {
     }
     cr_context* ctx = b->ctx;
     const cr_params prm = *params;
-    const bool prof = ctx->profiling && ctx->have_events;
+    const bool prof = ctx->slots > 0;
+    hipEvent_t* ev = prof ? &ctx->ev[(size_t)(ctx->runs_recorded % ctx->slots) * (CR_NUM_STAGES + 1)] : nullptr;
     const int threads = 64;
     const unsigned tblocks = (unsigned)((b->npairs + threads - 1) / threads);
-    if (prof) CR_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    if (prof) CR_HIP(hipEventRecord(ev[0], ctx->stream));
     rc = (b->r_seed == 3) ? launch_seed_d<3>(b, prm) : launch_seed_d<5>(b, prm);
     if (rc) return rc;
-    if (prof) CR_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    if (prof) CR_HIP(hipEventRecord(ev[1], ctx->stream));
     hipLaunchKernelGGL(cr::k_seed_trace, dim3(tblocks), dim3(threads), 0, ctx->stream, b->pairs.p, (int)b->npairs,
                        b->r_seed, b->coords.p, b->dirs.p, b->seed.p, b->pos.p, b->xf.p, b->seed_score.p);
     CR_HIP(hipGetLastError());
-    if (prof) CR_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+    if (prof) CR_HIP(hipEventRecord(ev[2], ctx->stream));
     rc = (b->r_align == 3) ? launch_align<3>(b, prm) : launch_align<5>(b, prm);
     if (rc) return rc;
-    if (prof) CR_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+    if (prof) CR_HIP(hipEventRecord(ev[3], ctx->stream));
     hipLaunchKernelGGL(cr::k_align_trace, dim3(tblocks), dim3(threads), 0, ctx->stream, b->pairs.p, (int)b->npairs,
                        b->r_align, b->coords.p, b->bits.p, b->ends.p, b->xf.p, b->seed_score.p, b->aln.p, b->res.p);
     CR_HIP(hipGetLastError());
-    if (prof) CR_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
+    if (prof) CR_HIP(hipEventRecord(ev[4], ctx->stream));
     if (d_sw_out) {
         // strided device-to-device copy of the first field of every PairResult
         CR_HIP(hipMemcpy2DAsync(d_sw_out, sizeof(double), b->res.p, sizeof(cr::PairResult), sizeof(double),
                                 (size_t)b->npairs, hipMemcpyDeviceToDevice, ctx->stream));
     }
+    if (prof) ctx->runs_recorded++;
     b->ran = true;
     return CR_OK;
 }
 
-int cr_batch_stage_ms(cr_batch* b, float ms[CR_NUM_STAGES]) {
+int cr_batch_stage_ms(cr_batch* b, float ms[CR_NUM_STAGES], int* runs_averaged) {
     CR_REQUIRE(b != nullptr && ms != nullptr, "null argument");
     cr_context* ctx = b->ctx;
-    if (!(ctx->profiling && ctx->have_events) || !b->ran) return fail(CR_ERR_STATE, "profiling not enabled or batch not run");
+    if (ctx->slots == 0 || ctx->runs_recorded == 0) return fail(CR_ERR_STATE, "profiling not enabled or nothing recorded");
     int rc = set_device(ctx);
     if (rc) return rc;
-    CR_HIP(hipEventSynchronize(ctx->ev[CR_NUM_STAGES]));
-    for (int s = 0; s < CR_NUM_STAGES; s++) CR_HIP(hipEventElapsedTime(&ms[s], ctx->ev[s], ctx->ev[s + 1]));
+    CR_HIP(hipStreamSynchronize(ctx->stream));
+    const int64_t n = std::min<int64_t>(ctx->runs_recorded, ctx->slots);
+    double acc[CR_NUM_STAGES] = {0, 0, 0, 0};
+    for (int64_t r = 0; r < n; r++) {
+        hipEvent_t* ev = &ctx->ev[(size_t)r * (CR_NUM_STAGES + 1)];
+        for (int s = 0; s < CR_NUM_STAGES; s++) {
+            float t = 0.f;
+            CR_HIP(hipEventElapsedTime(&t, ev[s], ev[s + 1]));
+            acc[s] += t;
+        }
+    }
+    for (int s = 0; s < CR_NUM_STAGES; s++) ms[s] = (float)(acc[s] / (double)n);
+    if (runs_averaged) *runs_averaged = (int)n;
     return CR_OK;
 }
 

@@ -1,0 +1,84 @@
+"""All-vs-all pair set sharded over the GPUs of one node.
+
+Pairs are independent (multiple_alignment.py:162-169 has no cross-pair dependency), so each rank
+runs the pipeline on its share with no data-path collective; ONE all-gather of the per-rank score
+vectors (RCCL over xGMI under the ``nccl`` backend, gloo in CPU tests) assembles the P x P matrix
+that neighbor joining consumes.  The result is independent of the number of ranks bit for bit.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import numpy as np
+
+
+def partition_pairs(pairs: np.ndarray, lengths: np.ndarray, world: int, rank: int) -> np.ndarray:
+    """Indices (into ``pairs``) owned by ``rank``: sort by DP cell count (descending, stable on the
+    pair id) and deal round-robin, so every rank gets the same mix of costs.  For equal-length
+    structures this is simply ``p % world``."""
+    pairs = np.asarray(pairs).reshape(-1, 2)
+    lengths = np.asarray(lengths, dtype=np.int64)
+    cost = lengths[pairs[:, 0]] * lengths[pairs[:, 1]]
+    order = np.argsort(-cost, kind="stable")
+    return np.sort(order[rank::world])
+
+
+def shard_size(npairs: int, world: int) -> int:
+    return (npairs + world - 1) // world
+
+
+def gather_scores(local_scores, world: int, group=None):
+    """All-gather equal-length per-rank score vectors (torch tensors, padded with NaN)."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return local_scores.unsqueeze(0)
+    out = torch.empty((world, local_scores.numel()), dtype=local_scores.dtype, device=local_scores.device)
+    dist.all_gather_into_tensor(out, local_scores.contiguous(), group=group)
+    return out
+
+
+def scatter_to_matrix(gathered: np.ndarray, pairs: np.ndarray, lengths: np.ndarray, num: int) -> np.ndarray:
+    """(world, shard) gathered scores -> symmetric P x P matrix (zero diagonal)."""
+    world = gathered.shape[0]
+    scores = np.full(len(pairs), np.nan)
+    for r in range(world):
+        idx = partition_pairs(pairs, lengths, world, r)
+        scores[idx] = gathered[r, :len(idx)]
+    if np.isnan(scores).any():
+        raise RuntimeError("all-gather left pairs without a score")
+    from .engine import assemble_matrix
+    return assemble_matrix(pairs, scores, num)
+
+
+def pairwise_matrix_sharded(coords, tensors, offsets, params=None, group=None,
+                            compute_fn: Optional[Callable] = None, device=None) -> np.ndarray:
+    """P x P smith_waterman_score matrix (multiple_alignment.py:158-170) with the pair set sharded
+    over the ranks of ``group``.  ``compute_fn(coords, tensors, offsets, pairs) -> scores`` replaces the
+    HIP engine in CPU tests (the product default fails loudly without a GPU)."""
+    import torch
+    import torch.distributed as dist
+    from .engine import all_pairs
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    offsets = np.asarray(offsets, dtype=np.int64)
+    lengths = np.diff(offsets)
+    num = len(lengths)
+    pairs = all_pairs(num)
+    mine = partition_pairs(pairs, lengths, world, rank)
+    size = shard_size(len(pairs), world)
+    if compute_fn is not None:
+        local = torch.full((size,), float("nan"), dtype=torch.float64)
+        local[:len(mine)] = torch.from_numpy(np.asarray(compute_fn(coords, tensors, offsets, pairs[mine]), dtype=np.float64))
+    else:
+        from .engine import Context, PairBatch
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        ctx = Context(dev.index or 0, stream=torch.cuda.current_stream(dev).cuda_stream)
+        local = torch.full((size,), float("nan"), dtype=torch.float64, device=dev)
+        batch = PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs[mine])
+        batch.run(params, sw_out_device_ptr=local.data_ptr())
+        ctx.synchronize()
+        batch.close()
+        ctx.close()
+    gathered = gather_scores(local, world, group)
+    return scatter_to_matrix(gathered.cpu().numpy(), pairs, lengths, num)

@@ -33,16 +33,17 @@ def device_count() -> int:
 
 
 class Context:
-    def __init__(self, device: int = 0, stream: Optional[int] = None, profiling: bool = False):
+    def __init__(self, device: int = 0, stream: Optional[int] = None, profiling: int = 0):
         self._lib = _capi.load()
         self._h = C.c_void_p()
         check(self._lib.cr_context_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self._h)))
         self.device = int(device)
         if profiling:
-            self.set_profiling(True)
+            self.set_profiling(profiling)
 
-    def set_profiling(self, enabled: bool):
-        check(self._lib.cr_context_set_profiling(self._h, 1 if enabled else 0))
+    def set_profiling(self, slots: int):
+        """Record per-stage HIP events for the next ``slots`` runs (ring); 0 switches it off."""
+        check(self._lib.cr_context_set_profiling(self._h, int(slots)))
 
     def synchronize(self):
         check(self._lib.cr_context_synchronize(self._h))
@@ -121,10 +122,12 @@ class PairBatch:
         check(self._lib.cr_batch_fetch(self._h, ptr(res), ptr(aln) if aln is not None else None, stride))
         return res, aln
 
-    def stage_ms(self) -> np.ndarray:
+    def stage_ms(self):
+        """(per-stage device ms averaged over the recorded runs, number of runs averaged)."""
         buf = (C.c_float * _capi.CR_NUM_STAGES)()
-        check(self._lib.cr_batch_stage_ms(self._h, C.byref(buf)))
-        return np.array(list(buf), dtype=np.float64)
+        n = C.c_int(0)
+        check(self._lib.cr_batch_stage_ms(self._h, C.byref(buf), C.byref(n)))
+        return np.array(list(buf), dtype=np.float64), n.value
 
     def work(self):
         """(algorithmic HBM bytes, DP cells per pass) of one run of the current pair list."""

@@ -80,7 +80,9 @@ int cr_context_create(int device, void *stream, cr_context **out);
 int cr_context_destroy(cr_context *ctx);
 int cr_context_synchronize(cr_context *ctx);
 int cr_context_stream(cr_context *ctx, void **stream_out);
-int cr_context_set_profiling(cr_context *ctx, int enabled);   /* record per-stage HIP events */
+/* Per-stage HIP events on the launch stream: a ring of `slots` event sets, one per cr_batch_run
+ * (0 disables; calling it again resets the ring). */
+int cr_context_set_profiling(cr_context *ctx, int slots);
 
 /* ---- batched all-vs-all pipeline -------------------------------------------------------- */
 /* Replaces the pair loop MultipleAlignment.make_pairwise_matrix (multiple_alignment.py:158-170)
@@ -101,8 +103,8 @@ int cr_batch_run(cr_batch *b, const cr_params *params, double *d_sw_out);
  * aln i64[npairs, 2, aln_stride] (rows padded with -2 after aln_len; aln_stride >= max(n+m)). */
 int cr_batch_fetch(cr_batch *b, cr_pair_result *results, int64_t *aln, int64_t aln_stride);
 int cr_batch_max_aln_len(cr_batch *b, int64_t *out);
-/* per-stage device time of the last run in ms (needs cr_context_set_profiling(ctx, 1)) */
-int cr_batch_stage_ms(cr_batch *b, float ms[CR_NUM_STAGES]);
+/* per-stage device time in ms, averaged over the recorded runs (at most `slots` of them) */
+int cr_batch_stage_ms(cr_batch *b, float ms[CR_NUM_STAGES], int *runs_averaged);
 /* algorithmic HBM bytes of one run of the current pair list (SURVEY.md 8(d) B_alg) and DP cells */
 int cr_batch_work(cr_batch *b, double *alg_bytes, double *cells);
 int cr_batch_destroy(cr_batch *b);
