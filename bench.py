@@ -132,12 +132,13 @@ def main():
     batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs[mine])
     params = engine.make_params()
     local = torch.full((shard,), float("nan"), dtype=torch.float64, device=dev)
-    gathered = torch.empty((world, shard), dtype=torch.float64, device=dev)
+    gathered_flat = torch.empty(world * shard, dtype=torch.float64, device=dev)
+    gathered = gathered_flat.view(world, shard)
 
     def step():
         batch.run(params, sw_out_device_ptr=local.data_ptr())
         if world > 1:
-            dist.all_gather_into_tensor(gathered, local)
+            dist.all_gather_into_tensor(gathered_flat, local)
 
     def fence():
         if world > 1:

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -115,16 +116,21 @@ int allow_lds(K kernel, size_t bytes) {
     return CR_OK;
 }
 
-template <int R, int D>
-int launch_seed(cr_batch* b, const cr_params& prm) {
+template <int R, int D, bool ZG>
+int launch_seed_zg(cr_batch* b, const cr_params& prm) {
     using Src = cr::RbfTensor<R, D>;
     size_t lds = cr::sweep_lds_doubles<R, cr::kSwTrace, Src>(b->n_max, b->m_max) * sizeof(double);
-    int rc = allow_lds(cr::k_seed_fill<R, D>, lds);
+    int rc = allow_lds(cr::k_seed_fill<R, D, ZG>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((cr::k_seed_fill<R, D>), dim3((unsigned)b->npairs), dim3(cr::kWave), lds, b->ctx->stream,
+    hipLaunchKernelGGL((cr::k_seed_fill<R, D, ZG>), dim3((unsigned)b->npairs), dim3(cr::kWave), lds, b->ctx->stream,
                        b->pairs.p, b->tensors.p, (int)b->d, prm.gamma_tensor, prm.sw_gap, b->dirs.p, b->seed.p);
     CR_HIP(hipGetLastError());
     return CR_OK;
+}
+
+template <int R, int D>
+int launch_seed(cr_batch* b, const cr_params& prm) {
+    return prm.sw_gap == 0.0 ? launch_seed_zg<R, D, true>(b, prm) : launch_seed_zg<R, D, false>(b, prm);
 }
 
 template <int R>
@@ -138,17 +144,28 @@ int launch_seed_d(cr_batch* b, const cr_params& prm) {
     }
 }
 
-template <int R>
-int launch_align(cr_batch* b, const cr_params& prm) {
+template <int R, bool ZG>
+int launch_align_zg(cr_batch* b, const cr_params& prm) {
     using Src = cr::RbfCoords<R>;
     size_t lds = cr::sweep_lds_doubles<R, cr::kSwScore | cr::kDtw, Src>(b->n_max, b->m_max) * sizeof(double);
-    int rc = allow_lds(cr::k_align_fill<R>, lds);
+    int rc = allow_lds(cr::k_align_fill<R, ZG>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((cr::k_align_fill<R>), dim3((unsigned)b->npairs), dim3(cr::kWave), lds, b->ctx->stream,
+    hipLaunchKernelGGL((cr::k_align_fill<R, ZG>), dim3((unsigned)b->npairs), dim3(cr::kWave), lds, b->ctx->stream,
                        b->pairs.p, b->coords.p, b->xf.p, prm.gamma_coords, prm.sw_gap, prm.gap_open, prm.gap_extend,
                        b->bits.p, b->ends.p);
     CR_HIP(hipGetLastError());
     return CR_OK;
+}
+
+bool all_finite(const double* v, size_t count) {
+    for (size_t x = 0; x < count; x++)
+        if (!std::isfinite(v[x])) return false;
+    return true;
+}
+
+template <int R>
+int launch_align(cr_batch* b, const cr_params& prm) {
+    return prm.sw_gap == 0.0 ? launch_align_zg<R, true>(b, prm) : launch_align_zg<R, false>(b, prm);
 }
 
 // widths the seed-fill kernel is instantiated for; narrower tensors are zero-padded in registers
@@ -264,6 +281,8 @@ int cr_batch_create(cr_context* ctx, const double* coords, const double* tensors
         CR_REQUIRE(offsets[s + 1] > offsets[s], "every structure needs at least one residue");
         CR_REQUIRE(offsets[s + 1] - offsets[s] < (1 << 24), "structure too long");
     }
+    CR_REQUIRE(all_finite(coords, (size_t)offsets[num_structures] * 3), "coordinates contain NaN or infinity");
+    CR_REQUIRE(all_finite(tensors, (size_t)offsets[num_structures] * (size_t)d), "tensors contain NaN or infinity");
     cr_batch* b = new (std::nothrow) cr_batch();
     if (!b) return fail(CR_ERR_MEMORY, "out of host memory");
     b->ctx = ctx;
@@ -363,23 +382,28 @@ int cr_batch_run(cr_batch* b, const cr_params* params, double* d_sw_out) {
     }
     cr_context* ctx = b->ctx;
     const cr_params prm = *params;
+    CR_REQUIRE(std::isfinite(prm.gamma_tensor) && prm.gamma_tensor >= 0.0 && std::isfinite(prm.gamma_coords) &&
+                   prm.gamma_coords >= 0.0,
+               "gamma_tensor and gamma_coords must be finite and >= 0");
+    CR_REQUIRE(std::isfinite(prm.gap_open) && std::isfinite(prm.gap_extend) && std::isfinite(prm.sw_gap),
+               "gap penalties must be finite");
     const bool prof = ctx->slots > 0;
     hipEvent_t* ev = prof ? &ctx->ev[(size_t)(ctx->runs_recorded % ctx->slots) * (CR_NUM_STAGES + 1)] : nullptr;
-    const int threads = 64;
-    const unsigned tblocks = (unsigned)((b->npairs + threads - 1) / threads);
+    const size_t trace_lds = cr::trace_lds_bytes(std::max(b->r_seed, b->r_align));
     if (prof) CR_HIP(hipEventRecord(ev[0], ctx->stream));
     rc = (b->r_seed == 3) ? launch_seed_d<3>(b, prm) : launch_seed_d<5>(b, prm);
     if (rc) return rc;
     if (prof) CR_HIP(hipEventRecord(ev[1], ctx->stream));
-    hipLaunchKernelGGL(cr::k_seed_trace, dim3(tblocks), dim3(threads), 0, ctx->stream, b->pairs.p, (int)b->npairs,
+    hipLaunchKernelGGL(cr::k_seed_trace, dim3((unsigned)b->npairs), dim3(cr::kWave), trace_lds, ctx->stream, b->pairs.p,
                        b->r_seed, b->coords.p, b->dirs.p, b->seed.p, b->pos.p, b->xf.p, b->seed_score.p);
     CR_HIP(hipGetLastError());
     if (prof) CR_HIP(hipEventRecord(ev[2], ctx->stream));
     rc = (b->r_align == 3) ? launch_align<3>(b, prm) : launch_align<5>(b, prm);
     if (rc) return rc;
     if (prof) CR_HIP(hipEventRecord(ev[3], ctx->stream));
-    hipLaunchKernelGGL(cr::k_align_trace, dim3(tblocks), dim3(threads), 0, ctx->stream, b->pairs.p, (int)b->npairs,
-                       b->r_align, b->coords.p, b->bits.p, b->ends.p, b->xf.p, b->seed_score.p, b->aln.p, b->res.p);
+    hipLaunchKernelGGL(cr::k_align_trace, dim3((unsigned)b->npairs), dim3(cr::kWave), trace_lds, ctx->stream, b->pairs.p,
+                       b->r_align, b->coords.p, b->bits.p, b->ends.p, b->xf.p, b->seed_score.p, b->aln.p, b->pos.p,
+                       b->res.p);
     CR_HIP(hipGetLastError());
     if (prof) CR_HIP(hipEventRecord(ev[4], ctx->stream));
     if (d_sw_out) {

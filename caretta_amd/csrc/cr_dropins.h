@@ -22,7 +22,7 @@ __global__ void k_score_matrix(const double* __restrict__ a, int n, const double
         df = ai[x] - bj[x];
         acc = acc + df * df;
     }
-    S[(int64_t)i * m + j] = exp_tab(neg_gamma * acc, tab);
+    S[(int64_t)i * m + j] = exp_tab<false>(neg_gamma * acc, tab);
 }
 
 // coordinate score matrix on the seed-superposed frames (multiple_alignment.py:344-349)
@@ -50,7 +50,7 @@ __global__ void k_score_matrix_xf(const double* __restrict__ xi, int n, const do
     }
     const double dx = a[0] - o[0], dy = a[1] - o[1], dz = a[2] - o[2];
     const double acc = (dx * dx + dy * dy) + dz * dz;
-    S[(int64_t)i * m + j] = exp_tab(neg_gamma * acc, tab);
+    S[(int64_t)i * m + j] = exp_tab<false>(neg_gamma * acc, tab);
 }
 
 // DP on an explicit score matrix (dtw_align / smith_waterman(_score) drop-ins).  One wave.
@@ -254,6 +254,8 @@ int cr_make_score_matrix(cr_context* ctx, const double* a, int64_t n, const doub
     if (n == 0 || m == 0) return CR_OK;
     CR_REQUIRE(a && b && S, "null array");
     CR_REQUIRE(n < (1 << 24) && m < (1 << 24), "matrix too large");
+    CR_REQUIRE(all_finite(a, (size_t)n * k) && all_finite(b, (size_t)m * k) && std::isfinite(gamma),
+               "inputs contain NaN or infinity");
     DevBuf<double> da, db, ds;
     if ((rc = upload(da, a, (size_t)n * k, ctx->stream))) return rc;
     if ((rc = upload(db, b, (size_t)m * k, ctx->stream))) return rc;
@@ -271,6 +273,8 @@ int cr_protein_score_function(cr_context* ctx, const double* coords_i, const dou
                               double gamma_tensor, double gamma_coords, double* S, uint32_t* flags) {
     CR_REQUIRE(coords_i && tensors_i && coords_j && tensors_j && S, "null array");
     CR_REQUIRE(n >= 1 && m >= 1, "empty structure");
+    CR_REQUIRE(std::isfinite(gamma_tensor) && gamma_tensor >= 0.0 && std::isfinite(gamma_coords) && gamma_coords >= 0.0,
+               "gamma_tensor and gamma_coords must be finite and >= 0");
     // a two-structure batch driven through stages 1-2, then the explicit matrix
     std::vector<double> coords((size_t)(n + m) * 3), tensors((size_t)(n + m) * d);
     std::memcpy(coords.data(), coords_i, sizeof(double) * (size_t)n * 3);
@@ -288,8 +292,8 @@ int cr_protein_score_function(cr_context* ctx, const double* coords_i, const dou
         rc = (b->r_seed == 3) ? launch_seed_d<3>(b, prm) : launch_seed_d<5>(b, prm);
     }
     if (rc == CR_OK) {
-        hipLaunchKernelGGL(cr::k_seed_trace, dim3(1), dim3(64), 0, ctx->stream, b->pairs.p, 1, b->r_seed, b->coords.p,
-                           b->dirs.p, b->seed.p, b->pos.p, b->xf.p, b->seed_score.p);
+        hipLaunchKernelGGL(cr::k_seed_trace, dim3(1), dim3(cr::kWave), cr::trace_lds_bytes(b->r_seed), ctx->stream,
+                           b->pairs.p, b->r_seed, b->coords.p, b->dirs.p, b->seed.p, b->pos.p, b->xf.p, b->seed_score.p);
         DevBuf<double> ds;
         hipError_t e = ds.ensure((size_t)n * m);
         if (e == hipSuccess) {

@@ -21,6 +21,7 @@ namespace cr {
 constexpr int kWave = 64;
 constexpr int kRing = 128;          // columns held in the LDS ring (two 64-column halves)
 constexpr double kMinF64 = -0x1.fffffffffffffp+1023;  // np.finfo(float64).min, dynamic_time_warping.py:4
+constexpr double kFarAway = 1e150;   // feature value of rows past the end: RBF score underflows to exactly 0
 
 enum : uint32_t {
     kFlagSeedSkipped = 1u,      // <=3 seed positions: no superposition (multiple_alignment.py:337-342)
@@ -69,6 +70,7 @@ CR_HD int tblocks(int m, int per_word) { return (m + kWave - 1 + per_word - 1) /
 // width (zero padding adds exact zeros to the sum); `d` is the stored width.
 template <int R, int D>
 struct RbfTensor {
+    static constexpr bool kNonNegative = true;   // scores are exp(.) >= 0
     const double* __restrict__ rows_g;   // (n, d)
     const double* __restrict__ cols_g;   // (m, d)
     int d;
@@ -76,14 +78,16 @@ struct RbfTensor {
     double row[R][D];
     double col[D];
     static constexpr int kRingDoubles = D * kRing;
+    static constexpr bool kMaskRows = false;
 
     CR_D void load_rows(int rowbase, int n) {
 #pragma unroll
         for (int q = 0; q < R; q++) {
-            int r = rowbase + q;
-            r = r < n ? r : n - 1;
+            const int r = rowbase + q;
+            const bool rv = r < n;
 #pragma unroll
-            for (int k = 0; k < D; k++) row[q][k] = (k < d) ? rows_g[(int64_t)r * d + k] : 0.0;
+            for (int k = 0; k < D; k++)
+                row[q][k] = (k < d) ? (rv ? rows_g[(int64_t)r * d + k] : kFarAway) : 0.0;
         }
     }
     CR_D void init_ring(double* ring, int lane) {
@@ -110,7 +114,7 @@ struct RbfTensor {
             df = row[q][k] - col[k];
             acc = acc + df * df;
         }
-        return exp_tab(neg_gamma * acc, tab);
+        return exp_tab<true>(neg_gamma * acc, tab);
     }
 };
 
@@ -118,6 +122,7 @@ struct RbfTensor {
 // (superposition_functions.py:57-58), or the raw coordinates when the seed was skipped.
 template <int R>
 struct RbfCoords {
+    static constexpr bool kNonNegative = true;
     const double* __restrict__ rows_g;   // (n, 3)
     const double* __restrict__ cols_g;   // (m, 3)
     const Transform* __restrict__ xf;
@@ -125,17 +130,21 @@ struct RbfCoords {
     double row[R][3];
     double col[3];
     static constexpr int kRingDoubles = 3 * kRing;
+    static constexpr bool kMaskRows = false;
 
     CR_D void load_rows(int rowbase, int n) {
         const bool raw = xf->flags & kFlagSeedSkipped;
 #pragma unroll
         for (int q = 0; q < R; q++) {
-            int r = rowbase + q;
-            r = r < n ? r : n - 1;
+            const int r = rowbase + q;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                double v = rows_g[(int64_t)r * 3 + k];
-                row[q][k] = raw ? v : v - xf->c1[k];
+                if (r < n) {
+                    double v = rows_g[(int64_t)r * 3 + k];
+                    row[q][k] = raw ? v : v - xf->c1[k];
+                } else {
+                    row[q][k] = kFarAway;
+                }
             }
         }
     }
@@ -165,13 +174,14 @@ struct RbfCoords {
     CR_D double score(int q, const ExpEntry* tab) const {
         double dx = row[q][0] - col[0], dy = row[q][1] - col[1], dz = row[q][2] - col[2];
         double acc = (dx * dx + dy * dy) + dz * dz;
-        return exp_tab(neg_gamma * acc, tab);
+        return exp_tab<true>(neg_gamma * acc, tab);
     }
 };
 
 // Explicit score matrix with index sequences: S[seq1[i], seq2[j]] (dynamic_time_warping.py:24-26,79).
 template <int R>
 struct Explicit {
+    static constexpr bool kNonNegative = false;
     const double* __restrict__ S;
     const int32_t* __restrict__ seq1;
     const int32_t* __restrict__ seq2;
@@ -179,6 +189,7 @@ struct Explicit {
     const double* rowp[R];
     int64_t colidx;
     static constexpr int kRingDoubles = 0;
+    static constexpr bool kMaskRows = true;
 
     CR_D void load_rows(int rowbase, int n) {
 #pragma unroll
@@ -195,7 +206,7 @@ struct Explicit {
     CR_D double score(int q, const ExpEntry*) const { return rowp[q][colidx]; }
 };
 
-enum : int { kSwTrace = 1, kSwScore = 2, kDtw = 4 };
+enum : int { kSwTrace = 1, kSwScore = 2, kDtw = 4, kZeroGap = 8 };   // kZeroGap: sw_gap == 0.0
 
 struct SweepParams {
     double sw_gap, gap_open, gap_extend;
@@ -207,6 +218,13 @@ struct SweepParams {
 //   kSwScore : SW fill, maximum only                        (dynamic_time_warping.py:205-222)
 //   kDtw     : 3-layer affine fill + 4-bit decisions        (dynamic_time_warping.py:8-86,181-182)
 // LDS layout (doubles): [0,32) exp table | ring | strip hand-off rows (nb * m, only if >1 strip).
+//
+// Lanes whose column c = t - lane lies outside [0, m) are switched off with the EXEC mask for the
+// whole cell block, so their state registers keep the DP border values without any select.
+// Rows past n (last strip only) are fed features of 1e150: their RBF score underflows to exactly 0,
+// so they can only repeat values of valid cells and lose every first-maximum tie (larger row).
+// Providers that cannot do that (explicit score matrix) set kMaskRows.
+// max(a, b) is v_max_f64: value-identical to the reference's compare-and-keep for non-NaN data.
 // ---------------------------------------------------------------------------------------------
 template <int R, int MODE, class Src>
 CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, double* lds,
@@ -215,6 +233,8 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
     constexpr bool SW = (MODE & (kSwTrace | kSwScore)) != 0;
     constexpr bool TRACE = (MODE & kSwTrace) != 0;
     constexpr bool DTW = (MODE & kDtw) != 0;
+    constexpr bool ZG = (MODE & kZeroGap) != 0;        // x - 0.0 == x: the gap subtractions vanish
+    constexpr bool NOFLOOR = ZG && Src::kNonNegative;  // all candidates >= +0: max(0, .) is the identity
     constexpr int NB = (SW ? 1 : 0) + (DTW ? 2 : 0);   // values handed from strip to strip per column
     const int lane = threadIdx.x;
     const ExpEntry* tab = reinterpret_cast<const ExpEntry*>(lds);
@@ -226,26 +246,32 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
     __syncthreads();
 
     const int nstrips = strips_of(n, R);
-    const int T = m + kWave - 1;
     const int TB_SW = tblocks(m, 16), TB_DTW = tblocks(m, 8);
     const double col0_m2 = kMinF64 - prm.gap_open;      // M[i][0][2], M[0][j][0] (dynamic_time_warping.py:45,49)
 
-    // first maximum of H in row-major order (smith_waterman, :241-247)
+    // first maximum of H in row-major order (smith_waterman, :241-247): lane-level running best
     double best_v = 0.0;
     int best_i = 0x7fffffff, best_j = 0x7fffffff;
     double sw_max = 0.0;
-    double fin0 = 0.0, fin1 = 0.0, fin2 = 0.0;          // M[n][m][0..2], held by the owning lane
+    double m0_left[R], m1_left[R], m2_left[R];          // DTW layers of this lane's rows, previous column
 
     for (int s = 0; s < nstrips; s++) {
         const int rowbase = (s * kWave + lane) * R;
+        const int rows_here = n - s * kWave * R;                        // rows left for this strip
+        const int lanes_here = rows_here >= kWave * R ? kWave : (rows_here + R - 1) / R;
+        const int T = m + lanes_here - 1;
         src.load_rows(rowbase, n);
-        double h_left[R], m1_left[R], m2_left[R];
+        double h_left[R], rowmax[R];
+        int rowarg[R];
         uint32_t swbits[R], dtbits[R];
 #pragma unroll
         for (int q = 0; q < R; q++) {
             h_left[q] = 0.0;
+            m0_left[q] = 0.0;
             m1_left[q] = 0.0;          // M[i][0][1] = 0
             m2_left[q] = col0_m2;      // M[i][0][2] = MIN - open
+            rowmax[q] = 0.0;
+            rowarg[q] = 0;
             swbits[q] = 0;
             dtbits[q] = 0;
         }
@@ -260,8 +286,6 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
             }
             const int c = t - lane;
             const bool active = (unsigned)c < (unsigned)m;
-            if constexpr (Src::kRingDoubles == 0) src.set_col(c, m);
-            src.fetch_col(ring, c & (kRing - 1));
 
             // row above this lane's block: lane 0 reads the DP border (strip 0) or the hand-off row
             double h_top0 = 0.0, m0_top0 = col0_m2, m1_top0 = 0.0;   // M[0][j][0] = MIN - open, M[0][j][1] = 0
@@ -278,77 +302,86 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
                 m0_top = wave_shr1(m0_bot, m0_top0);
                 m1_top = wave_shr1(m1_bot, m1_top0);
             }
-
-            double h_up = h_top, h_dg = h_diag;
-            double m0_up = m0_top, m1_up = m1_top, m1_dg = m1_diag;
             const int sh2 = (t & 15) * 2, sh4 = (t & 7) * 4;
+
+            if (active) {
+                if constexpr (Src::kRingDoubles == 0) src.set_col(c, m);
+                src.fetch_col(ring, c & (kRing - 1));
+                double h_up = h_top, h_dg = h_diag;
+                double m0_up = m0_top, m1_up = m1_top, m1_dg = m1_diag;
 #pragma unroll
-            for (int q = 0; q < R; q++) {
-                const double sc = src.score(q, tab);
-                const int row = rowbase + q;
-                const bool valid = active && row < n;
-                if constexpr (SW) {
-                    // H = max(0, diag + S, left - gap, up - gap), first maximal argument
-                    const double dg = h_dg + sc;
-                    const double lf = h_left[q] - prm.sw_gap;
-                    const double up = h_up - prm.sw_gap;
-                    double h = 0.0;
-                    h = dg > h ? dg : h;
-                    h = lf > h ? lf : h;
-                    h = up > h ? up : h;
-                    if constexpr (TRACE) {
-                        // decision replayed by the traceback's equality tests (:255-277)
-                        uint32_t code = (h == 0.0) ? 0u : (h == dg) ? 1u : (h == lf) ? 2u : 3u;
-                        swbits[q] |= (valid ? code : 0u) << sh2;
-                        const bool better = valid && (h > best_v || (h == best_v && row < best_i));
-                        best_v = better ? h : best_v;
-                        best_j = better ? c : best_j;
-                        best_i = better ? row : best_i;
-                    } else {
-                        sw_max = (valid && h > sw_max) ? h : sw_max;
+                for (int q = 0; q < R; q++) {
+                    const double sc = src.score(q, tab);
+                    if constexpr (SW) {
+                        // H = max(0, diag + S, left - gap, up - gap)
+                        const double dg = h_dg + sc;
+                        const double lf = ZG ? h_left[q] : h_left[q] - prm.sw_gap;
+                        const double up = ZG ? h_up : h_up - prm.sw_gap;
+                        const double h = NOFLOOR ? __builtin_fmax(__builtin_fmax(dg, lf), up)
+                                                 : __builtin_fmax(__builtin_fmax(__builtin_fmax(0.0, dg), lf), up);
+                        if constexpr (TRACE) {
+                            // decision replayed by the traceback's equality tests (:255-277)
+                            uint32_t code = (h == dg) ? 1u : (h == lf) ? 2u : 3u;
+                            code = (h > 0.0) ? code : 0u;
+                            bool gt = h > rowmax[q];
+                            if constexpr (Src::kMaskRows) {
+                                const bool rv = rowbase + q < n;
+                                gt = gt & rv;
+                                code = rv ? code : 0u;
+                            }
+                            swbits[q] |= code << sh2;
+                            rowmax[q] = gt ? h : rowmax[q];
+                            rowarg[q] = gt ? c : rowarg[q];
+                        } else {
+                            if constexpr (Src::kMaskRows) {
+                                sw_max = (rowbase + q < n) ? __builtin_fmax(sw_max, h) : sw_max;
+                            } else {
+                                sw_max = __builtin_fmax(sw_max, h);
+                            }
+                        }
+                        h_dg = h_left[q];
+                        h_up = h;
+                        h_left[q] = h;
                     }
-                    h_dg = h_left[q];
-                    h_up = h;
-                    h_left[q] = active ? h : h_left[q];
+                    if constexpr (DTW) {
+                        const double lo0 = m0_up - prm.gap_extend;
+                        const double lo1 = m1_up - prm.gap_open;
+                        const bool b0 = lo1 > lo0;                  // np.argmax keeps the first maximum
+                        const double m0 = __builtin_fmax(lo0, lo1);
+                        const double up0 = m1_left[q] - prm.gap_open;
+                        const double up1 = m2_left[q] - prm.gap_extend;
+                        const bool b2 = up1 > up0;
+                        const double m2 = __builtin_fmax(up0, up1);
+                        const double c1 = m1_dg + sc;
+                        const bool g1 = c1 > m0;
+                        const double m01 = __builtin_fmax(m0, c1);
+                        const bool g2 = m2 > m01;
+                        const double m1 = __builtin_fmax(m01, m2);
+                        const uint32_t nib = (b0 ? 1u : 0u) | (g2 ? 4u : (g1 ? 2u : 0u)) | (b2 ? 8u : 0u);
+                        dtbits[q] |= nib << sh4;
+                        m1_dg = m1_left[q];
+                        m0_up = m0;
+                        m1_up = m1;
+                        m0_left[q] = m0;
+                        m1_left[q] = m1;
+                        m2_left[q] = m2;
+                    }
+                }
+                if constexpr (SW) {
+                    h_diag = h_top;
+                    h_bot = h_up;
                 }
                 if constexpr (DTW) {
-                    const double lo0 = m0_up - prm.gap_extend;
-                    const double lo1 = m1_up - prm.gap_open;
-                    const bool b0 = lo1 > lo0;
-                    const double m0 = b0 ? lo1 : lo0;
-                    const double up0 = m1_left[q] - prm.gap_open;
-                    const double up1 = m2_left[q] - prm.gap_extend;
-                    const bool b2 = up1 > up0;
-                    const double m2 = b2 ? up1 : up0;
-                    const double c1 = m1_dg + sc;
-                    uint32_t idx = 0;
-                    double m1 = m0;
-                    if (c1 > m1) { m1 = c1; idx = 1; }
-                    if (m2 > m1) { m1 = m2; idx = 2; }
-                    const uint32_t nib = (b0 ? 1u : 0u) | (idx << 1) | (b2 ? 8u : 0u);
-                    dtbits[q] |= (valid ? nib : 0u) << sh4;
-                    if (valid && row == n - 1 && c == m - 1) { fin0 = m0; fin1 = m1; fin2 = m2; }
-                    m1_dg = m1_left[q];
-                    m0_up = m0;
-                    m1_up = m1;
-                    m1_left[q] = active ? m1 : m1_left[q];
-                    m2_left[q] = active ? m2 : m2_left[q];
+                    m1_diag = m1_top;
+                    m0_bot = m0_up;
+                    m1_bot = m1_up;
                 }
-            }
-            if constexpr (SW) {
-                h_diag = active ? h_top : h_diag;
-                h_bot = h_up;
-            }
-            if constexpr (DTW) {
-                m1_diag = active ? m1_top : m1_diag;
-                m0_bot = m0_up;
-                m1_bot = m1_up;
-            }
-            if (s + 1 < nstrips && lane == kWave - 1 && active) {
-                if constexpr (SW) bnd[c] = h_up;
-                if constexpr (DTW) {
-                    bnd[(NB - 2) * m + c] = m0_up;
-                    bnd[(NB - 1) * m + c] = m1_up;
+                if (s + 1 < nstrips && lane == kWave - 1) {
+                    if constexpr (SW) bnd[c] = h_up;
+                    if constexpr (DTW) {
+                        bnd[(NB - 2) * m + c] = m0_up;
+                        bnd[(NB - 1) * m + c] = m1_up;
+                    }
                 }
             }
             if constexpr (TRACE) {
@@ -370,6 +403,16 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
                         dtbits[q] = 0;
                     }
                 }
+            }
+        }
+        if constexpr (TRACE) {
+            // fold this strip's per-row first maxima into the lane's running best (rows ascending)
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const bool gt = rowmax[q] > best_v;
+                best_v = gt ? rowmax[q] : best_v;
+                best_i = gt ? rowbase + q : best_i;
+                best_j = gt ? rowarg[q] : best_j;
             }
         }
     }
@@ -394,13 +437,18 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
     }
     if constexpr ((MODE & kSwScore) != 0 || DTW) {
         if constexpr ((MODE & kSwScore) != 0) {
-            for (int off = 32; off > 0; off >>= 1) {
-                double ov = __shfl_xor(sw_max, off);
-                sw_max = ov > sw_max ? ov : sw_max;
-            }
+            for (int off = 32; off > 0; off >>= 1) sw_max = __builtin_fmax(sw_max, __shfl_xor(sw_max, off));
         }
-        const int owner = ((n - 1) / R) % kWave;       // lane that owns row n-1
+        const int owner = ((n - 1) / R) % kWave;       // lane and register slot that own row n-1
+        const int qo = (n - 1) % R;
         if (lane == owner) {
+            double fin0 = 0.0, fin1 = 0.0, fin2 = 0.0; // M[n][m][0..2]
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                fin0 = (q == qo) ? m0_left[q] : fin0;
+                fin1 = (q == qo) ? m1_left[q] : fin1;
+                fin2 = (q == qo) ? m2_left[q] : fin2;
+            }
             AlignEnd e;
             e.sw = sw_max;
             int idx = 0;                               // np.argmax of the three layers at (n, m), :181-182
@@ -429,7 +477,7 @@ __host__ __device__ inline size_t sweep_lds_doubles(int n_max, int m_max) {
 // ---------------------------------------------------------------------------------------------
 
 // Stage 1: tensor RBF + SW fill (multiple_alignment.py:328-335).  One wave per pair.
-template <int R, int D>
+template <int R, int D, bool ZG>
 __global__ __launch_bounds__(kWave) void k_seed_fill(const PairDesc* __restrict__ pairs,
                                                     const double* __restrict__ tensors, int d,
                                                     double gamma, double sw_gap,
@@ -442,12 +490,13 @@ __global__ __launch_bounds__(kWave) void k_seed_fill(const PairDesc* __restrict_
     src.d = d;
     src.neg_gamma = -gamma;
     SweepParams prm{sw_gap, 0.0, 0.0};
-    sweep<R, kSwTrace>(src, pd.n, pd.m, prm, lds, dirs + pd.dirs_off, nullptr, out + blockIdx.x, nullptr);
+    sweep<R, kSwTrace | (ZG ? kZeroGap : 0)>(src, pd.n, pd.m, prm, lds, dirs + pd.dirs_off, nullptr, out + blockIdx.x,
+                                              nullptr);
 }
 
 // Stage 3: coordinate RBF on the seed-superposed frames + SW score + affine DTW fill
 // (multiple_alignment.py:347-349, :164, :263-275).  One wave per pair.
-template <int R>
+template <int R, bool ZG>
 __global__ __launch_bounds__(kWave) void k_align_fill(const PairDesc* __restrict__ pairs,
                                                      const double* __restrict__ coords,
                                                      const Transform* __restrict__ xf, double gamma,
@@ -461,7 +510,8 @@ __global__ __launch_bounds__(kWave) void k_align_fill(const PairDesc* __restrict
     src.xf = xf + blockIdx.x;
     src.neg_gamma = -gamma;
     SweepParams prm{sw_gap, gap_open, gap_extend};
-    sweep<R, kSwScore | kDtw>(src, pd.n, pd.m, prm, lds, nullptr, bits + pd.bt_off, nullptr, out + blockIdx.x);
+    sweep<R, kSwScore | kDtw | (ZG ? kZeroGap : 0)>(src, pd.n, pd.m, prm, lds, nullptr, bits + pd.bt_off, nullptr,
+                                                     out + blockIdx.x);
 }
 
 CR_D uint32_t lookup_bits(const uint32_t* __restrict__ words, int R, int TB, int per_word_log2, int bits,
@@ -532,90 +582,6 @@ CR_D int sw_traceback(const uint32_t* __restrict__ w, int R, int TB, int i, int 
     return idx;
 }
 
-// sequential column means of gathered coordinates (helper.py:46-53 under numba: sum, then / k)
-CR_D void gathered_means(const double* __restrict__ X, const int32_t* __restrict__ pos, int stride, int first,
-                         int step, int k, double* c) {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int x = 0, p = first; x < k; x++, p += step) {
-        const double* v = X + (int64_t)pos[(int64_t)p * stride] * 3;
-        s0 += v[0];
-        s1 += v[1];
-        s2 += v[2];
-    }
-    c[0] = s0 / (double)k;
-    c[1] = s1 / (double)k;
-    c[2] = s2 / (double)k;
-}
-
-// Stage 2: SW traceback on the stored decisions, common positions, seed Kabsch
-// (dynamic_time_warping.py:249-278, helper.py:13-42, superposition_functions.py:39-60).
-// One lane per pair.  Positions are written back-to-front while walking and consumed front-to-back
-// so that every sum runs in the reference's order.
-__global__ void k_seed_trace(const PairDesc* __restrict__ pairs, int npairs, int R,
-                             const double* __restrict__ coords, const uint32_t* __restrict__ dirs,
-                             const SeedMax* __restrict__ seed, int32_t* __restrict__ pos,
-                             Transform* __restrict__ xf, double* __restrict__ seed_score) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= npairs) return;
-    const PairDesc pd = pairs[p];
-    const SeedMax sm = seed[p];
-    Transform tr;
-    for (int x = 0; x < 3; x++) tr.c1[x] = tr.c2[x] = 0.0;
-    for (int x = 0; x < 9; x++) tr.R[x] = (x % 4 == 0) ? 1.0 : 0.0;
-    tr.flags = 0;
-    tr.seed_len = 0;
-    seed_score[p] = sm.score;
-    const int cap = pd.n < pd.m ? pd.n : pd.m;
-    int32_t* pp = pos + pd.pos_off * 2;          // pairs (i, j) interleaved
-    int k = 0, len = 0;
-    if (sm.i == 0) {
-        tr.flags |= kFlagSeedAllZero;
-    } else {
-        const uint32_t* w = dirs + pd.dirs_off;
-        const int TB = tblocks(pd.m, 16);
-        int i = sm.i, j = sm.j;
-        while (i > 0 && j > 0) {
-            const uint32_t code = lookup_bits(w, R, TB, 4, 2, i - 1, j - 1);
-            if (code == 0) break;
-            if (code == 1) {
-                i--; j--;
-                k++;
-                pp[2 * (cap - k)] = i;
-                pp[2 * (cap - k) + 1] = j;
-            } else if (code == 2) {
-                j--;
-            } else {
-                i--;
-            }
-            len++;
-        }
-    }
-    tr.seed_len = len;
-    if (k <= 3) {
-        tr.flags |= kFlagSeedSkipped;
-    } else {
-        const double* Xi = coords + pd.off_i * 3;
-        const double* Xj = coords + pd.off_j * 3;
-        const int first = cap - k;
-        gathered_means(Xi, pp, 2, first, 1, k, tr.c1);
-        gathered_means(Xj, pp + 1, 2, first, 1, k, tr.c2);
-        double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int x = 0; x < k; x++) {
-            const double* v1 = Xi + (int64_t)pp[2 * (first + x)] * 3;
-            const double* v2 = Xj + (int64_t)pp[2 * (first + x) + 1] * 3;
-            const double a[3] = {v2[0] - tr.c2[0], v2[1] - tr.c2[1], v2[2] - tr.c2[2]};
-            const double b[3] = {v1[0] - tr.c1[0], v1[1] - tr.c1[1], v1[2] - tr.c1[2]};
-#pragma unroll
-            for (int r = 0; r < 3; r++)
-#pragma unroll
-                for (int c = 0; c < 3; c++) C[3 * r + c] += a[r] * b[c];
-        }
-        double t[3];
-        kabsch_from_correlation(C, tr.c1, tr.c2, tr.R, t);
-    }
-    xf[p] = tr;
-}
-
 struct PairResult {          // per-pair scalar outputs, device and host layout
     double sw, dtw_score;
     double R[9], t[3];
@@ -626,100 +592,352 @@ struct PairResult {          // per-pair scalar outputs, device and host layout
     uint32_t flags;
 };
 
+// ---------------------------------------------------------------------------------------------
+// Traceback + superposition stages.  ONE WAVE PER PAIR.
+//
+// The walk is a single logical thread, so it is written wave-uniform (every lane carries the same
+// state; the compiler keeps it in SGPRs) and never touches HBM directly: the packed decisions of
+// the current strip are streamed back through an LDS window of kWinBlocks word-blocks with 256-byte
+// coalesced loads issued by all 64 lanes, newest time step first, and the walk reads its 2/4 bits
+// from LDS.  The aligned positions are then gathered 64 at a time by all lanes, per-position terms
+// are computed in parallel, and the sums are taken by one lane per accumulator IN POSITION ORDER out
+// of LDS, so every sum has the reference's (numba's) sequential rounding.
+// ---------------------------------------------------------------------------------------------
+constexpr int kWinBlocks = 8;           // word-blocks (of 16 SW steps / 8 DTW steps) per LDS window
+constexpr int kMaxAcc = 9;              // accumulators summed in order (3x3 correlation matrix)
+
+// lane -> (strip, lane-in-strip, row slot) bookkeeping of a DP row, updated incrementally
+struct RowPos {
+    int s, l, q;
+    CR_D void set(int row, int R) {
+        s = row / (kWave * R);
+        const int rem = row - s * kWave * R;
+        l = rem / R;
+        q = rem - l * R;
+    }
+    CR_D void up(int R) {              // row -> row - 1
+        if (q > 0) {
+            q--;
+        } else {
+            q = R - 1;
+            if (l > 0) {
+                l--;
+            } else {
+                l = kWave - 1;
+                s--;
+            }
+        }
+    }
+};
+
+// LDS window over the packed decisions of one strip: word-blocks [hi - kWinBlocks + 1, hi]
+struct BitWindow {
+    uint32_t* win;        // LDS, kWinBlocks * R * 64 words
+    int s, hi;            // strip and newest word-block held; hi < 0: empty
+    CR_D void load(const uint32_t* __restrict__ words, int R, int TB, int strip, int tb_hi, int lane) {
+        __syncthreads();
+        for (int w = 0; w < kWinBlocks; w++) {
+            const int tb = tb_hi - w;
+            if (tb < 0) break;
+            for (int q = 0; q < R; q++)
+                win[(w * R + q) * kWave + lane] = words[((int64_t)(strip * TB + tb) * R + q) * kWave + lane];
+        }
+        s = strip;
+        hi = tb_hi;
+        __syncthreads();
+    }
+    CR_D bool holds(int strip, int tb) const { return strip == s && tb <= hi && tb > hi - kWinBlocks; }
+    CR_D uint32_t word(int R, int tb, int q, int l) const {
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)win[((hi - tb) * R + q) * kWave + l]);
+    }
+};
+
+// Sum `count` per-position term vectors in position order.  term(e, out[NACC]) is evaluated by the
+// lane that owns position e; lane a < NACC returns sum_e term(e)[a] accumulated e = 0, 1, 2, ...
+// (exactly the rounding sequence of a sequential loop).  `scratch` = 64 * NACC doubles of LDS.
+template <int NACC, class TermFn>
+CR_D double ordered_sums(int count, int lane, double* scratch, TermFn term) {
+    double acc = 0.0;
+    for (int base = 0; base < count; base += kWave) {
+        const int e = base + lane;
+        if (e < count) {
+            double tv[NACC];
+            term(e, tv);
+#pragma unroll
+            for (int a = 0; a < NACC; a++) scratch[lane * NACC + a] = tv[a];
+        }
+        __syncthreads();
+        const int cnt = count - base < kWave ? count - base : kWave;
+        if (lane < NACC) {
+#pragma unroll 8
+            for (int x = 0; x < cnt; x++) acc += scratch[x * NACC + lane];
+        }
+        __syncthreads();
+    }
+    return acc;
+}
+
+CR_D double lane_value(double v, int src_lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), src_lane));
+}
+
+// Kabsch on `k` paired positions (superposition_functions.py:7-35) with every sum in position order.
+// pos = interleaved (i, j) int32 pairs.  Results (c1, c2, R, t) are returned in all lanes.
+CR_D void kabsch_ordered(const double* __restrict__ Xi, const double* __restrict__ Xj,
+                         const int32_t* __restrict__ pos, int k, int lane, double* scratch,
+                         double* c1, double* c2, double* R, double* t) {
+    // column means (helper.py:46-53): lanes 0-2 sum X_i columns, lanes 3-5 X_j columns
+    const double msum = ordered_sums<6>(k, lane, scratch, [&](int e, double* out) {
+        const double* v1 = Xi + (int64_t)pos[2 * e] * 3;
+        const double* v2 = Xj + (int64_t)pos[2 * e + 1] * 3;
+        out[0] = v1[0]; out[1] = v1[1]; out[2] = v1[2];
+        out[3] = v2[0]; out[4] = v2[1]; out[5] = v2[2];
+    });
+    const double mean = msum / (double)k;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        c1[a] = lane_value(mean, a);
+        c2[a] = lane_value(mean, 3 + a);
+    }
+    // correlation matrix C = (X_j - c2)^T (X_i - c1)  (superposition_functions.py:26-27)
+    const double csum = ordered_sums<9>(k, lane, scratch, [&](int e, double* out) {
+        const double* v1 = Xi + (int64_t)pos[2 * e] * 3;
+        const double* v2 = Xj + (int64_t)pos[2 * e + 1] * 3;
+        const double a[3] = {v2[0] - c2[0], v2[1] - c2[1], v2[2] - c2[2]};
+        const double b[3] = {v1[0] - c1[0], v1[1] - c1[1], v1[2] - c1[2]};
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) out[3 * r + c] = a[r] * b[c];
+    });
+    double C[9];
+#pragma unroll
+    for (int a = 0; a < 9; a++) C[a] = lane_value(csum, a);
+    kabsch_from_correlation(C, c1, c2, R, t);     // every lane computes the same 3x3 SVD
+}
+
+// Stage 2: SW traceback on the stored decisions, common positions, seed Kabsch
+// (dynamic_time_warping.py:249-278, helper.py:13-42, superposition_functions.py:39-60).
+// LDS: window (kWinBlocks*R*64 words) | 64*kMaxAcc doubles.
+__global__ __launch_bounds__(kWave) void k_seed_trace(const PairDesc* __restrict__ pairs, int R,
+                                                     const double* __restrict__ coords,
+                                                     const uint32_t* __restrict__ dirs,
+                                                     const SeedMax* __restrict__ seed, int32_t* __restrict__ pos,
+                                                     Transform* __restrict__ xf, double* __restrict__ seed_score) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int p = blockIdx.x;
+    const PairDesc pd = pairs[p];
+    const SeedMax sm = seed[p];
+    double* scratch = lds;
+    BitWindow bw;
+    bw.win = reinterpret_cast<uint32_t*>(lds + kWave * kMaxAcc);
+    bw.s = -1;
+    bw.hi = -1;
+    const int cap = pd.n < pd.m ? pd.n : pd.m;
+    int32_t* pp = pos + pd.pos_off * 2;          // (i, j) pairs, filled back-to-front
+    uint32_t flags = 0;
+    int k = 0, len = 0;
+    if (sm.i == 0) {
+        flags |= kFlagSeedAllZero;
+    } else {
+        const uint32_t* w = dirs + pd.dirs_off;
+        const int TB = tblocks(pd.m, 16);
+        int i = sm.i, j = sm.j;
+        RowPos rp;
+        rp.set(i - 1, R);
+        while (i > 0 && j > 0) {
+            const int t = (j - 1) + rp.l;
+            const int tb = t >> 4;
+            if (!bw.holds(rp.s, tb)) bw.load(w, R, TB, rp.s, tb, lane);
+            const uint32_t code = (bw.word(R, tb, rp.q, rp.l) >> ((t & 15) * 2)) & 3u;
+            if (code == 0) break;
+            if (code == 1) {
+                i--; j--;
+                rp.up(R);
+                k++;
+                if (lane == 0) {
+                    pp[2 * (cap - k)] = i;
+                    pp[2 * (cap - k) + 1] = j;
+                }
+            } else if (code == 2) {
+                j--;
+            } else {
+                i--;
+                rp.up(R);
+            }
+            len++;
+        }
+    }
+    __syncthreads();
+    Transform tr;
+#pragma unroll
+    for (int x = 0; x < 3; x++) tr.c1[x] = tr.c2[x] = 0.0;
+#pragma unroll
+    for (int x = 0; x < 9; x++) tr.R[x] = (x % 4 == 0) ? 1.0 : 0.0;
+    if (k <= 3) {
+        flags |= kFlagSeedSkipped;
+    } else {
+        double t[3];
+        kabsch_ordered(coords + pd.off_i * 3, coords + pd.off_j * 3, pp + 2 * (cap - k), k, lane, scratch,
+                       tr.c1, tr.c2, tr.R, t);
+    }
+    tr.flags = flags;
+    tr.seed_len = len;
+    if (lane == 0) {
+        xf[p] = tr;
+        seed_score[p] = sm.score;
+    }
+}
+
 // Stage 4: DTW traceback (dynamic_time_warping.py:90-144), common positions, Kabsch on the
 // original coordinates, RMSD / coverage / TM (multiple_alignment.py:1033-1054, :59-70).
-// One lane per pair.  Alignment rows are written back-to-front into [aln_off, aln_off + n + m).
-__global__ void k_align_trace(const PairDesc* __restrict__ pairs, int npairs, int R,
-                              const double* __restrict__ coords, const uint32_t* __restrict__ bits,
-                              const AlignEnd* __restrict__ ends, const Transform* __restrict__ xf,
-                              const double* __restrict__ seed_score, int32_t* __restrict__ aln,
-                              PairResult* __restrict__ res) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= npairs) return;
+// Alignment rows are written back-to-front into [aln_off, aln_off + n + m).
+__global__ __launch_bounds__(kWave) void k_align_trace(const PairDesc* __restrict__ pairs, int R,
+                                                      const double* __restrict__ coords,
+                                                      const uint32_t* __restrict__ bits,
+                                                      const AlignEnd* __restrict__ ends,
+                                                      const Transform* __restrict__ xf,
+                                                      const double* __restrict__ seed_score,
+                                                      int32_t* __restrict__ aln, int32_t* __restrict__ pos,
+                                                      PairResult* __restrict__ res) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int p = blockIdx.x;
     const PairDesc pd = pairs[p];
     const AlignEnd e = ends[p];
+    double* scratch = lds;
+    BitWindow bw;
+    bw.win = reinterpret_cast<uint32_t*>(lds + kWave * kMaxAcc);
+    bw.s = -1;
+    bw.hi = -1;
+    const int cap = pd.n + pd.m;
+    const int pcap = pd.n < pd.m ? pd.n : pd.m;
+    int32_t* a1 = aln + pd.aln_off;
+    int32_t* a2 = a1 + cap;
+    int32_t* pp = pos + pd.pos_off * 2;
+    const uint32_t* w = bits + pd.bt_off;
+    const int TB = tblocks(pd.m, 8);
+    int n = pd.n, m = pd.m, dir = e.start_layer, idx = 0, k = 0;
+    RowPos rp;
+    rp.set(n - 1, R);
+    int guard = 3 * cap + 8;
+    while (!(n == 0 && m == 0) && guard-- > 0) {
+        int o1, o2;                                // emitted entry, or (-2, -2) for none
+        if (m == 0) {
+            n--;
+            o1 = n; o2 = -1;
+        } else if (n == 0) {
+            m--;
+            o1 = -1; o2 = m;
+        } else {
+            const int t = (m - 1) + rp.l;
+            const int tb = t >> 3;
+            if (!bw.holds(rp.s, tb)) bw.load(w, R, TB, rp.s, tb, lane);
+            const uint32_t nib = (bw.word(R, tb, rp.q, rp.l) >> ((t & 7) * 4)) & 15u;
+            if (dir == 0) {
+                dir = nib & 1u;
+                n--;
+                rp.up(R);
+                o1 = n; o2 = -1;
+            } else if (dir == 1) {
+                dir = (nib >> 1) & 3u;
+                if (dir == 1) {
+                    n--; m--;
+                    rp.up(R);
+                    o1 = n; o2 = m;
+                    k++;
+                    if (lane == 0) {
+                        pp[2 * (pcap - k)] = n;
+                        pp[2 * (pcap - k) + 1] = m;
+                    }
+                } else {
+                    o1 = -2; o2 = -2;
+                }
+            } else {
+                dir = ((nib >> 3) & 1u) + 1;
+                m--;
+                o1 = -1; o2 = m;
+            }
+        }
+        if (o1 != -2) {
+            idx++;
+            if (lane == 0) {
+                a1[cap - idx] = o1;
+                a2[cap - idx] = o2;
+            }
+        }
+    }
+    __syncthreads();
     PairResult r;
     r.sw = e.sw;
     r.dtw_score = e.dtw_score;
+#pragma unroll
     for (int x = 0; x < 9; x++) r.R[x] = 0.0;
+#pragma unroll
     for (int x = 0; x < 3; x++) r.t[x] = 0.0;
     r.rmsd = r.coverage = r.tm = 0.0;
     r.seed_score = seed_score[p];
     r.seed_len = xf[p].seed_len;
     r.flags = xf[p].flags;
-    const int cap = pd.n + pd.m;
-    int32_t* a1 = aln + pd.aln_off;
-    int32_t* a2 = a1 + cap;
-    const uint32_t* w = bits + pd.bt_off;
-    const int TB = tblocks(pd.m, 8);
-    const int idx = dtw_traceback(w, R, TB, pd.n, pd.m, e.start_layer, a1, a2, cap);
-    const int len = idx, first = cap - idx;
-    r.aln_len = len;
-    r.aln_start = first;
-    // common positions in alignment order (helper.py:13-42)
-    int k = 0;
-    for (int x = first; x < cap; x++) k += (a1[x] != -1 && a2[x] != -1) ? 1 : 0;
+    r.aln_len = idx;
+    r.aln_start = cap - idx;
     if (k < 3) {
         r.flags |= kFlagMetricsSkipped;
     } else {
         const double* Xi = coords + pd.off_i * 3;
         const double* Xj = coords + pd.off_j * 3;
-        double s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0};
-        for (int x = first; x < cap; x++) {
-            const int i = a1[x], j = a2[x];
-            if (i != -1 && j != -1) {
-                const double* v1 = Xi + (int64_t)i * 3;
-                const double* v2 = Xj + (int64_t)j * 3;
-                s1[0] += v1[0]; s1[1] += v1[1]; s1[2] += v1[2];
-                s2[0] += v2[0]; s2[1] += v2[1]; s2[2] += v2[2];
-            }
-        }
+        const int32_t* cp = pp + 2 * (pcap - k);
         double c1[3], c2[3];
-        for (int x = 0; x < 3; x++) { c1[x] = s1[x] / (double)k; c2[x] = s2[x] / (double)k; }
-        double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int x = first; x < cap; x++) {
-            const int i = a1[x], j = a2[x];
-            if (i != -1 && j != -1) {
-                const double* v1 = Xi + (int64_t)i * 3;
-                const double* v2 = Xj + (int64_t)j * 3;
-                const double a[3] = {v2[0] - c2[0], v2[1] - c2[1], v2[2] - c2[2]};
-                const double b[3] = {v1[0] - c1[0], v1[1] - c1[1], v1[2] - c1[2]};
-#pragma unroll
-                for (int rr = 0; rr < 3; rr++)
-#pragma unroll
-                    for (int cc = 0; cc < 3; cc++) C[3 * rr + cc] += a[rr] * b[cc];
-            }
-        }
-        kabsch_from_correlation(C, c1, c2, r.R, r.t);
-        // get_rmsd (score_functions.py:15-19) and tm_score (multiple_alignment.py:59-70)
+        kabsch_ordered(Xi, Xj, cp, k, lane, scratch, c1, c2, r.R, r.t);
+        // get_rmsd (score_functions.py:15-19) and tm_score (multiple_alignment.py:59-70):
+        // lane 0 sums the squared differences (three per position, in order), lanes 1/2 the two TM sums
         const double d1 = 1.24 * (double)(pd.n - 15) / 3.0 - 1.8;
         const double d2 = 1.24 * (double)(pd.m - 15) / 3.0 - 1.8;
-        double ss = 0.0, sum1 = 0.0, sum2 = 0.0;
-        for (int x = first; x < cap; x++) {
-            const int i = a1[x], j = a2[x];
-            if (i != -1 && j != -1) {
-                const double* v1 = Xi + (int64_t)i * 3;
-                const double* v2 = Xj + (int64_t)j * 3;
+        double acc = 0.0;
+        for (int base = 0; base < k; base += kWave) {
+            const int x = base + lane;
+            if (x < k) {
+                const double* v1 = Xi + (int64_t)cp[2 * x] * 3;
+                const double* v2 = Xj + (int64_t)cp[2 * x + 1] * 3;
                 double mv[3];
                 rot3(v2, r.R, mv);
-                mv[0] += r.t[0]; mv[1] += r.t[1]; mv[2] += r.t[2];
-                const double e0 = v1[0] - mv[0], e1 = v1[1] - mv[1], e2 = v1[2] - mv[2];
-                ss += e0 * e0;
-                ss += e1 * e1;
-                ss += e2 * e2;
+                const double e0 = v1[0] - (mv[0] + r.t[0]), e1 = v1[1] - (mv[1] + r.t[1]), e2 = v1[2] - (mv[2] + r.t[2]);
                 const double sg = (e0 + e1) + e2;
                 const double q1 = sg / d1, q2 = sg / d2;
-                sum1 += 1.0 / (1.0 + q1 * q1);
-                sum2 += 1.0 / (1.0 + q2 * q2);
+                scratch[lane * 5 + 0] = e0 * e0;
+                scratch[lane * 5 + 1] = e1 * e1;
+                scratch[lane * 5 + 2] = e2 * e2;
+                scratch[lane * 5 + 3] = 1.0 / (1.0 + q1 * q1);
+                scratch[lane * 5 + 4] = 1.0 / (1.0 + q2 * q2);
             }
+            __syncthreads();
+            const int cnt = k - base < kWave ? k - base : kWave;
+            if (lane == 0) {
+                for (int y = 0; y < cnt; y++) {
+                    acc += scratch[y * 5 + 0];
+                    acc += scratch[y * 5 + 1];
+                    acc += scratch[y * 5 + 2];
+                }
+            } else if (lane < 3) {
+#pragma unroll 8
+                for (int y = 0; y < cnt; y++) acc += scratch[y * 5 + 2 + lane];
+            }
+            __syncthreads();
         }
+        const double ss = lane_value(acc, 0), sum1 = lane_value(acc, 1), sum2 = lane_value(acc, 2);
         r.rmsd = sqrt(ss / (double)k);
-        r.coverage = (double)k / (double)len;
+        r.coverage = (double)k / (double)idx;
         const double t1 = (1.0 / (double)pd.n) * sum1;
         const double t2 = (1.0 / (double)pd.m) * sum2;
         r.tm = t1 > t2 ? t1 : t2;
     }
-    res[p] = r;
+    if (lane == 0) res[p] = r;
+}
+
+inline size_t trace_lds_bytes(int R) {
+    return sizeof(double) * kWave * kMaxAcc + sizeof(uint32_t) * kWinBlocks * R * kWave;
 }
 
 }  // namespace cr

@@ -46,6 +46,10 @@ static __device__ const ExpEntry kExpTable[16] = {
 };
 
 // `tab` points at a copy of kExpTable in LDS (16-byte aligned).
+// NONPOS: the caller guarantees x <= 0 (RBF with gamma >= 0), so the overflow clamp is dropped.
+// The final scaling y * 2^e is one v_ldexp_f64; it rounds once into the subnormal range, which is
+// bit-identical to the oracle's two exact-then-rounded power-of-two multiplies.
+template <bool NONPOS>
 CR_D double exp_tab(double x, const ExpEntry* tab) {
     const double INV_LN2_16 = 0x1.71547652b82fep+4;
     const double LN2_16_HI = 0x1.62e42fefa39efp-5;
@@ -53,15 +57,13 @@ CR_D double exp_tab(double x, const ExpEntry* tab) {
     const double SHIFT = 0x1.8p52;
     const double C2 = 0x1.0000000000000p-1, C3 = 0x1.5555555555555p-3, C4 = 0x1.5555555555555p-5;
     const double C5 = 0x1.1111111111111p-7, C6 = 0x1.6c16c16c16c17p-10, C7 = 0x1.a01a01a01a01ap-13;
-    x = x > 710.0 ? 710.0 : x;
-    x = x < -746.0 ? -746.0 : x;
+    if constexpr (!NONPOS) x = __builtin_fmin(x, 710.0);   // -> +inf through the scaling below
+    x = __builtin_fmax(x, -746.0);                         // -> 0
     double z = __builtin_fma(x, INV_LN2_16, SHIFT);
     int ki = __double2loint(z);
     double kd = z - SHIFT;
     double r = __builtin_fma(kd, -LN2_16_HI, x);
     r = __builtin_fma(kd, -LN2_16_LO, r);
-    int j = ki & 15;
-    int e = ki >> 4;
     double r2 = r * r;
     double q = __builtin_fma(r, C7, C6);
     q = __builtin_fma(r, q, C5);
@@ -69,13 +71,9 @@ CR_D double exp_tab(double x, const ExpEntry* tab) {
     q = __builtin_fma(r, q, C3);
     q = __builtin_fma(r, q, C2);
     double p = __builtin_fma(r2, q, r);
-    ExpEntry t = tab[j];
+    ExpEntry t = tab[ki & 15];
     double y = t.hi + __builtin_fma(t.hi, p, t.lo);
-    int e1 = e >> 1;
-    int e2 = e - e1;
-    double s1 = __hiloint2double((e1 + 1023) << 20, 0);
-    double s2 = __hiloint2double((e2 + 1023) << 20, 0);
-    return (y * s1) * s2;
+    return __builtin_ldexp(y, ki >> 4);
 }
 
 // ---------------------------------------------------------------------------------------------

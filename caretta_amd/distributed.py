@@ -33,9 +33,9 @@ def gather_scores(local_scores, world: int, group=None):
     import torch.distributed as dist
     if world == 1:
         return local_scores.unsqueeze(0)
-    out = torch.empty((world, local_scores.numel()), dtype=local_scores.dtype, device=local_scores.device)
+    out = torch.empty(world * local_scores.numel(), dtype=local_scores.dtype, device=local_scores.device)
     dist.all_gather_into_tensor(out, local_scores.contiguous(), group=group)
-    return out
+    return out.view(world, local_scores.numel())
 
 
 def scatter_to_matrix(gathered: np.ndarray, pairs: np.ndarray, lengths: np.ndarray, num: int) -> np.ndarray:

@@ -105,8 +105,8 @@ double cro_exp(double x) {
     const double SHIFT = 0x1.8p52;
     const double C2 = 0x1.0000000000000p-1, C3 = 0x1.5555555555555p-3, C4 = 0x1.5555555555555p-5;
     const double C5 = 0x1.1111111111111p-7, C6 = 0x1.6c16c16c16c17p-10, C7 = 0x1.a01a01a01a01ap-13;
-    if (x > 710.0) x = 710.0;      /* -> +inf through the scaling below */
-    if (x < -746.0) x = -746.0;    /* -> 0 */
+    x = (x < 710.0) ? x : 710.0;      /* minNum: -> +inf through the scaling below (NaN too) */
+    x = (x > -746.0) ? x : -746.0;    /* -> 0 */
     double z = fma(x, INV_LN2_16, SHIFT);
     uint64_t zb;
     memcpy(&zb, &z, 8);

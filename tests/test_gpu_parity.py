@@ -52,6 +52,8 @@ def test_exp_bit_identical_to_oracle(oracle):
         s = sf.make_score_matrix(a, b, sf.get_gaussian_score, gamma)
         assert np.array_equal(s, oracle.make_score_matrix(a, b, gamma))
     assert sf.get_gaussian_score(np.zeros(3), np.zeros(3)) == 1.0
+    with pytest.raises(ValueError):
+        sf.make_score_matrix(np.array([[np.nan, 0.0, 0.0]]), np.zeros((2, 3)), sf.get_gaussian_score, 0.03)
 
 
 def test_make_score_matrix_golden(oracle, golden):
