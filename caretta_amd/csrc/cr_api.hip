@@ -86,7 +86,7 @@ struct cr_batch {
     std::vector<cr::PairDesc> h_pairs;
     DevBuf<cr::PairDesc> pairs;
     DevBuf<uint32_t> dirs, bits;
-    DevBuf<int32_t> pos, aln;
+    DevBuf<int32_t> aln;
     DevBuf<cr::SeedMax> seed;
     DevBuf<cr::Transform> xf;
     DevBuf<cr::AlignEnd> ends;
@@ -279,7 +279,7 @@ int cr_batch_create(cr_context* ctx, const double* coords, const double* tensors
     CR_REQUIRE(offsets[0] == 0, "offsets[0] must be 0");
     for (int64_t s = 0; s < num_structures; s++) {
         CR_REQUIRE(offsets[s + 1] > offsets[s], "every structure needs at least one residue");
-        CR_REQUIRE(offsets[s + 1] - offsets[s] < (1 << 24), "structure too long");
+        CR_REQUIRE(offsets[s + 1] - offsets[s] <= cr::kMaxLength, "structure longer than 65534 residues");
     }
     CR_REQUIRE(all_finite(coords, (size_t)offsets[num_structures] * 3), "coordinates contain NaN or infinity");
     CR_REQUIRE(all_finite(tensors, (size_t)offsets[num_structures] * (size_t)d), "tensors contain NaN or infinity");
@@ -355,7 +355,6 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     hipError_t e = b->pairs.ensure((size_t)npairs);
     if (e == hipSuccess) e = b->dirs.ensure((size_t)dirs_off);
     if (e == hipSuccess) e = b->bits.ensure((size_t)bt_off);
-    if (e == hipSuccess) e = b->pos.ensure((size_t)pos_off * 2);
     if (e == hipSuccess) e = b->aln.ensure((size_t)aln_off);
     if (e == hipSuccess) e = b->seed.ensure((size_t)npairs);
     if (e == hipSuccess) e = b->xf.ensure((size_t)npairs);
@@ -389,20 +388,27 @@ int cr_batch_run(cr_batch* b, const cr_params* params, double* d_sw_out) {
                "gap penalties must be finite");
     const bool prof = ctx->slots > 0;
     hipEvent_t* ev = prof ? &ctx->ev[(size_t)(ctx->runs_recorded % ctx->slots) * (CR_NUM_STAGES + 1)] : nullptr;
-    const size_t trace_lds = cr::trace_lds_bytes(std::max(b->r_seed, b->r_align));
+    const int seed_entries = std::min(b->n_max, b->m_max), aln_entries = (int)b->max_aln;
+    const size_t seed_lds = cr::trace_lds_bytes(b->r_seed, seed_entries);
+    const size_t trace_lds = cr::trace_lds_bytes(b->r_align, aln_entries);
+    if ((rc = allow_lds(cr::k_seed_trace, seed_lds))) return rc;
+    if ((rc = allow_lds(cr::k_align_trace, trace_lds))) return rc;
     if (prof) CR_HIP(hipEventRecord(ev[0], ctx->stream));
     rc = (b->r_seed == 3) ? launch_seed_d<3>(b, prm) : launch_seed_d<5>(b, prm);
     if (rc) return rc;
     if (prof) CR_HIP(hipEventRecord(ev[1], ctx->stream));
-    hipLaunchKernelGGL(cr::k_seed_trace, dim3((unsigned)b->npairs), dim3(cr::kWave), trace_lds, ctx->stream, b->pairs.p,
-                       b->r_seed, b->coords.p, b->dirs.p, b->seed.p, b->pos.p, b->xf.p, b->seed_score.p);
+
+    hipLaunchKernelGGL(cr::k_seed_trace, dim3((unsigned)b->npairs), dim3(cr::kWave), seed_lds, ctx->stream, b->pairs.p,
+                       b->r_seed, seed_entries, b->coords.p, b->dirs.p, b->seed.p, b->xf.p, b->seed_score.p);
     CR_HIP(hipGetLastError());
     if (prof) CR_HIP(hipEventRecord(ev[2], ctx->stream));
+
     rc = (b->r_align == 3) ? launch_align<3>(b, prm) : launch_align<5>(b, prm);
     if (rc) return rc;
     if (prof) CR_HIP(hipEventRecord(ev[3], ctx->stream));
+
     hipLaunchKernelGGL(cr::k_align_trace, dim3((unsigned)b->npairs), dim3(cr::kWave), trace_lds, ctx->stream, b->pairs.p,
-                       b->r_align, b->coords.p, b->bits.p, b->ends.p, b->xf.p, b->seed_score.p, b->aln.p, b->pos.p,
+                       b->r_align, aln_entries, b->coords.p, b->bits.p, b->ends.p, b->xf.p, b->seed_score.p, b->aln.p,
                        b->res.p);
     CR_HIP(hipGetLastError());
     if (prof) CR_HIP(hipEventRecord(ev[4], ctx->stream));

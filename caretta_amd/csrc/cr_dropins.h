@@ -292,8 +292,14 @@ int cr_protein_score_function(cr_context* ctx, const double* coords_i, const dou
         rc = (b->r_seed == 3) ? launch_seed_d<3>(b, prm) : launch_seed_d<5>(b, prm);
     }
     if (rc == CR_OK) {
-        hipLaunchKernelGGL(cr::k_seed_trace, dim3(1), dim3(cr::kWave), cr::trace_lds_bytes(b->r_seed), ctx->stream,
-                           b->pairs.p, b->r_seed, b->coords.p, b->dirs.p, b->seed.p, b->pos.p, b->xf.p, b->seed_score.p);
+        const int seed_entries = (int)std::min(n, m);
+        const size_t seed_lds = cr::trace_lds_bytes(b->r_seed, seed_entries);
+        rc = allow_lds(cr::k_seed_trace, seed_lds);
+        if (rc == CR_OK)
+            hipLaunchKernelGGL(cr::k_seed_trace, dim3(1), dim3(cr::kWave), seed_lds, ctx->stream, b->pairs.p, b->r_seed,
+                               seed_entries, b->coords.p, b->dirs.p, b->seed.p, b->xf.p, b->seed_score.p);
+    }
+    if (rc == CR_OK) {
         DevBuf<double> ds;
         hipError_t e = ds.ensure((size_t)n * m);
         if (e == hipSuccess) {

@@ -599,12 +599,19 @@ struct PairResult {          // per-pair scalar outputs, device and host layout
 // state; the compiler keeps it in SGPRs) and never touches HBM directly: the packed decisions of
 // the current strip are streamed back through an LDS window of kWinBlocks word-blocks with 256-byte
 // coalesced loads issued by all 64 lanes, newest time step first, and the walk reads its 2/4 bits
-// from LDS.  The aligned positions are then gathered 64 at a time by all lanes, per-position terms
-// are computed in parallel, and the sums are taken by one lane per accumulator IN POSITION ORDER out
-// of LDS, so every sum has the reference's (numba's) sequential rounding.
+// from LDS.  Emitted alignment columns go to LDS as packed (i, j) 16-bit pairs and are written to
+// HBM at the end with coalesced stores.  The aligned positions are then gathered 64 at a time by
+// all lanes, per-position terms are computed in parallel, and the sums are taken by one lane per
+// accumulator IN POSITION ORDER out of LDS, so every sum has the reference's (numba's) sequential
+// rounding.  Gap columns contribute +0.0 terms, which never change a running sum that started at
+// +0.0 (such a sum can not be -0.0).
 // ---------------------------------------------------------------------------------------------
 constexpr int kWinBlocks = 8;           // word-blocks (of 16 SW steps / 8 DTW steps) per LDS window
 constexpr int kMaxAcc = 9;              // accumulators summed in order (3x3 correlation matrix)
+constexpr uint32_t kGap16 = 0xffffu;    // -1 in a packed 16-bit alignment entry
+constexpr int kMaxLength = 65534;       // longest structure the packed entries can index
+
+CR_D uint32_t pack_entry(int i, int j) { return ((uint32_t)i & 0xffffu) | ((uint32_t)j << 16); }
 
 // lane -> (strip, lane-in-strip, row slot) bookkeeping of a DP row, updated incrementally
 struct RowPos {
@@ -630,25 +637,26 @@ struct RowPos {
     }
 };
 
-// LDS window over the packed decisions of one strip: word-blocks [hi - kWinBlocks + 1, hi]
+// LDS window over the packed decisions of one strip: word-blocks [lo, hi], a contiguous range of
+// the strip's words, copied with coalesced loads that are all in flight together.
 struct BitWindow {
     uint32_t* win;        // LDS, kWinBlocks * R * 64 words
-    int s, hi;            // strip and newest word-block held; hi < 0: empty
+    int s, lo, hi;        // strip and word-block range held; hi < lo: empty
     CR_D void load(const uint32_t* __restrict__ words, int R, int TB, int strip, int tb_hi, int lane) {
         __syncthreads();
-        for (int w = 0; w < kWinBlocks; w++) {
-            const int tb = tb_hi - w;
-            if (tb < 0) break;
-            for (int q = 0; q < R; q++)
-                win[(w * R + q) * kWave + lane] = words[((int64_t)(strip * TB + tb) * R + q) * kWave + lane];
-        }
+        const int tb_lo = tb_hi - (kWinBlocks - 1) > 0 ? tb_hi - (kWinBlocks - 1) : 0;
+        const uint32_t* src = words + ((int64_t)(strip * TB + tb_lo) * R) * kWave;
+        const int total = (tb_hi - tb_lo + 1) * R * kWave;
+#pragma unroll 8
+        for (int x = lane; x < total; x += kWave) win[x] = src[x];
         s = strip;
+        lo = tb_lo;
         hi = tb_hi;
         __syncthreads();
     }
-    CR_D bool holds(int strip, int tb) const { return strip == s && tb <= hi && tb > hi - kWinBlocks; }
+    CR_D bool holds(int strip, int tb) const { return strip == s && tb >= lo && tb <= hi; }
     CR_D uint32_t word(int R, int tb, int q, int l) const {
-        return (uint32_t)__builtin_amdgcn_readfirstlane((int)win[((hi - tb) * R + q) * kWave + l]);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)win[((tb - lo) * R + q) * kWave + l]);
     }
 };
 
@@ -682,17 +690,22 @@ CR_D double lane_value(double v, int src_lane) {
                             __builtin_amdgcn_readlane(__double2loint(v), src_lane));
 }
 
-// Kabsch on `k` paired positions (superposition_functions.py:7-35) with every sum in position order.
-// pos = interleaved (i, j) int32 pairs.  Results (c1, c2, R, t) are returned in all lanes.
-CR_D void kabsch_ordered(const double* __restrict__ Xi, const double* __restrict__ Xj,
-                         const int32_t* __restrict__ pos, int k, int lane, double* scratch,
-                         double* c1, double* c2, double* R, double* t) {
+// Kabsch over `count` packed alignment entries of which `k` are aligned pairs
+// (superposition_functions.py:7-35), every sum in position order.  Results in all lanes.
+CR_D void kabsch_ordered(const double* __restrict__ Xi, const double* __restrict__ Xj, const uint32_t* entries,
+                         int count, int k, int lane, double* scratch, double* c1, double* c2, double* R, double* t) {
     // column means (helper.py:46-53): lanes 0-2 sum X_i columns, lanes 3-5 X_j columns
-    const double msum = ordered_sums<6>(k, lane, scratch, [&](int e, double* out) {
-        const double* v1 = Xi + (int64_t)pos[2 * e] * 3;
-        const double* v2 = Xj + (int64_t)pos[2 * e + 1] * 3;
-        out[0] = v1[0]; out[1] = v1[1]; out[2] = v1[2];
-        out[3] = v2[0]; out[4] = v2[1]; out[5] = v2[2];
+    const double msum = ordered_sums<6>(count, lane, scratch, [&](int e, double* out) {
+        const uint32_t u = entries[e];
+        const uint32_t i = u & 0xffffu, j = u >> 16;
+        const bool pair = i != kGap16 && j != kGap16;
+        const double* v1 = Xi + (int64_t)(pair ? i : 0) * 3;
+        const double* v2 = Xj + (int64_t)(pair ? j : 0) * 3;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            out[a] = pair ? v1[a] : 0.0;
+            out[3 + a] = pair ? v2[a] : 0.0;
+        }
     });
     const double mean = msum / (double)k;
 #pragma unroll
@@ -701,15 +714,18 @@ CR_D void kabsch_ordered(const double* __restrict__ Xi, const double* __restrict
         c2[a] = lane_value(mean, 3 + a);
     }
     // correlation matrix C = (X_j - c2)^T (X_i - c1)  (superposition_functions.py:26-27)
-    const double csum = ordered_sums<9>(k, lane, scratch, [&](int e, double* out) {
-        const double* v1 = Xi + (int64_t)pos[2 * e] * 3;
-        const double* v2 = Xj + (int64_t)pos[2 * e + 1] * 3;
+    const double csum = ordered_sums<9>(count, lane, scratch, [&](int e, double* out) {
+        const uint32_t u = entries[e];
+        const uint32_t i = u & 0xffffu, j = u >> 16;
+        const bool pair = i != kGap16 && j != kGap16;
+        const double* v1 = Xi + (int64_t)(pair ? i : 0) * 3;
+        const double* v2 = Xj + (int64_t)(pair ? j : 0) * 3;
         const double a[3] = {v2[0] - c2[0], v2[1] - c2[1], v2[2] - c2[2]};
         const double b[3] = {v1[0] - c1[0], v1[1] - c1[1], v1[2] - c1[2]};
 #pragma unroll
         for (int r = 0; r < 3; r++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) out[3 * r + c] = a[r] * b[c];
+            for (int c = 0; c < 3; c++) out[3 * r + c] = pair ? a[r] * b[c] : 0.0;
     });
     double C[9];
 #pragma unroll
@@ -717,26 +733,32 @@ CR_D void kabsch_ordered(const double* __restrict__ Xi, const double* __restrict
     kabsch_from_correlation(C, c1, c2, R, t);     // every lane computes the same 3x3 SVD
 }
 
+// LDS carve-up of the two traceback kernels: [entries: cap words][window / sum scratch (aliased)]
+inline size_t trace_lds_bytes(int R, int max_entries) {
+    const size_t win = sizeof(uint32_t) * kWinBlocks * R * kWave, scr = sizeof(double) * kWave * kMaxAcc;
+    return ((sizeof(uint32_t) * (size_t)max_entries + 15) / 16) * 16 + (win > scr ? win : scr);
+}
+
 // Stage 2: SW traceback on the stored decisions, common positions, seed Kabsch
 // (dynamic_time_warping.py:249-278, helper.py:13-42, superposition_functions.py:39-60).
-// LDS: window (kWinBlocks*R*64 words) | 64*kMaxAcc doubles.
-__global__ __launch_bounds__(kWave) void k_seed_trace(const PairDesc* __restrict__ pairs, int R,
+__global__ __launch_bounds__(kWave) void k_seed_trace(const PairDesc* __restrict__ pairs, int R, int max_entries,
                                                      const double* __restrict__ coords,
                                                      const uint32_t* __restrict__ dirs,
-                                                     const SeedMax* __restrict__ seed, int32_t* __restrict__ pos,
+                                                     const SeedMax* __restrict__ seed,
                                                      Transform* __restrict__ xf, double* __restrict__ seed_score) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
     const int p = blockIdx.x;
     const PairDesc pd = pairs[p];
     const SeedMax sm = seed[p];
-    double* scratch = lds;
+    uint32_t* plist = reinterpret_cast<uint32_t*>(lds);          // aligned pairs, filled back-to-front
+    double* scratch = lds + ((size_t)max_entries + 3) / 4 * 2;   // 16-byte aligned, after the list
     BitWindow bw;
-    bw.win = reinterpret_cast<uint32_t*>(lds + kWave * kMaxAcc);
+    bw.win = reinterpret_cast<uint32_t*>(scratch);
     bw.s = -1;
+    bw.lo = 0;
     bw.hi = -1;
     const int cap = pd.n < pd.m ? pd.n : pd.m;
-    int32_t* pp = pos + pd.pos_off * 2;          // (i, j) pairs, filled back-to-front
     uint32_t flags = 0;
     int k = 0, len = 0;
     if (sm.i == 0) {
@@ -747,27 +769,25 @@ __global__ __launch_bounds__(kWave) void k_seed_trace(const PairDesc* __restrict
         int i = sm.i, j = sm.j;
         RowPos rp;
         rp.set(i - 1, R);
+#pragma unroll 1
         while (i > 0 && j > 0) {
             const int t = (j - 1) + rp.l;
             const int tb = t >> 4;
             if (!bw.holds(rp.s, tb)) bw.load(w, R, TB, rp.s, tb, lane);
             const uint32_t code = (bw.word(R, tb, rp.q, rp.l) >> ((t & 15) * 2)) & 3u;
             if (code == 0) break;
-            if (code == 1) {
-                i--; j--;
-                rp.up(R);
-                k++;
-                if (lane == 0) {
-                    pp[2 * (cap - k)] = i;
-                    pp[2 * (cap - k) + 1] = j;
-                }
-            } else if (code == 2) {
+            len++;
+            if (code == 2) {
                 j--;
             } else {
                 i--;
                 rp.up(R);
+                if (code == 1) {
+                    j--;
+                    k++;
+                    plist[cap - k] = pack_entry(i, j);
+                }
             }
-            len++;
         }
     }
     __syncthreads();
@@ -780,7 +800,7 @@ __global__ __launch_bounds__(kWave) void k_seed_trace(const PairDesc* __restrict
         flags |= kFlagSeedSkipped;
     } else {
         double t[3];
-        kabsch_ordered(coords + pd.off_i * 3, coords + pd.off_j * 3, pp + 2 * (cap - k), k, lane, scratch,
+        kabsch_ordered(coords + pd.off_i * 3, coords + pd.off_j * 3, plist + (cap - k), k, k, lane, scratch,
                        tr.c1, tr.c2, tr.R, t);
     }
     tr.flags = flags;
@@ -793,83 +813,78 @@ __global__ __launch_bounds__(kWave) void k_seed_trace(const PairDesc* __restrict
 
 // Stage 4: DTW traceback (dynamic_time_warping.py:90-144), common positions, Kabsch on the
 // original coordinates, RMSD / coverage / TM (multiple_alignment.py:1033-1054, :59-70).
-// Alignment rows are written back-to-front into [aln_off, aln_off + n + m).
-__global__ __launch_bounds__(kWave) void k_align_trace(const PairDesc* __restrict__ pairs, int R,
+// Alignment rows end up back-to-front in [aln_off, aln_off + n + m).
+__global__ __launch_bounds__(kWave) void k_align_trace(const PairDesc* __restrict__ pairs, int R, int max_entries,
                                                       const double* __restrict__ coords,
                                                       const uint32_t* __restrict__ bits,
                                                       const AlignEnd* __restrict__ ends,
                                                       const Transform* __restrict__ xf,
                                                       const double* __restrict__ seed_score,
-                                                      int32_t* __restrict__ aln, int32_t* __restrict__ pos,
-                                                      PairResult* __restrict__ res) {
+                                                      int32_t* __restrict__ aln, PairResult* __restrict__ res) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
     const int p = blockIdx.x;
     const PairDesc pd = pairs[p];
     const AlignEnd e = ends[p];
-    double* scratch = lds;
+    uint32_t* arow = reinterpret_cast<uint32_t*>(lds);           // packed alignment columns, back-to-front
+    double* scratch = lds + ((size_t)max_entries + 3) / 4 * 2;
     BitWindow bw;
-    bw.win = reinterpret_cast<uint32_t*>(lds + kWave * kMaxAcc);
+    bw.win = reinterpret_cast<uint32_t*>(scratch);
     bw.s = -1;
+    bw.lo = 0;
     bw.hi = -1;
     const int cap = pd.n + pd.m;
-    const int pcap = pd.n < pd.m ? pd.n : pd.m;
-    int32_t* a1 = aln + pd.aln_off;
-    int32_t* a2 = a1 + cap;
-    int32_t* pp = pos + pd.pos_off * 2;
     const uint32_t* w = bits + pd.bt_off;
     const int TB = tblocks(pd.m, 8);
     int n = pd.n, m = pd.m, dir = e.start_layer, idx = 0, k = 0;
     RowPos rp;
     rp.set(n - 1, R);
-    int guard = 3 * cap + 8;
-    while (!(n == 0 && m == 0) && guard-- > 0) {
-        int o1, o2;                                // emitted entry, or (-2, -2) for none
-        if (m == 0) {
+#pragma unroll 1
+    while (n > 0 && m > 0) {
+        const int t = (m - 1) + rp.l;
+        const int tb = t >> 3;
+        if (!bw.holds(rp.s, tb)) bw.load(w, R, TB, rp.s, tb, lane);
+        const uint32_t nib = (bw.word(R, tb, rp.q, rp.l) >> ((t & 7) * 4)) & 15u;
+        // dynamic_time_warping.py:118-143.  In layer 1 the stored decision either keeps the walk on
+        // the diagonal or switches layer at the SAME cell; the switch and the move it then makes in
+        // layer 0 / 2 (which reads the same cell's decisions) are done in one iteration.
+        int layer = dir;
+        if (layer == 1) layer = (int)((nib >> 1) & 3u);
+        uint32_t entry;
+        if (layer == 1) {
+            n--; m--;
+            rp.up(R);
+            k++;
+            dir = 1;
+            entry = pack_entry(n, m);
+        } else if (layer == 0) {
+            dir = (int)(nib & 1u);
             n--;
-            o1 = n; o2 = -1;
-        } else if (n == 0) {
-            m--;
-            o1 = -1; o2 = m;
+            rp.up(R);
+            entry = pack_entry(n, -1);
         } else {
-            const int t = (m - 1) + rp.l;
-            const int tb = t >> 3;
-            if (!bw.holds(rp.s, tb)) bw.load(w, R, TB, rp.s, tb, lane);
-            const uint32_t nib = (bw.word(R, tb, rp.q, rp.l) >> ((t & 7) * 4)) & 15u;
-            if (dir == 0) {
-                dir = nib & 1u;
-                n--;
-                rp.up(R);
-                o1 = n; o2 = -1;
-            } else if (dir == 1) {
-                dir = (nib >> 1) & 3u;
-                if (dir == 1) {
-                    n--; m--;
-                    rp.up(R);
-                    o1 = n; o2 = m;
-                    k++;
-                    if (lane == 0) {
-                        pp[2 * (pcap - k)] = n;
-                        pp[2 * (pcap - k) + 1] = m;
-                    }
-                } else {
-                    o1 = -2; o2 = -2;
-                }
-            } else {
-                dir = ((nib >> 3) & 1u) + 1;
-                m--;
-                o1 = -1; o2 = m;
-            }
+            dir = (int)((nib >> 3) & 1u) + 1;
+            m--;
+            entry = pack_entry(-1, m);
         }
-        if (o1 != -2) {
-            idx++;
-            if (lane == 0) {
-                a1[cap - idx] = o1;
-                a2[cap - idx] = o2;
-            }
-        }
+        idx++;
+        arow[cap - idx] = entry;
     }
+    // border runs (dynamic_time_warping.py:108-117): only one of n, m is still positive
+    for (int x = lane; x < n; x += kWave) arow[cap - idx - 1 - x] = pack_entry(n - 1 - x, -1);
+    for (int x = lane; x < m; x += kWave) arow[cap - idx - 1 - x] = pack_entry(-1, m - 1 - x);
+    idx += n + m;
     __syncthreads();
+    const int first = cap - idx;
+    // alignment rows -> HBM, coalesced
+    int32_t* a1 = aln + pd.aln_off;
+    int32_t* a2 = a1 + cap;
+    for (int x = first + lane; x < cap; x += kWave) {
+        const uint32_t u = arow[x];
+        const uint32_t i = u & 0xffffu, j = u >> 16;
+        a1[x] = i == kGap16 ? -1 : (int)i;
+        a2[x] = j == kGap16 ? -1 : (int)j;
+    }
     PairResult r;
     r.sw = e.sw;
     r.dtw_score = e.dtw_score;
@@ -882,38 +897,41 @@ __global__ __launch_bounds__(kWave) void k_align_trace(const PairDesc* __restric
     r.seed_len = xf[p].seed_len;
     r.flags = xf[p].flags;
     r.aln_len = idx;
-    r.aln_start = cap - idx;
+    r.aln_start = first;
     if (k < 3) {
         r.flags |= kFlagMetricsSkipped;
     } else {
         const double* Xi = coords + pd.off_i * 3;
         const double* Xj = coords + pd.off_j * 3;
-        const int32_t* cp = pp + 2 * (pcap - k);
+        const uint32_t* ent = arow + first;
         double c1[3], c2[3];
-        kabsch_ordered(Xi, Xj, cp, k, lane, scratch, c1, c2, r.R, r.t);
+        kabsch_ordered(Xi, Xj, ent, idx, k, lane, scratch, c1, c2, r.R, r.t);
         // get_rmsd (score_functions.py:15-19) and tm_score (multiple_alignment.py:59-70):
         // lane 0 sums the squared differences (three per position, in order), lanes 1/2 the two TM sums
         const double d1 = 1.24 * (double)(pd.n - 15) / 3.0 - 1.8;
         const double d2 = 1.24 * (double)(pd.m - 15) / 3.0 - 1.8;
         double acc = 0.0;
-        for (int base = 0; base < k; base += kWave) {
+        for (int base = 0; base < idx; base += kWave) {
             const int x = base + lane;
-            if (x < k) {
-                const double* v1 = Xi + (int64_t)cp[2 * x] * 3;
-                const double* v2 = Xj + (int64_t)cp[2 * x + 1] * 3;
+            if (x < idx) {
+                const uint32_t u = ent[x];
+                const uint32_t i = u & 0xffffu, j = u >> 16;
+                const bool pair = i != kGap16 && j != kGap16;
+                const double* v1 = Xi + (int64_t)(pair ? i : 0) * 3;
+                const double* v2 = Xj + (int64_t)(pair ? j : 0) * 3;
                 double mv[3];
                 rot3(v2, r.R, mv);
                 const double e0 = v1[0] - (mv[0] + r.t[0]), e1 = v1[1] - (mv[1] + r.t[1]), e2 = v1[2] - (mv[2] + r.t[2]);
                 const double sg = (e0 + e1) + e2;
                 const double q1 = sg / d1, q2 = sg / d2;
-                scratch[lane * 5 + 0] = e0 * e0;
-                scratch[lane * 5 + 1] = e1 * e1;
-                scratch[lane * 5 + 2] = e2 * e2;
-                scratch[lane * 5 + 3] = 1.0 / (1.0 + q1 * q1);
-                scratch[lane * 5 + 4] = 1.0 / (1.0 + q2 * q2);
+                scratch[lane * 5 + 0] = pair ? e0 * e0 : 0.0;
+                scratch[lane * 5 + 1] = pair ? e1 * e1 : 0.0;
+                scratch[lane * 5 + 2] = pair ? e2 * e2 : 0.0;
+                scratch[lane * 5 + 3] = pair ? 1.0 / (1.0 + q1 * q1) : 0.0;
+                scratch[lane * 5 + 4] = pair ? 1.0 / (1.0 + q2 * q2) : 0.0;
             }
             __syncthreads();
-            const int cnt = k - base < kWave ? k - base : kWave;
+            const int cnt = idx - base < kWave ? idx - base : kWave;
             if (lane == 0) {
                 for (int y = 0; y < cnt; y++) {
                     acc += scratch[y * 5 + 0];
@@ -934,10 +952,6 @@ __global__ __launch_bounds__(kWave) void k_align_trace(const PairDesc* __restric
         r.tm = t1 > t2 ? t1 : t2;
     }
     if (lane == 0) res[p] = r;
-}
-
-inline size_t trace_lds_bytes(int R) {
-    return sizeof(double) * kWave * kMaxAcc + sizeof(uint32_t) * kWinBlocks * R * kWave;
 }
 
 }  // namespace cr
