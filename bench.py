@@ -41,8 +41,10 @@ def stage_bytes(lengths, pairs, d):
     """Algorithmic HBM bytes per launch of the two fill kernels."""
     n = lengths[pairs[:, 0]].astype(np.float64)
     m = lengths[pairs[:, 1]].astype(np.float64)
-    seed = 8.0 * d * (n + m) + n * m / 4 + 16            # tensors in, 2-bit decisions + first maximum out
-    align = 8.0 * 3 * (n + m) + 136 + n * m / 2 + 24     # coords + transform in, 4-bit decisions + scores out
+    # k_seed: tensors in, 2-bit decisions out and read back by the traceback, aligned coords, transform out
+    seed = 8.0 * d * (n + m) + 2 * (n * m / 4) + 24.0 * (n + m) + 144
+    # k_align: coords + transform in, 4-bit decisions out and back, alignment rows + results out
+    align = 24.0 * (n + m) + 144 + 2 * (n * m / 2) + 8.0 * (n + m) + 160
     return float(seed.sum()), float(align.sum())
 
 
@@ -170,9 +172,9 @@ def main():
         total_pairs = len(pairs)
         ms_per_step = elapsed / args.steps * 1e3
         seed_b, align_b = stage_bytes(lengths, pairs[mine], dim)
-        dom = 2 if stage_ms[2] >= stage_ms[0] else 0
-        dom_name = "k_align_fill" if dom == 2 else "k_seed_fill"
-        dom_bytes = align_b if dom == 2 else seed_b
+        dom = 1 if stage_ms[1] >= stage_ms[0] else 0
+        dom_name = "k_align" if dom == 1 else "k_seed"
+        dom_bytes = align_b if dom == 1 else seed_b
         achieved = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9
         cells_rank = float((lengths[pairs[mine][:, 0]] * lengths[pairs[mine][:, 1]]).sum())
         traffic = None
@@ -193,16 +195,15 @@ def main():
                                    f"coord-RBF SW score + affine DTW(1.0,0.01) -> Kabsch/RMSD/TM)",
                        "structures": num, "residues": length, "tensor_width": dim, "pairs": total_pairs,
                        "pairs_per_gpu": int(len(mine)), "seed": seed},
-            "dtw_mcells_per_s": cells_rank * world / (stage_ms[2] * 1e-3) / 1e6,
-            "stage_ms": {"seed_fill": stage_ms[0], "seed_trace_kabsch": stage_ms[1], "align_fill": stage_ms[2],
-                         "align_trace_metrics": stage_ms[3], "runs_averaged": runs},
+            "dtw_mcells_per_s": cells_rank * world / (stage_ms[1] * 1e-3) / 1e6,
+            "stage_ms": {"k_seed": stage_ms[0], "k_align": stage_ms[1], "runs_averaged": runs},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": stage_ms[dom],
                          "note": "fused RBF+DP is FP64-VALU/dependency bound, not HBM bound (DESIGN.md); "
                                  "cells/s and the VALU estimate are in dtw_mcells_per_s / valu_f64"},
             "valu_f64": {"est_flop_per_cell": {"seed_fill": 59, "align_fill": 49},
-                         "achieved_tflops": (59 * cells_rank / (stage_ms[0] * 1e-3) + 49 * cells_rank / (stage_ms[2] * 1e-3)) / 1e12 / 2,
+                         "achieved_tflops": (59 + 49) * cells_rank / ((stage_ms[0] + stage_ms[1]) * 1e-3) / 1e12,
                          "peak_tflops": FP64_VALU_PEAK_TFLOPS},
         }
         if world == 1 and not args.no_cpu_baseline:

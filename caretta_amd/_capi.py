@@ -13,7 +13,7 @@ import numpy as np
 
 LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libcaretta_hip.so"
 
-CR_NUM_STAGES = 4
+CR_NUM_STAGES = 2
 FLAG_SEED_SKIPPED, FLAG_METRICS_SKIPPED, FLAG_SEED_ALL_ZERO = 1, 2, 4
 
 

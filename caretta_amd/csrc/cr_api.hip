@@ -87,9 +87,7 @@ struct cr_batch {
     DevBuf<cr::PairDesc> pairs;
     DevBuf<uint32_t> dirs, bits;
     DevBuf<int32_t> aln;
-    DevBuf<cr::SeedMax> seed;
     DevBuf<cr::Transform> xf;
-    DevBuf<cr::AlignEnd> ends;
     DevBuf<double> seed_score;
     DevBuf<cr::PairResult> res;
     int64_t aln_elems = 0;
@@ -119,11 +117,14 @@ int allow_lds(K kernel, size_t bytes) {
 template <int R, int D, bool ZG>
 int launch_seed_zg(cr_batch* b, const cr_params& prm) {
     using Src = cr::RbfTensor<R, D>;
-    size_t lds = cr::sweep_lds_doubles<R, cr::kSwTrace, Src>(b->n_max, b->m_max) * sizeof(double);
-    int rc = allow_lds(cr::k_seed_fill<R, D, ZG>, lds);
+    const int entries = std::min(b->n_max, b->m_max);
+    const size_t fill = cr::sweep_lds_doubles<R, cr::kSwTrace, Src>(b->n_max, b->m_max);
+    const size_t lds = sizeof(double) * std::max(fill, 32 + cr::trace_lds_doubles(R, entries));
+    int rc = allow_lds(cr::k_seed<R, D, ZG>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((cr::k_seed_fill<R, D, ZG>), dim3((unsigned)b->npairs), dim3(cr::kWave), lds, b->ctx->stream,
-                       b->pairs.p, b->tensors.p, (int)b->d, prm.gamma_tensor, prm.sw_gap, b->dirs.p, b->seed.p);
+    hipLaunchKernelGGL((cr::k_seed<R, D, ZG>), dim3((unsigned)b->npairs), dim3(cr::kWave), lds, b->ctx->stream,
+                       b->pairs.p, b->tensors.p, (int)b->d, b->coords.p, prm.gamma_tensor, prm.sw_gap, entries,
+                       b->dirs.p, b->xf.p, b->seed_score.p);
     CR_HIP(hipGetLastError());
     return CR_OK;
 }
@@ -147,25 +148,27 @@ int launch_seed_d(cr_batch* b, const cr_params& prm) {
 template <int R, bool ZG>
 int launch_align_zg(cr_batch* b, const cr_params& prm) {
     using Src = cr::RbfCoords<R>;
-    size_t lds = cr::sweep_lds_doubles<R, cr::kSwScore | cr::kDtw, Src>(b->n_max, b->m_max) * sizeof(double);
-    int rc = allow_lds(cr::k_align_fill<R, ZG>, lds);
+    const int entries = (int)b->max_aln;
+    const size_t fill = cr::sweep_lds_doubles<R, cr::kSwScore | cr::kDtw, Src>(b->n_max, b->m_max);
+    const size_t lds = sizeof(double) * std::max(fill, 32 + cr::trace_lds_doubles(R, entries));
+    int rc = allow_lds(cr::k_align<R, ZG>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((cr::k_align_fill<R, ZG>), dim3((unsigned)b->npairs), dim3(cr::kWave), lds, b->ctx->stream,
-                       b->pairs.p, b->coords.p, b->xf.p, prm.gamma_coords, prm.sw_gap, prm.gap_open, prm.gap_extend,
-                       b->bits.p, b->ends.p);
+    hipLaunchKernelGGL((cr::k_align<R, ZG>), dim3((unsigned)b->npairs), dim3(cr::kWave), lds, b->ctx->stream,
+                       b->pairs.p, b->coords.p, b->xf.p, b->seed_score.p, prm.gamma_coords, prm.sw_gap, prm.gap_open,
+                       prm.gap_extend, entries, b->bits.p, b->aln.p, b->res.p);
     CR_HIP(hipGetLastError());
     return CR_OK;
+}
+
+template <int R>
+int launch_align(cr_batch* b, const cr_params& prm) {
+    return prm.sw_gap == 0.0 ? launch_align_zg<R, true>(b, prm) : launch_align_zg<R, false>(b, prm);
 }
 
 bool all_finite(const double* v, size_t count) {
     for (size_t x = 0; x < count; x++)
         if (!std::isfinite(v[x])) return false;
     return true;
-}
-
-template <int R>
-int launch_align(cr_batch* b, const cr_params& prm) {
-    return prm.sw_gap == 0.0 ? launch_align_zg<R, true>(b, prm) : launch_align_zg<R, false>(b, prm);
 }
 
 // widths the seed-fill kernel is instantiated for; narrower tensors are zero-padded in registers
@@ -356,9 +359,7 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     if (e == hipSuccess) e = b->dirs.ensure((size_t)dirs_off);
     if (e == hipSuccess) e = b->bits.ensure((size_t)bt_off);
     if (e == hipSuccess) e = b->aln.ensure((size_t)aln_off);
-    if (e == hipSuccess) e = b->seed.ensure((size_t)npairs);
     if (e == hipSuccess) e = b->xf.ensure((size_t)npairs);
-    if (e == hipSuccess) e = b->ends.ensure((size_t)npairs);
     if (e == hipSuccess) e = b->seed_score.ensure((size_t)npairs);
     if (e == hipSuccess) e = b->res.ensure((size_t)npairs);
     if (e == hipSuccess && npairs)
@@ -388,30 +389,13 @@ int cr_batch_run(cr_batch* b, const cr_params* params, double* d_sw_out) {
                "gap penalties must be finite");
     const bool prof = ctx->slots > 0;
     hipEvent_t* ev = prof ? &ctx->ev[(size_t)(ctx->runs_recorded % ctx->slots) * (CR_NUM_STAGES + 1)] : nullptr;
-    const int seed_entries = std::min(b->n_max, b->m_max), aln_entries = (int)b->max_aln;
-    const size_t seed_lds = cr::trace_lds_bytes(b->r_seed, seed_entries);
-    const size_t trace_lds = cr::trace_lds_bytes(b->r_align, aln_entries);
-    if ((rc = allow_lds(cr::k_seed_trace, seed_lds))) return rc;
-    if ((rc = allow_lds(cr::k_align_trace, trace_lds))) return rc;
     if (prof) CR_HIP(hipEventRecord(ev[0], ctx->stream));
     rc = (b->r_seed == 3) ? launch_seed_d<3>(b, prm) : launch_seed_d<5>(b, prm);
     if (rc) return rc;
     if (prof) CR_HIP(hipEventRecord(ev[1], ctx->stream));
-
-    hipLaunchKernelGGL(cr::k_seed_trace, dim3((unsigned)b->npairs), dim3(cr::kWave), seed_lds, ctx->stream, b->pairs.p,
-                       b->r_seed, seed_entries, b->coords.p, b->dirs.p, b->seed.p, b->xf.p, b->seed_score.p);
-    CR_HIP(hipGetLastError());
-    if (prof) CR_HIP(hipEventRecord(ev[2], ctx->stream));
-
     rc = (b->r_align == 3) ? launch_align<3>(b, prm) : launch_align<5>(b, prm);
     if (rc) return rc;
-    if (prof) CR_HIP(hipEventRecord(ev[3], ctx->stream));
-
-    hipLaunchKernelGGL(cr::k_align_trace, dim3((unsigned)b->npairs), dim3(cr::kWave), trace_lds, ctx->stream, b->pairs.p,
-                       b->r_align, aln_entries, b->coords.p, b->bits.p, b->ends.p, b->xf.p, b->seed_score.p, b->aln.p,
-                       b->res.p);
-    CR_HIP(hipGetLastError());
-    if (prof) CR_HIP(hipEventRecord(ev[4], ctx->stream));
+    if (prof) CR_HIP(hipEventRecord(ev[2], ctx->stream));
     if (d_sw_out) {
         // strided device-to-device copy of the first field of every PairResult
         CR_HIP(hipMemcpy2DAsync(d_sw_out, sizeof(double), b->res.p, sizeof(cr::PairResult), sizeof(double),
@@ -430,7 +414,7 @@ int cr_batch_stage_ms(cr_batch* b, float ms[CR_NUM_STAGES], int* runs_averaged) 
     if (rc) return rc;
     CR_HIP(hipStreamSynchronize(ctx->stream));
     const int64_t n = std::min<int64_t>(ctx->runs_recorded, ctx->slots);
-    double acc[CR_NUM_STAGES] = {0, 0, 0, 0};
+    double acc[CR_NUM_STAGES] = {};
     for (int64_t r = 0; r < n; r++) {
         hipEvent_t* ev = &ctx->ev[(size_t)r * (CR_NUM_STAGES + 1)];
         for (int s = 0; s < CR_NUM_STAGES; s++) {

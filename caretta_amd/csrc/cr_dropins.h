@@ -66,7 +66,13 @@ __global__ __launch_bounds__(kWave) void k_explicit(const int32_t* __restrict__ 
     src.seq1 = seq1;
     src.seq2 = seq2;
     src.s_cols = s_cols;
-    sweep<R, MODE>(src, n, m, prm, lds, dirs, bits, seed, end);
+    SeedMax sm;
+    AlignEnd ae;
+    sweep<R, MODE>(src, n, m, prm, lds, dirs, bits, sm, ae);
+    if (threadIdx.x == 0) {
+        if constexpr ((MODE & kSwTrace) != 0) *seed = sm;
+        if constexpr ((MODE & (kSwScore | kDtw)) != 0) *end = ae;
+    }
 }
 
 struct TraceOut {
@@ -290,14 +296,6 @@ int cr_protein_score_function(cr_context* ctx, const double* coords_i, const dou
     if (rc == CR_OK) {
         cr_params prm{gamma_tensor, gamma_coords, 1.0, 0.01, 0.0};
         rc = (b->r_seed == 3) ? launch_seed_d<3>(b, prm) : launch_seed_d<5>(b, prm);
-    }
-    if (rc == CR_OK) {
-        const int seed_entries = (int)std::min(n, m);
-        const size_t seed_lds = cr::trace_lds_bytes(b->r_seed, seed_entries);
-        rc = allow_lds(cr::k_seed_trace, seed_lds);
-        if (rc == CR_OK)
-            hipLaunchKernelGGL(cr::k_seed_trace, dim3(1), dim3(cr::kWave), seed_lds, ctx->stream, b->pairs.p, b->r_seed,
-                               seed_entries, b->coords.p, b->dirs.p, b->seed.p, b->xf.p, b->seed_score.p);
     }
     if (rc == CR_OK) {
         DevBuf<double> ds;

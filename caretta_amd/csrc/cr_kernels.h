@@ -57,6 +57,12 @@ struct AlignEnd {            // result of the coordinate fill
     int32_t pad;
 };
 
+// value of `v` in lane `src_lane` (wave-uniform index), broadcast to every lane
+CR_D double lane_value(double v, int src_lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), src_lane));
+}
+
 CR_HD int strips_of(int n, int R) { return (n + kWave * R - 1) / (kWave * R); }
 CR_HD int tblocks(int m, int per_word) { return (m + kWave - 1 + per_word - 1) / per_word; }
 
@@ -229,7 +235,7 @@ struct SweepParams {
 template <int R, int MODE, class Src>
 CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, double* lds,
                 uint32_t* __restrict__ sw_dirs, uint32_t* __restrict__ dtw_bits,
-                SeedMax* seed_out, AlignEnd* end_out) {
+                SeedMax& seed_out, AlignEnd& end_out) {
     constexpr bool SW = (MODE & (kSwTrace | kSwScore)) != 0;
     constexpr bool TRACE = (MODE & kSwTrace) != 0;
     constexpr bool DTW = (MODE & kDtw) != 0;
@@ -417,7 +423,7 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
         }
     }
 
-    // ---- wave reductions -------------------------------------------------------------------
+    // ---- wave reductions: results are returned in every lane ------------------------------------
     if constexpr (TRACE) {
         for (int off = 32; off > 0; off >>= 1) {
             double ov = __shfl_xor(best_v, off);
@@ -427,13 +433,9 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
             best_i = take ? oi : best_i;
             best_j = take ? oj : best_j;
         }
-        if (lane == 0) {
-            SeedMax r;
-            r.score = best_v;
-            r.i = best_v > 0.0 ? best_i + 1 : 0;
-            r.j = best_v > 0.0 ? best_j + 1 : 0;
-            *seed_out = r;
-        }
+        seed_out.score = best_v;
+        seed_out.i = best_v > 0.0 ? best_i + 1 : 0;
+        seed_out.j = best_v > 0.0 ? best_j + 1 : 0;
     }
     if constexpr ((MODE & kSwScore) != 0 || DTW) {
         if constexpr ((MODE & kSwScore) != 0) {
@@ -441,26 +443,26 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
         }
         const int owner = ((n - 1) / R) % kWave;       // lane and register slot that own row n-1
         const int qo = (n - 1) % R;
-        if (lane == owner) {
-            double fin0 = 0.0, fin1 = 0.0, fin2 = 0.0; // M[n][m][0..2]
+        double fin0 = 0.0, fin1 = 0.0, fin2 = 0.0;     // M[n][m][0..2]
 #pragma unroll
-            for (int q = 0; q < R; q++) {
-                fin0 = (q == qo) ? m0_left[q] : fin0;
-                fin1 = (q == qo) ? m1_left[q] : fin1;
-                fin2 = (q == qo) ? m2_left[q] : fin2;
-            }
-            AlignEnd e;
-            e.sw = sw_max;
-            int idx = 0;                               // np.argmax of the three layers at (n, m), :181-182
-            double best = fin0;
-            if (fin1 > best) { best = fin1; idx = 1; }
-            if (fin2 > best) { best = fin2; idx = 2; }
-            e.dtw_score = DTW ? best : 0.0;
-            e.start_layer = idx;
-            e.pad = 0;
-            *end_out = e;
+        for (int q = 0; q < R; q++) {
+            fin0 = (q == qo) ? m0_left[q] : fin0;
+            fin1 = (q == qo) ? m1_left[q] : fin1;
+            fin2 = (q == qo) ? m2_left[q] : fin2;
         }
+        fin0 = lane_value(fin0, owner);
+        fin1 = lane_value(fin1, owner);
+        fin2 = lane_value(fin2, owner);
+        end_out.sw = sw_max;
+        int idx = 0;                                   // np.argmax of the three layers at (n, m), :181-182
+        double best = fin0;
+        if (fin1 > best) { best = fin1; idx = 1; }
+        if (fin2 > best) { best = fin2; idx = 2; }
+        end_out.dtw_score = DTW ? best : 0.0;
+        end_out.start_layer = idx;
+        end_out.pad = 0;
     }
+    __syncthreads();                                   // the caller may reuse the LDS from here on
 }
 
 // LDS doubles needed by a sweep of the given provider/mode for column count m and row count n
@@ -470,48 +472,6 @@ __host__ __device__ inline size_t sweep_lds_doubles(int n_max, int m_max) {
     size_t v = 32 + Src::kRingDoubles;
     if (strips_of(n_max, R) > 1) v += (size_t)NB * m_max;
     return v;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Batch kernels
-// ---------------------------------------------------------------------------------------------
-
-// Stage 1: tensor RBF + SW fill (multiple_alignment.py:328-335).  One wave per pair.
-template <int R, int D, bool ZG>
-__global__ __launch_bounds__(kWave) void k_seed_fill(const PairDesc* __restrict__ pairs,
-                                                    const double* __restrict__ tensors, int d,
-                                                    double gamma, double sw_gap,
-                                                    uint32_t* __restrict__ dirs, SeedMax* __restrict__ out) {
-    extern __shared__ double lds[];
-    const PairDesc pd = pairs[blockIdx.x];
-    RbfTensor<R, D> src;
-    src.rows_g = tensors + pd.off_i * d;
-    src.cols_g = tensors + pd.off_j * d;
-    src.d = d;
-    src.neg_gamma = -gamma;
-    SweepParams prm{sw_gap, 0.0, 0.0};
-    sweep<R, kSwTrace | (ZG ? kZeroGap : 0)>(src, pd.n, pd.m, prm, lds, dirs + pd.dirs_off, nullptr, out + blockIdx.x,
-                                              nullptr);
-}
-
-// Stage 3: coordinate RBF on the seed-superposed frames + SW score + affine DTW fill
-// (multiple_alignment.py:347-349, :164, :263-275).  One wave per pair.
-template <int R, bool ZG>
-__global__ __launch_bounds__(kWave) void k_align_fill(const PairDesc* __restrict__ pairs,
-                                                     const double* __restrict__ coords,
-                                                     const Transform* __restrict__ xf, double gamma,
-                                                     double sw_gap, double gap_open, double gap_extend,
-                                                     uint32_t* __restrict__ bits, AlignEnd* __restrict__ out) {
-    extern __shared__ double lds[];
-    const PairDesc pd = pairs[blockIdx.x];
-    RbfCoords<R> src;
-    src.rows_g = coords + pd.off_i * 3;
-    src.cols_g = coords + pd.off_j * 3;
-    src.xf = xf + blockIdx.x;
-    src.neg_gamma = -gamma;
-    SweepParams prm{sw_gap, gap_open, gap_extend};
-    sweep<R, kSwScore | kDtw | (ZG ? kZeroGap : 0)>(src, pd.n, pd.m, prm, lds, nullptr, bits + pd.bt_off, nullptr,
-                                                     out + blockIdx.x);
 }
 
 CR_D uint32_t lookup_bits(const uint32_t* __restrict__ words, int R, int TB, int per_word_log2, int bits,
@@ -606,7 +566,7 @@ struct PairResult {          // per-pair scalar outputs, device and host layout
 // rounding.  Gap columns contribute +0.0 terms, which never change a running sum that started at
 // +0.0 (such a sum can not be -0.0).
 // ---------------------------------------------------------------------------------------------
-constexpr int kWinBlocks = 8;           // word-blocks (of 16 SW steps / 8 DTW steps) per LDS window
+constexpr int kWinBlocks = 4;           // word-blocks (of 16 SW steps / 8 DTW steps) per LDS window
 constexpr int kMaxAcc = 9;              // accumulators summed in order (3x3 correlation matrix)
 constexpr uint32_t kGap16 = 0xffffu;    // -1 in a packed 16-bit alignment entry
 constexpr int kMaxLength = 65534;       // longest structure the packed entries can index
@@ -685,11 +645,6 @@ CR_D double ordered_sums(int count, int lane, double* scratch, TermFn term) {
     return acc;
 }
 
-CR_D double lane_value(double v, int src_lane) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_lane),
-                            __builtin_amdgcn_readlane(__double2loint(v), src_lane));
-}
-
 // Kabsch over `count` packed alignment entries of which `k` are aligned pairs
 // (superposition_functions.py:7-35), every sum in position order.  Results in all lanes.
 CR_D void kabsch_ordered(const double* __restrict__ Xi, const double* __restrict__ Xj, const uint32_t* entries,
@@ -733,24 +688,18 @@ CR_D void kabsch_ordered(const double* __restrict__ Xi, const double* __restrict
     kabsch_from_correlation(C, c1, c2, R, t);     // every lane computes the same 3x3 SVD
 }
 
-// LDS carve-up of the two traceback kernels: [entries: cap words][window / sum scratch (aliased)]
-inline size_t trace_lds_bytes(int R, int max_entries) {
-    const size_t win = sizeof(uint32_t) * kWinBlocks * R * kWave, scr = sizeof(double) * kWave * kMaxAcc;
-    return ((sizeof(uint32_t) * (size_t)max_entries + 15) / 16) * 16 + (win > scr ? win : scr);
+// LDS carve-up of a traceback stage: [entries: max_entries words][window / sum scratch (aliased)]
+__host__ __device__ inline size_t trace_lds_doubles(int R, int max_entries) {
+    const size_t win = (sizeof(uint32_t) * kWinBlocks * R * kWave) / 8, scr = (size_t)kWave * kMaxAcc;
+    return ((size_t)max_entries + 3) / 4 * 2 + (win > scr ? win : scr);
 }
 
 // Stage 2: SW traceback on the stored decisions, common positions, seed Kabsch
 // (dynamic_time_warping.py:249-278, helper.py:13-42, superposition_functions.py:39-60).
-__global__ __launch_bounds__(kWave) void k_seed_trace(const PairDesc* __restrict__ pairs, int R, int max_entries,
-                                                     const double* __restrict__ coords,
-                                                     const uint32_t* __restrict__ dirs,
-                                                     const SeedMax* __restrict__ seed,
-                                                     Transform* __restrict__ xf, double* __restrict__ seed_score) {
-    extern __shared__ double lds[];
+// Wave-uniform; `lds` is this stage's LDS.  Returns the transform in every lane.
+CR_D void seed_trace(const PairDesc& pd, int R, int max_entries, const double* __restrict__ coords,
+                     const uint32_t* __restrict__ dirs, const SeedMax sm, double* lds, Transform& tr) {
     const int lane = threadIdx.x;
-    const int p = blockIdx.x;
-    const PairDesc pd = pairs[p];
-    const SeedMax sm = seed[p];
     uint32_t* plist = reinterpret_cast<uint32_t*>(lds);          // aligned pairs, filled back-to-front
     double* scratch = lds + ((size_t)max_entries + 3) / 4 * 2;   // 16-byte aligned, after the list
     BitWindow bw;
@@ -791,7 +740,6 @@ __global__ __launch_bounds__(kWave) void k_seed_trace(const PairDesc* __restrict
         }
     }
     __syncthreads();
-    Transform tr;
 #pragma unroll
     for (int x = 0; x < 3; x++) tr.c1[x] = tr.c2[x] = 0.0;
 #pragma unroll
@@ -805,27 +753,15 @@ __global__ __launch_bounds__(kWave) void k_seed_trace(const PairDesc* __restrict
     }
     tr.flags = flags;
     tr.seed_len = len;
-    if (lane == 0) {
-        xf[p] = tr;
-        seed_score[p] = sm.score;
-    }
 }
 
 // Stage 4: DTW traceback (dynamic_time_warping.py:90-144), common positions, Kabsch on the
 // original coordinates, RMSD / coverage / TM (multiple_alignment.py:1033-1054, :59-70).
-// Alignment rows end up back-to-front in [aln_off, aln_off + n + m).
-__global__ __launch_bounds__(kWave) void k_align_trace(const PairDesc* __restrict__ pairs, int R, int max_entries,
-                                                      const double* __restrict__ coords,
-                                                      const uint32_t* __restrict__ bits,
-                                                      const AlignEnd* __restrict__ ends,
-                                                      const Transform* __restrict__ xf,
-                                                      const double* __restrict__ seed_score,
-                                                      int32_t* __restrict__ aln, PairResult* __restrict__ res) {
-    extern __shared__ double lds[];
+// Alignment rows end up back-to-front in [aln_off, aln_off + n + m).  Wave-uniform.
+CR_D void align_trace(const PairDesc& pd, int R, int max_entries, const double* __restrict__ coords,
+                      const uint32_t* __restrict__ bits, const AlignEnd e, double* lds,
+                      int32_t* __restrict__ aln, PairResult& r) {
     const int lane = threadIdx.x;
-    const int p = blockIdx.x;
-    const PairDesc pd = pairs[p];
-    const AlignEnd e = ends[p];
     uint32_t* arow = reinterpret_cast<uint32_t*>(lds);           // packed alignment columns, back-to-front
     double* scratch = lds + ((size_t)max_entries + 3) / 4 * 2;
     BitWindow bw;
@@ -885,7 +821,6 @@ __global__ __launch_bounds__(kWave) void k_align_trace(const PairDesc* __restric
         a1[x] = i == kGap16 ? -1 : (int)i;
         a2[x] = j == kGap16 ? -1 : (int)j;
     }
-    PairResult r;
     r.sw = e.sw;
     r.dtw_score = e.dtw_score;
 #pragma unroll
@@ -893,9 +828,7 @@ __global__ __launch_bounds__(kWave) void k_align_trace(const PairDesc* __restric
 #pragma unroll
     for (int x = 0; x < 3; x++) r.t[x] = 0.0;
     r.rmsd = r.coverage = r.tm = 0.0;
-    r.seed_score = seed_score[p];
-    r.seed_len = xf[p].seed_len;
-    r.flags = xf[p].flags;
+    r.flags = 0;
     r.aln_len = idx;
     r.aln_start = first;
     if (k < 3) {
@@ -951,7 +884,80 @@ __global__ __launch_bounds__(kWave) void k_align_trace(const PairDesc* __restric
         const double t2 = (1.0 / (double)pd.m) * sum2;
         r.tm = t1 > t2 ? t1 : t2;
     }
-    if (lane == 0) res[p] = r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Batch kernels: two launches per batch, one wave per pair, each a fill followed by its traceback
+// in the same wave (the latency-bound walk of one wave hides under the FP64 fill of its neighbours).
+// LDS (doubles): [0,32) exp table | union { ring + strip hand-off rows , entries + window/scratch }.
+// ---------------------------------------------------------------------------------------------
+
+// Make this wave's own decision words (plain global stores) visible to its own later loads.
+CR_D void drain_stores() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+}
+
+// Stages 1+2: tensor RBF + SW fill (multiple_alignment.py:328-335), then traceback + seed Kabsch.
+template <int R, int D, bool ZG>
+__global__ __launch_bounds__(kWave) void k_seed(const PairDesc* __restrict__ pairs,
+                                               const double* __restrict__ tensors, int d,
+                                               const double* __restrict__ coords, double gamma, double sw_gap,
+                                               int max_entries, uint32_t* __restrict__ dirs,
+                                               Transform* __restrict__ xf, double* __restrict__ seed_score) {
+    extern __shared__ double lds[];
+    const PairDesc pd = pairs[blockIdx.x];
+    SeedMax sm;
+    AlignEnd unused;
+    {
+        RbfTensor<R, D> src;
+        src.rows_g = tensors + pd.off_i * d;
+        src.cols_g = tensors + pd.off_j * d;
+        src.d = d;
+        src.neg_gamma = -gamma;
+        SweepParams prm{sw_gap, 0.0, 0.0};
+        sweep<R, kSwTrace | (ZG ? kZeroGap : 0)>(src, pd.n, pd.m, prm, lds, dirs + pd.dirs_off, nullptr, sm, unused);
+    }
+    drain_stores();
+    Transform tr;
+    seed_trace(pd, R, max_entries, coords, dirs, sm, lds + 32, tr);
+    if (threadIdx.x == 0) {
+        xf[blockIdx.x] = tr;
+        seed_score[blockIdx.x] = sm.score;
+    }
+}
+
+// Stages 3+4: coordinate RBF on the seed-superposed frames + SW score + affine DTW fill
+// (multiple_alignment.py:347-349, :164, :263-275), then traceback + Kabsch + metrics.
+template <int R, bool ZG>
+__global__ __launch_bounds__(kWave) void k_align(const PairDesc* __restrict__ pairs,
+                                                const double* __restrict__ coords,
+                                                const Transform* __restrict__ xf,
+                                                const double* __restrict__ seed_score, double gamma,
+                                                double sw_gap, double gap_open, double gap_extend,
+                                                int max_entries, uint32_t* __restrict__ bits,
+                                                int32_t* __restrict__ aln, PairResult* __restrict__ res) {
+    extern __shared__ double lds[];
+    const PairDesc pd = pairs[blockIdx.x];
+    SeedMax unused;
+    AlignEnd e;
+    {
+        RbfCoords<R> src;
+        src.rows_g = coords + pd.off_i * 3;
+        src.cols_g = coords + pd.off_j * 3;
+        src.xf = xf + blockIdx.x;
+        src.neg_gamma = -gamma;
+        SweepParams prm{sw_gap, gap_open, gap_extend};
+        sweep<R, kSwScore | kDtw | (ZG ? kZeroGap : 0)>(src, pd.n, pd.m, prm, lds, nullptr, bits + pd.bt_off, unused, e);
+    }
+    drain_stores();
+    PairResult r;
+    align_trace(pd, R, max_entries, coords, bits, e, lds + 32, aln, r);
+    r.seed_score = seed_score[blockIdx.x];
+    r.seed_len = xf[blockIdx.x].seed_len;
+    r.flags |= xf[blockIdx.x].flags;
+    if (threadIdx.x == 0) res[blockIdx.x] = r;
 }
 
 }  // namespace cr

@@ -67,7 +67,7 @@ typedef struct {
     uint32_t flags;        /* CR_FLAG_* */
 } cr_pair_result;
 
-#define CR_NUM_STAGES 4    /* seed fill, seed traceback+Kabsch, alignment fill, alignment traceback+metrics */
+#define CR_NUM_STAGES 2    /* k_seed: tensor SW fill + traceback + Kabsch; k_align: SW score + DTW fill + traceback + metrics */
 
 const char *cr_last_error(void);
 int cr_abi_version(void);
@@ -95,7 +95,7 @@ int cr_batch_create(cr_context *ctx, const double *coords, const double *tensors
                     int64_t num_structures, int64_t d, cr_batch **out);
 /* pairs i32[npairs, 2]: ordered (i, j) = (rows, columns); structure j is superposed onto i. */
 int cr_batch_set_pairs(cr_batch *b, const int32_t *pairs, int64_t npairs);
-/* Enqueue the four stages on the context's stream (asynchronous).  `d_sw_out`, if not NULL, is a
+/* Enqueue the two kernels on the context's stream (asynchronous).  `d_sw_out`, if not NULL, is a
  * DEVICE pointer to f64[npairs] that also receives the `sw` scores (e.g. a torch tensor that is
  * then all-gathered over RCCL). */
 int cr_batch_run(cr_batch *b, const cr_params *params, double *d_sw_out);

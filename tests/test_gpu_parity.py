@@ -230,6 +230,31 @@ def test_pipeline_other_parameters_and_orientation(ctx, oracle):
     assert_bit_identical(res, aln, ref, ref_aln)
 
 
+def test_pipeline_tiny_and_degenerate(ctx, oracle):
+    """1..5-residue structures, identical structures, and a tensor score matrix that underflows to all
+    zeros (the reference raises there; the batch reports CR_FLAG_SEED_ALL_ZERO and carries on unsuperposed)."""
+    from caretta_amd import engine
+    rng = np.random.default_rng(123)
+    lens = [1, 2, 3, 4, 5, 9, 40, 40]
+    structs = []
+    for k, ln in enumerate(lens):
+        structs.append(synthetic.Structure(f"t{k}", rng.uniform(size=(ln, 10)), synthetic._walk(rng, ln), "A" * ln))
+    structs[7] = synthetic.Structure("copy", structs[6].tensors.copy(), structs[6].coordinates.copy(), "A" * 40)
+    far = synthetic.Structure("far", structs[6].tensors + 40.0, structs[6].coordinates + 5.0, "A" * 40)  # exp(-7*16000) = 0
+    structs.append(far)
+    coords, tensors, offsets = synthetic.pack(structs)
+    num = len(structs)
+    pairs = np.array([(i, j) for i in range(num) for j in range(num) if i != j], dtype=np.int32)
+    res, aln = run_batch(ctx, coords, tensors, offsets, pairs)
+    ref, ref_aln = oracle.pairwise_batch(coords, tensors, offsets, pairs)
+    assert_bit_identical(res, aln, ref, ref_aln)
+    flags = {tuple(p): int(f) for p, f in zip(pairs, res["flags"])}
+    assert flags[(6, 8)] & 4 and flags[(6, 8)] & 1          # all-zero seed -> no superposition
+    assert flags[(0, 1)] & 2                                 # fewer than 3 aligned positions -> no metrics
+    p67 = int(np.nonzero((pairs[:, 0] == 6) & (pairs[:, 1] == 7))[0][0])
+    assert res["rmsd"][p67] < 1e-12 and res["aln_len"][p67] == 40 and res["coverage"][p67] == 1.0
+
+
 def test_headline_config_sample_and_properties(ctx, oracle):
     """BASELINE config 3 (128 x 300, all 8128 pairs) on the GPU; a 2% sample re-done by the oracle,
     and size-independent properties on every pair."""
