@@ -67,8 +67,8 @@ struct cr_context {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    // profiling: a ring of event sets, one set (CR_NUM_STAGES + 1 events) per recorded run
-    std::vector<hipEvent_t> ev;
+    // profiling: a ring of event lists, one list (1 + 2 * chunks events) per recorded run
+    std::vector<std::vector<hipEvent_t>> ev;
     int slots = 0;
     int64_t runs_recorded = 0;
 };
@@ -93,6 +93,13 @@ struct cr_batch {
     int64_t aln_elems = 0;
     double alg_bytes = 0.0, cells = 0.0;
     bool ran = false;
+    // The decision scratch (dirs, bits) is sized for one CHUNK of the pair list and reused chunk after
+    // chunk in stream order, so an arbitrarily long pair list runs in bounded HBM.
+    struct Chunk {
+        int64_t first, count;
+        int n_max, m_max, max_aln;
+    };
+    std::vector<Chunk> chunks;
 };
 
 static_assert(sizeof(cr::PairResult) == sizeof(cr_pair_result), "device/host result layouts differ");
@@ -115,54 +122,55 @@ int allow_lds(K kernel, size_t bytes) {
 }
 
 template <int R, int D, bool ZG>
-int launch_seed_zg(cr_batch* b, const cr_params& prm) {
+int launch_seed_zg(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
     using Src = cr::RbfTensor<R, D>;
-    const int entries = std::min(b->n_max, b->m_max);
-    const size_t fill = cr::sweep_lds_doubles<R, cr::kSwTrace, Src>(b->n_max, b->m_max);
+    const int entries = std::min(ck.n_max, ck.m_max);
+    const size_t fill = cr::sweep_lds_doubles<R, cr::kSwTrace, Src>(ck.n_max, ck.m_max);
     const size_t lds = sizeof(double) * std::max(fill, 32 + cr::trace_lds_doubles(R, entries));
     int rc = allow_lds(cr::k_seed<R, D, ZG>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((cr::k_seed<R, D, ZG>), dim3((unsigned)b->npairs), dim3(cr::kWave), lds, b->ctx->stream,
-                       b->pairs.p, b->tensors.p, (int)b->d, b->coords.p, prm.gamma_tensor, prm.sw_gap, entries,
-                       b->dirs.p, b->xf.p, b->seed_score.p);
+    hipLaunchKernelGGL((cr::k_seed<R, D, ZG>), dim3((unsigned)ck.count), dim3(cr::kWave), lds, b->ctx->stream,
+                       b->pairs.p + ck.first, b->tensors.p, (int)b->d, b->coords.p, prm.gamma_tensor, prm.sw_gap,
+                       entries, b->dirs.p, b->xf.p + ck.first, b->seed_score.p + ck.first);
     CR_HIP(hipGetLastError());
     return CR_OK;
 }
 
 template <int R, int D>
-int launch_seed(cr_batch* b, const cr_params& prm) {
-    return prm.sw_gap == 0.0 ? launch_seed_zg<R, D, true>(b, prm) : launch_seed_zg<R, D, false>(b, prm);
+int launch_seed(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
+    return prm.sw_gap == 0.0 ? launch_seed_zg<R, D, true>(b, ck, prm) : launch_seed_zg<R, D, false>(b, ck, prm);
 }
 
 template <int R>
-int launch_seed_d(cr_batch* b, const cr_params& prm) {
+int launch_seed_d(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
     switch (b->d_pad) {
-        case 4: return launch_seed<R, 4>(b, prm);
-        case 8: return launch_seed<R, 8>(b, prm);
-        case 10: return launch_seed<R, 10>(b, prm);
-        case 16: return launch_seed<R, 16>(b, prm);
+        case 4: return launch_seed<R, 4>(b, ck, prm);
+        case 8: return launch_seed<R, 8>(b, ck, prm);
+        case 10: return launch_seed<R, 10>(b, ck, prm);
+        case 16: return launch_seed<R, 16>(b, ck, prm);
         default: return fail(CR_ERR_ARGUMENT, "unsupported tensor width");
     }
 }
 
 template <int R, bool ZG>
-int launch_align_zg(cr_batch* b, const cr_params& prm) {
+int launch_align_zg(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
     using Src = cr::RbfCoords<R>;
-    const int entries = (int)b->max_aln;
-    const size_t fill = cr::sweep_lds_doubles<R, cr::kSwScore | cr::kDtw, Src>(b->n_max, b->m_max);
+    const int entries = ck.max_aln;
+    const size_t fill = cr::sweep_lds_doubles<R, cr::kSwScore | cr::kDtw, Src>(ck.n_max, ck.m_max);
     const size_t lds = sizeof(double) * std::max(fill, 32 + cr::trace_lds_doubles(R, entries));
     int rc = allow_lds(cr::k_align<R, ZG>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((cr::k_align<R, ZG>), dim3((unsigned)b->npairs), dim3(cr::kWave), lds, b->ctx->stream,
-                       b->pairs.p, b->coords.p, b->xf.p, b->seed_score.p, prm.gamma_coords, prm.sw_gap, prm.gap_open,
-                       prm.gap_extend, entries, b->bits.p, b->aln.p, b->res.p);
+    hipLaunchKernelGGL((cr::k_align<R, ZG>), dim3((unsigned)ck.count), dim3(cr::kWave), lds, b->ctx->stream,
+                       b->pairs.p + ck.first, b->coords.p, b->xf.p + ck.first, b->seed_score.p + ck.first,
+                       prm.gamma_coords, prm.sw_gap, prm.gap_open, prm.gap_extend, entries, b->bits.p, b->aln.p,
+                       b->res.p + ck.first);
     CR_HIP(hipGetLastError());
     return CR_OK;
 }
 
 template <int R>
-int launch_align(cr_batch* b, const cr_params& prm) {
-    return prm.sw_gap == 0.0 ? launch_align_zg<R, true>(b, prm) : launch_align_zg<R, false>(b, prm);
+int launch_align(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
+    return prm.sw_gap == 0.0 ? launch_align_zg<R, true>(b, ck, prm) : launch_align_zg<R, false>(b, ck, prm);
 }
 
 bool all_finite(const double* v, size_t count) {
@@ -232,7 +240,8 @@ int cr_context_create(int device, void* stream, cr_context** out) {
 int cr_context_destroy(cr_context* ctx) {
     if (!ctx) return CR_OK;
     (void)hipSetDevice(ctx->device);
-    for (auto& e : ctx->ev) (void)hipEventDestroy(e);
+    for (auto& l : ctx->ev)
+        for (auto& e : l) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return CR_OK;
@@ -256,12 +265,11 @@ int cr_context_set_profiling(cr_context* ctx, int slots) {
     if (rc) return rc;
     CR_REQUIRE(slots >= 0 && slots <= 4096, "profiling slots must be in [0, 4096]");
     CR_HIP(hipStreamSynchronize(ctx->stream));
-    for (auto& e : ctx->ev) (void)hipEventDestroy(e);
+    for (auto& l : ctx->ev)
+        for (auto& e : l) (void)hipEventDestroy(e);
     ctx->ev.clear();
-    ctx->slots = 0;
     ctx->runs_recorded = 0;
-    ctx->ev.resize((size_t)slots * (CR_NUM_STAGES + 1));
-    for (auto& e : ctx->ev) CR_HIP(hipEventCreate(&e));
+    ctx->ev.resize((size_t)slots);
     ctx->slots = slots;
     return CR_OK;
 }
@@ -329,8 +337,16 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     }
     // rows per lane: 3 covers 192 rows in one strip, 5 covers 320
     b->r_seed = b->r_align = (b->n_max <= 3 * cr::kWave) ? 3 : 5;
-    int64_t dirs_off = 0, bt_off = 0, aln_off = 0, pos_off = 0, max_aln = 0;
+    // scratch budget per chunk (decision words); CARETTA_SCRATCH_MB overrides the 8 GiB default
+    int64_t budget_words = (int64_t)8192 * 1024 * 1024 / 4;
+    if (const char* env = std::getenv("CARETTA_SCRATCH_MB")) {
+        const long long mb = std::atoll(env);
+        if (mb > 0) budget_words = (int64_t)mb * 1024 * 1024 / 4;
+    }
+    int64_t dirs_off = 0, bt_off = 0, aln_off = 0, max_aln = 0, dirs_max = 0, bits_max = 0;
     double bytes = 0.0, cells = 0.0;
+    b->chunks.clear();
+    cr_batch::Chunk ck{0, 0, 0, 0, 0};
     for (int64_t p = 0; p < npairs; p++) {
         int64_t i = pairs[2 * p], j = pairs[2 * p + 1];
         cr::PairDesc& pd = b->h_pairs[(size_t)p];
@@ -338,26 +354,39 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
         pd.m = (int)(b->offsets[j + 1] - b->offsets[j]);
         pd.off_i = b->offsets[i];
         pd.off_j = b->offsets[j];
+        const int64_t dw = (int64_t)cr::strips_of(pd.n, b->r_seed) * cr::tblocks(pd.m, 16) * b->r_seed * cr::kWave;
+        const int64_t bw = (int64_t)cr::strips_of(pd.n, b->r_align) * cr::tblocks(pd.m, 8) * b->r_align * cr::kWave;
+        if (ck.count > 0 && dirs_off + bt_off + dw + bw > budget_words) {
+            b->chunks.push_back(ck);
+            ck = cr_batch::Chunk{p, 0, 0, 0, 0};
+            dirs_off = bt_off = 0;
+        }
         pd.dirs_off = dirs_off;
         pd.bt_off = bt_off;
         pd.aln_off = aln_off;
-        pd.pos_off = pos_off;
-        dirs_off += (int64_t)cr::strips_of(pd.n, b->r_seed) * cr::tblocks(pd.m, 16) * b->r_seed * cr::kWave;
-        bt_off += (int64_t)cr::strips_of(pd.n, b->r_align) * cr::tblocks(pd.m, 8) * b->r_align * cr::kWave;
+        pd.pos_off = 0;
+        dirs_off += dw;
+        bt_off += bw;
+        dirs_max = std::max(dirs_max, dirs_off);
+        bits_max = std::max(bits_max, bt_off);
         aln_off += 2 * (int64_t)(pd.n + pd.m);
-        pos_off += std::min(pd.n, pd.m);
         max_aln = std::max<int64_t>(max_aln, pd.n + pd.m);
+        ck.count++;
+        ck.n_max = std::max(ck.n_max, pd.n);
+        ck.m_max = std::max(ck.m_max, pd.m);
+        ck.max_aln = std::max(ck.max_aln, pd.n + pd.m);
         const double nm = (double)pd.n * pd.m, npm = (double)pd.n + pd.m;
         bytes += 8.0 * (3 + b->d) * npm + nm / 4 + nm / 2 + 16.0 * npm + 136.0;   // SURVEY.md 8(d) B_alg
         cells += nm;
     }
+    if (ck.count > 0) b->chunks.push_back(ck);
     b->max_aln = max_aln;
     b->aln_elems = aln_off;
     b->alg_bytes = bytes;
     b->cells = cells;
     hipError_t e = b->pairs.ensure((size_t)npairs);
-    if (e == hipSuccess) e = b->dirs.ensure((size_t)dirs_off);
-    if (e == hipSuccess) e = b->bits.ensure((size_t)bt_off);
+    if (e == hipSuccess) e = b->dirs.ensure((size_t)dirs_max);
+    if (e == hipSuccess) e = b->bits.ensure((size_t)bits_max);
     if (e == hipSuccess) e = b->aln.ensure((size_t)aln_off);
     if (e == hipSuccess) e = b->xf.ensure((size_t)npairs);
     if (e == hipSuccess) e = b->seed_score.ensure((size_t)npairs);
@@ -388,14 +417,26 @@ int cr_batch_run(cr_batch* b, const cr_params* params, double* d_sw_out) {
     CR_REQUIRE(std::isfinite(prm.gap_open) && std::isfinite(prm.gap_extend) && std::isfinite(prm.sw_gap),
                "gap penalties must be finite");
     const bool prof = ctx->slots > 0;
-    hipEvent_t* ev = prof ? &ctx->ev[(size_t)(ctx->runs_recorded % ctx->slots) * (CR_NUM_STAGES + 1)] : nullptr;
-    if (prof) CR_HIP(hipEventRecord(ev[0], ctx->stream));
-    rc = (b->r_seed == 3) ? launch_seed_d<3>(b, prm) : launch_seed_d<5>(b, prm);
-    if (rc) return rc;
-    if (prof) CR_HIP(hipEventRecord(ev[1], ctx->stream));
-    rc = (b->r_align == 3) ? launch_align<3>(b, prm) : launch_align<5>(b, prm);
-    if (rc) return rc;
-    if (prof) CR_HIP(hipEventRecord(ev[2], ctx->stream));
+    std::vector<hipEvent_t>* evl = nullptr;
+    if (prof) {
+        evl = &ctx->ev[(size_t)(ctx->runs_recorded % ctx->slots)];
+        const size_t need = 1 + 2 * b->chunks.size();
+        while (evl->size() < need) {
+            hipEvent_t e;
+            CR_HIP(hipEventCreate(&e));
+            evl->push_back(e);
+        }
+        CR_HIP(hipEventRecord((*evl)[0], ctx->stream));
+    }
+    size_t evi = 1;
+    for (const cr_batch::Chunk& ck : b->chunks) {
+        rc = (b->r_seed == 3) ? launch_seed_d<3>(b, ck, prm) : launch_seed_d<5>(b, ck, prm);
+        if (rc) return rc;
+        if (prof) CR_HIP(hipEventRecord((*evl)[evi++], ctx->stream));
+        rc = (b->r_align == 3) ? launch_align<3>(b, ck, prm) : launch_align<5>(b, ck, prm);
+        if (rc) return rc;
+        if (prof) CR_HIP(hipEventRecord((*evl)[evi++], ctx->stream));
+    }
     if (d_sw_out) {
         // strided device-to-device copy of the first field of every PairResult
         CR_HIP(hipMemcpy2DAsync(d_sw_out, sizeof(double), b->res.p, sizeof(cr::PairResult), sizeof(double),
@@ -416,11 +457,13 @@ int cr_batch_stage_ms(cr_batch* b, float ms[CR_NUM_STAGES], int* runs_averaged) 
     const int64_t n = std::min<int64_t>(ctx->runs_recorded, ctx->slots);
     double acc[CR_NUM_STAGES] = {};
     for (int64_t r = 0; r < n; r++) {
-        hipEvent_t* ev = &ctx->ev[(size_t)r * (CR_NUM_STAGES + 1)];
-        for (int s = 0; s < CR_NUM_STAGES; s++) {
-            float t = 0.f;
-            CR_HIP(hipEventElapsedTime(&t, ev[s], ev[s + 1]));
-            acc[s] += t;
+        const std::vector<hipEvent_t>& ev = ctx->ev[(size_t)r];
+        for (size_t c = 0; c < b->chunks.size() && 2 * c + 2 < ev.size(); c++) {
+            for (int s = 0; s < CR_NUM_STAGES; s++) {
+                float t = 0.f;
+                CR_HIP(hipEventElapsedTime(&t, ev[2 * c + s], ev[2 * c + s + 1]));
+                acc[s] += t;
+            }
         }
     }
     for (int s = 0; s < CR_NUM_STAGES; s++) ms[s] = (float)(acc[s] / (double)n);

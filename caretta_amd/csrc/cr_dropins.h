@@ -295,7 +295,7 @@ int cr_protein_score_function(cr_context* ctx, const double* coords_i, const dou
     rc = cr_batch_set_pairs(b, pair, 1);
     if (rc == CR_OK) {
         cr_params prm{gamma_tensor, gamma_coords, 1.0, 0.01, 0.0};
-        rc = (b->r_seed == 3) ? launch_seed_d<3>(b, prm) : launch_seed_d<5>(b, prm);
+        rc = (b->r_seed == 3) ? launch_seed_d<3>(b, b->chunks[0], prm) : launch_seed_d<5>(b, b->chunks[0], prm);
     }
     if (rc == CR_OK) {
         DevBuf<double> ds;

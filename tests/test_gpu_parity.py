@@ -230,6 +230,26 @@ def test_pipeline_other_parameters_and_orientation(ctx, oracle):
     assert_bit_identical(res, aln, ref, ref_aln)
 
 
+def test_chunked_scratch_is_invisible(ctx, monkeypatch):
+    """A pair list longer than the decision-scratch budget runs chunk after chunk with identical results."""
+    from caretta_amd import engine
+    fam = synthetic.make_family(10, 120, seed=91, ragged=True)
+    coords, tensors, offsets = synthetic.pack(fam)
+    pairs = engine.all_pairs(10)
+    res1, aln1 = run_batch(ctx, coords, tensors, offsets, pairs)
+    monkeypatch.setenv("CARETTA_SCRATCH_MB", "1")            # ~20 pairs of 120x120 per chunk
+    b = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
+    ctx.set_profiling(2)
+    b.run()
+    b.run()
+    res2, aln2 = b.fetch()
+    ms, runs = b.stage_ms()
+    ctx.set_profiling(0)
+    b.close()
+    assert runs == 2 and np.all(ms > 0)
+    assert res1.tobytes() == res2.tobytes() and np.array_equal(aln1, aln2)
+
+
 def test_pipeline_tiny_and_degenerate(ctx, oracle):
     """1..5-residue structures, identical structures, and a tensor score matrix that underflows to all
     zeros (the reference raises there; the batch reports CR_FLAG_SEED_ALL_ZERO and carries on unsuperposed)."""
