@@ -86,6 +86,7 @@ struct cr_batch {
     std::vector<cr::PairDesc> h_pairs;
     DevBuf<cr::PairDesc> pairs;
     DevBuf<uint32_t> dirs, bits;
+    DevBuf<double> hand;                // strip hand-off rows of multi-strip pairs (per chunk)
     DevBuf<int32_t> aln;
     DevBuf<cr::Transform> xf;
     DevBuf<double> seed_score;
@@ -131,7 +132,7 @@ int launch_seed_zg(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm)
     if (rc) return rc;
     hipLaunchKernelGGL((cr::k_seed<R, D, ZG>), dim3((unsigned)ck.count), dim3(cr::kWave), lds, b->ctx->stream,
                        b->pairs.p + ck.first, b->tensors.p, (int)b->d, b->coords.p, prm.gamma_tensor, prm.sw_gap,
-                       entries, b->dirs.p, b->xf.p + ck.first, b->seed_score.p + ck.first);
+                       entries, b->dirs.p, b->hand.p, b->xf.p + ck.first, b->seed_score.p + ck.first);
     CR_HIP(hipGetLastError());
     return CR_OK;
 }
@@ -162,7 +163,7 @@ int launch_align_zg(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm
     if (rc) return rc;
     hipLaunchKernelGGL((cr::k_align<R, ZG>), dim3((unsigned)ck.count), dim3(cr::kWave), lds, b->ctx->stream,
                        b->pairs.p + ck.first, b->coords.p, b->xf.p + ck.first, b->seed_score.p + ck.first,
-                       prm.gamma_coords, prm.sw_gap, prm.gap_open, prm.gap_extend, entries, b->bits.p, b->aln.p,
+                       prm.gamma_coords, prm.sw_gap, prm.gap_open, prm.gap_extend, entries, b->bits.p, b->hand.p, b->aln.p,
                        b->res.p + ck.first);
     CR_HIP(hipGetLastError());
     return CR_OK;
@@ -343,7 +344,7 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
         const long long mb = std::atoll(env);
         if (mb > 0) budget_words = (int64_t)mb * 1024 * 1024 / 4;
     }
-    int64_t dirs_off = 0, bt_off = 0, aln_off = 0, max_aln = 0, dirs_max = 0, bits_max = 0;
+    int64_t dirs_off = 0, bt_off = 0, aln_off = 0, max_aln = 0, dirs_max = 0, bits_max = 0, hand_off = 0, hand_max = 0;
     double bytes = 0.0, cells = 0.0;
     b->chunks.clear();
     cr_batch::Chunk ck{0, 0, 0, 0, 0};
@@ -359,12 +360,14 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
         if (ck.count > 0 && dirs_off + bt_off + dw + bw > budget_words) {
             b->chunks.push_back(ck);
             ck = cr_batch::Chunk{p, 0, 0, 0, 0};
-            dirs_off = bt_off = 0;
+            dirs_off = bt_off = hand_off = 0;
         }
         pd.dirs_off = dirs_off;
         pd.bt_off = bt_off;
         pd.aln_off = aln_off;
-        pd.pos_off = 0;
+        pd.hand_off = hand_off;
+        if (cr::strips_of(pd.n, std::min(b->r_seed, b->r_align)) > 1) hand_off += 3 * (int64_t)pd.m;
+        hand_max = std::max(hand_max, hand_off);
         dirs_off += dw;
         bt_off += bw;
         dirs_max = std::max(dirs_max, dirs_off);
@@ -387,6 +390,7 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     hipError_t e = b->pairs.ensure((size_t)npairs);
     if (e == hipSuccess) e = b->dirs.ensure((size_t)dirs_max);
     if (e == hipSuccess) e = b->bits.ensure((size_t)bits_max);
+    if (e == hipSuccess) e = b->hand.ensure((size_t)hand_max);
     if (e == hipSuccess) e = b->aln.ensure((size_t)aln_off);
     if (e == hipSuccess) e = b->xf.ensure((size_t)npairs);
     if (e == hipSuccess) e = b->seed_score.ensure((size_t)npairs);

@@ -59,7 +59,8 @@ __global__ __launch_bounds__(kWave) void k_explicit(const int32_t* __restrict__ 
                                                    const int32_t* __restrict__ seq2, int m,
                                                    const double* __restrict__ S, int64_t s_cols, SweepParams prm,
                                                    uint32_t* __restrict__ dirs, uint32_t* __restrict__ bits,
-                                                   SeedMax* __restrict__ seed, AlignEnd* __restrict__ end) {
+                                                   double* __restrict__ hand, SeedMax* __restrict__ seed,
+                                                   AlignEnd* __restrict__ end) {
     extern __shared__ double lds[];
     Explicit<R> src;
     src.S = S;
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(kWave) void k_explicit(const int32_t* __restrict__ 
     src.s_cols = s_cols;
     SeedMax sm;
     AlignEnd ae;
-    sweep<R, MODE>(src, n, m, prm, lds, dirs, bits, sm, ae);
+    sweep<R, MODE>(src, n, m, prm, lds, dirs, bits, hand, sm, ae);
     if (threadIdx.x == 0) {
         if constexpr ((MODE & kSwTrace) != 0) *seed = sm;
         if constexpr ((MODE & (kSwScore | kDtw)) != 0) *end = ae;
@@ -193,6 +194,7 @@ struct ExplicitRun {
     DevBuf<double> S;
     DevBuf<int32_t> s1, s2, aln;
     DevBuf<uint32_t> dirs, bits;
+    DevBuf<double> hand;
     DevBuf<cr::SeedMax> seed;
     DevBuf<cr::AlignEnd> end;
     DevBuf<cr::TraceOut> tout;
@@ -220,6 +222,7 @@ int run_explicit(cr_context* ctx, const int64_t* seq1, int64_t n, const int64_t*
     const size_t nb = (size_t)cr::strips_of((int)n, R) * cr::tblocks((int)m, 8) * R * cr::kWave;
     CR_HIP(r.dirs.ensure((MODE & cr::kSwTrace) ? nd : 1));
     CR_HIP(r.bits.ensure((MODE & cr::kDtw) ? nb : 1));
+    CR_HIP(r.hand.ensure(3 * (size_t)m));
     CR_HIP(r.seed.ensure(1));
     CR_HIP(r.end.ensure(1));
     CR_HIP(r.tout.ensure(1));
@@ -227,7 +230,7 @@ int run_explicit(cr_context* ctx, const int64_t* seq1, int64_t n, const int64_t*
     const size_t lds = cr::sweep_lds_doubles<R, MODE, cr::Explicit<R>>((int)n, (int)m) * sizeof(double);
     if ((rc = allow_lds(cr::k_explicit<R, MODE>, lds))) return rc;
     hipLaunchKernelGGL((cr::k_explicit<R, MODE>), dim3(1), dim3(cr::kWave), lds, ctx->stream, r.s1.p, (int)n, r.s2.p,
-                       (int)m, r.S.p, s_cols, prm, r.dirs.p, r.bits.p, r.seed.p, r.end.p);
+                       (int)m, r.S.p, s_cols, prm, r.dirs.p, r.bits.p, r.hand.p, r.seed.p, r.end.p);
     CR_HIP(hipGetLastError());
     return CR_OK;
 }

@@ -36,7 +36,7 @@ struct PairDesc {
     int64_t dirs_off;        // word offset of this pair's SW decisions
     int64_t bt_off;          // word offset of this pair's DTW decisions
     int64_t aln_off;         // element offset of this pair's alignment rows (2 rows of n+m)
-    int64_t pos_off;         // element offset of this pair's seed position list (min(n,m))
+    int64_t hand_off;        // double offset of this pair's strip hand-off rows (3 planes of m; multi-strip pairs)
 };
 
 struct SeedMax {             // result of the tensor SW fill
@@ -223,7 +223,8 @@ struct SweepParams {
 //   kSwTrace : SW fill + 2-bit decisions + first maximum   (dynamic_time_warping.py:226-247)
 //   kSwScore : SW fill, maximum only                        (dynamic_time_warping.py:205-222)
 //   kDtw     : 3-layer affine fill + 4-bit decisions        (dynamic_time_warping.py:8-86,181-182)
-// LDS layout (doubles): [0,32) exp table | ring | strip hand-off rows (nb * m, only if >1 strip).
+// LDS layout (doubles): [0,32) exp table | ring | hand-off in-ring NB*64 | hand-off out-ring NB*128
+// (the last two only if the pair needs more than one strip).
 //
 // Lanes whose column c = t - lane lies outside [0, m) are switched off with the EXEC mask for the
 // whole cell block, so their state registers keep the DP border values without any select.
@@ -234,7 +235,7 @@ struct SweepParams {
 // ---------------------------------------------------------------------------------------------
 template <int R, int MODE, class Src>
 CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, double* lds,
-                uint32_t* __restrict__ sw_dirs, uint32_t* __restrict__ dtw_bits,
+                uint32_t* __restrict__ sw_dirs, uint32_t* __restrict__ dtw_bits, double* __restrict__ hand_g,
                 SeedMax& seed_out, AlignEnd& end_out) {
     constexpr bool SW = (MODE & (kSwTrace | kSwScore)) != 0;
     constexpr bool TRACE = (MODE & kSwTrace) != 0;
@@ -245,7 +246,10 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
     const int lane = threadIdx.x;
     const ExpEntry* tab = reinterpret_cast<const ExpEntry*>(lds);
     double* ring = lds + 32;
-    double* bnd = ring + Src::kRingDoubles;
+    // A strip's last row is handed to the next strip through HBM (hand_g: NB planes of m doubles, L2
+    // resident), staged on both sides through small LDS rings with coalesced transfers every 64 steps.
+    double* hin = ring + Src::kRingDoubles;            // [NB][64]  row above lane 0, current 64 columns
+    double* hout = hin + NB * kWave;                   // [NB][128] last row of lane 63, most recent columns
 
     if (lane < 16) reinterpret_cast<ExpEntry*>(lds)[lane] = kExpTable[lane];
     src.init_ring(ring, lane);
@@ -288,6 +292,16 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
             if ((t & (kWave - 1)) == 0) {
                 __syncthreads();
                 src.load_chunk(ring, t >> 6, m, lane);
+                if (nstrips > 1) {
+                    if (s + 1 < nstrips && t >= 2 * kWave) {    // columns [t-128, t-65] are complete
+                        const int cc = t - 2 * kWave + lane;
+                        if (cc < m)
+                            for (int k = 0; k < NB; k++) hand_g[(int64_t)k * m + cc] = hout[k * kRing + (cc & (kRing - 1))];
+                    }
+                    if (s > 0 && t + lane < m)
+                        for (int k = 0; k < NB; k++)
+                            hin[k * kWave + lane] = __builtin_nontemporal_load(hand_g + (int64_t)k * m + t + lane);
+                }
                 __syncthreads();
             }
             const int c = t - lane;
@@ -296,10 +310,10 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
             // row above this lane's block: lane 0 reads the DP border (strip 0) or the hand-off row
             double h_top0 = 0.0, m0_top0 = col0_m2, m1_top0 = 0.0;   // M[0][j][0] = MIN - open, M[0][j][1] = 0
             if (s > 0 && lane == 0 && active) {
-                if constexpr (SW) h_top0 = bnd[c];
+                if constexpr (SW) h_top0 = hin[c & (kWave - 1)];
                 if constexpr (DTW) {
-                    m0_top0 = bnd[(NB - 2) * m + c];
-                    m1_top0 = bnd[(NB - 1) * m + c];
+                    m0_top0 = hin[(NB - 2) * kWave + (c & (kWave - 1))];
+                    m1_top0 = hin[(NB - 1) * kWave + (c & (kWave - 1))];
                 }
             }
             double h_top = 0.0, m0_top = 0.0, m1_top = 0.0;
@@ -383,10 +397,10 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
                     m1_bot = m1_up;
                 }
                 if (s + 1 < nstrips && lane == kWave - 1) {
-                    if constexpr (SW) bnd[c] = h_up;
+                    if constexpr (SW) hout[c & (kRing - 1)] = h_up;
                     if constexpr (DTW) {
-                        bnd[(NB - 2) * m + c] = m0_up;
-                        bnd[(NB - 1) * m + c] = m1_up;
+                        hout[(NB - 2) * kRing + (c & (kRing - 1))] = m0_up;
+                        hout[(NB - 1) * kRing + (c & (kRing - 1))] = m1_up;
                     }
                 }
             }
@@ -410,6 +424,17 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
                     }
                 }
             }
+        }
+        if (s + 1 < nstrips) {
+            // flush the hand-off columns not yet written (at most 127) and make them visible to this
+            // wave's own loads in the next strip
+            __syncthreads();
+            const int tl = (T - 1) & ~(kWave - 1);                        // last chunk boundary seen
+            for (int cc = (tl >= 2 * kWave ? tl - kWave : 0) + lane; cc < m; cc += kWave)
+                for (int k = 0; k < NB; k++) hand_g[(int64_t)k * m + cc] = hout[k * kRing + (cc & (kRing - 1))];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
         }
         if constexpr (TRACE) {
             // fold this strip's per-row first maxima into the lane's running best (rows ascending)
@@ -470,7 +495,7 @@ template <int R, int MODE, class Src>
 __host__ __device__ inline size_t sweep_lds_doubles(int n_max, int m_max) {
     constexpr int NB = ((MODE & (kSwTrace | kSwScore)) ? 1 : 0) + ((MODE & kDtw) ? 2 : 0);
     size_t v = 32 + Src::kRingDoubles;
-    if (strips_of(n_max, R) > 1) v += (size_t)NB * m_max;
+    if (strips_of(n_max, R) > 1) v += (size_t)NB * (kWave + kRing);
     return v;
 }
 
@@ -901,11 +926,12 @@ CR_D void drain_stores() {
 
 // Stages 1+2: tensor RBF + SW fill (multiple_alignment.py:328-335), then traceback + seed Kabsch.
 template <int R, int D, bool ZG>
-__global__ __launch_bounds__(kWave) void k_seed(const PairDesc* __restrict__ pairs,
+__global__ __launch_bounds__(kWave, 2) void k_seed(const PairDesc* __restrict__ pairs,
                                                const double* __restrict__ tensors, int d,
                                                const double* __restrict__ coords, double gamma, double sw_gap,
                                                int max_entries, uint32_t* __restrict__ dirs,
-                                               Transform* __restrict__ xf, double* __restrict__ seed_score) {
+                                               double* __restrict__ hand, Transform* __restrict__ xf,
+                                               double* __restrict__ seed_score) {
     extern __shared__ double lds[];
     const PairDesc pd = pairs[blockIdx.x];
     SeedMax sm;
@@ -917,7 +943,8 @@ __global__ __launch_bounds__(kWave) void k_seed(const PairDesc* __restrict__ pai
         src.d = d;
         src.neg_gamma = -gamma;
         SweepParams prm{sw_gap, 0.0, 0.0};
-        sweep<R, kSwTrace | (ZG ? kZeroGap : 0)>(src, pd.n, pd.m, prm, lds, dirs + pd.dirs_off, nullptr, sm, unused);
+        sweep<R, kSwTrace | (ZG ? kZeroGap : 0)>(src, pd.n, pd.m, prm, lds, dirs + pd.dirs_off, nullptr,
+                                                  hand + pd.hand_off, sm, unused);
     }
     drain_stores();
     Transform tr;
@@ -931,13 +958,14 @@ __global__ __launch_bounds__(kWave) void k_seed(const PairDesc* __restrict__ pai
 // Stages 3+4: coordinate RBF on the seed-superposed frames + SW score + affine DTW fill
 // (multiple_alignment.py:347-349, :164, :263-275), then traceback + Kabsch + metrics.
 template <int R, bool ZG>
-__global__ __launch_bounds__(kWave) void k_align(const PairDesc* __restrict__ pairs,
+__global__ __launch_bounds__(kWave, 4) void k_align(const PairDesc* __restrict__ pairs,
                                                 const double* __restrict__ coords,
                                                 const Transform* __restrict__ xf,
                                                 const double* __restrict__ seed_score, double gamma,
                                                 double sw_gap, double gap_open, double gap_extend,
                                                 int max_entries, uint32_t* __restrict__ bits,
-                                                int32_t* __restrict__ aln, PairResult* __restrict__ res) {
+                                                double* __restrict__ hand, int32_t* __restrict__ aln,
+                                                PairResult* __restrict__ res) {
     extern __shared__ double lds[];
     const PairDesc pd = pairs[blockIdx.x];
     SeedMax unused;
@@ -949,7 +977,8 @@ __global__ __launch_bounds__(kWave) void k_align(const PairDesc* __restrict__ pa
         src.xf = xf + blockIdx.x;
         src.neg_gamma = -gamma;
         SweepParams prm{sw_gap, gap_open, gap_extend};
-        sweep<R, kSwScore | kDtw | (ZG ? kZeroGap : 0)>(src, pd.n, pd.m, prm, lds, nullptr, bits + pd.bt_off, unused, e);
+        sweep<R, kSwScore | kDtw | (ZG ? kZeroGap : 0)>(src, pd.n, pd.m, prm, lds, nullptr, bits + pd.bt_off,
+                                                         hand + pd.hand_off, unused, e);
     }
     drain_stores();
     PairResult r;
