@@ -127,7 +127,7 @@ int launch_seed_zg(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm)
     using Src = cr::RbfTensor<R, D>;
     const int entries = std::min(ck.n_max, ck.m_max);
     const size_t fill = cr::sweep_lds_doubles<R, cr::kSwTrace, Src>(ck.n_max, ck.m_max);
-    const size_t lds = sizeof(double) * std::max(fill, 32 + cr::trace_lds_doubles(R, entries));
+    const size_t lds = sizeof(double) * std::max(fill, (size_t)cr::kExpDoubles + cr::trace_lds_doubles(R, entries));
     int rc = allow_lds(cr::k_seed<R, D, ZG>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL((cr::k_seed<R, D, ZG>), dim3((unsigned)ck.count), dim3(cr::kWave), lds, b->ctx->stream,
@@ -158,7 +158,7 @@ int launch_align_zg(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm
     using Src = cr::RbfCoords<R>;
     const int entries = ck.max_aln;
     const size_t fill = cr::sweep_lds_doubles<R, cr::kSwScore | cr::kDtw, Src>(ck.n_max, ck.m_max);
-    const size_t lds = sizeof(double) * std::max(fill, 32 + cr::trace_lds_doubles(R, entries));
+    const size_t lds = sizeof(double) * std::max(fill, (size_t)cr::kExpDoubles + cr::trace_lds_doubles(R, entries));
     int rc = allow_lds(cr::k_align<R, ZG>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL((cr::k_align<R, ZG>), dim3((unsigned)ck.count), dim3(cr::kWave), lds, b->ctx->stream,

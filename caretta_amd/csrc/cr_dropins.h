@@ -7,9 +7,9 @@ namespace cr {
 // make_score_matrix (score_functions.py:23-51): one thread per cell, coalesced along j.
 __global__ void k_score_matrix(const double* __restrict__ a, int n, const double* __restrict__ b, int m, int k,
                                double neg_gamma, double* __restrict__ S) {
-    __shared__ ExpEntry tab[16];
+    __shared__ ExpEntry tab[kExpEntries];
     const int tid = threadIdx.y * blockDim.x + threadIdx.x;
-    if (tid < 16) tab[tid] = kExpTable[tid];
+    for (int x = tid; x < kExpEntries; x += blockDim.x * blockDim.y) tab[x] = kExpTable[x];
     __syncthreads();
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y * blockDim.y + threadIdx.y;
@@ -28,9 +28,9 @@ __global__ void k_score_matrix(const double* __restrict__ a, int n, const double
 // coordinate score matrix on the seed-superposed frames (multiple_alignment.py:344-349)
 __global__ void k_score_matrix_xf(const double* __restrict__ xi, int n, const double* __restrict__ xj, int m,
                                   const Transform* __restrict__ xf, double neg_gamma, double* __restrict__ S) {
-    __shared__ ExpEntry tab[16];
+    __shared__ ExpEntry tab[kExpEntries];
     const int tid = threadIdx.y * blockDim.x + threadIdx.x;
-    if (tid < 16) tab[tid] = kExpTable[tid];
+    for (int x = tid; x < kExpEntries; x += blockDim.x * blockDim.y) tab[x] = kExpTable[x];
     __syncthreads();
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y * blockDim.y + threadIdx.y;

@@ -223,7 +223,7 @@ struct SweepParams {
 //   kSwTrace : SW fill + 2-bit decisions + first maximum   (dynamic_time_warping.py:226-247)
 //   kSwScore : SW fill, maximum only                        (dynamic_time_warping.py:205-222)
 //   kDtw     : 3-layer affine fill + 4-bit decisions        (dynamic_time_warping.py:8-86,181-182)
-// LDS layout (doubles): [0,32) exp table | ring | hand-off in-ring NB*64 | hand-off out-ring NB*128
+// LDS layout (doubles): [0,kExpDoubles) exp table | ring | hand-off in-ring NB*64 | hand-off out-ring NB*128
 // (the last two only if the pair needs more than one strip).
 //
 // Lanes whose column c = t - lane lies outside [0, m) are switched off with the EXEC mask for the
@@ -245,13 +245,13 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
     constexpr int NB = (SW ? 1 : 0) + (DTW ? 2 : 0);   // values handed from strip to strip per column
     const int lane = threadIdx.x;
     const ExpEntry* tab = reinterpret_cast<const ExpEntry*>(lds);
-    double* ring = lds + 32;
+    double* ring = lds + kExpDoubles;
     // A strip's last row is handed to the next strip through HBM (hand_g: NB planes of m doubles, L2
     // resident), staged on both sides through small LDS rings with coalesced transfers every 64 steps.
     double* hin = ring + Src::kRingDoubles;            // [NB][64]  row above lane 0, current 64 columns
     double* hout = hin + NB * kWave;                   // [NB][128] last row of lane 63, most recent columns
 
-    if (lane < 16) reinterpret_cast<ExpEntry*>(lds)[lane] = kExpTable[lane];
+    load_exp_table(lds, lane);
     src.init_ring(ring, lane);
     __syncthreads();
 
@@ -494,7 +494,7 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
 template <int R, int MODE, class Src>
 __host__ __device__ inline size_t sweep_lds_doubles(int n_max, int m_max) {
     constexpr int NB = ((MODE & (kSwTrace | kSwScore)) ? 1 : 0) + ((MODE & kDtw) ? 2 : 0);
-    size_t v = 32 + Src::kRingDoubles;
+    size_t v = kExpDoubles + Src::kRingDoubles;
     if (strips_of(n_max, R) > 1) v += (size_t)NB * (kWave + kRing);
     return v;
 }
@@ -914,7 +914,7 @@ CR_D void align_trace(const PairDesc& pd, int R, int max_entries, const double* 
 // ---------------------------------------------------------------------------------------------
 // Batch kernels: two launches per batch, one wave per pair, each a fill followed by its traceback
 // in the same wave (the latency-bound walk of one wave hides under the FP64 fill of its neighbours).
-// LDS (doubles): [0,32) exp table | union { ring + strip hand-off rows , entries + window/scratch }.
+// LDS (doubles): [0,kExpDoubles) exp table | union { ring + strip hand-off rows , entries + window/scratch }.
 // ---------------------------------------------------------------------------------------------
 
 // Make this wave's own decision words (plain global stores) visible to its own later loads.
@@ -948,7 +948,7 @@ __global__ __launch_bounds__(kWave, 2) void k_seed(const PairDesc* __restrict__ 
     }
     drain_stores();
     Transform tr;
-    seed_trace(pd, R, max_entries, coords, dirs, sm, lds + 32, tr);
+    seed_trace(pd, R, max_entries, coords, dirs, sm, lds + kExpDoubles, tr);
     if (threadIdx.x == 0) {
         xf[blockIdx.x] = tr;
         seed_score[blockIdx.x] = sm.score;
@@ -982,7 +982,7 @@ __global__ __launch_bounds__(kWave, 4) void k_align(const PairDesc* __restrict__
     }
     drain_stores();
     PairResult r;
-    align_trace(pd, R, max_entries, coords, bits, e, lds + 32, aln, r);
+    align_trace(pd, R, max_entries, coords, bits, e, lds + kExpDoubles, aln, r);
     r.seed_score = seed_score[blockIdx.x];
     r.seed_len = xf[blockIdx.x].seed_len;
     r.flags |= xf[blockIdx.x].flags;

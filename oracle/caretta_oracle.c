@@ -65,28 +65,12 @@ static double sum_strided(const double *a, int64_t n, int64_t stride) {
 }
 
 /* ------------------------------------------------------------------------------------------
- * exp.  k = RN(x*16/ln2), r = x - k*ln2/16, exp(x) = 2^(k/16) * (1 + p(r)), |r| <= ln2/32.
+ * exp.  k = RN(x*N/ln2), r = x - k*ln2/N, exp(x) = 2^(k/N) * (1 + p(r)), |r| <= ln2/(2N), N = CR_EXP_N.
  * Restated identically (same constants, same operation order) in caretta_amd/csrc/cr_math.h.
  * Constants: tools/gen_exp_constants.py.
  * ---------------------------------------------------------------------------------------- */
-static const double EXP_TAB[16][2] = {
-    {0x1.0000000000000p+0, 0x0.0p+0},
-    {0x1.0b5586cf9890fp+0, 0x1.8a62e4adc610bp-54},
-    {0x1.172b83c7d517bp+0, -0x1.19041b9d78a76p-55},
-    {0x1.2387a6e756238p+0, 0x1.9b07eb6c70573p-54},
-    {0x1.306fe0a31b715p+0, 0x1.6f46ad23182e4p-55},
-    {0x1.3dea64c123422p+0, 0x1.ada0911f09ebcp-55},
-    {0x1.4bfdad5362a27p+0, 0x1.d4397afec42e2p-56},
-    {0x1.5ab07dd485429p+0, 0x1.6324c054647adp-54},
-    {0x1.6a09e667f3bcdp+0, -0x1.bdd3413b26456p-54},
-    {0x1.7a11473eb0187p+0, -0x1.41577ee04992fp-55},
-    {0x1.8ace5422aa0dbp+0, 0x1.6e9f156864b27p-54},
-    {0x1.9c49182a3f090p+0, 0x1.c7c46b071f2bep-56},
-    {0x1.ae89f995ad3adp+0, 0x1.7a1cd345dcc81p-54},
-    {0x1.c199bdd85529cp+0, 0x1.11065895048ddp-55},
-    {0x1.d5818dcfba487p+0, 0x1.2ed02d75b3707p-55},
-    {0x1.ea4afa2a490dap+0, -0x1.e9c23179c2893p-54},
-};
+#include "exp_table.inc"
+static const double EXP_TAB[CR_EXP_N][2] = {CR_EXP_TABLE};
 
 static inline double pow2i(int e) { /* 2^e for -1022 <= e <= 1023 */
     uint64_t bits = (uint64_t)(e + 1023) << 52;
@@ -99,27 +83,29 @@ double cro_exp(double x) {
 #ifdef CRO_LIBM_EXP
     return exp(x);
 #else
-    const double INV_LN2_16 = 0x1.71547652b82fep+4;
-    const double LN2_16_HI = 0x1.62e42fefa39efp-5;
-    const double LN2_16_LO = 0x1.abc9e3b39803fp-60;
     const double SHIFT = 0x1.8p52;
     const double C2 = 0x1.0000000000000p-1, C3 = 0x1.5555555555555p-3, C4 = 0x1.5555555555555p-5;
-    const double C5 = 0x1.1111111111111p-7, C6 = 0x1.6c16c16c16c17p-10, C7 = 0x1.a01a01a01a01ap-13;
+    const double C5 = 0x1.1111111111111p-7;
     x = (x < 710.0) ? x : 710.0;      /* minNum: -> +inf through the scaling below (NaN too) */
     x = (x > -746.0) ? x : -746.0;    /* -> 0 */
-    double z = fma(x, INV_LN2_16, SHIFT);
+    double z = fma(x, CR_EXP_INV_LN2_N, SHIFT);
     uint64_t zb;
     memcpy(&zb, &z, 8);
     int32_t ki = (int32_t)(uint32_t)zb;
     double kd = z - SHIFT;
-    double r = fma(kd, -LN2_16_HI, x);
-    r = fma(kd, -LN2_16_LO, r);
-    int j = ki & 15;
-    int e = (ki - j) / 16;
+    double r = fma(kd, -CR_EXP_LN2_N_HI, x);
+    r = fma(kd, -CR_EXP_LN2_N_LO, r);
+    int j = ki & (CR_EXP_N - 1);
+    int e = (ki - j) / CR_EXP_N;
     double r2 = r * r;
+#if CR_EXP_N >= 128
+    double q = fma(r, C5, C4);        /* |r| <= ln2/256: degree 5 leaves 5e-19 */
+#else
+    const double C6 = 0x1.6c16c16c16c17p-10, C7 = 0x1.a01a01a01a01ap-13;
     double q = fma(r, C7, C6);
     q = fma(r, q, C5);
     q = fma(r, q, C4);
+#endif
     q = fma(r, q, C3);
     q = fma(r, q, C2);
     double p = fma(r2, q, r);
