@@ -14,7 +14,7 @@ import numpy as np
 LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libcaretta_hip.so"
 
 CR_NUM_STAGES = 2
-FLAG_SEED_SKIPPED, FLAG_METRICS_SKIPPED, FLAG_SEED_ALL_ZERO = 1, 2, 4
+FLAG_SEED_SKIPPED, FLAG_METRICS_SKIPPED, FLAG_SEED_ALL_ZERO, FLAG_MEAN_UNSUPERPOSED = 1, 2, 4, 8
 
 
 class CarettaHipError(RuntimeError):
@@ -53,6 +53,8 @@ SIGNATURES = {
     "cr_batch_destroy": [_vp],
     "cr_make_score_matrix": [_vp, _vp, _i64, _vp, _i64, _i64, _f64, _vp],
     "cr_protein_score_function": [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _f64, _f64, _vp, C.POINTER(C.c_uint32)],
+    "cr_progressive_node": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _f64, _f64, C.POINTER(Params), _f64,
+                            _vp, _vp, C.POINTER(C.c_int64), _vp, _vp, _vp, C.POINTER(C.c_uint32)],
     "cr_dtw_align": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _f64, _f64, _vp, _vp, C.POINTER(C.c_int64),
                      C.POINTER(C.c_double)],
     "cr_smith_waterman_score": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _f64, C.POINTER(C.c_double)],

@@ -320,6 +320,87 @@ int cr_protein_score_function(cr_context* ctx, const double* coords_i, const dou
     return rc;
 }
 
+int cr_progressive_node(cr_context* ctx, const double* coords_1, const double* tensors_1, const double* weights_1,
+                        int64_t n, const double* coords_2, const double* tensors_2, const double* weights_2, int64_t m,
+                        int64_t d, double mult1, double mult2, const cr_params* params, double gamma_weight,
+                        int64_t* aln1, int64_t* aln2, int64_t* aln_len, double* coords_out, double* tensors_out,
+                        double* weights_out, uint32_t* flags) {
+    CR_REQUIRE(coords_1 && tensors_1 && weights_1 && coords_2 && tensors_2 && weights_2 && params, "null input");
+    CR_REQUIRE(aln1 && aln2 && aln_len && coords_out && tensors_out && weights_out, "null output");
+    CR_REQUIRE(n >= 1 && m >= 1, "empty node");
+    CR_REQUIRE(std::isfinite(gamma_weight) && gamma_weight >= 0.0 && std::isfinite(mult1) && std::isfinite(mult2),
+               "gamma_weight must be finite and >= 0, multipliers finite");
+    CR_REQUIRE(all_finite(weights_1, (size_t)n) && all_finite(weights_2, (size_t)m), "weights contain NaN or infinity");
+    // the two children as a two-structure batch: k_seed gives the seed superposition, k_node the rest
+    std::vector<double> coords((size_t)(n + m) * 3), tensors((size_t)(n + m) * d), weights((size_t)(n + m));
+    std::memcpy(coords.data(), coords_1, sizeof(double) * (size_t)n * 3);
+    std::memcpy(coords.data() + n * 3, coords_2, sizeof(double) * (size_t)m * 3);
+    std::memcpy(tensors.data(), tensors_1, sizeof(double) * (size_t)n * d);
+    std::memcpy(tensors.data() + n * d, tensors_2, sizeof(double) * (size_t)m * d);
+    std::memcpy(weights.data(), weights_1, sizeof(double) * (size_t)n);
+    std::memcpy(weights.data() + n, weights_2, sizeof(double) * (size_t)m);
+    const int64_t offsets[3] = {0, n, n + m};
+    const int32_t pair[2] = {0, 1};
+    cr_batch* b = nullptr;
+    int rc = cr_batch_create(ctx, coords.data(), tensors.data(), offsets, 2, d, &b);
+    if (rc) return rc;
+    struct Guard {
+        cr_batch* b;
+        ~Guard() { cr_batch_destroy(b); }
+    } guard{b};
+    if ((rc = cr_batch_set_pairs(b, pair, 1))) return rc;
+    const cr_params prm = *params;
+    CR_REQUIRE(std::isfinite(prm.gamma_tensor) && prm.gamma_tensor >= 0.0 && std::isfinite(prm.gamma_coords) &&
+                   prm.gamma_coords >= 0.0 && std::isfinite(prm.gap_open) && std::isfinite(prm.gap_extend) &&
+                   std::isfinite(prm.sw_gap),
+               "parameters must be finite, gammas >= 0");
+    const cr_batch::Chunk& ck = b->chunks[0];
+    rc = (b->r_seed == 3) ? launch_seed_d<3>(b, ck, prm) : launch_seed_d<5>(b, ck, prm);
+    if (rc) return rc;
+    const int64_t cap = n + m;
+    DevBuf<double> dw, dxn, dtn, dwn;
+    DevBuf<cr::NodeOut> dout;
+    if ((rc = upload(dw, weights.data(), (size_t)cap, ctx->stream))) return rc;
+    CR_HIP(dxn.ensure((size_t)cap * 3));
+    CR_HIP(dtn.ensure((size_t)cap * d));
+    CR_HIP(dwn.ensure((size_t)cap));
+    CR_HIP(dout.ensure(1));
+    const int R = b->r_align;
+    const int entries = (int)cap;
+    size_t lds;
+    if (R == 3) {
+        lds = sizeof(double) * std::max(cr::sweep_lds_doubles<3, cr::kDtw, cr::RbfNode<3>>((int)n, (int)m),
+                                        (size_t)cr::kExpDoubles + cr::trace_lds_doubles(3, entries));
+        if ((rc = allow_lds(cr::k_node<3>, lds))) return rc;
+        hipLaunchKernelGGL(cr::k_node<3>, dim3(1), dim3(cr::kWave), lds, ctx->stream, b->pairs.p, b->coords.p, b->tensors.p,
+                           (int)d, dw.p, mult1, mult2, b->xf.p, prm.gamma_coords, gamma_weight, prm.gap_open,
+                           prm.gap_extend, entries, b->bits.p, b->hand.p, b->aln.p, dxn.p, dtn.p, dwn.p, dout.p);
+    } else {
+        lds = sizeof(double) * std::max(cr::sweep_lds_doubles<5, cr::kDtw, cr::RbfNode<5>>((int)n, (int)m),
+                                        (size_t)cr::kExpDoubles + cr::trace_lds_doubles(5, entries));
+        if ((rc = allow_lds(cr::k_node<5>, lds))) return rc;
+        hipLaunchKernelGGL(cr::k_node<5>, dim3(1), dim3(cr::kWave), lds, ctx->stream, b->pairs.p, b->coords.p, b->tensors.p,
+                           (int)d, dw.p, mult1, mult2, b->xf.p, prm.gamma_coords, gamma_weight, prm.gap_open,
+                           prm.gap_extend, entries, b->bits.p, b->hand.p, b->aln.p, dxn.p, dtn.p, dwn.p, dout.p);
+    }
+    CR_HIP(hipGetLastError());
+    cr::NodeOut no;
+    CR_HIP(hipMemcpyAsync(&no, dout.p, sizeof(no), hipMemcpyDeviceToHost, ctx->stream));
+    CR_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<int32_t> ha((size_t)(2 * cap));
+    CR_HIP(hipMemcpy(ha.data(), b->aln.p, sizeof(int32_t) * (size_t)(2 * cap), hipMemcpyDeviceToHost));
+    for (int x = 0; x < no.len; x++) {
+        aln1[x] = ha[(size_t)(no.first + x)];
+        aln2[x] = ha[(size_t)(cap + no.first + x)];
+    }
+    CR_HIP(hipMemcpy(coords_out, dxn.p + (size_t)no.first * 3, sizeof(double) * (size_t)no.len * 3, hipMemcpyDeviceToHost));
+    CR_HIP(hipMemcpy(tensors_out, dtn.p + (size_t)no.first * d, sizeof(double) * (size_t)no.len * d, hipMemcpyDeviceToHost));
+    CR_HIP(hipMemcpy(weights_out, dwn.p + no.first, sizeof(double) * (size_t)no.len, hipMemcpyDeviceToHost));
+    *aln_len = no.len;
+    if (flags) *flags = no.flags;
+    return CR_OK;
+}
+
 int cr_dtw_align(cr_context* ctx, const int64_t* seq1, int64_t n, const int64_t* seq2, int64_t m, const double* S,
                  int64_t s_rows, int64_t s_cols, double gap_open, double gap_extend, int64_t* aln1, int64_t* aln2,
                  int64_t* aln_len, double* score) {

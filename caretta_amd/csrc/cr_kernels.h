@@ -184,6 +184,43 @@ struct RbfCoords {
     }
 };
 
+// Progressive-alignment node score (multiple_alignment.py:204-210): the coordinate RBF of RbfCoords
+// PLUS the RBF of the scaled consensus weights, exp(-gw * (w1[i]*mult1 - w2[j]*mult2)^2).
+template <int R>
+struct RbfNode {
+    static constexpr bool kNonNegative = true;
+    RbfCoords<R> xyz;
+    const double* __restrict__ w_rows;   // (n) consensus weights of node 1
+    const double* __restrict__ w_cols;   // (m) consensus weights of node 2
+    double mult1, mult2, neg_gamma_w;
+    double wrow[R], wcol;
+    static constexpr int kRingDoubles = 4 * kRing;
+    static constexpr bool kMaskRows = false;
+
+    CR_D void load_rows(int rowbase, int n) {
+        xyz.load_rows(rowbase, n);
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const int r = rowbase + q;
+            wrow[q] = r < n ? w_rows[r] * mult1 : kFarAway;
+        }
+    }
+    CR_D void init_ring(double*, int) {}
+    CR_D void load_chunk(double* ring, int chunk, int m, int lane) {
+        xyz.load_chunk(ring, chunk, m, lane);
+        const int c = chunk * kWave + lane;
+        if (c < m) ring[3 * kRing + (c & (kRing - 1))] = w_cols[c] * mult2;
+    }
+    CR_D void fetch_col(const double* ring, int slot) {
+        xyz.fetch_col(ring, slot);
+        wcol = ring[3 * kRing + slot];
+    }
+    CR_D double score(int q, const ExpEntry* tab) const {
+        const double dw = wrow[q] - wcol;
+        return xyz.score(q, tab) + exp_tab<true>(neg_gamma_w * (dw * dw), tab);
+    }
+};
+
 // Explicit score matrix with index sequences: S[seq1[i], seq2[j]] (dynamic_time_warping.py:24-26,79).
 template <int R>
 struct Explicit {
@@ -780,12 +817,11 @@ CR_D void seed_trace(const PairDesc& pd, int R, int max_entries, const double* _
     tr.seed_len = len;
 }
 
-// Stage 4: DTW traceback (dynamic_time_warping.py:90-144), common positions, Kabsch on the
-// original coordinates, RMSD / coverage / TM (multiple_alignment.py:1033-1054, :59-70).
-// Alignment rows end up back-to-front in [aln_off, aln_off + n + m).  Wave-uniform.
-CR_D void align_trace(const PairDesc& pd, int R, int max_entries, const double* __restrict__ coords,
-                      const uint32_t* __restrict__ bits, const AlignEnd e, double* lds,
-                      int32_t* __restrict__ aln, PairResult& r) {
+// DTW traceback (dynamic_time_warping.py:90-144) on the packed decisions: leaves the alignment columns
+// as packed entries in lds[first .. cap) (cap = n + m), writes the rows to HBM (back-to-front in
+// [aln, aln + 2*cap)), returns the number of columns and of aligned pairs.  Wave-uniform.
+CR_D void dtw_walk(int n0, int m0, int R, int max_entries, const uint32_t* __restrict__ w, int start_layer,
+                   double* lds, int32_t* __restrict__ aln, int& len_out, int& pairs_out) {
     const int lane = threadIdx.x;
     uint32_t* arow = reinterpret_cast<uint32_t*>(lds);           // packed alignment columns, back-to-front
     double* scratch = lds + ((size_t)max_entries + 3) / 4 * 2;
@@ -794,10 +830,9 @@ CR_D void align_trace(const PairDesc& pd, int R, int max_entries, const double* 
     bw.s = -1;
     bw.lo = 0;
     bw.hi = -1;
-    const int cap = pd.n + pd.m;
-    const uint32_t* w = bits + pd.bt_off;
-    const int TB = tblocks(pd.m, 8);
-    int n = pd.n, m = pd.m, dir = e.start_layer, idx = 0, k = 0;
+    const int cap = n0 + m0;
+    const int TB = tblocks(m0, 8);
+    int n = n0, m = m0, dir = start_layer, idx = 0, k = 0;
     RowPos rp;
     rp.set(n - 1, R);
 #pragma unroll 1
@@ -837,8 +872,7 @@ CR_D void align_trace(const PairDesc& pd, int R, int max_entries, const double* 
     idx += n + m;
     __syncthreads();
     const int first = cap - idx;
-    // alignment rows -> HBM, coalesced
-    int32_t* a1 = aln + pd.aln_off;
+    int32_t* a1 = aln;                                           // alignment rows -> HBM, coalesced
     int32_t* a2 = a1 + cap;
     for (int x = first + lane; x < cap; x += kWave) {
         const uint32_t u = arow[x];
@@ -846,6 +880,22 @@ CR_D void align_trace(const PairDesc& pd, int R, int max_entries, const double* 
         a1[x] = i == kGap16 ? -1 : (int)i;
         a2[x] = j == kGap16 ? -1 : (int)j;
     }
+    len_out = idx;
+    pairs_out = k;
+}
+
+// Stage 4: DTW traceback, common positions, Kabsch on the original coordinates, RMSD / coverage / TM
+// (multiple_alignment.py:1033-1054, :59-70).  Wave-uniform.
+CR_D void align_trace(const PairDesc& pd, int R, int max_entries, const double* __restrict__ coords,
+                      const uint32_t* __restrict__ bits, const AlignEnd e, double* lds,
+                      int32_t* __restrict__ aln, PairResult& r) {
+    const int lane = threadIdx.x;
+    uint32_t* arow = reinterpret_cast<uint32_t*>(lds);
+    double* scratch = lds + ((size_t)max_entries + 3) / 4 * 2;
+    const int cap = pd.n + pd.m;
+    int idx, k;
+    dtw_walk(pd.n, pd.m, R, max_entries, bits + pd.bt_off, e.start_layer, lds, aln + pd.aln_off, idx, k);
+    const int first = cap - idx;
     r.sw = e.sw;
     r.dtw_score = e.dtw_score;
 #pragma unroll
@@ -987,6 +1037,100 @@ __global__ __launch_bounds__(kWave, 4) void k_align(const PairDesc* __restrict__
     r.seed_len = xf[blockIdx.x].seed_len;
     r.flags |= xf[blockIdx.x].flags;
     if (threadIdx.x == 0) res[blockIdx.x] = r;
+}
+
+// One node of progressive alignment (multiple_alignment.py:193-234), after k_seed has produced the seed
+// superposition of the two children: node score -> affine DTW fill -> traceback -> Protein.mean_function
+// (:351-381: tensors averaged column by column, coordinates averaged after superposing on the aligned
+// positions) and get_mean_weights (:73-82).  One wave.  Outputs have cap = n + m rows, valid from `first`.
+struct NodeOut {
+    int32_t len, first;
+    uint32_t flags;
+    int32_t pad;
+};
+
+template <int R>
+__global__ __launch_bounds__(kWave) void k_node(const PairDesc* __restrict__ pairs, const double* __restrict__ coords,
+                                               const double* __restrict__ tensors, int d,
+                                               const double* __restrict__ weights, double mult1, double mult2,
+                                               const Transform* __restrict__ xf, double gamma_coords,
+                                               double gamma_weight, double gap_open, double gap_extend,
+                                               int max_entries, uint32_t* __restrict__ bits,
+                                               double* __restrict__ hand, int32_t* __restrict__ aln,
+                                               double* __restrict__ Xn, double* __restrict__ Tn,
+                                               double* __restrict__ Wn, NodeOut* __restrict__ out) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const PairDesc pd = pairs[0];
+    SeedMax unused;
+    AlignEnd e;
+    {
+        RbfNode<R> src;
+        src.xyz.rows_g = coords + pd.off_i * 3;
+        src.xyz.cols_g = coords + pd.off_j * 3;
+        src.xyz.xf = xf;
+        src.xyz.neg_gamma = -gamma_coords;
+        src.w_rows = weights + pd.off_i;
+        src.w_cols = weights + pd.off_j;
+        src.mult1 = mult1;
+        src.mult2 = mult2;
+        src.neg_gamma_w = -gamma_weight;
+        SweepParams prm{0.0, gap_open, gap_extend};
+        sweep<R, kDtw>(src, pd.n, pd.m, prm, lds, nullptr, bits, hand, unused, e);
+    }
+    drain_stores();
+    double* tl = lds + kExpDoubles;
+    const int cap = pd.n + pd.m;
+    int idx, k;
+    dtw_walk(pd.n, pd.m, R, max_entries, bits, e.start_layer, tl, aln, idx, k);
+    const int first = cap - idx;
+    const uint32_t* ent = reinterpret_cast<const uint32_t*>(tl) + first;
+    double* scratch = tl + ((size_t)max_entries + 3) / 4 * 2;
+    const double* X1 = coords + pd.off_i * 3;
+    const double* X2 = coords + pd.off_j * 3;
+    const double* T1 = tensors + pd.off_i * d;
+    const double* T2 = tensors + pd.off_j * d;
+    const double* W1 = weights + pd.off_i;
+    const double* W2 = weights + pd.off_j;
+    uint32_t flags = xf->flags;
+    double c1[3] = {0, 0, 0}, c2[3] = {0, 0, 0}, Rm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3];
+    const bool superpose = k > 3;                        // multiple_alignment.py:364
+    if (superpose) kabsch_ordered(X1, X2, ent, idx, k, lane, scratch, c1, c2, Rm, t);
+    else flags |= 8u;
+    for (int x = lane; x < idx; x += kWave) {
+        const uint32_t u = ent[x];
+        const uint32_t i = u & 0xffffu, j = u >> 16;
+        const bool has1 = i != kGap16, has2 = j != kGap16;
+        double a[3] = {0, 0, 0}, b[3] = {0, 0, 0};
+        if (has1)
+            for (int c = 0; c < 3; c++) a[c] = superpose ? X1[(int64_t)i * 3 + c] - c1[c] : X1[(int64_t)i * 3 + c];
+        if (has2) {
+            if (superpose) {
+                const double v[3] = {X2[(int64_t)j * 3] - c2[0], X2[(int64_t)j * 3 + 1] - c2[1], X2[(int64_t)j * 3 + 2] - c2[2]};
+                rot3(v, Rm, b);
+            } else {
+                for (int c = 0; c < 3; c++) b[c] = X2[(int64_t)j * 3 + c];
+            }
+        }
+        const int64_t o = first + x;
+        for (int c = 0; c < 3; c++) Xn[o * 3 + c] = !has1 ? b[c] : (!has2 ? a[c] : (a[c] + b[c]) / 2);
+        for (int c = 0; c < d; c++) {
+            const double ta = has1 ? T1[(int64_t)i * d + c] : 0.0, tb = has2 ? T2[(int64_t)j * d + c] : 0.0;
+            Tn[o * d + c] = !has1 ? tb : (!has2 ? ta : (ta + tb) / 2);
+        }
+        double wsum = 0.0;
+        if (has1) wsum += W1[i];
+        if (has2) wsum += W2[j];
+        Wn[o] = wsum;
+    }
+    if (lane == 0) {
+        NodeOut no;
+        no.len = idx;
+        no.first = first;
+        no.flags = flags;
+        no.pad = 0;
+        *out = no;
+    }
 }
 
 }  // namespace cr

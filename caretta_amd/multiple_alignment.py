@@ -129,6 +129,33 @@ class Protein(SequenceBase):
         return self.sequence
 
 
+def _progressive_node(s1: Protein, s2: Protein, w1, w2, mult1, mult2, name_int, gap_open, gap_extend, gamma_weight,
+                      score_function_params, mean_function_params):
+    """make_intermediate_node (multiple_alignment.py:193-234) for two Proteins through cr_progressive_node."""
+    x1, t1, x2, t2 = f64(s1.coordinates), f64(s1.tensors), f64(s2.coordinates), f64(s2.tensors)
+    w1, w2 = f64(w1).reshape(-1), f64(w2).reshape(-1)
+    n, m, d = x1.shape[0], x2.shape[0], t1.shape[1]
+    if t2.shape[1] != d:
+        raise ValueError("tensor widths differ")
+    prm = make_params(gamma_tensor=score_function_params.get("gamma_tensor", 0.03),
+                      gamma_coords=score_function_params.get("gamma_coords", 0.03),
+                      gap_open=gap_open, gap_extend=gap_extend)
+    a1, a2 = np.empty(n + m, np.int64), np.empty(n + m, np.int64)
+    xn, tn, wn = np.empty((n + m, 3)), np.empty((n + m, d)), np.empty(n + m)
+    ln, flags = C.c_int64(0), C.c_uint32(0)
+    check(_capi.load().cr_progressive_node(default_context()._h, ptr(x1), ptr(t1), ptr(w1), n, ptr(x2), ptr(t2), ptr(w2),
+                                           m, d, float(mult1), float(mult2), C.byref(prm), float(gamma_weight), ptr(a1),
+                                           ptr(a2), C.byref(ln), ptr(xn), ptr(tn), ptr(wn), C.byref(flags)))
+    if flags.value & _capi.FLAG_SEED_ALL_ZERO:
+        raise TypeError("tensor score matrix has no positive local alignment (reference: max_pos is None)")
+    verbose = score_function_params.get("verbose", True) or mean_function_params.get("verbose", True)
+    if verbose and flags.value & (_capi.FLAG_SEED_SKIPPED | _capi.FLAG_MEAN_UNSUPERPOSED):
+        print(f"Too few aligning positions for {s1.name} and {s2.name}, continuing without superposition")
+    k = ln.value
+    node = Protein(name_int, tn[:k].copy(), xn[:k].copy())
+    return a1[:k].copy(), a2[:k].copy(), node, wn[:k].reshape(-1, 1).copy()
+
+
 def pack_proteins(proteins: typing.Sequence[Protein]):
     lens = [len(p) for p in proteins]
     offsets = np.zeros(len(proteins) + 1, dtype=np.int64)
@@ -228,15 +255,25 @@ class MultipleAlignment:
             multiplier_n1 = len(final_alignments[name_2]) / (2 * total)
             multiplier_n2 = len(final_alignments[name_1]) / (2 * total)
             name_int = f"int-{n_int}"
-            score_matrix = final_sequences[n1].score_function(final_sequences[n2], **score_function_params)
-            score_matrix += score_functions.make_score_matrix(n1_weights * multiplier_n1, n2_weights * multiplier_n2,
-                                                              score_functions.get_gaussian_score, gamma_weight)
-            aln_1, aln_2, _ = dtw.dtw_align(np.arange(score_matrix.shape[0]), np.arange(score_matrix.shape[1]),
-                                            score_matrix, gap_open_penalty=gap_open_penalty,
-                                            gap_extend_penalty=gap_extend_penalty)
-            intermediate = final_sequences[n1].mean_function(final_sequences[n2], aln_1, aln_2, name_int,
-                                                             **mean_function_params)
-            weights = get_mean_weights(n1_weights, n2_weights, aln_1, aln_2)
+            s1, s2 = final_sequences[n1], final_sequences[n2]
+            fused = (type(s1) is Protein and type(s2) is Protein and s1.coordinates is not None
+                     and s2.coordinates is not None and not score_function_params.get("flexible", False)
+                     and not mean_function_params.get("flexible", False))
+            if fused:
+                # the whole node (score matrices, dtw_align, mean_function, get_mean_weights) in two launches
+                aln_1, aln_2, intermediate, weights = _progressive_node(
+                    s1, s2, n1_weights, n2_weights, multiplier_n1, multiplier_n2, name_int, gap_open_penalty,
+                    gap_extend_penalty, gamma_weight, score_function_params, mean_function_params)
+            else:
+                score_matrix = s1.score_function(s2, **score_function_params)
+                score_matrix += score_functions.make_score_matrix(n1_weights * multiplier_n1,
+                                                                  n2_weights * multiplier_n2,
+                                                                  score_functions.get_gaussian_score, gamma_weight)
+                aln_1, aln_2, _ = dtw.dtw_align(np.arange(score_matrix.shape[0]), np.arange(score_matrix.shape[1]),
+                                                score_matrix, gap_open_penalty=gap_open_penalty,
+                                                gap_extend_penalty=gap_extend_penalty)
+                intermediate = s1.mean_function(s2, aln_1, aln_2, name_int, **mean_function_params)
+                weights = get_mean_weights(n1_weights, n2_weights, aln_1, aln_2)
             final_alignments[name_1] = {name: np.array([seq[i] if i != -1 else -1 for i in aln_1])
                                         for name, seq in final_alignments[name_1].items()}
             final_alignments[name_2] = {name: np.array([seq[i] if i != -1 else -1 for i in aln_2])

@@ -35,6 +35,7 @@ typedef enum {
 #define CR_FLAG_SEED_SKIPPED 1u     /* <=3 seed positions: superposition skipped (multiple_alignment.py:337-342) */
 #define CR_FLAG_METRICS_SKIPPED 2u  /* <3 aligned positions: RMSD/coverage/TM not computed (assert at :1034)     */
 #define CR_FLAG_SEED_ALL_ZERO 4u    /* tensor Smith-Waterman matrix all zero (the reference raises TypeError)    */
+#define CR_FLAG_MEAN_UNSUPERPOSED 8u /* progressive node: <=3 aligned positions, mean taken on raw coordinates (:364-368) */
 
 typedef struct cr_context cr_context;   /* device + stream + profiling events */
 typedef struct cr_batch cr_batch;       /* structures resident in HBM + per-pair scratch */
@@ -117,6 +118,17 @@ int cr_make_score_matrix(cr_context *ctx, const double *a, int64_t n, const doub
 int cr_protein_score_function(cr_context *ctx, const double *coords_i, const double *tensors_i, int64_t n,
                               const double *coords_j, const double *tensors_j, int64_t m, int64_t d,
                               double gamma_tensor, double gamma_coords, double *S, uint32_t *flags);
+/* One node of MultipleAlignment.progressive_align for two Proteins: make_intermediate_node
+ * (multiple_alignment.py:193-234) = score_function (:204) + consensus-weight RBF (:207-210) -> dtw_align
+ * (:211-214) -> Protein.mean_function (:351-381) + get_mean_weights (:73-82).  mult1/mult2 are the
+ * multipliers of :199-202.  aln1/aln2: n+m entries; coords_out (n+m,3), tensors_out (n+m,d),
+ * weights_out (n+m): the first *aln_len rows are the new node.  flags: CR_FLAG_* of the seed, bit 3 set when
+ * the mean was taken without superposition (<=3 aligned positions, :364-368). */
+int cr_progressive_node(cr_context *ctx, const double *coords_1, const double *tensors_1, const double *weights_1,
+                        int64_t n, const double *coords_2, const double *tensors_2, const double *weights_2,
+                        int64_t m, int64_t d, double mult1, double mult2, const cr_params *params,
+                        double gamma_weight, int64_t *aln1, int64_t *aln2, int64_t *aln_len,
+                        double *coords_out, double *tensors_out, double *weights_out, uint32_t *flags);
 /* dynamic_time_warping.dtw_align / dtw_align_score (aln1 == NULL)      dynamic_time_warping.py:148-201
  * S f64[s_rows, s_cols] indexed S[seq1[i], seq2[j]]; aln1/aln2 need n+m entries. */
 int cr_dtw_align(cr_context *ctx, const int64_t *seq1, int64_t n, const int64_t *seq2, int64_t m,

@@ -594,6 +594,69 @@ void cro_pipeline_pair(const double *Xi, const double *Ti, int64_t n,
     free(p1); free(p2); free(s1); free(s2); free(S);
 }
 
+/* multiple_alignment.py:193-234 (make_intermediate_node), :351-381 (mean_function), :73-82 (get_mean_weights) */
+uint32_t cro_progressive_node(const double *X1, const double *T1, const double *W1, int64_t n,
+                              const double *X2, const double *T2, const double *W2, int64_t m, int64_t d,
+                              double mult1, double mult2, const cro_params *prm, double gamma_weight,
+                              int64_t *aln1, int64_t *aln2, int64_t *aln_len,
+                              double *Xn, double *Tn, double *Wn) {
+    double *S = (double *)malloc(sizeof(double) * (size_t)n * (size_t)m);
+    uint32_t flags = cro_protein_score_function(X1, T1, n, X2, T2, m, d, prm->gamma_tensor, prm->gamma_coords,
+                                                prm->sw_gap, S, NULL, NULL, NULL, NULL);       /* :204-206 */
+    double *a = (double *)malloc(sizeof(double) * (size_t)n), *b = (double *)malloc(sizeof(double) * (size_t)m);
+    for (int64_t i = 0; i < n; i++) a[i] = W1[i] * mult1;                                     /* :207 */
+    for (int64_t j = 0; j < m; j++) b[j] = W2[j] * mult2;                                     /* :208 */
+    double *Sw = (double *)malloc(sizeof(double) * (size_t)n * (size_t)m);
+    cro_make_score_matrix(a, n, b, m, 1, gamma_weight, Sw);                                   /* :207-210 */
+    for (int64_t x = 0; x < n * m; x++) S[x] += Sw[x];
+    int64_t *s1 = arange64(n), *s2 = arange64(m);
+    double score;
+    int64_t len = 0;
+    cro_dtw_align(s1, n, s2, m, S, m, prm->gap_open, prm->gap_extend, aln1, aln2, &len, &score, NULL, NULL); /* :211-214 */
+    *aln_len = len;
+    /* Protein.mean_function, :351-381 */
+    for (int64_t e = 0; e < len; e++) {
+        int64_t x = aln1[e], y = aln2[e];
+        for (int64_t c = 0; c < d; c++) {
+            if (x == -1) Tn[e * d + c] = T2[y * d + c];
+            else if (y == -1) Tn[e * d + c] = T1[x * d + c];
+            else Tn[e * d + c] = (T1[x * d + c] + T2[y * d + c]) / 2;
+        }
+    }
+    int64_t *p1 = (int64_t *)malloc(sizeof(int64_t) * (size_t)(len + 1));
+    int64_t *p2 = (int64_t *)malloc(sizeof(int64_t) * (size_t)(len + 1));
+    int64_t k = cro_get_common_positions(aln1, aln2, len, p1, p2);                            /* :363 */
+    double *c1 = (double *)malloc(sizeof(double) * 3 * (size_t)n), *c2 = (double *)malloc(sizeof(double) * 3 * (size_t)m);
+    if (k <= 3) {                                                                             /* :364-368 */
+        flags |= 8;
+        memcpy(c1, X1, sizeof(double) * 3 * (size_t)n);
+        memcpy(c2, X2, sizeof(double) * 3 * (size_t)m);
+    } else {
+        double *sub1 = (double *)malloc(sizeof(double) * 3 * (size_t)k), *sub2 = (double *)malloc(sizeof(double) * 3 * (size_t)k);
+        for (int64_t x = 0; x < k; x++)
+            for (int c = 0; c < 3; c++) {
+                sub1[3 * x + c] = X1[3 * p1[x] + c];
+                sub2[3 * x + c] = X2[3 * p2[x] + c];
+            }
+        cro_paired_svd_superpose_with_subset(X1, n, X2, m, sub1, sub2, k, c1, c2, NULL);      /* :370-372 */
+        free(sub1); free(sub2);
+    }
+    for (int64_t e = 0; e < len; e++) {                                                       /* :373-380 */
+        int64_t x = aln1[e], y = aln2[e];
+        for (int c = 0; c < 3; c++) {
+            if (x == -1) Xn[3 * e + c] = c2[3 * y + c];
+            else if (y == -1) Xn[3 * e + c] = c1[3 * x + c];
+            else Xn[3 * e + c] = (c1[3 * x + c] + c2[3 * y + c]) / 2;
+        }
+        double w = 0.0;                                                                       /* get_mean_weights, :73-82 */
+        if (x != -1) w += W1[x];
+        if (y != -1) w += W2[y];
+        Wn[e] = w;
+    }
+    free(S); free(Sw); free(a); free(b); free(s1); free(s2); free(p1); free(p2); free(c1); free(c2);
+    return flags;
+}
+
 int cro_pairwise_batch(const double *coords, const double *tensors, const int64_t *offsets,
                        int64_t d, const int32_t *pairs, int64_t npairs, const cro_params *prm,
                        cro_pair_out *outs, int64_t *aln, int64_t aln_stride, int nthreads) {

@@ -104,6 +104,16 @@ int cro_pairwise_batch(const double *coords, const double *tensors, const int64_
                        int64_t d, const int32_t *pairs, int64_t npairs, const cro_params *prm,
                        cro_pair_out *outs, int64_t *aln, int64_t aln_stride, int nthreads);
 
+/* One node of progressive_align (multiple_alignment.py:193-234: make_intermediate_node) for two Proteins:
+ * score_function (:204) + consensus-weight RBF (:207-210) -> dtw_align (:211-214) -> Protein.mean_function
+ * (:351-381) and get_mean_weights (:73-82).  mult1/mult2 are the multipliers of :199-202.
+ * Outputs: alignment rows (n+m entries), the node's coordinates (len,3), tensors (len,d), weights (len). */
+uint32_t cro_progressive_node(const double *X1, const double *T1, const double *W1, int64_t n,
+                              const double *X2, const double *T2, const double *W2, int64_t m, int64_t d,
+                              double mult1, double mult2, const cro_params *prm, double gamma_weight,
+                              int64_t *aln1, int64_t *aln2, int64_t *aln_len,
+                              double *Xn, double *Tn, double *Wn);
+
 /* neighbor_joining.py:19-157.  tree: (2P-3, 2) uint64, branch_lengths: (2P-3).
  * hoist=0 recomputes the row sums inside the double loop exactly as written (O(P^4));
  * hoist=1 computes each row sum once per iteration (identical values, O(P^3)). */

@@ -76,6 +76,10 @@ class Oracle:
         lib.cro_svd3.argtypes = [_f64p, _f64p, _f64p, _f64p]
         lib.cro_pairwise_batch.argtypes = [_f64p, _f64p, _i64p, C.c_int64, _i32p, C.c_int64, C.POINTER(Params),
                                            C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
+        lib.cro_progressive_node.restype = C.c_uint32
+        lib.cro_progressive_node.argtypes = [_f64p, _f64p, _f64p, C.c_int64, _f64p, _f64p, _f64p, C.c_int64, C.c_int64,
+                                             C.c_double, C.c_double, C.POINTER(Params), C.c_double, _i64p, _i64p,
+                                             C.POINTER(C.c_int64), _f64p, _f64p, _f64p]
         lib.cro_neighbor_joining.argtypes = [_f64p, C.c_int64, C.c_int, _u64p, _f64p]
         lib.cro_max_threads.restype = C.c_int
 
@@ -189,6 +193,20 @@ class Oracle:
         self.lib.cro_pairwise_batch(coords, tensors, offsets, tensors.shape[1], pairs, len(pairs), C.byref(params),
                                     outs.ctypes.data, aln.ctypes.data if want_aln else None, stride, int(nthreads))
         return outs, aln
+
+    def progressive_node(self, x1, t1, w1, x2, t2, w2, mult1, mult2, params: Params | None = None, gamma_weight=1.0):
+        """make_intermediate_node for two Proteins -> (aln1, aln2, coords, tensors, weights (len,1), flags)."""
+        x1, t1, w1, x2, t2, w2 = (self._f(v) for v in (x1, t1, w1, x2, t2, w2))
+        n, m, d = x1.shape[0], x2.shape[0], t1.shape[1]
+        params = params or default_params()
+        a1, a2 = np.empty(n + m + 1, np.int64), np.empty(n + m + 1, np.int64)
+        ln = C.c_int64(0)
+        xn, tn, wn = np.empty((n + m, 3)), np.empty((n + m, d)), np.empty(n + m)
+        flags = self.lib.cro_progressive_node(x1, t1, w1.reshape(-1), n, x2, t2, w2.reshape(-1), m, d, float(mult1),
+                                              float(mult2), C.byref(params), float(gamma_weight), a1, a2, C.byref(ln),
+                                              xn, tn, wn)
+        k = ln.value
+        return a1[:k].copy(), a2[:k].copy(), xn[:k].copy(), tn[:k].copy(), wn[:k].reshape(-1, 1).copy(), flags
 
     def neighbor_joining(self, d, hoist=True):
         d = self._f(d)

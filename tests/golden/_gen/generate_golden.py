@@ -349,6 +349,33 @@ def gen_tree(rng):
     save("f3_tree.npz", out)
 
 
+# --------------------------------------------------------------------------- F4: progressive alignment internals
+def gen_progressive():
+    """Every intermediate node of progressive_align (multiple_alignment.py:172-253) for two small families:
+    the node's mean tensors / coordinates / consensus weights and the final alignment."""
+    out = {}
+    for tag, fam in (("P8", synthetic.make_family(8, 60, seed=20231, ragged=True)),
+                     ("P5", synthetic.make_family(5, 40, seed=20238, ragged=True, clades=2))):
+        store_family(out, f"fam{tag}", fam)
+        msa = multiple_alignment.MultipleAlignment(to_proteins(fam))
+        m = msa.make_pairwise_matrix(score_function_params=dict(SF_PARAMS, verbose=False))
+        d = m.max() - m
+        aln = msa.multiple_align(d, gap_open_penalty=1.0, gap_extend_penalty=0.01, consensus_weight=1.0,
+                                 gamma_weight=1.0, score_function_params=dict(SF_PARAMS, verbose=False),
+                                 mean_function_params=dict(flexible=False, verbose=False))
+        out[f"fam{tag}_D"] = d
+        out[f"fam{tag}_tree"] = msa.tree
+        out[f"fam{tag}_msa"] = np.array([aln[s.name] for s in fam], dtype=np.int64)
+        nleaf = len(fam)
+        out[f"fam{tag}_nnodes"] = np.int64(len(msa.final_sequences) - nleaf)
+        for k, node in enumerate(msa.final_sequences[nleaf:]):
+            out[f"fam{tag}_n{k}_tensors"] = node.tensors
+            out[f"fam{tag}_n{k}_coords"] = node.coordinates
+            out[f"fam{tag}_n{k}_weights"] = msa.final_consensus_weights[nleaf + k]
+            out[f"fam{tag}_n{k}_name"] = np.array(node.name)
+    save("f4_progressive.npz", out)
+
+
 def main():
     only = set(sys.argv[1:])
     rng = np.random.default_rng(20230)
@@ -361,7 +388,8 @@ def main():
               ("misc", lambda: gen_misc(np.random.default_rng(20225))),
               ("pipeline", gen_pipeline),
               ("long", gen_pipeline_long),
-              ("tree", lambda: gen_tree(np.random.default_rng(20224)))]
+              ("tree", lambda: gen_tree(np.random.default_rng(20224))),
+              ("progressive", gen_progressive)]
     for name, fn in steps:
         if only and name not in only:
             continue

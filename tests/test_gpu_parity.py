@@ -344,6 +344,45 @@ def test_multiple_align_golden(golden):
     assert np.array_equal(got, g["famT8_msa"])
 
 
+@pytest.mark.parametrize("tag", ["P8", "P5"])
+def test_progressive_nodes_golden_and_oracle(oracle, golden, tag):
+    """Every intermediate node of progressive_align: alignment identical to the reference's, node tensors /
+    coordinates / weights bit-identical to the oracle and within 1e-9 of the reference's."""
+    from caretta_amd import multiple_alignment as ma
+    g = golden("f4_progressive.npz")
+    coords, tensors, offsets = g[f"fam{tag}_coords"], g[f"fam{tag}_tensors"], g[f"fam{tag}_offsets"]
+    p = len(offsets) - 1
+    prots = [ma.Protein(f"s{i:04d}", tensors[offsets[i]:offsets[i + 1]], coords[offsets[i]:offsets[i + 1]], "")
+             for i in range(p)]
+    msa = ma.MultipleAlignment(prots)
+    prm = dict(flexible=False, gamma_tensor=7.0, gamma_coords=0.03, verbose=False)
+    aln = msa.multiple_align(g[f"fam{tag}_D"], gap_open_penalty=1.0, gap_extend_penalty=0.01, consensus_weight=1.0,
+                             gamma_weight=1.0, score_function_params=prm,
+                             mean_function_params=dict(flexible=False, verbose=False))
+    assert np.array_equal(np.array([aln[q.name] for q in prots]), g[f"fam{tag}_msa"])
+    assert np.array_equal(msa.tree, g[f"fam{tag}_tree"])
+    nn = int(g[f"fam{tag}_nnodes"])
+    assert len(msa.final_sequences) == p + nn
+    for k in range(nn):
+        node, w = msa.final_sequences[p + k], msa.final_consensus_weights[p + k]
+        np.testing.assert_allclose(node.coordinates, g[f"fam{tag}_n{k}_coords"], atol=1e-9)
+        assert np.array_equal(node.tensors, g[f"fam{tag}_n{k}_tensors"]) and np.array_equal(w, g[f"fam{tag}_n{k}_weights"])
+    # oracle: replay every join on the GPU's own child nodes
+    tree = msa.tree.astype(np.int64)
+    joins = [(int(tree[x, 0]), int(tree[x + 1, 0])) for x in range(0, tree.shape[0] - 1, 2)] + [(int(tree[-1, 0]), int(tree[-1, 1]))]
+    sizes = [1] * p
+    for k, (n1, n2) in enumerate(joins):
+        tot = sizes[n1] + sizes[n2]
+        s1, s2 = msa.final_sequences[n1], msa.final_sequences[n2]
+        a1, a2, xn, tn, wn, _ = oracle.progressive_node(s1.coordinates, s1.tensors, msa.final_consensus_weights[n1],
+                                                        s2.coordinates, s2.tensors, msa.final_consensus_weights[n2],
+                                                        sizes[n2] / (2 * tot), sizes[n1] / (2 * tot))
+        node = msa.final_sequences[p + k]
+        assert np.array_equal(xn, node.coordinates) and np.array_equal(tn, node.tensors)
+        assert np.array_equal(wn, msa.final_consensus_weights[p + k])
+        sizes.append(tot)
+
+
 def test_two_sequence_alignment_and_metrics(ctx, golden):
     """multiple_align's 2-sequence branch and make_rmsd_coverage_tm_matrix through the drop-ins."""
     from caretta_amd import multiple_alignment as ma

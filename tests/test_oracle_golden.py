@@ -220,3 +220,28 @@ def test_neighbor_joining(oracle, golden):
         oracle.set_sum_mode(0)                            # numba's order: same topology
         tree, bl = oracle.neighbor_joining(d)
         assert tree_bipartitions(tree, p) == tree_bipartitions(g[f"nj{c}_tree"], p)
+
+
+@pytest.mark.parametrize("tag", ["P8", "P5"])
+def test_progressive_alignment(oracle, golden, tag):
+    """Oracle restatement of make_intermediate_node / mean_function / get_mean_weights driven over the
+    golden guide tree: identical MSA, node tensors and weights exact, node coordinates to 1e-9."""
+    g = golden("f4_progressive.npz")
+    coords, tensors, off = g[f"fam{tag}_coords"], g[f"fam{tag}_tensors"], g[f"fam{tag}_offsets"]
+    p = len(off) - 1
+    nodes = [(coords[off[i]:off[i + 1]], tensors[off[i]:off[i + 1]], np.full((off[i + 1] - off[i], 1), 1.0)) for i in range(p)]
+    alns = [{i: np.arange(off[i + 1] - off[i])} for i in range(p)]
+    tree = g[f"fam{tag}_tree"].astype(np.int64)
+    joins = [(int(tree[x, 0]), int(tree[x + 1, 0])) for x in range(0, tree.shape[0] - 1, 2)] + [(int(tree[-1, 0]), int(tree[-1, 1]))]
+    for n1, n2 in joins:
+        tot = len(alns[n1]) + len(alns[n2])            # multiple_alignment.py:199-202
+        a1, a2, xn, tn, wn, _ = oracle.progressive_node(*nodes[n1], *nodes[n2], len(alns[n2]) / (2 * tot), len(alns[n1]) / (2 * tot))
+        merged = {k: np.array([v[i] if i != -1 else -1 for i in a1]) for k, v in alns[n1].items()}
+        merged.update({k: np.array([v[i] if i != -1 else -1 for i in a2]) for k, v in alns[n2].items()})
+        nodes.append((xn, tn, wn))
+        alns.append(merged)
+    assert np.array_equal(np.array([alns[-1][i] for i in range(p)]), g[f"fam{tag}_msa"])
+    for k in range(int(g[f"fam{tag}_nnodes"])):
+        xn, tn, wn = nodes[p + k]
+        np.testing.assert_allclose(xn, g[f"fam{tag}_n{k}_coords"], atol=1e-9)
+        assert np.array_equal(tn, g[f"fam{tag}_n{k}_tensors"]) and np.array_equal(wn, g[f"fam{tag}_n{k}_weights"])
