@@ -274,9 +274,10 @@ class MultipleAlignment:
                                                 gap_extend_penalty=gap_extend_penalty)
                 intermediate = s1.mean_function(s2, aln_1, aln_2, name_int, **mean_function_params)
                 weights = get_mean_weights(n1_weights, n2_weights, aln_1, aln_2)
-            final_alignments[name_1] = {name: np.array([seq[i] if i != -1 else -1 for i in aln_1])
+            # re-index every member row through the node alignment (:218-229), vectorised
+            final_alignments[name_1] = {name: np.where(aln_1 != -1, np.asarray(seq)[aln_1], -1)
                                         for name, seq in final_alignments[name_1].items()}
-            final_alignments[name_2] = {name: np.array([seq[i] if i != -1 else -1 for i in aln_2])
+            final_alignments[name_2] = {name: np.where(aln_2 != -1, np.asarray(seq)[aln_2], -1)
                                         for name, seq in final_alignments[name_2].items()}
             final_alignments[name_int] = {**final_alignments[name_1], **final_alignments[name_2]}
             final_sequences.append(intermediate)
