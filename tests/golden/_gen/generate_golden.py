@@ -376,6 +376,21 @@ def gen_progressive():
     save("f4_progressive.npz", out)
 
 
+def gen_c1_inputs():
+    """BASELINE config 1 inputs: C-alpha coordinates and sequences of the three kringle-domain PDB files the
+    reference ships as its README example (test_data/), read with the product's own minimal reader."""
+    from caretta_amd import helper as amd_helper
+    out = {}
+    ref_root = Path(sys.modules["caretta"].__path__[0]).parent
+    names = []
+    for path in sorted((ref_root / "test_data").glob("*.pdb")):
+        xyz, seq = amd_helper.read_calpha_pdb(path)
+        out[f"{path.stem}_coords"], out[f"{path.stem}_sequence"] = xyz, np.array(seq)
+        names.append(path.stem)
+    out["names"] = np.array(names)
+    save("c1_kringle_calpha.npz", out)
+
+
 def main():
     only = set(sys.argv[1:])
     rng = np.random.default_rng(20230)
@@ -389,7 +404,8 @@ def main():
               ("pipeline", gen_pipeline),
               ("long", gen_pipeline_long),
               ("tree", lambda: gen_tree(np.random.default_rng(20224))),
-              ("progressive", gen_progressive)]
+              ("progressive", gen_progressive),
+              ("c1", gen_c1_inputs)]
     for name, fn in steps:
         if only and name not in only:
             continue

@@ -105,3 +105,35 @@ def test_synthetic_family_shapes():
     assert o[-1] == c.shape[0] == t.shape[0]
     again = synthetic.make_family(8, 100, seed=3, ragged=True)
     assert all(np.array_equal(a.coordinates, b.coordinates) for a, b in zip(rag, again))
+
+
+def test_on_disk_formats(tmp_path):
+    from caretta_amd import helper
+    names = ["a", "b/chainA", "c"]
+    m = np.array([[0.0, 1.23456, 2.5], [1.23456, 0.0, 3.0], [2.5, 3.0, 0.0]])
+    helper.write_distance_matrix(names, m, tmp_path / "m.txt")
+    text = (tmp_path / "m.txt").read_text().splitlines()
+    assert text[0] == "3" and text[1] == "a 0.0000 1.2346 2.5000"       # helper.py:183-202: "%.4f", count first
+    rnames, rm = helper.read_distance_matrix(tmp_path / "m.txt")
+    assert rnames == ["a", "b", "c"] and np.allclose(rm, m, atol=5e-5)
+    pdb = tmp_path / "x.pdb"
+    pdb.write_text(
+        "ATOM      1  N   THR A   1      37.078  -8.422  -5.315  1.00  0.00           N\n"
+        "ATOM      2  CA  THR A   1      37.419  -8.016  -3.919  1.00  0.00           C\n"
+        "ATOM      3  CA AGLY A   2      38.000  -7.000  -2.000  0.50  0.00           C\n"
+        "ATOM      4  CA BGLY A   2      39.000  -7.000  -2.000  0.50  0.00           C\n"
+        "HETATM    5  CA  MSE A   3      40.000  -6.000  -1.000  1.00  0.00           C\n"
+        "ATOM      6  CA  ALA B   1      50.000   0.000   0.000  1.00  0.00           C\n"
+        "ENDMDL\n"
+        "ATOM      7  CA  ALA A   4      60.000   0.000   0.000  1.00  0.00           C\n")
+    xyz, seq = helper.read_calpha_pdb(pdb)
+    assert seq == "TGM" and xyz.shape == (3, 3) and xyz[1, 0] == 38.0
+    desc = helper.local_shape_descriptor(xyz, 10)
+    assert desc.shape == (3, 10) and np.all((desc >= 0) & (desc < 1))
+
+
+def test_c1_fixture(golden):
+    g = golden("c1_kringle_calpha.npz")
+    assert list(g["names"]) == ["1kdu", "1pk4", "1pkr"]
+    assert [g[f"{n}_coords"].shape[0] for n in g["names"]] == [85, 79, 80]
+    assert all(len(str(g[f"{n}_sequence"])) == g[f"{n}_coords"].shape[0] for n in g["names"])

@@ -397,3 +397,35 @@ def test_two_sequence_alignment_and_metrics(ctx, golden):
     rmsd, cov, tm = ma.make_rmsd_coverage_tm_matrix(aln, prots)
     assert abs(rmsd[0, 1] - float(g["famB_p0_rmsd"])) < 1e-5 and abs(tm[0, 1] - float(g["famB_p0_tm"])) < 1e-5
     assert cov[0, 1] == float(g["famB_p0_coverage"])
+
+
+def test_config1_three_kringle_domains(golden, tmp_path):
+    """BASELINE config 1 (the reference's README example, 3 PDB files) as plumbing through the GPU path:
+    pairwise matrix -> max - M -> neighbor joining -> progressive alignment -> FASTA and matrix files.
+    Tensors come from the documented stand-in descriptor (geometricus is not available): non-parity, so the
+    checks are structural."""
+    from caretta_amd import helper, multiple_alignment as ma
+    g = golden("c1_kringle_calpha.npz")
+    prots = []
+    for name in g["names"]:
+        xyz = g[f"{name}_coords"]
+        prots.append(ma.Protein(str(name), helper.local_shape_descriptor(xyz, 10), xyz, str(g[f"{name}_sequence"])))
+    msa = ma.MultipleAlignment(prots)
+    prm = dict(flexible=False, gamma_tensor=7.0, gamma_coords=0.03, verbose=False)
+    m = msa.make_pairwise_matrix(prm)
+    assert m.shape == (3, 3) and np.array_equal(m, m.T) and np.all(m[np.triu_indices(3, 1)] > 0)
+    d = m.max() - m
+    aln = msa.multiple_align(d, gap_open_penalty=1.0, gap_extend_penalty=0.01, consensus_weight=1.0, gamma_weight=1.0,
+                             score_function_params=prm, mean_function_params=dict(flexible=False, verbose=False))
+    rows = [aln[p.name] for p in prots]
+    assert len({len(r) for r in rows}) == 1
+    for r, p in zip(rows, prots):
+        assert np.array_equal(r[r >= 0], np.arange(len(p)))          # every residue once, in order
+    msa.write_alignment(tmp_path / "result.fasta")
+    fasta = (tmp_path / "result.fasta").read_text().split("\n")
+    assert fasta[0] == ">1kdu" and len(fasta[1]) == len(rows[0]) and fasta[1].replace("-", "") == str(prots[0])
+    helper.write_distance_matrix([p.name for p in prots], d, tmp_path / "distance_matrix_guide_tree.txt")
+    names, back = helper.read_distance_matrix(tmp_path / "distance_matrix_guide_tree.txt")
+    assert names == [p.name for p in prots] and np.allclose(back, d, atol=5e-5)
+    rmsd, cov, tm = ma.make_rmsd_coverage_tm_matrix(aln, prots)
+    assert np.all(rmsd[np.triu_indices(3, 1)] > 0) and np.all(rmsd < 15) and np.all((cov > 0.5) & (cov <= 1))
