@@ -560,9 +560,74 @@ int cr_tm_score(cr_context* ctx, const double* x1, const double* x2, int64_t k, 
     return rc;
 }
 
+int cr_msa_metrics(cr_context* ctx, const double* coords, const int64_t* offsets, int64_t P, const int32_t* msa,
+                   int64_t W, int superpose, double* rmsd, double* coverage, double* tm) {
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    CR_REQUIRE(coords && offsets && msa && rmsd && coverage && tm, "null argument");
+    CR_REQUIRE(P >= 1 && W >= 1 && W <= 65534 && P < 46000, "bad alignment shape");
+    const int64_t total = offsets[P];
+    CR_REQUIRE(all_finite(coords, (size_t)total * 3), "coordinates contain NaN or infinity");
+    for (int64_t s = 0; s < P; s++) {
+        const int64_t len = offsets[s + 1] - offsets[s];
+        CR_REQUIRE(len >= 1 && len <= cr::kMaxLength, "bad structure length");
+        for (int64_t x = 0; x < W; x++)
+            CR_REQUIRE(msa[s * W + x] >= -1 && msa[s * W + x] < len, "alignment index outside its structure");
+    }
+    for (int64_t x = 0; x < P * P; x++) {
+        rmsd[x] = 0.0;
+        coverage[x] = 1.0;
+        tm[x] = 1.0;
+    }
+    const int64_t npairs = P * (P - 1) / 2;
+    if (npairs == 0) return CR_OK;
+    std::vector<int32_t> pairs((size_t)npairs * 2);
+    size_t q = 0;
+    for (int64_t i = 0; i < P - 1; i++)
+        for (int64_t j = i + 1; j < P; j++) {
+            pairs[q++] = (int32_t)i;
+            pairs[q++] = (int32_t)j;
+        }
+    DevBuf<double> dc, dout;
+    DevBuf<int64_t> doff;
+    DevBuf<int32_t> dmsa, dpairs;
+    if ((rc = upload(dc, coords, (size_t)total * 3, ctx->stream))) return rc;
+    if ((rc = upload(doff, offsets, (size_t)P + 1, ctx->stream))) return rc;
+    if ((rc = upload(dmsa, msa, (size_t)P * W, ctx->stream))) return rc;
+    if ((rc = upload(dpairs, pairs.data(), pairs.size(), ctx->stream))) return rc;
+    CR_HIP(dout.ensure((size_t)npairs * 4));
+    const size_t lds = sizeof(double) * (((size_t)W + 3) / 4 * 2 + (size_t)cr::kWave * cr::kMaxAcc);
+    if ((rc = allow_lds(cr::k_msa_metrics, lds))) return rc;
+    hipLaunchKernelGGL(cr::k_msa_metrics, dim3((unsigned)npairs), dim3(cr::kWave), lds, ctx->stream, dc.p, doff.p, dmsa.p,
+                       (int)P, (int)W, superpose, dpairs.p, dout.p);
+    CR_HIP(hipGetLastError());
+    std::vector<double> h((size_t)npairs * 4);
+    CR_HIP(hipMemcpyAsync(h.data(), dout.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
+    CR_HIP(hipStreamSynchronize(ctx->stream));
+    for (int64_t p = 0; p < npairs; p++) {
+        const int64_t i = pairs[(size_t)2 * p], j = pairs[(size_t)2 * p + 1];
+        const bool ok = h[(size_t)4 * p + 3] >= 3.0;
+        const double nan = std::numeric_limits<double>::quiet_NaN();
+        rmsd[i * P + j] = rmsd[j * P + i] = ok ? h[(size_t)4 * p] : nan;
+        coverage[i * P + j] = coverage[j * P + i] = h[(size_t)4 * p + 1];
+        tm[i * P + j] = tm[j * P + i] = ok ? h[(size_t)4 * p + 2] : nan;
+    }
+    return CR_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-side integer / tree work
 // ---------------------------------------------------------------------------------------------
+int cr_mean_axis0(const double* x, int64_t rows, int64_t cols, double* out) {
+    CR_REQUIRE(x && out && rows >= 1 && cols >= 1, "bad argument");
+    for (int64_t c = 0; c < cols; c++) {
+        double s = 0.0;
+        for (int64_t r = 0; r < rows; r++) s += x[r * cols + c];
+        out[c] = s / (double)rows;
+    }
+    return CR_OK;
+}
+
 int cr_get_common_positions(const int64_t* a1, const int64_t* a2, int64_t len, int64_t* p1, int64_t* p2, int64_t* k) {
     CR_REQUIRE(len >= 0 && (len == 0 || (a1 && a2 && p1 && p2)) && k, "bad argument");
     int64_t c = 0;

@@ -817,6 +817,61 @@ CR_D void seed_trace(const PairDesc& pd, int R, int max_entries, const double* _
     tr.seed_len = len;
 }
 
+// get_rmsd (score_functions.py:15-19) and tm_score (multiple_alignment.py:59-70) over `count` packed entries of
+// which `k` are aligned pairs, sums in position order: lane 0 sums the squared differences (three per
+// position), lanes 1/2 the two TM sums.  MOVE: compare X_i with X_j @ R + t, else with X_j as it is.
+template <bool MOVE>
+CR_D void rmsd_tm_ordered(const double* __restrict__ Xi, const double* __restrict__ Xj, const uint32_t* ent,
+                          int count, int k, int len1, int len2, const double* R, const double* t, int lane,
+                          double* scratch, double& rmsd, double& tm) {
+    const double d1 = 1.24 * (double)(len1 - 15) / 3.0 - 1.8;
+    const double d2 = 1.24 * (double)(len2 - 15) / 3.0 - 1.8;
+    double acc = 0.0;
+    for (int base = 0; base < count; base += kWave) {
+        const int x = base + lane;
+        if (x < count) {
+            const uint32_t u = ent[x];
+            const uint32_t i = u & 0xffffu, j = u >> 16;
+            const bool pair = i != kGap16 && j != kGap16;
+            const double* v1 = Xi + (int64_t)(pair ? i : 0) * 3;
+            const double* v2 = Xj + (int64_t)(pair ? j : 0) * 3;
+            double mv[3] = {v2[0], v2[1], v2[2]};
+            if constexpr (MOVE) {
+                rot3(v2, R, mv);
+                mv[0] = mv[0] + t[0];
+                mv[1] = mv[1] + t[1];
+                mv[2] = mv[2] + t[2];
+            }
+            const double e0 = v1[0] - mv[0], e1 = v1[1] - mv[1], e2 = v1[2] - mv[2];
+            const double sg = (e0 + e1) + e2;
+            const double q1 = sg / d1, q2 = sg / d2;
+            scratch[lane * 5 + 0] = pair ? e0 * e0 : 0.0;
+            scratch[lane * 5 + 1] = pair ? e1 * e1 : 0.0;
+            scratch[lane * 5 + 2] = pair ? e2 * e2 : 0.0;
+            scratch[lane * 5 + 3] = pair ? 1.0 / (1.0 + q1 * q1) : 0.0;
+            scratch[lane * 5 + 4] = pair ? 1.0 / (1.0 + q2 * q2) : 0.0;
+        }
+        __syncthreads();
+        const int cnt = count - base < kWave ? count - base : kWave;
+        if (lane == 0) {
+            for (int y = 0; y < cnt; y++) {
+                acc += scratch[y * 5 + 0];
+                acc += scratch[y * 5 + 1];
+                acc += scratch[y * 5 + 2];
+            }
+        } else if (lane < 3) {
+#pragma unroll 8
+            for (int y = 0; y < cnt; y++) acc += scratch[y * 5 + 2 + lane];
+        }
+        __syncthreads();
+    }
+    const double ss = lane_value(acc, 0), sum1 = lane_value(acc, 1), sum2 = lane_value(acc, 2);
+    rmsd = sqrt(ss / (double)k);
+    const double t1 = (1.0 / (double)len1) * sum1;
+    const double t2 = (1.0 / (double)len2) * sum2;
+    tm = t1 > t2 ? t1 : t2;
+}
+
 // DTW traceback (dynamic_time_warping.py:90-144) on the packed decisions: leaves the alignment columns
 // as packed entries in lds[first .. cap) (cap = n + m), writes the rows to HBM (back-to-front in
 // [aln, aln + 2*cap)), returns the number of columns and of aligned pairs.  Wave-uniform.
@@ -914,50 +969,8 @@ CR_D void align_trace(const PairDesc& pd, int R, int max_entries, const double* 
         const uint32_t* ent = arow + first;
         double c1[3], c2[3];
         kabsch_ordered(Xi, Xj, ent, idx, k, lane, scratch, c1, c2, r.R, r.t);
-        // get_rmsd (score_functions.py:15-19) and tm_score (multiple_alignment.py:59-70):
-        // lane 0 sums the squared differences (three per position, in order), lanes 1/2 the two TM sums
-        const double d1 = 1.24 * (double)(pd.n - 15) / 3.0 - 1.8;
-        const double d2 = 1.24 * (double)(pd.m - 15) / 3.0 - 1.8;
-        double acc = 0.0;
-        for (int base = 0; base < idx; base += kWave) {
-            const int x = base + lane;
-            if (x < idx) {
-                const uint32_t u = ent[x];
-                const uint32_t i = u & 0xffffu, j = u >> 16;
-                const bool pair = i != kGap16 && j != kGap16;
-                const double* v1 = Xi + (int64_t)(pair ? i : 0) * 3;
-                const double* v2 = Xj + (int64_t)(pair ? j : 0) * 3;
-                double mv[3];
-                rot3(v2, r.R, mv);
-                const double e0 = v1[0] - (mv[0] + r.t[0]), e1 = v1[1] - (mv[1] + r.t[1]), e2 = v1[2] - (mv[2] + r.t[2]);
-                const double sg = (e0 + e1) + e2;
-                const double q1 = sg / d1, q2 = sg / d2;
-                scratch[lane * 5 + 0] = pair ? e0 * e0 : 0.0;
-                scratch[lane * 5 + 1] = pair ? e1 * e1 : 0.0;
-                scratch[lane * 5 + 2] = pair ? e2 * e2 : 0.0;
-                scratch[lane * 5 + 3] = pair ? 1.0 / (1.0 + q1 * q1) : 0.0;
-                scratch[lane * 5 + 4] = pair ? 1.0 / (1.0 + q2 * q2) : 0.0;
-            }
-            __syncthreads();
-            const int cnt = idx - base < kWave ? idx - base : kWave;
-            if (lane == 0) {
-                for (int y = 0; y < cnt; y++) {
-                    acc += scratch[y * 5 + 0];
-                    acc += scratch[y * 5 + 1];
-                    acc += scratch[y * 5 + 2];
-                }
-            } else if (lane < 3) {
-#pragma unroll 8
-                for (int y = 0; y < cnt; y++) acc += scratch[y * 5 + 2 + lane];
-            }
-            __syncthreads();
-        }
-        const double ss = lane_value(acc, 0), sum1 = lane_value(acc, 1), sum2 = lane_value(acc, 2);
-        r.rmsd = sqrt(ss / (double)k);
+        rmsd_tm_ordered<true>(Xi, Xj, ent, idx, k, pd.n, pd.m, r.R, r.t, lane, scratch, r.rmsd, r.tm);
         r.coverage = (double)k / (double)idx;
-        const double t1 = (1.0 / (double)pd.n) * sum1;
-        const double t2 = (1.0 / (double)pd.m) * sum2;
-        r.tm = t1 > t2 ? t1 : t2;
     }
 }
 
@@ -1130,6 +1143,50 @@ __global__ __launch_bounds__(kWave) void k_node(const PairDesc* __restrict__ pai
         no.flags = flags;
         no.pad = 0;
         *out = no;
+    }
+}
+
+// Pairwise RMSD / coverage / TM matrices of a finished multiple alignment (make_rmsd_coverage_tm_matrix,
+// multiple_alignment.py:1000-1055).  msa: int32 [P][W] residue indices, -1 = gap.  One wave per pair i<j
+// (blockIdx.x enumerates them row-major).  superpose != 0: Kabsch per pair first (superpose_first=False);
+// otherwise the coordinates are compared as they are.  out: [npairs][4] = rmsd, coverage, tm, k.
+__global__ __launch_bounds__(kWave) void k_msa_metrics(const double* __restrict__ coords,
+                                                      const int64_t* __restrict__ offsets,
+                                                      const int32_t* __restrict__ msa, int P, int W, int superpose,
+                                                      const int32_t* __restrict__ pairs, double* __restrict__ out) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int i = pairs[2 * blockIdx.x], j = pairs[2 * blockIdx.x + 1];
+    uint32_t* ent = reinterpret_cast<uint32_t*>(lds);
+    double* scratch = lds + ((size_t)W + 3) / 4 * 2;
+    int kloc = 0;
+    for (int x = lane; x < W; x += kWave) {
+        const int a = msa[(int64_t)i * W + x], b = msa[(int64_t)j * W + x];
+        const bool pair = a != -1 && b != -1;
+        ent[x] = pair ? pack_entry(a, b) : pack_entry(-1, -1);
+        kloc += pair ? 1 : 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) kloc += __shfl_xor(kloc, off);
+    __syncthreads();
+    const int k = kloc;
+    const double* Xi = coords + offsets[i] * 3;
+    const double* Xj = coords + offsets[j] * 3;
+    const int n = (int)(offsets[i + 1] - offsets[i]), m = (int)(offsets[j + 1] - offsets[j]);
+    double rmsd = 0.0, tm = 0.0;
+    if (k >= 3) {
+        if (superpose) {
+            double c1[3], c2[3], Rm[9], t[3];
+            kabsch_ordered(Xi, Xj, ent, W, k, lane, scratch, c1, c2, Rm, t);
+            rmsd_tm_ordered<true>(Xi, Xj, ent, W, k, n, m, Rm, t, lane, scratch, rmsd, tm);
+        } else {
+            rmsd_tm_ordered<false>(Xi, Xj, ent, W, k, n, m, nullptr, nullptr, lane, scratch, rmsd, tm);
+        }
+    }
+    if (lane == 0) {
+        out[4 * (int64_t)blockIdx.x + 0] = rmsd;
+        out[4 * (int64_t)blockIdx.x + 1] = (double)k / (double)W;
+        out[4 * (int64_t)blockIdx.x + 2] = tm;
+        out[4 * (int64_t)blockIdx.x + 3] = (double)k;
     }
 }
 

@@ -28,6 +28,15 @@ def get_common_positions(aln_array_1, aln_array_2):
     return p1[:k.value].copy(), p2[:k.value].copy()
 
 
+def nb_mean_axis_0(array) -> np.ndarray:
+    """Column means accumulated sequentially, as numba evaluates the reference's helper.nb_mean_axis_0
+    (helper.py:46-53)."""
+    x = np.ascontiguousarray(array, dtype=np.float64)
+    out = np.empty(x.shape[1])
+    check(_capi.load().cr_mean_axis0(ptr(x), x.shape[0], x.shape[1], ptr(out)))
+    return out
+
+
 def write_distance_matrix(names, distance_matrix, filename):
     """CLUSTAL-style text matrix: first line = count, then ``name v v v ...`` with 4 decimals
     (format of the reference's helper.write_distance_matrix, helper.py:183-202)."""

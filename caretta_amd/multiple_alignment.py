@@ -331,25 +331,15 @@ class MultipleAlignment:
                 f.write(f">{p.name}\n{aligned}\n")
 
 
-def make_rmsd_coverage_tm_matrix(alignment, proteins, superpose_first: bool = False):
-    """multiple_alignment.py:1000-1055 with per-pair superposition (``superpose_first=False`` is what
-    the reference's CLI uses, :571; the in-place ``superpose()`` variant is outside this path)."""
-    if superpose_first:
-        raise NotImplementedError("superpose_first=True (in-place superpose()) is outside the pairwise path")
-    num = len(alignment)
-    rmsd = np.zeros((num, num))
-    coverage = np.ones((num, num))
-    tm = np.ones((num, num))
-    names = [p.name for p in proteins]
-    for i in range(num - 1):
-        for j in range(i + 1, num):
-            aln_1, aln_2 = alignment[names[i]], alignment[names[j]]
-            pos_1, pos_2 = helper.get_common_positions(aln_1, aln_2)
-            assert len(pos_1) >= 3
-            c1, c2 = proteins[i].coordinates[pos_1], proteins[j].coordinates[pos_2]
-            rot, tran = superposition_functions.paired_svd_superpose(c1, c2)
-            c2 = superposition_functions.apply_rotran(c2, rot, tran)
-            rmsd[i, j] = rmsd[j, i] = score_functions.get_rmsd(c1, c2)
-            coverage[i, j] = coverage[j, i] = c1.shape[0] / len(aln_1)
-            tm[i, j] = tm[j, i] = tm_score(c1, c2, len(proteins[i]), len(proteins[j]))
-    return rmsd, coverage, tm
+def make_rmsd_coverage_tm_matrix(alignment, proteins, superpose_first: bool = True):
+    """multiple_alignment.py:1000-1055 (see caretta_amd.msa_superposition)."""
+    from .msa_superposition import make_rmsd_coverage_tm_matrix as impl
+    return impl(alignment, proteins, superpose_first)
+
+
+def __getattr__(name):
+    # superpose*, get_reference_structures, make_coverage_gap_distance_matrix live in msa_superposition
+    from . import msa_superposition
+    if hasattr(msa_superposition, name):
+        return getattr(msa_superposition, name)
+    raise AttributeError(name)

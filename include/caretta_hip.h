@@ -155,6 +155,17 @@ int cr_get_rmsd(cr_context *ctx, const double *x1, const double *x2, int64_t k, 
 /* multiple_alignment.tm_score                                          multiple_alignment.py:59-70 */
 int cr_tm_score(cr_context *ctx, const double *x1, const double *x2, int64_t k, int64_t l1, int64_t l2, double *out);
 
+/* make_rmsd_coverage_tm_matrix over a finished multiple alignment       multiple_alignment.py:1000-1055
+ * coords f64[total,3] + offsets i64[P+1] as in cr_batch_create; msa i32[P, W] residue index per column, -1 = gap.
+ * superpose != 0: per-pair Kabsch on the common positions first (superpose_first=False, what the reference's
+ * --matrix output uses, :571); 0: coordinates compared as given (after the caller's own superpose()).
+ * rmsd/coverage/tm: f64[P, P], diagonals 0 / 1 / 1 as the reference initialises them.  Pairs with fewer than 3
+ * common positions (the reference asserts) get rmsd = tm = NaN. */
+int cr_msa_metrics(cr_context *ctx, const double *coords, const int64_t *offsets, int64_t P, const int32_t *msa,
+                   int64_t W, int superpose, double *rmsd, double *coverage, double *tm);
+/* helper.nb_mean_axis_0 (sequential column means, as numba computes them)   helper.py:46-53 */
+int cr_mean_axis0(const double *x, int64_t rows, int64_t cols, double *out);
+
 /* ---- host-side integer / tree work ------------------------------------------------------ */
 /* helper.get_common_positions                                          helper.py:13-42 */
 int cr_get_common_positions(const int64_t *a1, const int64_t *a2, int64_t len, int64_t *p1, int64_t *p2, int64_t *k);

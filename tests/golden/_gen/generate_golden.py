@@ -376,6 +376,45 @@ def gen_progressive():
     save("f4_progressive.npz", out)
 
 
+def gen_post_msa():
+    """Post-alignment products on the 8-structure family's MSA: superpose() (multiple_alignment.py:896-997),
+    make_coverage_gap_distance_matrix (:45-56), get_reference_structures (:741-783),
+    make_rmsd_coverage_tm_matrix with and without superpose_first (:1000-1055)."""
+    import copy
+    import contextlib
+    import io
+    out = {}
+    g = np.load(OUT / "f4_progressive.npz")
+    for tag in ("P8", "P5"):
+        fam_coords, fam_tensors, off = g[f"fam{tag}_coords"], g[f"fam{tag}_tensors"], g[f"fam{tag}_offsets"]
+        num = len(off) - 1
+        names = [f"s{i:04d}" for i in range(num)]
+        prots = [multiple_alignment.Protein(names[i], fam_tensors[off[i]:off[i + 1]].copy(), fam_coords[off[i]:off[i + 1]].copy(), "")
+                 for i in range(num)]
+        aln = {names[i]: g[f"fam{tag}_msa"][i] for i in range(num)}
+        arr = np.array([aln[n] for n in names])
+        dist, aligning = multiple_alignment.make_coverage_gap_distance_matrix(arr)
+        out[f"{tag}_cov_dist"], out[f"{tag}_cov_aligning"] = dist, aligning
+        first, refs, none = multiple_alignment.get_reference_structures(aln, 50)
+        out[f"{tag}_ref_first"] = np.array(first)
+        out[f"{tag}_ref_keys"] = np.array(list(refs.keys()))
+        for k, v in refs.items():
+            out[f"{tag}_ref_{k}"] = np.array(v)
+        out[f"{tag}_ref_none"] = np.array(none, dtype=str)
+        r0, c0, t0 = multiple_alignment.make_rmsd_coverage_tm_matrix(aln, copy.deepcopy(prots), superpose_first=False)
+        out[f"{tag}_rmsd"], out[f"{tag}_coverage"], out[f"{tag}_tm"] = r0, c0, t0
+        moved = copy.deepcopy(prots)
+        with contextlib.redirect_stdout(io.StringIO()):
+            r1, c1, t1 = multiple_alignment.make_rmsd_coverage_tm_matrix(aln, moved, superpose_first=True)
+        out[f"{tag}_rmsd_sf"], out[f"{tag}_coverage_sf"], out[f"{tag}_tm_sf"] = r1, c1, t1
+        for i in range(num):
+            out[f"{tag}_superposed_{i}"] = moved[i].coordinates
+        ref_moved = multiple_alignment.superpose_reference(aln, copy.deepcopy(prots), names[1])
+        for i in range(num):
+            out[f"{tag}_superposed_ref1_{i}"] = ref_moved[i].coordinates
+    save("f5_post_msa.npz", out)
+
+
 def gen_c1_inputs():
     """BASELINE config 1 inputs: C-alpha coordinates and sequences of the three kringle-domain PDB files the
     reference ships as its README example (test_data/), read with the product's own minimal reader."""
@@ -405,7 +444,8 @@ def main():
               ("long", gen_pipeline_long),
               ("tree", lambda: gen_tree(np.random.default_rng(20224))),
               ("progressive", gen_progressive),
-              ("c1", gen_c1_inputs)]
+              ("c1", gen_c1_inputs),
+              ("postmsa", gen_post_msa)]
     for name, fn in steps:
         if only and name not in only:
             continue

@@ -394,7 +394,7 @@ def test_two_sequence_alignment_and_metrics(ctx, golden):
     aln = msa.multiple_align(None, 1.0, 0.01, 1.0, 1.0,
                              score_function_params=dict(flexible=False, gamma_tensor=7.0, gamma_coords=0.03))
     assert np.array_equal(aln["s0"], g["famB_p0_aln1"]) and np.array_equal(aln["s1"], g["famB_p0_aln2"])
-    rmsd, cov, tm = ma.make_rmsd_coverage_tm_matrix(aln, prots)
+    rmsd, cov, tm = ma.make_rmsd_coverage_tm_matrix(aln, prots, superpose_first=False)
     assert abs(rmsd[0, 1] - float(g["famB_p0_rmsd"])) < 1e-5 and abs(tm[0, 1] - float(g["famB_p0_tm"])) < 1e-5
     assert cov[0, 1] == float(g["famB_p0_coverage"])
 
@@ -427,5 +427,40 @@ def test_config1_three_kringle_domains(golden, tmp_path):
     helper.write_distance_matrix([p.name for p in prots], d, tmp_path / "distance_matrix_guide_tree.txt")
     names, back = helper.read_distance_matrix(tmp_path / "distance_matrix_guide_tree.txt")
     assert names == [p.name for p in prots] and np.allclose(back, d, atol=5e-5)
-    rmsd, cov, tm = ma.make_rmsd_coverage_tm_matrix(aln, prots)
+    rmsd, cov, tm = ma.make_rmsd_coverage_tm_matrix(aln, prots, superpose_first=False)
     assert np.all(rmsd[np.triu_indices(3, 1)] > 0) and np.all(rmsd < 15) and np.all((cov > 0.5) & (cov <= 1))
+
+
+@pytest.mark.parametrize("tag", ["P8", "P5"])
+def test_post_msa_products_golden(golden, tag):
+    """superpose(), coverage/gap matrices, reference-structure selection and the RMSD / coverage / TM matrices of
+    a finished MSA against the reference's outputs (tests/golden/f5_post_msa.npz)."""
+    import copy
+    from caretta_amd import msa_superposition as post, multiple_alignment as ma
+    g, f = golden("f5_post_msa.npz"), golden("f4_progressive.npz")
+    coords, tensors, off = f[f"fam{tag}_coords"], f[f"fam{tag}_tensors"], f[f"fam{tag}_offsets"]
+    num = len(off) - 1
+    names = [f"s{i:04d}" for i in range(num)]
+    prots = [ma.Protein(names[i], tensors[off[i]:off[i + 1]].copy(), coords[off[i]:off[i + 1]].copy(), "") for i in range(num)]
+    aln = {names[i]: f[f"fam{tag}_msa"][i] for i in range(num)}
+    dist, aligning = post.make_coverage_gap_distance_matrix(np.array([aln[n] for n in names]))
+    assert np.array_equal(aligning, g[f"{tag}_cov_aligning"]) and np.allclose(dist, g[f"{tag}_cov_dist"], rtol=0, atol=1e-15)
+    first, refs, none = post.get_reference_structures(aln, 50)
+    assert first == str(g[f"{tag}_ref_first"]) and list(refs) == list(g[f"{tag}_ref_keys"]) and list(none) == list(g[f"{tag}_ref_none"])
+    for k, v in refs.items():
+        assert list(v) == list(g[f"{tag}_ref_{k}"])
+    r0, c0, t0 = post.make_rmsd_coverage_tm_matrix(aln, copy.deepcopy(prots), superpose_first=False)
+    np.testing.assert_allclose(r0, g[f"{tag}_rmsd"], atol=1e-9)
+    np.testing.assert_allclose(t0, g[f"{tag}_tm"], atol=1e-9)
+    assert np.array_equal(c0, g[f"{tag}_coverage"])
+    moved = copy.deepcopy(prots)
+    r1, c1, t1 = post.make_rmsd_coverage_tm_matrix(aln, moved, superpose_first=True)
+    np.testing.assert_allclose(r1, g[f"{tag}_rmsd_sf"], atol=1e-8)
+    np.testing.assert_allclose(t1, g[f"{tag}_tm_sf"], atol=1e-8)
+    assert np.array_equal(c1, g[f"{tag}_coverage_sf"])
+    for i in range(num):
+        np.testing.assert_allclose(moved[i].coordinates, g[f"{tag}_superposed_{i}"], atol=1e-8)
+    ref_moved = post.superpose_reference(aln, copy.deepcopy(prots), names[1])
+    for i in range(num):
+        np.testing.assert_allclose(ref_moved[i].coordinates, g[f"{tag}_superposed_ref1_{i}"], atol=1e-8)
+    assert ma.superpose is post.superpose                      # reachable under the reference's module name too
