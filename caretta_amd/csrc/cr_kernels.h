@@ -249,11 +249,119 @@ struct Explicit {
     CR_D double score(int q, const ExpEntry*) const { return rowp[q][colidx]; }
 };
 
+// Registers a lane carries from column to column of its R rows.
+template <int R>
+struct DpState {
+    double h_left[R];                       // SW: H of this lane's rows, previous column
+    double m0_left[R], m1_left[R], m2_left[R];   // DTW layers, previous column (m0: current column, kept for (n, m))
+    double rowmax[R];                       // SW trace: running first maximum of each row ...
+    int rowarg[R];                          // ... and its column
+    uint32_t swbits[R], dtbits[R];          // decisions of the current word
+    double h_diag, m1_diag;                 // row above the lane's block, previous column
+    double h_bot, m0_bot, m1_bot;           // this lane's last row, current column (handed down by DPP)
+    double sw_max;                          // SW score: running maximum
+
+    CR_D void reset_column0(double col0_m2) {   // DP border left of column 0
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            h_left[q] = 0.0;
+            m0_left[q] = 0.0;
+            m1_left[q] = 0.0;          // M[i][0][1] = 0
+            m2_left[q] = col0_m2;      // M[i][0][2] = MIN - open
+            rowmax[q] = 0.0;
+            rowarg[q] = 0;
+        }
+        h_diag = 0.0;
+        m1_diag = 0.0;
+    }
+};
+
 enum : int { kSwTrace = 1, kSwScore = 2, kDtw = 4, kZeroGap = 8 };   // kZeroGap: sw_gap == 0.0
 
 struct SweepParams {
     double sw_gap, gap_open, gap_extend;
 };
+
+// The R cells of one column of one lane.  *_top: the row above the lane's block in this column.
+// max(a, b) is v_max_f64: value-identical to the reference's compare-and-keep for non-NaN data.
+template <int R, int MODE, class Src>
+CR_D void dp_column(const Src& src, DpState<R>& st, const SweepParams& prm, const ExpEntry* tab, int c, int rowbase,
+                    int n, int sh2, int sh4, double h_top, double m0_top, double m1_top) {
+    constexpr bool SW = (MODE & (kSwTrace | kSwScore)) != 0;
+    constexpr bool TRACE = (MODE & kSwTrace) != 0;
+    constexpr bool DTW = (MODE & kDtw) != 0;
+    constexpr bool ZG = (MODE & kZeroGap) != 0;        // x - 0.0 == x: the gap subtractions vanish
+    constexpr bool NOFLOOR = ZG && Src::kNonNegative;  // all candidates >= +0: max(0, .) is the identity
+    double h_up = h_top, h_dg = st.h_diag;
+    double m0_up = m0_top, m1_up = m1_top, m1_dg = st.m1_diag;
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+        const double sc = src.score(q, tab);
+        if constexpr (SW) {
+            // H = max(0, diag + S, left - gap, up - gap)
+            const double dg = h_dg + sc;
+            const double lf = ZG ? st.h_left[q] : st.h_left[q] - prm.sw_gap;
+            const double up = ZG ? h_up : h_up - prm.sw_gap;
+            const double h = NOFLOOR ? __builtin_fmax(__builtin_fmax(dg, lf), up)
+                                     : __builtin_fmax(__builtin_fmax(__builtin_fmax(0.0, dg), lf), up);
+            if constexpr (TRACE) {
+                // decision replayed by the traceback's equality tests (:255-277)
+                uint32_t code = (h == dg) ? 1u : (h == lf) ? 2u : 3u;
+                code = (h > 0.0) ? code : 0u;
+                bool gt = h > st.rowmax[q];
+                if constexpr (Src::kMaskRows) {
+                    const bool rv = rowbase + q < n;
+                    gt = gt & rv;
+                    code = rv ? code : 0u;
+                }
+                st.swbits[q] |= code << sh2;
+                st.rowmax[q] = gt ? h : st.rowmax[q];
+                st.rowarg[q] = gt ? c : st.rowarg[q];
+            } else {
+                if constexpr (Src::kMaskRows) {
+                    st.sw_max = (rowbase + q < n) ? __builtin_fmax(st.sw_max, h) : st.sw_max;
+                } else {
+                    st.sw_max = __builtin_fmax(st.sw_max, h);
+                }
+            }
+            h_dg = st.h_left[q];
+            h_up = h;
+            st.h_left[q] = h;
+        }
+        if constexpr (DTW) {
+            const double lo0 = m0_up - prm.gap_extend;
+            const double lo1 = m1_up - prm.gap_open;
+            const bool b0 = lo1 > lo0;                  // np.argmax keeps the first maximum
+            const double m0 = __builtin_fmax(lo0, lo1);
+            const double up0 = st.m1_left[q] - prm.gap_open;
+            const double up1 = st.m2_left[q] - prm.gap_extend;
+            const bool b2 = up1 > up0;
+            const double m2 = __builtin_fmax(up0, up1);
+            const double c1 = m1_dg + sc;
+            const bool g1 = c1 > m0;
+            const double m01 = __builtin_fmax(m0, c1);
+            const bool g2 = m2 > m01;
+            const double m1 = __builtin_fmax(m01, m2);
+            const uint32_t nib = (b0 ? 1u : 0u) | (g2 ? 4u : (g1 ? 2u : 0u)) | (b2 ? 8u : 0u);
+            st.dtbits[q] |= nib << sh4;
+            m1_dg = st.m1_left[q];
+            m0_up = m0;
+            m1_up = m1;
+            st.m0_left[q] = m0;
+            st.m1_left[q] = m1;
+            st.m2_left[q] = m2;
+        }
+    }
+    if constexpr (SW) {
+        st.h_diag = h_top;
+        st.h_bot = h_up;
+    }
+    if constexpr (DTW) {
+        st.m1_diag = m1_top;
+        st.m0_bot = m0_up;
+        st.m1_bot = m1_up;
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // The sweep.  One wave, one pair.  MODE selects the recurrences evaluated per cell:
@@ -277,8 +385,6 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
     constexpr bool SW = (MODE & (kSwTrace | kSwScore)) != 0;
     constexpr bool TRACE = (MODE & kSwTrace) != 0;
     constexpr bool DTW = (MODE & kDtw) != 0;
-    constexpr bool ZG = (MODE & kZeroGap) != 0;        // x - 0.0 == x: the gap subtractions vanish
-    constexpr bool NOFLOOR = ZG && Src::kNonNegative;  // all candidates >= +0: max(0, .) is the identity
     constexpr int NB = (SW ? 1 : 0) + (DTW ? 2 : 0);   // values handed from strip to strip per column
     const int lane = threadIdx.x;
     const ExpEntry* tab = reinterpret_cast<const ExpEntry*>(lds);
@@ -299,8 +405,8 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
     // first maximum of H in row-major order (smith_waterman, :241-247): lane-level running best
     double best_v = 0.0;
     int best_i = 0x7fffffff, best_j = 0x7fffffff;
-    double sw_max = 0.0;
-    double m0_left[R], m1_left[R], m2_left[R];          // DTW layers of this lane's rows, previous column
+    DpState<R> st;
+    st.sw_max = 0.0;
 
     for (int s = 0; s < nstrips; s++) {
         const int rowbase = (s * kWave + lane) * R;
@@ -308,22 +414,10 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
         const int lanes_here = rows_here >= kWave * R ? kWave : (rows_here + R - 1) / R;
         const int T = m + lanes_here - 1;
         src.load_rows(rowbase, n);
-        double h_left[R], rowmax[R];
-        int rowarg[R];
-        uint32_t swbits[R], dtbits[R];
+        st.reset_column0(col0_m2);
 #pragma unroll
-        for (int q = 0; q < R; q++) {
-            h_left[q] = 0.0;
-            m0_left[q] = 0.0;
-            m1_left[q] = 0.0;          // M[i][0][1] = 0
-            m2_left[q] = col0_m2;      // M[i][0][2] = MIN - open
-            rowmax[q] = 0.0;
-            rowarg[q] = 0;
-            swbits[q] = 0;
-            dtbits[q] = 0;
-        }
-        double h_diag = 0.0, m1_diag = 0.0;             // row above, previous column
-        double h_bot = 0.0, m0_bot = 0.0, m1_bot = 0.0; // this lane's last row, current column
+        for (int q = 0; q < R; q++) st.swbits[q] = st.dtbits[q] = 0;
+        st.h_bot = st.m0_bot = st.m1_bot = 0.0;
 
         for (int t = 0; t < T; t++) {
             if ((t & (kWave - 1)) == 0) {
@@ -354,90 +448,22 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
                 }
             }
             double h_top = 0.0, m0_top = 0.0, m1_top = 0.0;
-            if constexpr (SW) h_top = wave_shr1(h_bot, h_top0);
+            if constexpr (SW) h_top = wave_shr1(st.h_bot, h_top0);
             if constexpr (DTW) {
-                m0_top = wave_shr1(m0_bot, m0_top0);
-                m1_top = wave_shr1(m1_bot, m1_top0);
+                m0_top = wave_shr1(st.m0_bot, m0_top0);
+                m1_top = wave_shr1(st.m1_bot, m1_top0);
             }
             const int sh2 = (t & 15) * 2, sh4 = (t & 7) * 4;
 
             if (active) {
                 if constexpr (Src::kRingDoubles == 0) src.set_col(c, m);
                 src.fetch_col(ring, c & (kRing - 1));
-                double h_up = h_top, h_dg = h_diag;
-                double m0_up = m0_top, m1_up = m1_top, m1_dg = m1_diag;
-#pragma unroll
-                for (int q = 0; q < R; q++) {
-                    const double sc = src.score(q, tab);
-                    if constexpr (SW) {
-                        // H = max(0, diag + S, left - gap, up - gap)
-                        const double dg = h_dg + sc;
-                        const double lf = ZG ? h_left[q] : h_left[q] - prm.sw_gap;
-                        const double up = ZG ? h_up : h_up - prm.sw_gap;
-                        const double h = NOFLOOR ? __builtin_fmax(__builtin_fmax(dg, lf), up)
-                                                 : __builtin_fmax(__builtin_fmax(__builtin_fmax(0.0, dg), lf), up);
-                        if constexpr (TRACE) {
-                            // decision replayed by the traceback's equality tests (:255-277)
-                            uint32_t code = (h == dg) ? 1u : (h == lf) ? 2u : 3u;
-                            code = (h > 0.0) ? code : 0u;
-                            bool gt = h > rowmax[q];
-                            if constexpr (Src::kMaskRows) {
-                                const bool rv = rowbase + q < n;
-                                gt = gt & rv;
-                                code = rv ? code : 0u;
-                            }
-                            swbits[q] |= code << sh2;
-                            rowmax[q] = gt ? h : rowmax[q];
-                            rowarg[q] = gt ? c : rowarg[q];
-                        } else {
-                            if constexpr (Src::kMaskRows) {
-                                sw_max = (rowbase + q < n) ? __builtin_fmax(sw_max, h) : sw_max;
-                            } else {
-                                sw_max = __builtin_fmax(sw_max, h);
-                            }
-                        }
-                        h_dg = h_left[q];
-                        h_up = h;
-                        h_left[q] = h;
-                    }
-                    if constexpr (DTW) {
-                        const double lo0 = m0_up - prm.gap_extend;
-                        const double lo1 = m1_up - prm.gap_open;
-                        const bool b0 = lo1 > lo0;                  // np.argmax keeps the first maximum
-                        const double m0 = __builtin_fmax(lo0, lo1);
-                        const double up0 = m1_left[q] - prm.gap_open;
-                        const double up1 = m2_left[q] - prm.gap_extend;
-                        const bool b2 = up1 > up0;
-                        const double m2 = __builtin_fmax(up0, up1);
-                        const double c1 = m1_dg + sc;
-                        const bool g1 = c1 > m0;
-                        const double m01 = __builtin_fmax(m0, c1);
-                        const bool g2 = m2 > m01;
-                        const double m1 = __builtin_fmax(m01, m2);
-                        const uint32_t nib = (b0 ? 1u : 0u) | (g2 ? 4u : (g1 ? 2u : 0u)) | (b2 ? 8u : 0u);
-                        dtbits[q] |= nib << sh4;
-                        m1_dg = m1_left[q];
-                        m0_up = m0;
-                        m1_up = m1;
-                        m0_left[q] = m0;
-                        m1_left[q] = m1;
-                        m2_left[q] = m2;
-                    }
-                }
-                if constexpr (SW) {
-                    h_diag = h_top;
-                    h_bot = h_up;
-                }
-                if constexpr (DTW) {
-                    m1_diag = m1_top;
-                    m0_bot = m0_up;
-                    m1_bot = m1_up;
-                }
+                dp_column<R, MODE>(src, st, prm, tab, c, rowbase, n, sh2, sh4, h_top, m0_top, m1_top);
                 if (s + 1 < nstrips && lane == kWave - 1) {
-                    if constexpr (SW) hout[c & (kRing - 1)] = h_up;
+                    if constexpr (SW) hout[c & (kRing - 1)] = st.h_bot;
                     if constexpr (DTW) {
-                        hout[(NB - 2) * kRing + (c & (kRing - 1))] = m0_up;
-                        hout[(NB - 1) * kRing + (c & (kRing - 1))] = m1_up;
+                        hout[(NB - 2) * kRing + (c & (kRing - 1))] = st.m0_bot;
+                        hout[(NB - 1) * kRing + (c & (kRing - 1))] = st.m1_bot;
                     }
                 }
             }
@@ -446,8 +472,8 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
                     const int64_t base = ((int64_t)(s * TB_SW + (t >> 4)) * R) * kWave + lane;
 #pragma unroll
                     for (int q = 0; q < R; q++) {
-                        sw_dirs[base + q * kWave] = swbits[q];
-                        swbits[q] = 0;
+                        sw_dirs[base + q * kWave] = st.swbits[q];
+                        st.swbits[q] = 0;
                     }
                 }
             }
@@ -456,8 +482,8 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
                     const int64_t base = ((int64_t)(s * TB_DTW + (t >> 3)) * R) * kWave + lane;
 #pragma unroll
                     for (int q = 0; q < R; q++) {
-                        dtw_bits[base + q * kWave] = dtbits[q];
-                        dtbits[q] = 0;
+                        dtw_bits[base + q * kWave] = st.dtbits[q];
+                        st.dtbits[q] = 0;
                     }
                 }
             }
@@ -477,13 +503,14 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
             // fold this strip's per-row first maxima into the lane's running best (rows ascending)
 #pragma unroll
             for (int q = 0; q < R; q++) {
-                const bool gt = rowmax[q] > best_v;
-                best_v = gt ? rowmax[q] : best_v;
+                const bool gt = st.rowmax[q] > best_v;
+                best_v = gt ? st.rowmax[q] : best_v;
                 best_i = gt ? rowbase + q : best_i;
-                best_j = gt ? rowarg[q] : best_j;
+                best_j = gt ? st.rowarg[q] : best_j;
             }
         }
     }
+    double sw_max = st.sw_max;
 
     // ---- wave reductions: results are returned in every lane ------------------------------------
     if constexpr (TRACE) {
@@ -508,9 +535,9 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
         double fin0 = 0.0, fin1 = 0.0, fin2 = 0.0;     // M[n][m][0..2]
 #pragma unroll
         for (int q = 0; q < R; q++) {
-            fin0 = (q == qo) ? m0_left[q] : fin0;
-            fin1 = (q == qo) ? m1_left[q] : fin1;
-            fin2 = (q == qo) ? m2_left[q] : fin2;
+            fin0 = (q == qo) ? st.m0_left[q] : fin0;
+            fin1 = (q == qo) ? st.m1_left[q] : fin1;
+            fin2 = (q == qo) ? st.m2_left[q] : fin2;
         }
         fin0 = lane_value(fin0, owner);
         fin1 = lane_value(fin1, owner);
