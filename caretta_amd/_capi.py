@@ -55,6 +55,12 @@ SIGNATURES = {
     "cr_protein_score_function": [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _f64, _f64, _vp, C.POINTER(C.c_uint32)],
     "cr_progressive_node": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _f64, _f64, C.POINTER(Params), _f64,
                             _vp, _vp, C.POINTER(C.c_int64), _vp, _vp, _vp, C.POINTER(C.c_uint32)],
+    "cr_progressive_align": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, C.POINTER(Params), _f64, _f64, C.POINTER(_vp)],
+    "cr_progressive_sizes": [_vp, _vp],
+    "cr_progressive_fetch_msa": [_vp, _vp],
+    "cr_progressive_node_table": [_vp, _vp],
+    "cr_progressive_fetch_nodes": [_vp, _vp, _vp, _vp, _vp],
+    "cr_progressive_destroy": [_vp],
     "cr_dtw_align": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _f64, _f64, _vp, _vp, C.POINTER(C.c_int64),
                      C.POINTER(C.c_double)],
     "cr_smith_waterman_score": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _f64, C.POINTER(C.c_double)],

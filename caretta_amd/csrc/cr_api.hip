@@ -535,3 +535,4 @@ int cr_batch_destroy(cr_batch* b) {
 }  // extern "C"
 
 #include "cr_dropins.h"
+#include "cr_progressive.h"

@@ -251,6 +251,28 @@ int fetch_alignment(cr_context* ctx, ExplicitRun& r, int64_t n, int64_t m, int64
     return CR_OK;
 }
 
+// k_node<R> over `count` tree nodes (one wave each); n_max / m_max / entries bound the LDS of the launch
+template <int R>
+int launch_node_r(hipStream_t stream, int count, int n_max, int m_max, int entries, const cr::PairDesc* pairs,
+                  const double* coords, const double* tensors, int d, const double* weights, const cr::NodeDesc* nodes,
+                  const cr::Transform* xf, const cr_params& prm, double gamma_weight, uint32_t* bits, double* hand,
+                  int32_t* aln, double* xn, double* tn, double* wn, cr::NodeOut* out) {
+    const size_t lds = sizeof(double) * std::max(cr::sweep_lds_doubles<R, cr::kDtw, cr::RbfNode<R>>(n_max, m_max),
+                                                 (size_t)cr::kExpDoubles + cr::trace_lds_doubles(R, entries));
+    int rc = allow_lds(cr::k_node<R>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(cr::k_node<R>, dim3((unsigned)count), dim3(cr::kWave), lds, stream, pairs, coords, tensors, d, weights,
+                       nodes, xf, prm.gamma_coords, gamma_weight, prm.gap_open, prm.gap_extend, entries, bits, hand, aln, xn,
+                       tn, wn, out);
+    CR_HIP(hipGetLastError());
+    return CR_OK;
+}
+
+template <class... A>
+int launch_node(int R, A... a) {
+    return R == 3 ? launch_node_r<3>(a...) : launch_node_r<5>(a...);
+}
+
 }  // namespace
 
 extern "C" {
@@ -367,22 +389,12 @@ int cr_progressive_node(cr_context* ctx, const double* coords_1, const double* t
     CR_HIP(dout.ensure(1));
     const int R = b->r_align;
     const int entries = (int)cap;
-    size_t lds;
-    if (R == 3) {
-        lds = sizeof(double) * std::max(cr::sweep_lds_doubles<3, cr::kDtw, cr::RbfNode<3>>((int)n, (int)m),
-                                        (size_t)cr::kExpDoubles + cr::trace_lds_doubles(3, entries));
-        if ((rc = allow_lds(cr::k_node<3>, lds))) return rc;
-        hipLaunchKernelGGL(cr::k_node<3>, dim3(1), dim3(cr::kWave), lds, ctx->stream, b->pairs.p, b->coords.p, b->tensors.p,
-                           (int)d, dw.p, mult1, mult2, b->xf.p, prm.gamma_coords, gamma_weight, prm.gap_open,
-                           prm.gap_extend, entries, b->bits.p, b->hand.p, b->aln.p, dxn.p, dtn.p, dwn.p, dout.p);
-    } else {
-        lds = sizeof(double) * std::max(cr::sweep_lds_doubles<5, cr::kDtw, cr::RbfNode<5>>((int)n, (int)m),
-                                        (size_t)cr::kExpDoubles + cr::trace_lds_doubles(5, entries));
-        if ((rc = allow_lds(cr::k_node<5>, lds))) return rc;
-        hipLaunchKernelGGL(cr::k_node<5>, dim3(1), dim3(cr::kWave), lds, ctx->stream, b->pairs.p, b->coords.p, b->tensors.p,
-                           (int)d, dw.p, mult1, mult2, b->xf.p, prm.gamma_coords, gamma_weight, prm.gap_open,
-                           prm.gap_extend, entries, b->bits.p, b->hand.p, b->aln.p, dxn.p, dtn.p, dwn.p, dout.p);
-    }
+    const cr::NodeDesc hnd{mult1, mult2, 0};
+    DevBuf<cr::NodeDesc> dnd;
+    if ((rc = upload(dnd, &hnd, 1, ctx->stream))) return rc;
+    if ((rc = launch_node(R, ctx->stream, 1, (int)n, (int)m, entries, b->pairs.p, b->coords.p, b->tensors.p, (int)d, dw.p,
+                          dnd.p, b->xf.p, prm, gamma_weight, b->bits.p, b->hand.p, b->aln.p, dxn.p, dtn.p, dwn.p, dout.p)))
+        return rc;
     CR_HIP(hipGetLastError());
     cr::NodeOut no;
     CR_HIP(hipMemcpyAsync(&no, dout.p, sizeof(no), hipMemcpyDeviceToHost, ctx->stream));

@@ -709,6 +709,47 @@ struct BitWindow {
     }
 };
 
+// Decision lookup for the walk.  On top of the LDS window it keeps, in ONE VGPR, the words of a block of
+// cells around the walk: kDeep consecutive fill lanes (row blocks) x 2 word-blocks x R rows, one word per
+// lane of this wave.  A lookup inside the block is a v_readlane (no memory access); the block is refilled
+// with a single ds_read when the walk leaves it, about once per kDeep * R steps on a diagonal path.
+struct DecisionReader {
+    BitWindow bw;
+    uint32_t blk;             // lane x holds the word (fill lane bl - ls, word-block bhi - tsel, row qq)
+    int ls, tsel, qq;         // this lane's slot in the block
+    int deep;                 // fill lanes per block = 32 / R
+    int bs, bl, bhi, blo;     // block key: strip, top fill lane, word-block range
+    CR_D void init(uint32_t* win, int R, int lane) {
+        bw.win = win;
+        bw.s = -1;
+        bw.lo = 0;
+        bw.hi = -1;
+        deep = 32 / R;
+        ls = lane / (2 * R);
+        const int rest = lane - ls * 2 * R;
+        tsel = rest / R;
+        qq = rest - tsel * R;
+        bs = -1;
+        bl = bhi = blo = 0;
+        blk = 0;
+    }
+    CR_D uint32_t get(const uint32_t* __restrict__ words, int R, int TB, int strip, int l, int q, int tb, int lane) {
+        const bool hit = strip == bs && l <= bl && l > bl - deep && tb <= bhi && tb >= blo;
+        if (!hit) {
+            if (!bw.holds(strip, tb)) bw.load(words, R, TB, strip, tb, lane);
+            bs = strip;
+            bl = l;
+            bhi = tb;
+            blo = tb - 1 > bw.lo ? tb - 1 : bw.lo;
+            const int fl = bl - ls, tbx = bhi - tsel;
+            const bool valid = ls < deep && fl >= 0 && tbx >= blo;
+            blk = valid ? bw.win[((tbx - bw.lo) * R + qq) * kWave + fl] : 0u;
+        }
+        const int idx = __builtin_amdgcn_readfirstlane(((bl - l) * 2 + (bhi - tb)) * R + q);
+        return (uint32_t)__builtin_amdgcn_readlane((int)blk, idx);
+    }
+};
+
 // Sum `count` per-position term vectors in position order.  term(e, out[NACC]) is evaluated by the
 // lane that owns position e; lane a < NACC returns sum_e term(e)[a] accumulated e = 0, 1, 2, ...
 // (exactly the rounding sequence of a sequential loop).  `scratch` = 64 * NACC doubles of LDS.
@@ -791,11 +832,8 @@ CR_D void seed_trace(const PairDesc& pd, int R, int max_entries, const double* _
     const int lane = threadIdx.x;
     uint32_t* plist = reinterpret_cast<uint32_t*>(lds);          // aligned pairs, filled back-to-front
     double* scratch = lds + ((size_t)max_entries + 3) / 4 * 2;   // 16-byte aligned, after the list
-    BitWindow bw;
-    bw.win = reinterpret_cast<uint32_t*>(scratch);
-    bw.s = -1;
-    bw.lo = 0;
-    bw.hi = -1;
+    DecisionReader rd;
+    rd.init(reinterpret_cast<uint32_t*>(scratch), R, lane);
     const int cap = pd.n < pd.m ? pd.n : pd.m;
     uint32_t flags = 0;
     int k = 0, len = 0;
@@ -804,15 +842,15 @@ CR_D void seed_trace(const PairDesc& pd, int R, int max_entries, const double* _
     } else {
         const uint32_t* w = dirs + pd.dirs_off;
         const int TB = tblocks(pd.m, 16);
-        int i = sm.i, j = sm.j;
+        // the walk is wave-uniform: pin its state to SGPRs so that it compiles to scalar code
+        int i = __builtin_amdgcn_readfirstlane(sm.i), j = __builtin_amdgcn_readfirstlane(sm.j);
         RowPos rp;
         rp.set(i - 1, R);
 #pragma unroll 1
         while (i > 0 && j > 0) {
             const int t = (j - 1) + rp.l;
             const int tb = t >> 4;
-            if (!bw.holds(rp.s, tb)) bw.load(w, R, TB, rp.s, tb, lane);
-            const uint32_t code = (bw.word(R, tb, rp.q, rp.l) >> ((t & 15) * 2)) & 3u;
+            const uint32_t code = (rd.get(w, R, TB, rp.s, rp.l, rp.q, tb, lane) >> ((t & 15) * 2)) & 3u;
             if (code == 0) break;
             len++;
             if (code == 2) {
@@ -907,22 +945,20 @@ CR_D void dtw_walk(int n0, int m0, int R, int max_entries, const uint32_t* __res
     const int lane = threadIdx.x;
     uint32_t* arow = reinterpret_cast<uint32_t*>(lds);           // packed alignment columns, back-to-front
     double* scratch = lds + ((size_t)max_entries + 3) / 4 * 2;
-    BitWindow bw;
-    bw.win = reinterpret_cast<uint32_t*>(scratch);
-    bw.s = -1;
-    bw.lo = 0;
-    bw.hi = -1;
+    DecisionReader rd;
+    rd.init(reinterpret_cast<uint32_t*>(scratch), R, lane);
     const int cap = n0 + m0;
     const int TB = tblocks(m0, 8);
-    int n = n0, m = m0, dir = start_layer, idx = 0, k = 0;
+    // the walk is wave-uniform: pin its state to SGPRs so that it compiles to scalar code
+    int n = __builtin_amdgcn_readfirstlane(n0), m = __builtin_amdgcn_readfirstlane(m0);
+    int dir = __builtin_amdgcn_readfirstlane(start_layer), idx = 0, k = 0;
     RowPos rp;
     rp.set(n - 1, R);
 #pragma unroll 1
     while (n > 0 && m > 0) {
         const int t = (m - 1) + rp.l;
         const int tb = t >> 3;
-        if (!bw.holds(rp.s, tb)) bw.load(w, R, TB, rp.s, tb, lane);
-        const uint32_t nib = (bw.word(R, tb, rp.q, rp.l) >> ((t & 7) * 4)) & 15u;
+        const uint32_t nib = (rd.get(w, R, TB, rp.s, rp.l, rp.q, tb, lane) >> ((t & 7) * 4)) & 15u;
         // dynamic_time_warping.py:118-143.  In layer 1 the stored decision either keeps the walk on
         // the diagonal or switches layer at the SAME cell; the switch and the move it then makes in
         // layer 0 / 2 (which reads the same cell's decisions) are done in one iteration.
@@ -1089,19 +1125,38 @@ struct NodeOut {
     int32_t pad;
 };
 
+// Per-node launch arguments: the multipliers of multiple_alignment.py:199-202 and where the node goes.
+struct NodeDesc {
+    double mult1, mult2;
+    int64_t out_off;         // residue offset of this node's cap-sized output region in Xn / Tn / Wn
+};
+
+// One wave per tree node; blockIdx.x indexes pairs / nodes / xf / out.  The children are read from
+// coords / tensors / weights at pd.off_i, pd.off_j; the node is written to Xn / Tn / Wn at out_off (the
+// output arrays may be the input arrays: a level of the guide tree appends to the arena it reads from).
 template <int R>
-__global__ __launch_bounds__(kWave) void k_node(const PairDesc* __restrict__ pairs, const double* __restrict__ coords,
-                                               const double* __restrict__ tensors, int d,
-                                               const double* __restrict__ weights, double mult1, double mult2,
-                                               const Transform* __restrict__ xf, double gamma_coords,
+__global__ __launch_bounds__(kWave) void k_node(const PairDesc* __restrict__ pairs, const double* coords,
+                                               const double* tensors, int d, const double* weights,
+                                               const NodeDesc* __restrict__ nodes,
+                                               const Transform* __restrict__ xfs, double gamma_coords,
                                                double gamma_weight, double gap_open, double gap_extend,
-                                               int max_entries, uint32_t* __restrict__ bits,
-                                               double* __restrict__ hand, int32_t* __restrict__ aln,
-                                               double* __restrict__ Xn, double* __restrict__ Tn,
-                                               double* __restrict__ Wn, NodeOut* __restrict__ out) {
+                                               int max_entries, uint32_t* __restrict__ bits_base,
+                                               double* __restrict__ hand_base, int32_t* __restrict__ aln_base,
+                                               double* Xn_base, double* Tn_base, double* Wn_base,
+                                               NodeOut* __restrict__ outs) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
-    const PairDesc pd = pairs[0];
+    const PairDesc pd = pairs[blockIdx.x];
+    const NodeDesc nd = nodes[blockIdx.x];
+    const Transform* xf = xfs + blockIdx.x;
+    const double mult1 = nd.mult1, mult2 = nd.mult2;
+    uint32_t* bits = bits_base + pd.bt_off;
+    double* hand = hand_base + pd.hand_off;
+    int32_t* aln = aln_base + pd.aln_off;
+    double* Xn = Xn_base + nd.out_off * 3;
+    double* Tn = Tn_base + nd.out_off * d;
+    double* Wn = Wn_base + nd.out_off;
+    NodeOut* out = outs + blockIdx.x;
     SeedMax unused;
     AlignEnd e;
     {

@@ -1,0 +1,327 @@
+// Whole-tree progressive alignment (MultipleAlignment.progressive_align, multiple_alignment.py:172-253) with
+// every node resident in HBM.  Included at the end of cr_api.hip (after cr_dropins.h).
+//
+// The guide tree is cut into LEVELS: a node's level is 1 + the larger level of its children, leaves are level
+// 0.  Nodes of one level are independent (:193-234 reads only the two children), so a level is one k_seed
+// launch plus one k_node launch with one wave per node.  Node lengths are data dependent, so the host reads the
+// level's NodeOut records (and its alignment rows) back before it lays out the next level: one small
+// device->host copy per level, no other traffic until the caller fetches results.
+//
+// Arena: coordinates / tensors / weights of all nodes live in three growing device arrays.  Leaves occupy
+// the front in input order; every internal node reserves cap = n + m rows (k_node fills them back to front) and
+// ends up at [out_off + first, out_off + first + len).
+
+struct cr_progressive {
+    cr_context* ctx = nullptr;
+    int64_t P = 0, d = 0;
+    cr_batch scratch;                        // k_seed launch state: arena (coords, tensors) + decision scratch
+    DevBuf<double> weights;                  // arena, one double per row
+    int64_t used = 0, capacity = 0;          // arena rows
+    DevBuf<cr::NodeDesc> d_nodes;
+    DevBuf<cr::NodeOut> d_outs;
+    std::vector<int64_t> off, len;           // per node id (0 .. 2P-2): arena row offset, rows
+    std::vector<int64_t> child1, child2, level, members;   // per node id
+    std::vector<uint32_t> flags;             // per internal node k
+    std::vector<std::vector<int32_t>> aln;   // per internal node k: row 1 then row 2, `len` entries each
+    int64_t levels = 0;
+    uint32_t any_flags = 0;
+};
+
+namespace {
+
+// grow a device array to `rows * width` elements, keeping its first `keep_rows * width`
+int grow_keep(DevBuf<double>& buf, int64_t rows, int64_t keep_rows, int64_t width, hipStream_t stream) {
+    DevBuf<double> bigger;
+    CR_HIP(bigger.ensure((size_t)(rows * width)));
+    if (keep_rows > 0 && buf.p)
+        CR_HIP(hipMemcpyAsync(bigger.p, buf.p, sizeof(double) * (size_t)(keep_rows * width), hipMemcpyDeviceToDevice, stream));
+    CR_HIP(hipStreamSynchronize(stream));
+    std::swap(buf.p, bigger.p);
+    std::swap(buf.n, bigger.n);
+    return CR_OK;
+}
+
+int arena_reserve(cr_progressive* h, int64_t rows) {
+    if (rows <= h->capacity) return CR_OK;
+    const int64_t want = std::max(rows, h->capacity + h->capacity / 2);
+    int rc = grow_keep(h->scratch.coords, want, h->used, 3, h->ctx->stream);
+    if (!rc) rc = grow_keep(h->scratch.tensors, want, h->used, h->d, h->ctx->stream);
+    if (!rc) rc = grow_keep(h->weights, want, h->used, 1, h->ctx->stream);
+    if (!rc) h->capacity = want;
+    return rc;
+}
+
+// one level of the tree: the internal nodes `ids` (node ids), children complete
+int run_level(cr_progressive* h, const std::vector<int64_t>& ids, const cr_params& prm, double gamma_weight) {
+    cr_batch& b = h->scratch;
+    hipStream_t stream = h->ctx->stream;
+    const size_t count = ids.size();
+    std::vector<cr::PairDesc> pairs(count);
+    std::vector<cr::NodeDesc> nodes(count);
+    int n_max = 0, m_max = 0, cap_max = 0;
+    for (int64_t id : ids) n_max = std::max<int>(n_max, (int)h->len[(size_t)h->child1[(size_t)id]]);
+    const int R = n_max <= 3 * cr::kWave ? 3 : 5;
+    int64_t dirs_off = 0, bt_off = 0, aln_off = 0, hand_off = 0, rows = h->used;
+    for (size_t x = 0; x < count; x++) {
+        const int64_t id = ids[x], c1 = h->child1[(size_t)id], c2 = h->child2[(size_t)id];
+        cr::PairDesc& pd = pairs[x];
+        pd.n = (int)h->len[(size_t)c1];
+        pd.m = (int)h->len[(size_t)c2];
+        CR_REQUIRE(pd.n + pd.m <= cr::kMaxLength, "tree node longer than 65534 columns");
+        pd.off_i = h->off[(size_t)c1];
+        pd.off_j = h->off[(size_t)c2];
+        pd.dirs_off = dirs_off;
+        pd.bt_off = bt_off;
+        pd.aln_off = aln_off;
+        pd.hand_off = hand_off;
+        dirs_off += (int64_t)cr::strips_of(pd.n, R) * cr::tblocks(pd.m, 16) * R * cr::kWave;
+        bt_off += (int64_t)cr::strips_of(pd.n, R) * cr::tblocks(pd.m, 8) * R * cr::kWave;
+        aln_off += 2 * (int64_t)(pd.n + pd.m);
+        if (cr::strips_of(pd.n, R) > 1) hand_off += 3 * (int64_t)pd.m;
+        m_max = std::max(m_max, pd.m);
+        cap_max = std::max(cap_max, pd.n + pd.m);
+        // multiple_alignment.py:199-202: each side is weighted by the OTHER side's share of the members
+        const double total = (double)(h->members[(size_t)c1] + h->members[(size_t)c2]);
+        nodes[x].mult1 = (double)h->members[(size_t)c2] / (2.0 * total);
+        nodes[x].mult2 = (double)h->members[(size_t)c1] / (2.0 * total);
+        nodes[x].out_off = rows;
+        rows += pd.n + pd.m;
+    }
+    int rc = arena_reserve(h, rows);
+    if (rc) return rc;
+    CR_HIP(b.pairs.ensure(count));
+    CR_HIP(b.dirs.ensure((size_t)dirs_off));
+    CR_HIP(b.bits.ensure((size_t)bt_off));
+    CR_HIP(b.hand.ensure((size_t)hand_off));
+    CR_HIP(b.aln.ensure((size_t)aln_off));
+    CR_HIP(b.xf.ensure(count));
+    CR_HIP(b.seed_score.ensure(count));
+    CR_HIP(h->d_nodes.ensure(count));
+    CR_HIP(h->d_outs.ensure(count));
+    CR_HIP(hipMemcpyAsync(b.pairs.p, pairs.data(), sizeof(cr::PairDesc) * count, hipMemcpyHostToDevice, stream));
+    CR_HIP(hipMemcpyAsync(h->d_nodes.p, nodes.data(), sizeof(cr::NodeDesc) * count, hipMemcpyHostToDevice, stream));
+    b.r_seed = b.r_align = R;
+    const cr_batch::Chunk ck{0, (int64_t)count, n_max, m_max, cap_max};
+    rc = (R == 3) ? launch_seed_d<3>(&b, ck, prm) : launch_seed_d<5>(&b, ck, prm);
+    if (rc) return rc;
+    rc = launch_node(R, stream, (int)count, n_max, m_max, cap_max, b.pairs.p, b.coords.p, b.tensors.p, (int)h->d,
+                     h->weights.p, h->d_nodes.p, b.xf.p, prm, gamma_weight, b.bits.p, b.hand.p, b.aln.p, b.coords.p,
+                     b.tensors.p, h->weights.p, h->d_outs.p);
+    if (rc) return rc;
+    std::vector<cr::NodeOut> outs(count);
+    std::vector<int32_t> rows_host((size_t)aln_off);
+    CR_HIP(hipMemcpyAsync(outs.data(), h->d_outs.p, sizeof(cr::NodeOut) * count, hipMemcpyDeviceToHost, stream));
+    CR_HIP(hipMemcpyAsync(rows_host.data(), b.aln.p, sizeof(int32_t) * (size_t)aln_off, hipMemcpyDeviceToHost, stream));
+    CR_HIP(hipStreamSynchronize(stream));
+    for (size_t x = 0; x < count; x++) {
+        const int64_t id = ids[x], k = id - h->P;
+        const cr::NodeOut& no = outs[x];
+        const int64_t cap = pairs[x].n + pairs[x].m;
+        h->len[(size_t)id] = no.len;
+        h->off[(size_t)id] = nodes[x].out_off + no.first;
+        h->flags[(size_t)k] = no.flags;
+        h->any_flags |= no.flags;
+        std::vector<int32_t>& a = h->aln[(size_t)k];
+        a.resize((size_t)(2 * no.len));
+        const int32_t* src = rows_host.data() + pairs[x].aln_off;
+        std::copy(src + no.first, src + no.first + no.len, a.begin());
+        std::copy(src + cap + no.first, src + cap + no.first + no.len, a.begin() + no.len);
+    }
+    h->used = rows;
+    return CR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cr_progressive_align(cr_context* ctx, const double* coords, const double* tensors, const int64_t* offsets,
+                         int64_t P, int64_t d, const uint64_t* tree, int64_t tree_rows, const cr_params* params,
+                         double consensus_weight, double gamma_weight, cr_progressive** out) {
+    CR_REQUIRE(out != nullptr, "null out");
+    *out = nullptr;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    CR_REQUIRE(coords && tensors && offsets && tree && params, "null input");
+    CR_REQUIRE(P >= 2 && tree_rows == 2 * P - 3, "tree must have 2P-3 rows");
+    CR_REQUIRE(d >= 1 && padded_width(d) != 0 && padded_width(d) <= 16, "tensor width > 16 is not supported by this build");
+    CR_REQUIRE(offsets[0] == 0, "offsets[0] must be 0");
+    for (int64_t s = 0; s < P; s++)
+        CR_REQUIRE(offsets[s + 1] > offsets[s] && offsets[s + 1] - offsets[s] <= cr::kMaxLength,
+                   "every structure needs 1 .. 65534 residues");
+    const cr_params prm = *params;
+    CR_REQUIRE(std::isfinite(prm.gamma_tensor) && prm.gamma_tensor >= 0.0 && std::isfinite(prm.gamma_coords) &&
+                   prm.gamma_coords >= 0.0 && std::isfinite(prm.gap_open) && std::isfinite(prm.gap_extend) &&
+                   std::isfinite(prm.sw_gap),
+               "parameters must be finite, gammas >= 0");
+    CR_REQUIRE(std::isfinite(gamma_weight) && gamma_weight >= 0.0 && std::isfinite(consensus_weight),
+               "gamma_weight must be finite and >= 0, consensus_weight finite");
+    const int64_t total = offsets[P];
+    CR_REQUIRE(all_finite(coords, (size_t)total * 3), "coordinates contain NaN or infinity");
+    CR_REQUIRE(all_finite(tensors, (size_t)total * (size_t)d), "tensors contain NaN or infinity");
+
+    // tree -> children of every internal node (ids P .. 2P-2), validated
+    const int64_t num_ids = 2 * P - 1;
+    cr_progressive* h = new (std::nothrow) cr_progressive();
+    if (!h) return fail(CR_ERR_MEMORY, "out of host memory");
+    struct Guard {
+        cr_progressive* h;
+        ~Guard() { delete h; }
+    } guard{h};
+    h->ctx = ctx;
+    h->P = P;
+    h->d = d;
+    h->scratch.ctx = ctx;
+    h->scratch.P = P;
+    h->scratch.d = d;
+    h->scratch.d_pad = padded_width(d);
+    h->off.assign((size_t)num_ids, 0);
+    h->len.assign((size_t)num_ids, 0);
+    h->child1.assign((size_t)num_ids, -1);
+    h->child2.assign((size_t)num_ids, -1);
+    h->level.assign((size_t)num_ids, 0);
+    h->members.assign((size_t)num_ids, 1);
+    h->flags.assign((size_t)(P - 1), 0);
+    h->aln.resize((size_t)(P - 1));
+    std::vector<char> used_as_child((size_t)num_ids, 0);
+    auto claim = [&](uint64_t c, int64_t parent) -> bool {
+        if (c >= (uint64_t)parent || used_as_child[(size_t)c]) return false;
+        used_as_child[(size_t)c] = 1;
+        return true;
+    };
+    for (int64_t k = 0; k < P - 1; k++) {
+        const int64_t id = P + k;
+        uint64_t c1, c2;
+        if (k < P - 2) {
+            c1 = tree[(2 * k) * 2];
+            c2 = tree[(2 * k + 1) * 2];
+            CR_REQUIRE(tree[(2 * k) * 2 + 1] == (uint64_t)id && tree[(2 * k + 1) * 2 + 1] == (uint64_t)id,
+                       "tree rows 2x, 2x+1 must both name node P + x as the parent");
+        } else {
+            c1 = tree[(tree_rows - 1) * 2];
+            c2 = tree[(tree_rows - 1) * 2 + 1];
+        }
+        CR_REQUIRE(claim(c1, id) && claim(c2, id), "tree: child id out of order or joined twice");
+        h->child1[(size_t)id] = (int64_t)c1;
+        h->child2[(size_t)id] = (int64_t)c2;
+        h->level[(size_t)id] = 1 + std::max(h->level[(size_t)c1], h->level[(size_t)c2]);
+        h->members[(size_t)id] = h->members[(size_t)c1] + h->members[(size_t)c2];
+        h->levels = std::max(h->levels, h->level[(size_t)id]);
+    }
+    CR_REQUIRE(h->members[(size_t)(num_ids - 1)] == P, "tree does not join every structure");
+
+    // leaves into the arena
+    for (int64_t s = 0; s < P; s++) {
+        h->off[(size_t)s] = offsets[s];
+        h->len[(size_t)s] = offsets[s + 1] - offsets[s];
+    }
+    h->used = total;
+    if ((rc = arena_reserve(h, total + total / 2 + 2 * cr::kWave))) return rc;
+    {
+        std::vector<double> w((size_t)total, consensus_weight);
+        hipStream_t st = ctx->stream;
+        CR_HIP(hipMemcpyAsync(h->scratch.coords.p, coords, sizeof(double) * (size_t)total * 3, hipMemcpyHostToDevice, st));
+        CR_HIP(hipMemcpyAsync(h->scratch.tensors.p, tensors, sizeof(double) * (size_t)(total * d), hipMemcpyHostToDevice, st));
+        CR_HIP(hipMemcpyAsync(h->weights.p, w.data(), sizeof(double) * (size_t)total, hipMemcpyHostToDevice, st));
+        CR_HIP(hipStreamSynchronize(st));
+    }
+    std::vector<std::vector<int64_t>> by_level((size_t)h->levels + 1);
+    for (int64_t id = P; id < num_ids; id++) by_level[(size_t)h->level[(size_t)id]].push_back(id);
+    for (int64_t lv = 1; lv <= h->levels; lv++)
+        if ((rc = run_level(h, by_level[(size_t)lv], prm, gamma_weight))) return rc;
+    guard.h = nullptr;
+    *out = h;
+    return CR_OK;
+}
+
+int cr_progressive_sizes(cr_progressive* h, int64_t sizes[5]) {
+    CR_REQUIRE(h != nullptr && sizes != nullptr, "null argument");
+    int64_t sum = 0;
+    for (int64_t id = h->P; id < 2 * h->P - 1; id++) sum += h->len[(size_t)id];
+    sizes[0] = h->len[(size_t)(2 * h->P - 2)];
+    sizes[1] = h->P - 1;
+    sizes[2] = sum;
+    sizes[3] = h->levels;
+    sizes[4] = (int64_t)h->any_flags;
+    return CR_OK;
+}
+
+int cr_progressive_fetch_msa(cr_progressive* h, int64_t* msa) {
+    CR_REQUIRE(h != nullptr && msa != nullptr, "null argument");
+    // top down: colmap[id][x] = column of node id shown in final column x, or -1 (multiple_alignment.py:218-229
+    // re-indexes every member row bottom up; composing the maps from the root gives the same rows)
+    const int64_t root = 2 * h->P - 2, L = h->len[(size_t)root];
+    std::vector<std::vector<int32_t>> colmap((size_t)(2 * h->P - 1));
+    colmap[(size_t)root].resize((size_t)L);
+    for (int64_t x = 0; x < L; x++) colmap[(size_t)root][(size_t)x] = (int32_t)x;
+    for (int64_t id = root; id >= h->P; id--) {
+        const std::vector<int32_t>& mine = colmap[(size_t)id];
+        const std::vector<int32_t>& a = h->aln[(size_t)(id - h->P)];
+        const int64_t ln = h->len[(size_t)id];
+        for (int side = 0; side < 2; side++) {
+            const int64_t c = side == 0 ? h->child1[(size_t)id] : h->child2[(size_t)id];
+            std::vector<int32_t>& cm = colmap[(size_t)c];
+            cm.resize((size_t)L);
+            const int32_t* row = a.data() + side * ln;
+            for (int64_t x = 0; x < L; x++) cm[(size_t)x] = mine[(size_t)x] < 0 ? -1 : row[mine[(size_t)x]];
+        }
+        colmap[(size_t)id] = std::vector<int32_t>();
+    }
+    for (int64_t s = 0; s < h->P; s++)
+        for (int64_t x = 0; x < L; x++) msa[s * L + x] = colmap[(size_t)s][(size_t)x];
+    return CR_OK;
+}
+
+int cr_progressive_node_table(cr_progressive* h, int64_t* table) {
+    CR_REQUIRE(h != nullptr && table != nullptr, "null argument");
+    for (int64_t k = 0; k < h->P - 1; k++) {
+        const int64_t id = h->P + k;
+        int64_t* t = table + 6 * k;
+        t[0] = h->child1[(size_t)id];
+        t[1] = h->child2[(size_t)id];
+        t[2] = h->len[(size_t)id];
+        t[3] = h->level[(size_t)id];
+        t[4] = (int64_t)h->flags[(size_t)k];
+        t[5] = h->members[(size_t)id];
+    }
+    return CR_OK;
+}
+
+int cr_progressive_fetch_nodes(cr_progressive* h, int64_t* aln, double* coords, double* tensors, double* weights) {
+    CR_REQUIRE(h != nullptr, "null argument");
+    int rc = set_device(h->ctx);
+    if (rc) return rc;
+    if (aln) {
+        int64_t o = 0;
+        for (int64_t k = 0; k < h->P - 1; k++)
+            for (int32_t v : h->aln[(size_t)k]) aln[o++] = v;
+    }
+    if (!coords && !tensors && !weights) return CR_OK;
+    // the arena comes back in one copy per array; nodes are sliced out on the host
+    std::vector<double> host;
+    auto slice = [&](const double* dev, int64_t width, double* dst) -> int {
+        host.resize((size_t)(h->used * width));
+        CR_HIP(hipMemcpy(host.data(), dev, sizeof(double) * (size_t)(h->used * width), hipMemcpyDeviceToHost));
+        int64_t o = 0;
+        for (int64_t id = h->P; id < 2 * h->P - 1; id++) {
+            const int64_t cnt = h->len[(size_t)id] * width;
+            std::memcpy(dst + o, host.data() + h->off[(size_t)id] * width, sizeof(double) * (size_t)cnt);
+            o += cnt;
+        }
+        return CR_OK;
+    };
+    CR_HIP(hipStreamSynchronize(h->ctx->stream));
+    if (coords && (rc = slice(h->scratch.coords.p, 3, coords))) return rc;
+    if (tensors && (rc = slice(h->scratch.tensors.p, h->d, tensors))) return rc;
+    if (weights && (rc = slice(h->weights.p, 1, weights))) return rc;
+    return CR_OK;
+}
+
+int cr_progressive_destroy(cr_progressive* h) {
+    if (!h) return CR_OK;
+    (void)hipSetDevice(h->ctx->device);
+    delete h;
+    return CR_OK;
+}
+
+}  // extern "C"

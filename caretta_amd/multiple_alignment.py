@@ -244,6 +244,14 @@ class MultipleAlignment:
         """multiple_alignment.py:172-253"""
         mean_function_params = mean_function_params or {}
         score_function_params = score_function_params or {}
+        tree = np.asarray(tree)
+        if (len(self.sequences) >= 2 and tree.shape == (2 * len(self.sequences) - 3, 2)
+                and all(type(s) is Protein and s.coordinates is not None for s in self.sequences)
+                and not score_function_params.get("flexible", False)
+                and not mean_function_params.get("flexible", False)):
+            # every node of the tree on the device, one launch pair per tree level (cr_progressive_align)
+            return self._progressive_align_resident(tree, gap_open_penalty, gap_extend_penalty, consensus_weight,
+                                                    gamma_weight, score_function_params, mean_function_params)
         final_sequences = [s for s in self.sequences]
         final_alignments = {s.name: {s.name: np.arange(len(s))} for s in final_sequences}
         final_consensus_weights = [np.full((len(s), 1), consensus_weight, dtype=np.float64) for s in final_sequences]
@@ -293,6 +301,77 @@ class MultipleAlignment:
         self.final_consensus_weights = final_consensus_weights
         self.final_alignments = final_alignments
         self.final_sequences = final_sequences
+        return alignment
+
+    def _progressive_align_resident(self, tree, gap_open_penalty, gap_extend_penalty, consensus_weight, gamma_weight,
+                                    score_function_params, mean_function_params):
+        """progressive_align (multiple_alignment.py:172-253) for Proteins through cr_progressive_align: the same
+        nodes, alignments and attributes, computed level by level of the guide tree with everything resident in HBM."""
+        lib = _capi.load()
+        P = len(self.sequences)
+        coords, tensors, offsets = pack_proteins(self.sequences)
+        d = tensors.shape[1]
+        prm = make_params(gamma_tensor=score_function_params.get("gamma_tensor", 0.03),
+                          gamma_coords=score_function_params.get("gamma_coords", 0.03),
+                          gap_open=gap_open_penalty, gap_extend=gap_extend_penalty)
+        tree_u = np.ascontiguousarray(tree, dtype=np.uint64)
+        h = C.c_void_p()
+        check(lib.cr_progressive_align(default_context()._h, ptr(coords), ptr(tensors), ptr(offsets), P, d, ptr(tree_u),
+                                       tree_u.shape[0], C.byref(prm), float(consensus_weight), float(gamma_weight),
+                                       C.byref(h)))
+        try:
+            sizes = np.zeros(5, np.int64)
+            check(lib.cr_progressive_sizes(h, ptr(sizes)))
+            width, num_nodes, total = int(sizes[0]), int(sizes[1]), int(sizes[2])
+            table = np.zeros((num_nodes, 6), np.int64)
+            check(lib.cr_progressive_node_table(h, ptr(table)))
+            msa = np.zeros((P, width), np.int64)
+            check(lib.cr_progressive_fetch_msa(h, ptr(msa)))
+            aln = np.zeros(2 * total, np.int64)
+            xn, tn, wn = np.zeros((total, 3)), np.zeros((total, d)), np.zeros(total)
+            check(lib.cr_progressive_fetch_nodes(h, ptr(aln), ptr(xn), ptr(tn), ptr(wn)))
+        finally:
+            lib.cr_progressive_destroy(h)
+        names = [s.name for s in self.sequences]
+        node_names = [f"int-{P + k}" for k in range(num_nodes - 1)] + ["int-final"]
+        all_names = names + node_names
+        bad = np.flatnonzero(table[:, 4] & _capi.FLAG_SEED_ALL_ZERO)
+        if len(bad):
+            k = int(bad[0])
+            raise TypeError(f"tensor score matrix of {all_names[table[k, 0]]} and {all_names[table[k, 1]]} has no "
+                            "positive local alignment (reference: max_pos is None)")
+        verbose = score_function_params.get("verbose", True) or mean_function_params.get("verbose", True)
+        if verbose:
+            for k in np.flatnonzero(table[:, 4] & (_capi.FLAG_SEED_SKIPPED | _capi.FLAG_MEAN_UNSUPERPOSED)):
+                print(f"Too few aligning positions for {all_names[table[k, 0]]} and {all_names[table[k, 1]]}, "
+                      "continuing without superposition")
+        # attributes of :248-251, rebuilt from the node table
+        final_sequences = [s for s in self.sequences]
+        final_consensus_weights = [np.full((len(s), 1), consensus_weight, dtype=np.float64) for s in self.sequences]
+        members = [[i] for i in range(P)]            # leaf indices below every node, in the reference's dict order
+        rows = [np.arange(len(s), dtype=np.int64)[None, :] for s in self.sequences]   # member rows in node columns
+        node_alignments = []
+        o = 0
+        for k in range(num_nodes):
+            c1, c2, ln = int(table[k, 0]), int(table[k, 1]), int(table[k, 2])
+            a1, a2 = aln[2 * o:2 * o + ln], aln[2 * o + ln:2 * o + 2 * ln]
+            final_sequences.append(Protein(node_names[k], tn[o:o + ln].copy(), xn[o:o + ln].copy()))
+            final_consensus_weights.append(wn[o:o + ln].reshape(-1, 1).copy())
+            rows[c1] = np.where(a1 != -1, rows[c1][:, a1], -1)          # :218-229, all member rows at once
+            rows[c2] = np.where(a2 != -1, rows[c2][:, a2], -1)
+            members.append(members[c1] + members[c2])
+            rows.append(np.vstack([rows[c1], rows[c2]]))
+            node_alignments.append((a1, a2))
+            o += ln
+        final_alignments = {all_names[x]: {names[s]: rows[x][r] for r, s in enumerate(members[x])}
+                            for x in range(len(all_names))}
+        root = P + num_nodes - 1
+        assert all(np.array_equal(rows[root][r], msa[s]) for r, s in enumerate(members[root]))
+        alignment = {names[s]: msa[s] for s in members[root]}
+        self.final_consensus_weights = final_consensus_weights
+        self.final_alignments = final_alignments
+        self.final_sequences = final_sequences
+        self.node_table = table
         return alignment
 
     def multiple_align(self, pairwise_distance_matrix, gap_open_penalty, gap_extend_penalty, consensus_weight,

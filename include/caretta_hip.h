@@ -129,6 +129,30 @@ int cr_progressive_node(cr_context *ctx, const double *coords_1, const double *t
                         int64_t m, int64_t d, double mult1, double mult2, const cr_params *params,
                         double gamma_weight, int64_t *aln1, int64_t *aln2, int64_t *aln_len,
                         double *coords_out, double *tensors_out, double *weights_out, uint32_t *flags);
+/* ---- whole guide tree: MultipleAlignment.progressive_align           multiple_alignment.py:172-253 --------
+ * All leaves are uploaded once; every node of the tree (make_intermediate_node, :193-234) stays resident in
+ * HBM, and nodes whose children are complete (one LEVEL of the tree) run as one launch pair, one wave per node.
+ * tree: uint64 (tree_rows = 2P-3, 2) exactly as neighbor_joining returns it (neighbor_joining.py:19-95): rows
+ * 2x, 2x+1 = (child, P + x) for x = 0 .. P-3, last row = the two nodes joined by the final node (:244-247).
+ * Leaf weights are `consensus_weight` everywhere (:189-193).  Internal nodes are numbered 0 .. P-2 in creation
+ * order (node id P + k; the final node is k = P-2). */
+typedef struct cr_progressive cr_progressive;
+int cr_progressive_align(cr_context *ctx, const double *coords, const double *tensors, const int64_t *offsets,
+                         int64_t num_structures, int64_t d, const uint64_t *tree, int64_t tree_rows,
+                         const cr_params *params, double consensus_weight, double gamma_weight,
+                         cr_progressive **out);
+/* sizes[0] = columns of the final alignment, [1] = internal nodes (P-1), [2] = sum of their lengths,
+ * [3] = levels (= launch pairs), [4] = OR of all node flags (CR_FLAG_*) */
+int cr_progressive_sizes(cr_progressive *h, int64_t sizes[5]);
+/* msa: int64 (P, columns): residue index of structure s in every column, -1 = gap (the dict that
+ * progressive_align returns, :248-251, as a matrix in input order) */
+int cr_progressive_fetch_msa(cr_progressive *h, int64_t *msa);
+/* table: int64 (P-1, 6) = child id 1, child id 2, length, level, flags, number of member structures */
+int cr_progressive_node_table(cr_progressive *h, int64_t *table);
+/* Internal nodes concatenated in creation order; any pointer may be NULL.  aln: for node k the two dtw_align rows
+ * (2 * length entries, row 1 then row 2); coords (sum,3); tensors (sum,d); weights (sum). */
+int cr_progressive_fetch_nodes(cr_progressive *h, int64_t *aln, double *coords, double *tensors, double *weights);
+int cr_progressive_destroy(cr_progressive *h);
 /* dynamic_time_warping.dtw_align / dtw_align_score (aln1 == NULL)      dynamic_time_warping.py:148-201
  * S f64[s_rows, s_cols] indexed S[seq1[i], seq2[j]]; aln1/aln2 need n+m entries. */
 int cr_dtw_align(cr_context *ctx, const int64_t *seq1, int64_t n, const int64_t *seq2, int64_t m,

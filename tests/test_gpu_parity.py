@@ -383,6 +383,60 @@ def test_progressive_nodes_golden_and_oracle(oracle, golden, tag):
         sizes.append(tot)
 
 
+def _replay_tree(msa, tree, p):
+    tree = np.asarray(tree).astype(np.int64)
+    joins = [(int(tree[x, 0]), int(tree[x + 1, 0])) for x in range(0, tree.shape[0] - 1, 2)]
+    return joins + [(int(tree[-1, 0]), int(tree[-1, 1]))]
+
+
+@pytest.mark.parametrize("num,length,ragged,seed", [(6, 250, True, 11), (9, 70, True, 12), (4, 330, False, 13)])
+def test_progressive_resident_vs_oracle_and_single_node(oracle, num, length, ragged, seed):
+    """cr_progressive_align (whole tree resident, level by level) against (a) the oracle replaying every join on the
+    GPU's own children and (b) the single-node entry point cr_progressive_node; rows > 192 use the 5-rows-per-lane
+    kernels, 330-residue leaves make nodes that need two strips."""
+    from caretta_amd import multiple_alignment as ma, neighbor_joining as nj, synthetic
+    fam = synthetic.make_family(num, length, seed=seed, ragged=ragged, clades=2)
+    prots = [ma.Protein(s.name, s.tensors, s.coordinates, "") for s in fam]
+    msa = ma.MultipleAlignment(prots)
+    prm = dict(flexible=False, gamma_tensor=7.0, gamma_coords=0.03, verbose=False)
+    m = msa.make_pairwise_matrix(prm)
+    tree, _ = nj.neighbor_joining(m.max() - m)
+    aln = msa.progressive_align(tree, 1.0, 0.01, 1.0, 1.0, prm, dict(flexible=False, verbose=False))
+    assert msa.node_table.shape == (num - 1, 6) and msa.node_table[-1, 5] == num
+    width = len(aln[prots[0].name])
+    for q in prots:                                   # every residue exactly once, in order
+        row = aln[q.name]
+        assert len(row) == width and np.array_equal(row[row != -1], np.arange(len(q)))
+    sizes, rows = [1] * num, [np.arange(len(q))[None, :] for q in prots]
+    for k, (n1, n2) in enumerate(_replay_tree(msa, tree, num)):
+        tot = sizes[n1] + sizes[n2]
+        s1, s2 = msa.final_sequences[n1], msa.final_sequences[n2]
+        w1, w2 = msa.final_consensus_weights[n1], msa.final_consensus_weights[n2]
+        m1, m2 = sizes[n2] / (2 * tot), sizes[n1] / (2 * tot)
+        a1, a2, xn, tn, wn, _ = oracle.progressive_node(s1.coordinates, s1.tensors, w1, s2.coordinates, s2.tensors, w2, m1, m2)
+        node, w = msa.final_sequences[num + k], msa.final_consensus_weights[num + k]
+        assert np.array_equal(xn, node.coordinates) and np.array_equal(tn, node.tensors) and np.array_equal(wn, w)
+        b1, b2, node2, w2n = ma._progressive_node(s1, s2, w1, w2, m1, m2, "x", 1.0, 0.01, 1.0, prm, dict(verbose=False))
+        assert np.array_equal(a1, b1) and np.array_equal(a2, b2)
+        assert np.array_equal(node2.coordinates, node.coordinates) and np.array_equal(node2.tensors, node.tensors)
+        assert np.array_equal(w2n, w)
+        rows[n1] = np.where(a1 != -1, rows[n1][:, a1], -1)
+        rows[n2] = np.where(a2 != -1, rows[n2][:, a2], -1)
+        rows.append(np.vstack([rows[n1], rows[n2]]))
+        sizes.append(tot)
+    order = [q for q in msa.final_alignments["int-final"]]
+    assert np.array_equal(np.array([aln[q] for q in order]), rows[-1])
+
+
+def test_progressive_tree_validation(ctx):
+    from caretta_amd import multiple_alignment as ma, synthetic
+    fam = synthetic.make_family(4, 40, seed=5, clades=2)
+    msa = ma.MultipleAlignment([ma.Protein(s.name, s.tensors, s.coordinates, "") for s in fam])
+    bad = np.array([[0, 4], [1, 4], [0, 5], [2, 5], [5, 3]], dtype=np.uint64)      # leaf 0 joined twice
+    with pytest.raises(ValueError):
+        msa.progressive_align(bad, 1.0, 0.01, 1.0, 1.0, dict(verbose=False), dict(verbose=False))
+
+
 def test_two_sequence_alignment_and_metrics(ctx, golden):
     """multiple_align's 2-sequence branch and make_rmsd_coverage_tm_matrix through the drop-ins."""
     from caretta_amd import multiple_alignment as ma

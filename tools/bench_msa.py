@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """End-to-end timing of the path and its immediate consumers on one MI355X:
-make_pairwise_matrix (batched GPU) -> max - M -> neighbor_joining (host C++) -> progressive_align (GPU, node by node).
+make_pairwise_matrix (batched GPU) -> max - M -> neighbor_joining (host C++) -> progressive_align (GPU, whole tree resident, one launch pair per tree level).
 
     python tools/bench_msa.py [P] [L]
 """
@@ -31,10 +31,14 @@ def main():
     aln = msa.multiple_align(d, gap_open_penalty=1.0, gap_extend_penalty=0.01, consensus_weight=1.0, gamma_weight=1.0,
                              score_function_params=prm, mean_function_params=dict(flexible=False, verbose=False))
     t3 = time.perf_counter()
+    msa.progressive_align(tree, 1.0, 0.01, 1.0, 1.0, prm, dict(flexible=False, verbose=False))
+    t4 = time.perf_counter()
+    levels = int(msa.node_table[:, 3].max())
     width = len(next(iter(aln.values())))
     print(f"P={num} L={length}: pairwise matrix {1e3 * (t1 - t0):.1f} ms (incl. upload/download), "
           f"neighbor joining {1e3 * (t2 - t1):.1f} ms, NJ+progressive alignment {1e3 * (t3 - t2):.1f} ms "
-          f"({num - 1} nodes), MSA width {width}")
+          f"({num - 1} nodes), progressive alignment alone {1e3 * (t4 - t3):.1f} ms in {levels} tree levels, "
+          f"MSA width {width}")
 
 
 if __name__ == "__main__":
