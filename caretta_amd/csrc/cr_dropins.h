@@ -667,60 +667,179 @@ int cr_assemble_matrix(const int32_t* pairs, const double* scores, int64_t npair
 // neighbor_joining.py:19-157.  The reference recomputes both row sums for every (i, j) (O(P^4));
 // here each row sum is formed once per iteration with the same sequential left-to-right order
 // (numba's np.sum), so every Q value, hence every decision, is bit-identical to the reference's.
+//
+// Layout.  The reference rebuilds the matrix every iteration with the new node FIRST and the survivors behind
+// it in their old order (:60-83); that order decides ties.  Here the matrix keeps a fixed row stride between
+// compactions: slots are never moved, a new node takes the next free slot of a LEFT margin (so slot order is
+// the reference's order), and the two joined slots are zeroed.  A zero adds nothing to a left-to-right sum
+// (the sums start at +0.0, so they are never -0.0) and a dead column gets the row-sum -inf, i.e. Q = +inf.
+// When the margin is used up the live slots are packed again (once per ~n/16 iterations).
 int cr_neighbor_joining(const double* D0, int64_t P, uint64_t* tree, double* bl) {
     CR_REQUIRE(D0 && tree && bl, "null argument");
     CR_REQUIRE(P >= 3, "neighbor joining needs at least 3 taxa");
-    std::vector<double> D(D0, D0 + P * P), N((size_t)(P * P)), rs((size_t)P);
-    std::vector<int64_t> true_idx((size_t)P), idx((size_t)P), nt((size_t)P);
-    for (int64_t i = 0; i < P; i++) true_idx[(size_t)i] = i;
-    auto rowsum = [](const double* row, int64_t n) {
-        double s = 0.0;
-        for (int64_t k = 0; k < n; k++) s += row[k];
-        return s;
+    const double inf = std::numeric_limits<double>::infinity();
+    std::vector<double> A, B, rs, rsx;
+    std::vector<int64_t> ident, ident2;          // node id of every slot
+    std::vector<char> alive, alive2;
+    int64_t W = 0, left = -1, n = P;            // row stride, next free margin slot, live slots
+    // pack the live slots of (src, sw) in order behind a fresh margin
+    auto compact = [&](const double* src, int64_t sw, const std::vector<int64_t>& slots, const std::vector<int64_t>& ids) {
+        const int64_t cnt = (int64_t)slots.size(), g = std::max<int64_t>(8, cnt / 16), w = cnt + g;
+        B.assign((size_t)(w * w), 0.0);
+        for (int64_t a = 0; a < cnt; a++) {
+            const double* r = src + slots[(size_t)a] * sw;
+            double* d = &B[(size_t)((g + a) * w + g)];
+            for (int64_t b = 0; b < cnt; b++) d[b] = r[slots[(size_t)b]];
+        }
+        A.swap(B);
+        ident2.assign((size_t)w, -1);
+        alive2.assign((size_t)w, 0);
+        for (int64_t a = 0; a < cnt; a++) {
+            ident2[(size_t)(g + a)] = ids[(size_t)a];
+            alive2[(size_t)(g + a)] = 1;
+        }
+        ident.swap(ident2);
+        alive.swap(alive2);
+        W = w;
+        left = g - 1;
+        rs.assign((size_t)w, 0.0);
+        rsx.assign((size_t)w, 0.0);
     };
-    int64_t n = P, index = 0, nint = 0;
+    {
+        std::vector<int64_t> slots((size_t)P), ids((size_t)P);
+        for (int64_t i = 0; i < P; i++) slots[(size_t)i] = ids[(size_t)i] = i;
+        compact(D0, P, slots, ids);
+    }
+    // Row sums of 8 rows at a time: each row is still summed left to right, but the 8 add chains are
+    // independent, so the loop runs at the adder's throughput, not its latency.
+    auto rowsums = [&](int64_t lo) {
+        const int64_t cnt = W - lo;
+        int64_t i = lo;
+        for (; i + 8 <= W; i += 8) {
+            const double* r = &A[(size_t)(i * W + lo)];
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
+            for (int64_t k = 0; k < cnt; k++) {
+                s0 += r[k];
+                s1 += r[W + k];
+                s2 += r[2 * W + k];
+                s3 += r[3 * W + k];
+                s4 += r[4 * W + k];
+                s5 += r[5 * W + k];
+                s6 += r[6 * W + k];
+                s7 += r[7 * W + k];
+            }
+            rs[(size_t)i] = s0; rs[(size_t)i + 1] = s1; rs[(size_t)i + 2] = s2; rs[(size_t)i + 3] = s3;
+            rs[(size_t)i + 4] = s4; rs[(size_t)i + 5] = s5; rs[(size_t)i + 6] = s6; rs[(size_t)i + 7] = s7;
+        }
+        for (; i < W; i++) {
+            const double* r = &A[(size_t)(i * W + lo)];
+            double s = 0.0;
+            for (int64_t k = 0; k < cnt; k++) s += r[k];
+            rs[(size_t)i] = s;
+        }
+    };
+    typedef double v4 __attribute__((ext_vector_type(4)));
+    int64_t index = 0, nint = 0;
     while (n > 3) {
-        for (int64_t i = 0; i < n; i++) rs[(size_t)i] = rowsum(&D[(size_t)(i * n)], n);
-        double min_q = std::numeric_limits<double>::infinity();
-        int64_t mi = 0, mj = 0;
-        for (int64_t i = 0; i < n; i++)
-            for (int64_t j = 0; j < n; j++)
-                if (i != j) {
-                    const double q = ((double)(n - 2) * D[(size_t)(i * n + j)] - rs[(size_t)i]) - rs[(size_t)j];
-                    if (q < min_q) { mi = i; mj = j; min_q = q; }
+        if (left < 0) {
+            std::vector<int64_t> slots, ids;
+            for (int64_t x = 0; x < W; x++)
+                if (alive[(size_t)x]) {
+                    slots.push_back(x);
+                    ids.push_back(ident[(size_t)x]);
                 }
-        const double dij = D[(size_t)(mi * n + mj)];
+            std::vector<double> old;
+            old.swap(A);
+            const int64_t sw = W;
+            compact(old.data(), sw, slots, ids);
+        }
+        const int64_t lo = left + 1;
+        rowsums(lo);
+        for (int64_t x = lo; x < W; x++) rsx[(size_t)x] = alive[(size_t)x] ? rs[(size_t)x] : -inf;
+        // first minimum of Q in row-major order (neighbor_joining.py:98-121, strict <): per row the minimum
+        // value (min is exact, so four interleaved chains give the same value) and, only when it beats the
+        // running minimum, the first column that attains it.
+        double min_q = inf;
+        int64_t mi = 0, mj = 0;
+        const double nm2 = (double)(n - 2);
+        for (int64_t i = lo; i < W; i++) {
+            if (!alive[(size_t)i]) continue;
+            const double* r = &A[(size_t)(i * W)];
+            const double ri = rs[(size_t)i];
+            auto qv = [&](int64_t j) { return (nm2 * r[j] - ri) - rsx[(size_t)j]; };
+            double m = inf;
+            v4 mv = {inf, inf, inf, inf};
+            int64_t j = lo;
+            for (; j + 4 <= W; j += 4) {
+                if (i >= j && i < j + 4) {                       // the block holding the diagonal: i != j
+                    for (int64_t c = j; c < j + 4; c++)
+                        if (c != i) {
+                            const double q = qv(c);
+                            m = q < m ? q : m;
+                        }
+                    continue;
+                }
+                v4 rv, sv;
+                std::memcpy(&rv, r + j, sizeof(rv));
+                std::memcpy(&sv, &rsx[(size_t)j], sizeof(sv));
+                const v4 q = (rv * nm2 - ri) - sv;
+                mv = q < mv ? q : mv;
+            }
+            for (; j < W; j++)
+                if (j != i) {
+                    const double q = qv(j);
+                    m = q < m ? q : m;
+                }
+            for (int c = 0; c < 4; c++) m = mv[c] < m ? mv[c] : m;
+            if (m < min_q) {
+                int64_t c = lo;
+                while (c == i || qv(c) != m) c++;
+                mi = i;
+                mj = c;
+                min_q = m;
+            }
+        }
+        const double dij = A[(size_t)(mi * W + mj)];
         const double di = 0.5 * dij + (0.5 / (double)(n - 2)) * (rs[(size_t)mi] - rs[(size_t)mj]);
         const double dj = dij - di;
         const int64_t node = nint + P;
         nint++;
-        tree[2 * index] = (uint64_t)true_idx[(size_t)mi]; tree[2 * index + 1] = (uint64_t)node; bl[index++] = di;
-        tree[2 * index] = (uint64_t)true_idx[(size_t)mj]; tree[2 * index + 1] = (uint64_t)node; bl[index++] = dj;
-        int64_t cnt = 0;
-        for (int64_t i = 0; i < n; i++)
-            if (i != mi && i != mj) idx[(size_t)cnt++] = i;
-        const int64_t nn = n - 1;
-        N[0] = 0.0;
-        for (int64_t a = 0; a < cnt; a++) {
-            for (int64_t b = 0; b < cnt; b++) N[(size_t)((a + 1) * nn + b + 1)] = D[(size_t)(idx[(size_t)a] * n + idx[(size_t)b])];
-            const double v = 0.5 * ((D[(size_t)(mi * n + idx[(size_t)a])] + D[(size_t)(mj * n + idx[(size_t)a])]) - dij);
-            N[(size_t)(a + 1)] = v;
-            N[(size_t)((a + 1) * nn)] = v;
+        tree[2 * index] = (uint64_t)ident[(size_t)mi]; tree[2 * index + 1] = (uint64_t)node; bl[index++] = di;
+        tree[2 * index] = (uint64_t)ident[(size_t)mj]; tree[2 * index + 1] = (uint64_t)node; bl[index++] = dj;
+        // the new node takes the next margin slot (:60-83)
+        const int64_t v = left--;
+        double* rv = &A[(size_t)(v * W)];
+        const double* rmi = &A[(size_t)(mi * W)];
+        const double* rmj = &A[(size_t)(mj * W)];
+        for (int64_t k = lo; k < W; k++) {
+            if (!alive[(size_t)k] || k == mi || k == mj) continue;
+            const double val = 0.5 * ((rmi[k] + rmj[k]) - dij);
+            rv[k] = val;
+            A[(size_t)(k * W + v)] = val;
         }
-        nt[0] = node;
-        for (int64_t a = 0; a < cnt; a++) nt[(size_t)(a + 1)] = true_idx[(size_t)idx[(size_t)a]];
-        std::copy(nt.begin(), nt.begin() + nn, true_idx.begin());
-        D.swap(N);
-        n = nn;
+        rv[v] = 0.0;
+        for (int64_t dead : {mi, mj}) {
+            std::fill(&A[(size_t)(dead * W + v)], &A[(size_t)(dead * W + W)], 0.0);
+            for (int64_t k = v; k < W; k++) A[(size_t)(k * W + dead)] = 0.0;
+            alive[(size_t)dead] = 0;
+        }
+        alive[(size_t)v] = 1;
+        ident[(size_t)v] = node;
+        n--;
     }
-    const double s1 = rowsum(&D[(size_t)(1 * n)], n), s2 = rowsum(&D[(size_t)(2 * n)], n);
-    const double d12 = D[(size_t)(1 * n + 2)];
+    // the last three nodes in order (:85-94)
+    int64_t s3[3], c3 = 0;
+    for (int64_t x = 0; x < W && c3 < 3; x++)
+        if (alive[(size_t)x]) s3[c3++] = x;
+    auto at = [&](int a, int b) { return A[(size_t)(s3[a] * W + s3[b])]; };
+    const double s1 = ((0.0 + at(1, 0)) + at(1, 1)) + at(1, 2), s2 = ((0.0 + at(2, 0)) + at(2, 1)) + at(2, 2);
+    const double d12 = at(1, 2);
     const double di = 0.5 * d12 + (0.5 / (double)(n - 2)) * (s1 - s2);
     const int64_t node = nint + P;
-    tree[2 * index] = (uint64_t)true_idx[1]; tree[2 * index + 1] = (uint64_t)node; bl[index++] = di;
-    tree[2 * index] = (uint64_t)true_idx[2]; tree[2 * index + 1] = (uint64_t)node; bl[index++] = d12 - di;
-    tree[2 * index] = (uint64_t)true_idx[0]; tree[2 * index + 1] = (uint64_t)node;
-    bl[index++] = 0.5 * ((D[(size_t)(1 * n + 0)] + D[(size_t)(2 * n + 0)]) - d12);
+    tree[2 * index] = (uint64_t)ident[(size_t)s3[1]]; tree[2 * index + 1] = (uint64_t)node; bl[index++] = di;
+    tree[2 * index] = (uint64_t)ident[(size_t)s3[2]]; tree[2 * index + 1] = (uint64_t)node; bl[index++] = d12 - di;
+    tree[2 * index] = (uint64_t)ident[(size_t)s3[0]]; tree[2 * index + 1] = (uint64_t)node;
+    bl[index++] = 0.5 * ((at(1, 0) + at(2, 0)) - d12);
     return CR_OK;
 }
 
