@@ -107,14 +107,17 @@ def main():
         raise SystemExit("bench.py needs an MI355X: caretta_amd has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # CARETTA_FORCE_DIST=1 runs the RCCL code path (process group, all-gather, barrier, max-reduce) even with a single
+    # rank, so that it can be exercised on a 1-GPU box under torch.distributed.run
+    use_dist = world > 1 or (os.environ.get("CARETTA_FORCE_DIST") == "1" and "MASTER_PORT" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import __graft_entry__ as ge
     if rank == 0:
         ge.build()
-    if world > 1:
+    if use_dist:
         dist.barrier()
 
     from caretta_amd import distributed as cdist
@@ -139,11 +142,11 @@ def main():
 
     def step():
         batch.run(params, sw_out_device_ptr=local.data_ptr())
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered_flat, local)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -157,12 +160,12 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     stage_ms, runs = batch.stage_ms()
-    if world == 1:
+    if not use_dist:
         gathered.copy_(local.unsqueeze(0))
 
     res, aln = batch.fetch(want_alignments=(rank == 0))
@@ -213,7 +216,7 @@ def main():
             out["cpu_baseline"] = None
         out["matrix_checksum"] = float(matrix.sum())
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -90,6 +91,7 @@ struct cr_batch {
     DevBuf<int32_t> aln;
     DevBuf<cr::Transform> xf;
     DevBuf<double> seed_score;
+    DevBuf<double> sw_stage;            // cr_batch_fetch_scores: the sw field gathered on the device
     DevBuf<cr::PairResult> res;
     int64_t aln_elems = 0;
     double alg_bytes = 0.0, cells = 0.0;
@@ -521,6 +523,33 @@ int cr_batch_fetch(cr_batch* b, cr_pair_result* results, int64_t* aln, int64_t a
             for (int64_t x = len; x < aln_stride; x++) o1[x] = o2[x] = -2;
         }
     }
+    return CR_OK;
+}
+
+int cr_batch_fetch_scores(cr_batch* b, double* sw, uint32_t* flags) {
+    CR_REQUIRE(b != nullptr, "null batch");
+    if (!b->ran) return fail(CR_ERR_STATE, "cr_batch_fetch_scores before cr_batch_run");
+    int rc = set_device(b->ctx);
+    if (rc) return rc;
+    if (b->npairs == 0) return CR_OK;
+    // gather the field on the device, then one contiguous copy (8 or 4 bytes per pair instead of 160)
+    hipStream_t st = b->ctx->stream;
+    const size_t np = (size_t)b->npairs;
+    if (sw) {
+        CR_HIP(b->sw_stage.ensure(np));
+        CR_HIP(hipMemcpy2DAsync(b->sw_stage.p, sizeof(double), reinterpret_cast<const char*>(b->res.p) + offsetof(cr_pair_result, sw),
+                                sizeof(cr::PairResult), sizeof(double), np, hipMemcpyDeviceToDevice, st));
+        CR_HIP(hipMemcpyAsync(sw, b->sw_stage.p, sizeof(double) * np, hipMemcpyDeviceToHost, st));
+    }
+    if (flags) {
+        DevBuf<uint32_t> stage;
+        CR_HIP(stage.ensure(np));
+        CR_HIP(hipMemcpy2DAsync(stage.p, sizeof(uint32_t), reinterpret_cast<const char*>(b->res.p) + offsetof(cr_pair_result, flags),
+                                sizeof(cr::PairResult), sizeof(uint32_t), np, hipMemcpyDeviceToDevice, st));
+        CR_HIP(hipMemcpyAsync(flags, stage.p, sizeof(uint32_t) * np, hipMemcpyDeviceToHost, st));
+        CR_HIP(hipStreamSynchronize(st));
+    }
+    CR_HIP(hipStreamSynchronize(st));
     return CR_OK;
 }
 

@@ -122,6 +122,13 @@ class PairBatch:
         check(self._lib.cr_batch_fetch(self._h, ptr(res), ptr(aln) if aln is not None else None, stride))
         return res, aln
 
+    def fetch_scores(self):
+        """-> (sw f64[npairs], flags u32[npairs]): the P x P matrix entries only (8 + 4 bytes per pair)."""
+        n = len(self.pairs)
+        sw, flags = np.zeros(n), np.zeros(n, np.uint32)
+        check(self._lib.cr_batch_fetch_scores(self._h, ptr(sw), ptr(flags)))
+        return sw, flags
+
     def stage_ms(self):
         """(per-stage device ms averaged over the recorded runs, number of runs averaged)."""
         buf = (C.c_float * _capi.CR_NUM_STAGES)()

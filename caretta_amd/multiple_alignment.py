@@ -192,7 +192,8 @@ class MultipleAlignment:
         return all(type(s) is Protein and s.coordinates is not None for s in self.sequences)
 
     def pairwise(self, score_function_params=None, gap_open_penalty=1.0, gap_extend_penalty=0.01, pairs=None,
-                 want_alignments=True, context: typing.Optional[Context] = None) -> PairwiseResults:
+                 want_alignments=True, context: typing.Optional[Context] = None,
+                 scores_only=False) -> PairwiseResults:
         """Pipeline H over a pair list (default: all i<j): the P x P score entry, the pairwise
         dtw_align alignment and its RMSD / coverage / TM, in one batched launch sequence."""
         prm = dict(score_function_params or {})
@@ -210,7 +211,12 @@ class MultipleAlignment:
             pairs = all_pairs(len(self.sequences)) if pairs is None else np.asarray(pairs, np.int32).reshape(-1, 2)
             batch.set_pairs(pairs)
             batch.run(params)
-            res, aln = batch.fetch(want_alignments)
+            if scores_only:                       # the matrix entries only: 12 bytes per pair come back
+                sw, flags = batch.fetch_scores()
+                res, aln = np.zeros(len(pairs), dtype=_capi.PAIR_RESULT_DTYPE), None
+                res["sw"], res["flags"] = sw, flags
+            else:
+                res, aln = batch.fetch(want_alignments)
         finally:
             batch.close()
         if np.any(res["flags"] & _capi.FLAG_SEED_ALL_ZERO):
@@ -227,7 +233,7 @@ class MultipleAlignment:
         if num < 2:
             return np.zeros((num, num))
         if self._all_proteins() and not score_function_params.get("flexible", False):
-            out = self.pairwise(score_function_params, want_alignments=False)
+            out = self.pairwise(score_function_params, want_alignments=False, scores_only=True)
             return assemble_matrix(out.pairs, out.results["sw"], num)
         # third-party SequenceBase plugins: their own score_function, our smith_waterman_score
         matrix = np.zeros((num, num))

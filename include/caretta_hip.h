@@ -103,6 +103,9 @@ int cr_batch_run(cr_batch *b, const cr_params *params, double *d_sw_out);
 /* Synchronise and copy results to host.  Any pointer may be NULL.  results[npairs];
  * aln i64[npairs, 2, aln_stride] (rows padded with -2 after aln_len; aln_stride >= max(n+m)). */
 int cr_batch_fetch(cr_batch *b, cr_pair_result *results, int64_t *aln, int64_t aln_stride);
+/* Only what make_pairwise_matrix needs (multiple_alignment.py:158-170): sw f64[npairs] = the smith_waterman_score of
+ * every pair, flags u32[npairs].  Either pointer may be NULL. */
+int cr_batch_fetch_scores(cr_batch *b, double *sw, uint32_t *flags);
 int cr_batch_max_aln_len(cr_batch *b, int64_t *out);
 /* per-stage device time in ms, averaged over the recorded runs (at most `slots` of them) */
 int cr_batch_stage_ms(cr_batch *b, float ms[CR_NUM_STAGES], int *runs_averaged);
