@@ -62,6 +62,29 @@ struct DevBuf {
     }
 };
 
+// page-locked host staging buffer (device <-> host copies without the driver's bounce buffer)
+template <class T>
+struct PinnedBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    ~PinnedBuf() {
+        if (p) (void)hipHostFree(p);
+    }
+    hipError_t ensure(size_t count) {
+        if (count <= n && p) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        n = 0;
+        const size_t want = std::max<size_t>(count + count / 2, 64);
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), want * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) n = want;
+        return e;
+    }
+};
+
 }  // namespace
 
 struct cr_context {

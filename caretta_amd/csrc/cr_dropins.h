@@ -268,6 +268,59 @@ int launch_node_r(hipStream_t stream, int count, int n_max, int m_max, int entri
     return CR_OK;
 }
 
+// team kernels (kTeamWaves waves per node): R rows per lane, strips_of(n_max, R) <= kTeamWaves
+template <int R>
+int launch_node_team_r(hipStream_t stream, int count, int n_max, int m_max, int entries, const cr::PairDesc* pairs,
+                       const double* coords, const double* tensors, int d, const double* weights,
+                       const cr::NodeDesc* nodes, const cr::Transform* xf, const cr_params& prm, double gamma_weight,
+                       uint32_t* bits, double* hand, int32_t* aln, double* xn, double* tn, double* wn, cr::NodeOut* out) {
+    const size_t lds = sizeof(double) * std::max(cr::sweep_team_lds_doubles<R, cr::kDtw, cr::RbfNode<R>>(cr::kTeamWaves),
+                                                 (size_t)cr::kExpDoubles + cr::trace_lds_doubles(R, entries));
+    int rc = allow_lds(cr::k_node_team<R>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(cr::k_node_team<R>, dim3((unsigned)count), dim3(cr::kTeamWaves * cr::kWave), lds, stream, pairs, coords,
+                       tensors, d, weights, nodes, xf, prm.gamma_coords, gamma_weight, prm.gap_open, prm.gap_extend, entries,
+                       bits, hand, aln, xn, tn, wn, out);
+    CR_HIP(hipGetLastError());
+    return CR_OK;
+}
+
+template <class... A>
+int launch_node_team(int R, A... a) {
+    return R == 1 ? launch_node_team_r<1>(a...) : R == 2 ? launch_node_team_r<2>(a...) : launch_node_team_r<3>(a...);
+}
+
+template <int R, int D, bool ZG>
+int launch_seed_team_zg(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
+    using Src = cr::RbfTensor<R, D>;
+    const int entries = std::min(ck.n_max, ck.m_max);
+    const size_t lds = sizeof(double) * std::max(cr::sweep_team_lds_doubles<R, cr::kSwTrace, Src>(cr::kTeamWaves),
+                                                 (size_t)cr::kExpDoubles + cr::trace_lds_doubles(R, entries));
+    int rc = allow_lds(cr::k_seed_team<R, D, ZG>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((cr::k_seed_team<R, D, ZG>), dim3((unsigned)ck.count), dim3(cr::kTeamWaves * cr::kWave), lds,
+                       b->ctx->stream, b->pairs.p + ck.first, b->tensors.p, (int)b->d, b->coords.p, prm.gamma_tensor,
+                       prm.sw_gap, entries, b->dirs.p, b->xf.p + ck.first, b->seed_score.p + ck.first);
+    CR_HIP(hipGetLastError());
+    return CR_OK;
+}
+
+template <int R>
+int launch_seed_team_r(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
+    const bool zg = prm.sw_gap == 0.0;
+    switch (b->d_pad) {
+        case 4: return zg ? launch_seed_team_zg<R, 4, true>(b, ck, prm) : launch_seed_team_zg<R, 4, false>(b, ck, prm);
+        case 8: return zg ? launch_seed_team_zg<R, 8, true>(b, ck, prm) : launch_seed_team_zg<R, 8, false>(b, ck, prm);
+        case 10: return zg ? launch_seed_team_zg<R, 10, true>(b, ck, prm) : launch_seed_team_zg<R, 10, false>(b, ck, prm);
+        case 16: return zg ? launch_seed_team_zg<R, 16, true>(b, ck, prm) : launch_seed_team_zg<R, 16, false>(b, ck, prm);
+        default: return fail(CR_ERR_ARGUMENT, "unsupported tensor width");
+    }
+}
+
+int launch_seed_team(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
+    return R == 1 ? launch_seed_team_r<1>(b, ck, prm) : R == 2 ? launch_seed_team_r<2>(b, ck, prm) : launch_seed_team_r<3>(b, ck, prm);
+}
+
 template <class... A>
 int launch_node(int R, A... a) {
     return R == 3 ? launch_node_r<3>(a...) : launch_node_r<5>(a...);

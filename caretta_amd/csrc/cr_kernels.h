@@ -563,6 +563,213 @@ __host__ __device__ inline size_t sweep_lds_doubles(int n_max, int m_max) {
     return v;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The team sweep: one WORKGROUP per pair, one wave per strip, all strips in flight at once.
+// For launches with too few pairs to fill the chip (a level of the guide tree, a small pair list) the
+// single-wave sweep is latency bound: one wave issues one instruction every few cycles and walks the
+// strips one after the other.  Here strip s runs on wave s, kTeamDelay steps behind strip s-1, and takes
+// the row above it from an LDS ring that strip s-1's last lane fills.  A value is written at least 65 steps
+// before it is read and the waves meet at a barrier every 64 steps (the column-chunk load), so no other
+// synchronisation is needed.  Decision words use the same (strip, time block, row, lane) layout as the
+// single-wave sweep, so the traceback code is shared.  Results are returned in every lane of every wave.
+// LDS (doubles): exp table | NW column rings | NW edge rings of NB * kEdgeRing | NW * 8 reduction slots.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTeamDelay = 2 * kWave;
+constexpr int kEdgeRing = 4 * kWave;
+constexpr int kTeamWaves = 4;
+
+template <int R, int MODE, class Src>
+CR_D void sweep_team(Src& src, const int n, const int m, const SweepParams prm, double* lds,
+                     uint32_t* __restrict__ sw_dirs, uint32_t* __restrict__ dtw_bits, SeedMax& seed_out,
+                     AlignEnd& end_out) {
+    constexpr bool SW = (MODE & (kSwTrace | kSwScore)) != 0;
+    constexpr bool TRACE = (MODE & kSwTrace) != 0;
+    constexpr bool DTW = (MODE & kDtw) != 0;
+    constexpr int NB = (SW ? 1 : 0) + (DTW ? 2 : 0);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int NW = (int)(blockDim.x >> 6);
+    const ExpEntry* tab = reinterpret_cast<const ExpEntry*>(lds);
+    double* ring = lds + kExpDoubles + w * Src::kRingDoubles;
+    double* edges = lds + kExpDoubles + NW * Src::kRingDoubles;
+    double* edge_out = edges + w * (NB * kEdgeRing);
+    const double* edge_in = edges + (w > 0 ? w - 1 : 0) * (NB * kEdgeRing);
+    double* red = edges + NW * (NB * kEdgeRing);
+
+    load_exp_table(lds, lane);
+    src.init_ring(ring, lane);
+    __syncthreads();
+
+    const int nstrips = strips_of(n, R);                 // <= NW, guaranteed by the launcher
+    const int TB_SW = tblocks(m, 16), TB_DTW = tblocks(m, 8);
+    const double col0_m2 = kMinF64 - prm.gap_open;
+    const bool mine = w < nstrips;
+    const int rowbase = (w * kWave + lane) * R;
+    const int rows_here = n - w * kWave * R;
+    const int lanes_here = rows_here >= kWave * R ? kWave : (rows_here + R - 1) / R;
+    const int T = mine ? m + lanes_here - 1 : 0;
+
+    DpState<R> st;
+    st.sw_max = 0.0;
+    if (mine) src.load_rows(rowbase, n);
+    st.reset_column0(col0_m2);
+#pragma unroll
+    for (int q = 0; q < R; q++) st.swbits[q] = st.dtbits[q] = 0;
+    st.h_bot = st.m0_bot = st.m1_bot = 0.0;
+
+    const int G = kTeamDelay * (nstrips - 1) + m + kWave - 1;
+    for (int g = 0; g < G; g++) {
+        const int t = g - kTeamDelay * w;
+        const bool live = mine && t >= 0 && t < T;
+        if ((g & (kWave - 1)) == 0) {
+            __syncthreads();
+            if (live) src.load_chunk(ring, t >> 6, m, lane);
+            __syncthreads();
+        }
+        if (!live) continue;
+        const int c = t - lane;
+        const bool active = (unsigned)c < (unsigned)m;
+
+        double h_top0 = 0.0, m0_top0 = col0_m2, m1_top0 = 0.0;
+        if (w > 0 && lane == 0 && active) {
+            if constexpr (SW) h_top0 = edge_in[c & (kEdgeRing - 1)];
+            if constexpr (DTW) {
+                m0_top0 = edge_in[(NB - 2) * kEdgeRing + (c & (kEdgeRing - 1))];
+                m1_top0 = edge_in[(NB - 1) * kEdgeRing + (c & (kEdgeRing - 1))];
+            }
+        }
+        double h_top = 0.0, m0_top = 0.0, m1_top = 0.0;
+        if constexpr (SW) h_top = wave_shr1(st.h_bot, h_top0);
+        if constexpr (DTW) {
+            m0_top = wave_shr1(st.m0_bot, m0_top0);
+            m1_top = wave_shr1(st.m1_bot, m1_top0);
+        }
+        const int sh2 = (t & 15) * 2, sh4 = (t & 7) * 4;
+
+        if (active) {
+            if constexpr (Src::kRingDoubles == 0) src.set_col(c, m);
+            src.fetch_col(ring, c & (kRing - 1));
+            dp_column<R, MODE>(src, st, prm, tab, c, rowbase, n, sh2, sh4, h_top, m0_top, m1_top);
+            if (w + 1 < nstrips && lane == kWave - 1) {
+                if constexpr (SW) edge_out[c & (kEdgeRing - 1)] = st.h_bot;
+                if constexpr (DTW) {
+                    edge_out[(NB - 2) * kEdgeRing + (c & (kEdgeRing - 1))] = st.m0_bot;
+                    edge_out[(NB - 1) * kEdgeRing + (c & (kEdgeRing - 1))] = st.m1_bot;
+                }
+            }
+        }
+        if constexpr (TRACE) {
+            if ((t & 15) == 15 || t == T - 1) {
+                const int64_t base = ((int64_t)(w * TB_SW + (t >> 4)) * R) * kWave + lane;
+#pragma unroll
+                for (int q = 0; q < R; q++) {
+                    sw_dirs[base + q * kWave] = st.swbits[q];
+                    st.swbits[q] = 0;
+                }
+            }
+        }
+        if constexpr (DTW) {
+            if ((t & 7) == 7 || t == T - 1) {
+                const int64_t base = ((int64_t)(w * TB_DTW + (t >> 3)) * R) * kWave + lane;
+#pragma unroll
+                for (int q = 0; q < R; q++) {
+                    dtw_bits[base + q * kWave] = st.dtbits[q];
+                    st.dtbits[q] = 0;
+                }
+            }
+        }
+    }
+
+    // ---- per-wave results, then across the waves through LDS ----------------------------------------
+    double best_v = 0.0;
+    int best_i = 0x7fffffff, best_j = 0x7fffffff;
+    if constexpr (TRACE) {
+        if (mine) {
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const bool gt = st.rowmax[q] > best_v;
+                best_v = gt ? st.rowmax[q] : best_v;
+                best_i = gt ? rowbase + q : best_i;
+                best_j = gt ? st.rowarg[q] : best_j;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            double ov = __shfl_xor(best_v, off);
+            int oi = __shfl_xor(best_i, off), oj = __shfl_xor(best_j, off);
+            bool take = ov > best_v || (ov == best_v && (oi < best_i || (oi == best_i && oj < best_j)));
+            best_v = take ? ov : best_v;
+            best_i = take ? oi : best_i;
+            best_j = take ? oj : best_j;
+        }
+    }
+    double sw_max = mine ? st.sw_max : 0.0;
+    if constexpr ((MODE & kSwScore) != 0) {
+        for (int off = 32; off > 0; off >>= 1) sw_max = __builtin_fmax(sw_max, __shfl_xor(sw_max, off));
+    }
+    const int owner_wave = (n - 1) / (kWave * R);
+    if (lane == 0) {
+        red[w * 8 + 0] = best_v;
+        red[w * 8 + 1] = (double)best_i;
+        red[w * 8 + 2] = (double)best_j;
+        red[w * 8 + 3] = sw_max;
+    }
+    if constexpr (DTW) {
+        if (w == owner_wave) {
+            const int owner = ((n - 1) / R) % kWave;
+            const int qo = (n - 1) % R;
+            double fin0 = 0.0, fin1 = 0.0, fin2 = 0.0;
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                fin0 = (q == qo) ? st.m0_left[q] : fin0;
+                fin1 = (q == qo) ? st.m1_left[q] : fin1;
+                fin2 = (q == qo) ? st.m2_left[q] : fin2;
+            }
+            if (lane == owner) {
+                red[w * 8 + 4] = fin0;
+                red[w * 8 + 5] = fin1;
+                red[w * 8 + 6] = fin2;
+            }
+        }
+    }
+    __threadfence();                                   // decision words of every wave visible to wave 0's walk
+    __syncthreads();
+    if constexpr (TRACE) {
+        best_v = 0.0;
+        best_i = best_j = 0x7fffffff;
+        for (int x = 0; x < nstrips; x++) {
+            const double ov = red[x * 8 + 0];
+            const int oi = (int)red[x * 8 + 1], oj = (int)red[x * 8 + 2];
+            const bool take = ov > best_v || (ov == best_v && (oi < best_i || (oi == best_i && oj < best_j)));
+            best_v = take ? ov : best_v;
+            best_i = take ? oi : best_i;
+            best_j = take ? oj : best_j;
+        }
+        seed_out.score = best_v;
+        seed_out.i = best_v > 0.0 ? best_i + 1 : 0;
+        seed_out.j = best_v > 0.0 ? best_j + 1 : 0;
+    }
+    if constexpr ((MODE & kSwScore) != 0 || DTW) {
+        double smax = 0.0;
+        for (int x = 0; x < nstrips; x++) smax = __builtin_fmax(smax, red[x * 8 + 3]);
+        const double fin0 = red[owner_wave * 8 + 4], fin1 = red[owner_wave * 8 + 5], fin2 = red[owner_wave * 8 + 6];
+        end_out.sw = smax;
+        int idx = 0;
+        double best = fin0;
+        if (fin1 > best) { best = fin1; idx = 1; }
+        if (fin2 > best) { best = fin2; idx = 2; }
+        end_out.dtw_score = DTW ? best : 0.0;
+        end_out.start_layer = idx;
+        end_out.pad = 0;
+    }
+    __syncthreads();
+}
+
+template <int R, int MODE, class Src>
+__host__ __device__ inline size_t sweep_team_lds_doubles(int waves) {
+    constexpr int NB = ((MODE & (kSwTrace | kSwScore)) ? 1 : 0) + ((MODE & kDtw) ? 2 : 0);
+    return kExpDoubles + (size_t)waves * (Src::kRingDoubles + NB * kEdgeRing + 8);
+}
+
 CR_D uint32_t lookup_bits(const uint32_t* __restrict__ words, int R, int TB, int per_word_log2, int bits,
                           int row, int col) {
     const int s = row / (kWave * R);
@@ -1134,8 +1341,8 @@ struct NodeDesc {
 // One wave per tree node; blockIdx.x indexes pairs / nodes / xf / out.  The children are read from
 // coords / tensors / weights at pd.off_i, pd.off_j; the node is written to Xn / Tn / Wn at out_off (the
 // output arrays may be the input arrays: a level of the guide tree appends to the arena it reads from).
-template <int R>
-__global__ __launch_bounds__(kWave) void k_node(const PairDesc* __restrict__ pairs, const double* coords,
+template <int R, bool TEAM>
+CR_D void node_body(const PairDesc* __restrict__ pairs, const double* coords,
                                                const double* tensors, int d, const double* weights,
                                                const NodeDesc* __restrict__ nodes,
                                                const Transform* __restrict__ xfs, double gamma_coords,
@@ -1171,9 +1378,14 @@ __global__ __launch_bounds__(kWave) void k_node(const PairDesc* __restrict__ pai
         src.mult2 = mult2;
         src.neg_gamma_w = -gamma_weight;
         SweepParams prm{0.0, gap_open, gap_extend};
-        sweep<R, kDtw>(src, pd.n, pd.m, prm, lds, nullptr, bits, hand, unused, e);
+        if constexpr (TEAM) sweep_team<R, kDtw>(src, pd.n, pd.m, prm, lds, nullptr, bits, unused, e);
+        else sweep<R, kDtw>(src, pd.n, pd.m, prm, lds, nullptr, bits, hand, unused, e);
     }
-    drain_stores();
+    if constexpr (TEAM) {
+        if (threadIdx.x >= kWave) return;              // s_barrier only waits for the waves still running
+    } else {
+        drain_stores();
+    }
     double* tl = lds + kExpDoubles;
     const int cap = pd.n + pd.m;
     int idx, k;
@@ -1225,6 +1437,65 @@ __global__ __launch_bounds__(kWave) void k_node(const PairDesc* __restrict__ pai
         no.flags = flags;
         no.pad = 0;
         *out = no;
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(kWave) void k_node(const PairDesc* __restrict__ pairs, const double* coords, const double* tensors,
+                                               int d, const double* weights, const NodeDesc* __restrict__ nodes,
+                                               const Transform* __restrict__ xfs, double gamma_coords,
+                                               double gamma_weight, double gap_open, double gap_extend,
+                                               int max_entries, uint32_t* __restrict__ bits_base,
+                                               double* __restrict__ hand_base, int32_t* __restrict__ aln_base,
+                                               double* Xn_base, double* Tn_base, double* Wn_base,
+                                               NodeOut* __restrict__ outs) {
+    node_body<R, false>(pairs, coords, tensors, d, weights, nodes, xfs, gamma_coords, gamma_weight, gap_open, gap_extend,
+                        max_entries, bits_base, hand_base, aln_base, Xn_base, Tn_base, Wn_base, outs);
+}
+
+template <int R>
+__global__ __launch_bounds__(kTeamWaves* kWave) void k_node_team(const PairDesc* __restrict__ pairs, const double* coords, const double* tensors,
+                                               int d, const double* weights, const NodeDesc* __restrict__ nodes,
+                                               const Transform* __restrict__ xfs, double gamma_coords,
+                                               double gamma_weight, double gap_open, double gap_extend,
+                                               int max_entries, uint32_t* __restrict__ bits_base,
+                                               double* __restrict__ hand_base, int32_t* __restrict__ aln_base,
+                                               double* Xn_base, double* Tn_base, double* Wn_base,
+                                               NodeOut* __restrict__ outs) {
+    node_body<R, true>(pairs, coords, tensors, d, weights, nodes, xfs, gamma_coords, gamma_weight, gap_open, gap_extend,
+                        max_entries, bits_base, hand_base, aln_base, Xn_base, Tn_base, Wn_base, outs);
+}
+
+// Team versions of k_seed and k_node for launches with few blocks (progressive alignment levels, small pair
+// lists): kTeamWaves waves sweep the strips of one pair concurrently (sweep_team); wave 0 then runs the same
+// traceback / Kabsch / mean code as the single-wave kernels.  Requires strips_of(n, R) <= kTeamWaves.
+template <int R, int D, bool ZG>
+__global__ __launch_bounds__(kTeamWaves* kWave) void k_seed_team(const PairDesc* __restrict__ pairs,
+                                                                const double* __restrict__ tensors, int d,
+                                                                const double* __restrict__ coords, double gamma,
+                                                                double sw_gap, int max_entries,
+                                                                uint32_t* __restrict__ dirs,
+                                                                Transform* __restrict__ xf,
+                                                                double* __restrict__ seed_score) {
+    extern __shared__ double lds[];
+    const PairDesc pd = pairs[blockIdx.x];
+    SeedMax sm;
+    AlignEnd unused;
+    {
+        RbfTensor<R, D> src;
+        src.rows_g = tensors + pd.off_i * d;
+        src.cols_g = tensors + pd.off_j * d;
+        src.d = d;
+        src.neg_gamma = -gamma;
+        SweepParams prm{sw_gap, 0.0, 0.0};
+        sweep_team<R, kSwTrace | (ZG ? kZeroGap : 0)>(src, pd.n, pd.m, prm, lds, dirs + pd.dirs_off, nullptr, sm, unused);
+    }
+    if (threadIdx.x >= kWave) return;                  // s_barrier only waits for the waves still running
+    Transform tr;
+    seed_trace(pd, R, max_entries, coords, dirs, sm, lds + kExpDoubles, tr);
+    if (threadIdx.x == 0) {
+        xf[blockIdx.x] = tr;
+        seed_score[blockIdx.x] = sm.score;
     }
 }
 

@@ -19,6 +19,10 @@ struct cr_progressive {
     int64_t used = 0, capacity = 0;          // arena rows
     DevBuf<cr::NodeDesc> d_nodes;
     DevBuf<cr::NodeOut> d_outs;
+    PinnedBuf<cr::PairDesc> p_pairs;         // page-locked staging of the per-level uploads and read-backs
+    PinnedBuf<cr::NodeDesc> p_nodes;
+    PinnedBuf<cr::NodeOut> p_outs;
+    PinnedBuf<int32_t> p_rows;
     std::vector<int64_t> off, len;           // per node id (0 .. 2P-2): arena row offset, rows
     std::vector<int64_t> child1, child2, level, members;   // per node id
     std::vector<uint32_t> flags;             // per internal node k
@@ -56,11 +60,17 @@ int run_level(cr_progressive* h, const std::vector<int64_t>& ids, const cr_param
     cr_batch& b = h->scratch;
     hipStream_t stream = h->ctx->stream;
     const size_t count = ids.size();
-    std::vector<cr::PairDesc> pairs(count);
-    std::vector<cr::NodeDesc> nodes(count);
+    CR_HIP(h->p_pairs.ensure(count));
+    CR_HIP(h->p_nodes.ensure(count));
+    CR_HIP(h->p_outs.ensure(count));
+    cr::PairDesc* pairs = h->p_pairs.p;
+    cr::NodeDesc* nodes = h->p_nodes.p;
     int n_max = 0, m_max = 0, cap_max = 0;
     for (int64_t id : ids) n_max = std::max<int>(n_max, (int)h->len[(size_t)h->child1[(size_t)id]]);
-    const int R = n_max <= 3 * cr::kWave ? 3 : 5;
+    // few blocks per launch: the team kernels (kTeamWaves waves per node) whenever the rows fit their strips
+    const bool team = n_max <= 3 * cr::kTeamWaves * cr::kWave && !std::getenv("CARETTA_NO_TEAM");
+    const int R = team ? (n_max + cr::kTeamWaves * cr::kWave - 1) / (cr::kTeamWaves * cr::kWave)
+                       : (n_max <= 3 * cr::kWave ? 3 : 5);
     int64_t dirs_off = 0, bt_off = 0, aln_off = 0, hand_off = 0, rows = h->used;
     for (size_t x = 0; x < count; x++) {
         const int64_t id = ids[x], c1 = h->child1[(size_t)id], c2 = h->child2[(size_t)id];
@@ -98,20 +108,24 @@ int run_level(cr_progressive* h, const std::vector<int64_t>& ids, const cr_param
     CR_HIP(b.seed_score.ensure(count));
     CR_HIP(h->d_nodes.ensure(count));
     CR_HIP(h->d_outs.ensure(count));
-    CR_HIP(hipMemcpyAsync(b.pairs.p, pairs.data(), sizeof(cr::PairDesc) * count, hipMemcpyHostToDevice, stream));
-    CR_HIP(hipMemcpyAsync(h->d_nodes.p, nodes.data(), sizeof(cr::NodeDesc) * count, hipMemcpyHostToDevice, stream));
+    CR_HIP(hipMemcpyAsync(b.pairs.p, pairs, sizeof(cr::PairDesc) * count, hipMemcpyHostToDevice, stream));
+    CR_HIP(hipMemcpyAsync(h->d_nodes.p, nodes, sizeof(cr::NodeDesc) * count, hipMemcpyHostToDevice, stream));
     b.r_seed = b.r_align = R;
     const cr_batch::Chunk ck{0, (int64_t)count, n_max, m_max, cap_max};
-    rc = (R == 3) ? launch_seed_d<3>(&b, ck, prm) : launch_seed_d<5>(&b, ck, prm);
+    rc = team ? launch_seed_team(R, &b, ck, prm) : (R == 3) ? launch_seed_d<3>(&b, ck, prm) : launch_seed_d<5>(&b, ck, prm);
     if (rc) return rc;
-    rc = launch_node(R, stream, (int)count, n_max, m_max, cap_max, b.pairs.p, b.coords.p, b.tensors.p, (int)h->d,
+    rc = team ? launch_node_team(R, stream, (int)count, n_max, m_max, cap_max, b.pairs.p, b.coords.p, b.tensors.p, (int)h->d,
+                                 h->weights.p, h->d_nodes.p, b.xf.p, prm, gamma_weight, b.bits.p, b.hand.p, b.aln.p, b.coords.p,
+                                 b.tensors.p, h->weights.p, h->d_outs.p)
+              : launch_node(R, stream, (int)count, n_max, m_max, cap_max, b.pairs.p, b.coords.p, b.tensors.p, (int)h->d,
                      h->weights.p, h->d_nodes.p, b.xf.p, prm, gamma_weight, b.bits.p, b.hand.p, b.aln.p, b.coords.p,
                      b.tensors.p, h->weights.p, h->d_outs.p);
     if (rc) return rc;
-    std::vector<cr::NodeOut> outs(count);
-    std::vector<int32_t> rows_host((size_t)aln_off);
-    CR_HIP(hipMemcpyAsync(outs.data(), h->d_outs.p, sizeof(cr::NodeOut) * count, hipMemcpyDeviceToHost, stream));
-    CR_HIP(hipMemcpyAsync(rows_host.data(), b.aln.p, sizeof(int32_t) * (size_t)aln_off, hipMemcpyDeviceToHost, stream));
+    CR_HIP(h->p_rows.ensure((size_t)aln_off));
+    cr::NodeOut* outs = h->p_outs.p;
+    int32_t* rows_host = h->p_rows.p;
+    CR_HIP(hipMemcpyAsync(outs, h->d_outs.p, sizeof(cr::NodeOut) * count, hipMemcpyDeviceToHost, stream));
+    CR_HIP(hipMemcpyAsync(rows_host, b.aln.p, sizeof(int32_t) * (size_t)aln_off, hipMemcpyDeviceToHost, stream));
     CR_HIP(hipStreamSynchronize(stream));
     for (size_t x = 0; x < count; x++) {
         const int64_t id = ids[x], k = id - h->P;
@@ -123,7 +137,7 @@ int run_level(cr_progressive* h, const std::vector<int64_t>& ids, const cr_param
         h->any_flags |= no.flags;
         std::vector<int32_t>& a = h->aln[(size_t)k];
         a.resize((size_t)(2 * no.len));
-        const int32_t* src = rows_host.data() + pairs[x].aln_off;
+        const int32_t* src = rows_host + pairs[x].aln_off;
         std::copy(src + no.first, src + no.first + no.len, a.begin());
         std::copy(src + cap + no.first, src + cap + no.first + no.len, a.begin() + no.len);
     }

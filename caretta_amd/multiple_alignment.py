@@ -177,15 +177,33 @@ class PairwiseResults:
         return self.alignments[p, 0, :ln], self.alignments[p, 1, :ln]
 
 
+class _NodeAttribute:
+    """final_sequences / final_consensus_weights / final_alignments (multiple_alignment.py:248-251).  After a
+    device-resident progressive_align the intermediate nodes stay in HBM until one of these is first read."""
+
+    def __init__(self, name):
+        self.slot = "_" + name
+
+    def __get__(self, obj, owner):
+        if obj is None:
+            return self
+        if obj.__dict__.get("_pending_nodes") is not None:
+            obj._materialize_nodes()
+        return obj.__dict__.get(self.slot)
+
+    def __set__(self, obj, value):
+        obj.__dict__[self.slot] = value
+
+
 @dataclass
 class MultipleAlignment:
     sequences: typing.List[SequenceBase]
     tree: typing.Optional[np.ndarray] = None
     branch_lengths: typing.Optional[np.ndarray] = None
     alignment: typing.Optional[typing.Dict[str, np.ndarray]] = None
-    final_sequences: typing.Optional[typing.List[SequenceBase]] = None
-    final_consensus_weights: typing.Optional[typing.List[np.ndarray]] = None
-    final_alignments: typing.Optional[typing.Dict[str, typing.Dict[str, np.ndarray]]] = None
+    final_sequences = _NodeAttribute("final_sequences")
+    final_consensus_weights = _NodeAttribute("final_consensus_weights")
+    final_alignments = _NodeAttribute("final_alignments")
 
     # -- batched GPU path ---------------------------------------------------------------------
     def _all_proteins(self) -> bool:
@@ -258,6 +276,7 @@ class MultipleAlignment:
             # every node of the tree on the device, one launch pair per tree level (cr_progressive_align)
             return self._progressive_align_resident(tree, gap_open_penalty, gap_extend_penalty, consensus_weight,
                                                     gamma_weight, score_function_params, mean_function_params)
+        self._drop_pending_nodes()
         final_sequences = [s for s in self.sequences]
         final_alignments = {s.name: {s.name: np.arange(len(s))} for s in final_sequences}
         final_consensus_weights = [np.full((len(s), 1), consensus_weight, dtype=np.float64) for s in final_sequences]
@@ -325,6 +344,7 @@ class MultipleAlignment:
         check(lib.cr_progressive_align(default_context()._h, ptr(coords), ptr(tensors), ptr(offsets), P, d, ptr(tree_u),
                                        tree_u.shape[0], C.byref(prm), float(consensus_weight), float(gamma_weight),
                                        C.byref(h)))
+        self._drop_pending_nodes()
         try:
             sizes = np.zeros(5, np.int64)
             check(lib.cr_progressive_sizes(h, ptr(sizes)))
@@ -333,16 +353,15 @@ class MultipleAlignment:
             check(lib.cr_progressive_node_table(h, ptr(table)))
             msa = np.zeros((P, width), np.int64)
             check(lib.cr_progressive_fetch_msa(h, ptr(msa)))
-            aln = np.zeros(2 * total, np.int64)
-            xn, tn, wn = np.zeros((total, 3)), np.zeros((total, d)), np.zeros(total)
-            check(lib.cr_progressive_fetch_nodes(h, ptr(aln), ptr(xn), ptr(tn), ptr(wn)))
-        finally:
+        except Exception:
             lib.cr_progressive_destroy(h)
+            raise
         names = [s.name for s in self.sequences]
         node_names = [f"int-{P + k}" for k in range(num_nodes - 1)] + ["int-final"]
         all_names = names + node_names
         bad = np.flatnonzero(table[:, 4] & _capi.FLAG_SEED_ALL_ZERO)
         if len(bad):
+            lib.cr_progressive_destroy(h)
             k = int(bad[0])
             raise TypeError(f"tensor score matrix of {all_names[table[k, 0]]} and {all_names[table[k, 1]]} has no "
                             "positive local alignment (reference: max_pos is None)")
@@ -351,12 +370,50 @@ class MultipleAlignment:
             for k in np.flatnonzero(table[:, 4] & (_capi.FLAG_SEED_SKIPPED | _capi.FLAG_MEAN_UNSUPERPOSED)):
                 print(f"Too few aligning positions for {all_names[table[k, 0]]} and {all_names[table[k, 1]]}, "
                       "continuing without superposition")
-        # attributes of :248-251, rebuilt from the node table
+        # the alignment in the reference's dict order (:244-247): members of the final node's children, depth first
+        order, stack = [], [P + num_nodes - 1]
+        while stack:
+            x = stack.pop()
+            if x < P:
+                order.append(x)
+            else:
+                stack.extend((int(table[x - P, 1]), int(table[x - P, 0])))
+        alignment = {names[s]: msa[s] for s in order}
+        # the intermediate nodes (:248-251) stay on the device until final_* is read
+        self._pending_nodes = dict(handle=h, lib=lib, d=d, total=total, table=table, names=names, node_names=node_names,
+                                   consensus_weight=consensus_weight, msa=msa)
+        self.node_table = table
+        return alignment
+
+    def _drop_pending_nodes(self):
+        pending = self.__dict__.pop("_pending_nodes", None)
+        if pending is not None:
+            pending["lib"].cr_progressive_destroy(pending["handle"])
+
+    def __del__(self):
+        try:
+            self._drop_pending_nodes()
+        except Exception:
+            pass
+
+    def _materialize_nodes(self):
+        """Fetch the intermediate nodes of the last device-resident progressive_align and rebuild
+        final_sequences / final_consensus_weights / final_alignments exactly as multiple_alignment.py:193-251 leaves them."""
+        pending = self.__dict__.pop("_pending_nodes")
+        lib, h, d, total, table = pending["lib"], pending["handle"], pending["d"], pending["total"], pending["table"]
+        try:
+            aln = np.zeros(2 * total, np.int64)
+            xn, tn, wn = np.zeros((total, 3)), np.zeros((total, d)), np.zeros(total)
+            check(lib.cr_progressive_fetch_nodes(h, ptr(aln), ptr(xn), ptr(tn), ptr(wn)))
+        finally:
+            lib.cr_progressive_destroy(h)
+        names, node_names, msa = pending["names"], pending["node_names"], pending["msa"]
+        P, num_nodes = len(names), len(node_names)
+        all_names = names + node_names
         final_sequences = [s for s in self.sequences]
-        final_consensus_weights = [np.full((len(s), 1), consensus_weight, dtype=np.float64) for s in self.sequences]
+        final_consensus_weights = [np.full((len(s), 1), pending["consensus_weight"], dtype=np.float64) for s in self.sequences]
         members = [[i] for i in range(P)]            # leaf indices below every node, in the reference's dict order
         rows = [np.arange(len(s), dtype=np.int64)[None, :] for s in self.sequences]   # member rows in node columns
-        node_alignments = []
         o = 0
         for k in range(num_nodes):
             c1, c2, ln = int(table[k, 0]), int(table[k, 1]), int(table[k, 2])
@@ -367,18 +424,13 @@ class MultipleAlignment:
             rows[c2] = np.where(a2 != -1, rows[c2][:, a2], -1)
             members.append(members[c1] + members[c2])
             rows.append(np.vstack([rows[c1], rows[c2]]))
-            node_alignments.append((a1, a2))
             o += ln
-        final_alignments = {all_names[x]: {names[s]: rows[x][r] for r, s in enumerate(members[x])}
-                            for x in range(len(all_names))}
         root = P + num_nodes - 1
         assert all(np.array_equal(rows[root][r], msa[s]) for r, s in enumerate(members[root]))
-        alignment = {names[s]: msa[s] for s in members[root]}
+        self.final_alignments = {all_names[x]: {names[s]: rows[x][r] for r, s in enumerate(members[x])}
+                                 for x in range(len(all_names))}
         self.final_consensus_weights = final_consensus_weights
-        self.final_alignments = final_alignments
         self.final_sequences = final_sequences
-        self.node_table = table
-        return alignment
 
     def multiple_align(self, pairwise_distance_matrix, gap_open_penalty, gap_extend_penalty, consensus_weight,
                        gamma_weight, score_function_params=None, mean_function_params=None):
