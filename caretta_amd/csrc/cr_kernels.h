@@ -276,6 +276,15 @@ struct DpState {
     }
 };
 
+// v_max_f64 as is.  __builtin_fmax makes the compiler canonicalise operands it cannot prove quiet (values that came
+// through DPP or LDS) with an extra v_max_f64 x, x; the data here is never NaN, and the instruction itself returns the
+// larger operand unchanged.
+CR_D double vmax(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 enum : int { kSwTrace = 1, kSwScore = 2, kDtw = 4, kZeroGap = 8 };   // kZeroGap: sw_gap == 0.0
 
 struct SweepParams {
@@ -302,8 +311,8 @@ CR_D void dp_column(const Src& src, DpState<R>& st, const SweepParams& prm, cons
             const double dg = h_dg + sc;
             const double lf = ZG ? st.h_left[q] : st.h_left[q] - prm.sw_gap;
             const double up = ZG ? h_up : h_up - prm.sw_gap;
-            const double h = NOFLOOR ? __builtin_fmax(__builtin_fmax(dg, lf), up)
-                                     : __builtin_fmax(__builtin_fmax(__builtin_fmax(0.0, dg), lf), up);
+            const double h = NOFLOOR ? vmax(vmax(dg, lf), up)
+                                     : vmax(vmax(vmax(0.0, dg), lf), up);
             if constexpr (TRACE) {
                 // decision replayed by the traceback's equality tests (:255-277)
                 uint32_t code = (h == dg) ? 1u : (h == lf) ? 2u : 3u;
@@ -319,9 +328,9 @@ CR_D void dp_column(const Src& src, DpState<R>& st, const SweepParams& prm, cons
                 st.rowarg[q] = gt ? c : st.rowarg[q];
             } else {
                 if constexpr (Src::kMaskRows) {
-                    st.sw_max = (rowbase + q < n) ? __builtin_fmax(st.sw_max, h) : st.sw_max;
+                    st.sw_max = (rowbase + q < n) ? vmax(st.sw_max, h) : st.sw_max;
                 } else {
-                    st.sw_max = __builtin_fmax(st.sw_max, h);
+                    st.sw_max = vmax(st.sw_max, h);
                 }
             }
             h_dg = st.h_left[q];
@@ -332,16 +341,16 @@ CR_D void dp_column(const Src& src, DpState<R>& st, const SweepParams& prm, cons
             const double lo0 = m0_up - prm.gap_extend;
             const double lo1 = m1_up - prm.gap_open;
             const bool b0 = lo1 > lo0;                  // np.argmax keeps the first maximum
-            const double m0 = __builtin_fmax(lo0, lo1);
+            const double m0 = vmax(lo0, lo1);
             const double up0 = st.m1_left[q] - prm.gap_open;
             const double up1 = st.m2_left[q] - prm.gap_extend;
             const bool b2 = up1 > up0;
-            const double m2 = __builtin_fmax(up0, up1);
+            const double m2 = vmax(up0, up1);
             const double c1 = m1_dg + sc;
             const bool g1 = c1 > m0;
-            const double m01 = __builtin_fmax(m0, c1);
+            const double m01 = vmax(m0, c1);
             const bool g2 = m2 > m01;
-            const double m1 = __builtin_fmax(m01, m2);
+            const double m1 = vmax(m01, m2);
             const uint32_t nib = (b0 ? 1u : 0u) | (g2 ? 4u : (g1 ? 2u : 0u)) | (b2 ? 8u : 0u);
             st.dtbits[q] |= nib << sh4;
             m1_dg = st.m1_left[q];
