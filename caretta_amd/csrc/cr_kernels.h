@@ -324,7 +324,8 @@ CR_D void dp_column(const Src& src, DpState<R>& st, const SweepParams& prm, cons
                     code = rv ? code : 0u;
                 }
                 st.swbits[q] |= code << sh2;
-                st.rowmax[q] = gt ? h : st.rowmax[q];
+                if constexpr (Src::kMaskRows) st.rowmax[q] = gt ? h : st.rowmax[q];
+                else st.rowmax[q] = vmax(st.rowmax[q], h);       // same value as the select, one instruction
                 st.rowarg[q] = gt ? c : st.rowarg[q];
             } else {
                 if constexpr (Src::kMaskRows) {
