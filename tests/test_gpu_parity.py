@@ -275,36 +275,50 @@ def test_pipeline_tiny_and_degenerate(ctx, oracle):
     assert res["rmsd"][p67] < 1e-12 and res["aln_len"][p67] == 40 and res["coverage"][p67] == 1.0
 
 
-def test_headline_config_sample_and_properties(ctx, oracle):
-    """BASELINE config 3 (128 x 300, all 8128 pairs) on the GPU; a 2% sample re-done by the oracle,
-    and size-independent properties on every pair."""
+@pytest.mark.parametrize("num,length,seed,stride", [(128, 300, 20242, 50), (512, 300, 20243, 1400), (64, 1200, 20244, 130)],
+                         ids=["config3_128x300", "config4_512x300", "config5_64x1200"])
+def test_full_size_configs_sample_and_properties(ctx, oracle, num, length, seed, stride):
+    """BASELINE configs 3, 4 and 5 at full size on the GPU (all pairs): a deterministic sample re-done by the oracle
+    (bit-identical), and size-independent properties on every pair."""
     from caretta_amd import engine
-    fam = synthetic.make_family(128, 300, seed=20242)
+    fam = synthetic.make_family(num, length, seed=seed)
     coords, tensors, offsets = synthetic.pack(fam)
-    pairs = engine.all_pairs(128)
-    res, aln = run_batch(ctx, coords, tensors, offsets, pairs)
-    n = m = 300
+    pairs = engine.all_pairs(num)
+    batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
+    batch.run(engine.make_params())
+    res, _ = batch.fetch(want_alignments=False)
+    sw_only, flags_only = batch.fetch_scores()
+    assert np.array_equal(sw_only, res["sw"]) and np.array_equal(flags_only, res["flags"])
+    batch.close()
+    n = length
     ln = res["aln_len"]
-    assert np.all((ln >= 300) & (ln <= 600)) and np.all(res["flags"] == 0)
-    for row in (0, 1):
-        a = aln[:, row, :]
-        # every residue index appears exactly once, in increasing order
-        present = np.sort(np.where(a >= 0, a, 10 ** 6), axis=1)[:, :n]
-        assert np.array_equal(present, np.tile(np.arange(n), (len(pairs), 1)))
-        srt = np.where(a >= 0, a, -1)
-        for p in range(0, len(pairs), 97):
-            x = srt[p][srt[p] >= 0]
-            assert np.all(np.diff(x) == 1)
-    matched = ((aln[:, 0, :] >= 0) & (aln[:, 1, :] >= 0)).sum(axis=1)
-    np.testing.assert_allclose(res["coverage"], matched / ln, rtol=0, atol=0)
-    assert np.all(ln == 2 * n - matched)
+    assert np.all((ln >= n) & (ln <= 2 * n)) and np.all(res["flags"] == 0)
     assert np.all(res["sw"] > 0) and np.all(np.isfinite(res["dtw_score"])) and np.all(res["rmsd"] >= 0)
-    dets = np.linalg.det(res["R"].reshape(-1, 3, 3))
-    np.testing.assert_allclose(dets, 1.0, atol=1e-12)
-    # oracle on a deterministic sample
-    sample = np.arange(0, len(pairs), 50)
+    assert np.all((res["coverage"] > 0) & (res["coverage"] <= 1)) and np.all((res["tm"] > 0) & (res["tm"] <= 1))
+    matched = np.rint(res["coverage"] * ln).astype(np.int64)
+    assert np.all(ln == 2 * n - matched)                       # every residue of both structures exactly once
+    np.testing.assert_allclose(np.linalg.det(res["R"].reshape(-1, 3, 3)), 1.0, atol=1e-12)
+    # the P x P matrix of multiple_alignment.py:158-170: symmetric, zero diagonal
+    m = engine.assemble_matrix(pairs, res["sw"], num)
+    assert np.array_equal(m, m.T) and np.all(np.diag(m) == 0)
+    # alignments and the oracle on a deterministic sample of pairs
+    sample = np.arange(0, len(pairs), stride)
+    sub = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs[sample])
+    sub.run(engine.make_params())
+    sres, saln = sub.fetch(want_alignments=True)
+    sub.close()
+    assert sres.tobytes() == res[sample].tobytes()             # a pair's result does not depend on its batch
+    for row in (0, 1):
+        a = saln[:, row, :]
+        present = np.sort(np.where(a >= 0, a, 10 ** 6), axis=1)[:, :n]
+        assert np.array_equal(present, np.tile(np.arange(n), (len(sample), 1)))
+        for p in range(len(sample)):
+            x = a[p][a[p] >= 0]
+            assert np.all(np.diff(x) == 1)
+    both = ((saln[:, 0, :] >= 0) & (saln[:, 1, :] >= 0)).sum(axis=1)
+    np.testing.assert_allclose(sres["coverage"], both / sres["aln_len"], rtol=0, atol=0)
     ref, ref_aln = oracle.pairwise_batch(coords, tensors, offsets, pairs[sample], nthreads=8)
-    assert_bit_identical(res[sample], aln[sample], ref, ref_aln)
+    assert_bit_identical(sres, saln, ref, ref_aln)
 
 
 def test_guide_tree_from_gpu_matrix(ctx, oracle, golden):
