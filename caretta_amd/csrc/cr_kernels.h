@@ -577,14 +577,16 @@ __host__ __device__ inline size_t sweep_lds_doubles(int n_max, int m_max) {
 // The team sweep: one WORKGROUP per pair, one wave per strip, all strips in flight at once.
 // For launches with too few pairs to fill the chip (a level of the guide tree, a small pair list) the
 // single-wave sweep is latency bound: one wave issues one instruction every few cycles and walks the
-// strips one after the other.  Here strip s runs on wave s, kTeamDelay steps behind strip s-1, and takes
-// the row above it from an LDS ring that strip s-1's last lane fills.  A value is written at least 65 steps
-// before it is read and the waves meet at a barrier every 64 steps (the column-chunk load), so no other
-// synchronisation is needed.  Decision words use the same (strip, time block, row, lane) layout as the
-// single-wave sweep, so the traceback code is shared.  Results are returned in every lane of every wave.
+// strips one after the other.  Here strip s runs on wave s, kTeamDelay = 64 steps behind strip s-1 (the
+// smallest lag: lane 63 of strip s-1 finishes column c one step before lane 0 of strip s needs it), and takes
+// the row above it from an LDS ring that strip s-1's last lane fills; the waves meet at a barrier every step.
+// (A 128-step lag needs no barrier beyond those of the column-chunk loads, but the longer pipeline costs more
+// than the barriers: 15.8 vs 13.8 ms for the 17 levels of the 128 x 300 guide tree.)  Decision words use the
+// same (strip, time block, row, lane) layout as the single-wave sweep, so the traceback code is shared.
+// Results are returned in every lane of every wave.
 // LDS (doubles): exp table | NW column rings | NW edge rings of NB * kEdgeRing | NW * 8 reduction slots.
 // ---------------------------------------------------------------------------------------------
-constexpr int kTeamDelay = 2 * kWave;
+constexpr int kTeamDelay = kWave;
 constexpr int kEdgeRing = 4 * kWave;
 constexpr int kTeamWaves = 4;
 
@@ -631,8 +633,9 @@ CR_D void sweep_team(Src& src, const int n, const int m, const SweepParams prm, 
     for (int g = 0; g < G; g++) {
         const int t = g - kTeamDelay * w;
         const bool live = mine && t >= 0 && t < T;
-        if ((g & (kWave - 1)) == 0) {
-            __syncthreads();
+        const bool boundary = (g & (kWave - 1)) == 0;
+        __syncthreads();                                   // edge values of step g-1 visible to the next strip
+        if (boundary) {
             if (live) src.load_chunk(ring, t >> 6, m, lane);
             __syncthreads();
         }
