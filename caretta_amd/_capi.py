@@ -38,6 +38,7 @@ _pp = C.POINTER(C.c_void_p)
 SIGNATURES = {
     "cr_abi_version": [],
     "cr_device_count": [C.POINTER(C.c_int)],
+    "cr_device_trim": [_i32],
     "cr_context_create": [_i32, _vp, _pp],
     "cr_context_destroy": [_vp],
     "cr_context_synchronize": [_vp],

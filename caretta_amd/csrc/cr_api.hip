@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
+#include <map>
 #include <new>
 #include <string>
 #include <vector>
@@ -39,24 +41,117 @@ int fail(int code, const std::string& msg) {
         if (!(cond)) return fail(CR_ERR_ARGUMENT, (msg));     \
     } while (0)
 
-// device buffer that frees itself
+// Device blocks are recycled instead of returned to the driver: hipMalloc / hipFree cost tens of microseconds to
+// milliseconds each, which is most of the wall time of a single-call drop-in and ~20 % of a 128-structure
+// make_pairwise_matrix.  Blocks are binned by size class (8 steps per power of two); a block goes back to its bin
+// only after the device has drained (every caller has synchronised its stream by then; the device-wide wait is the
+// safety net hipFree used to provide).  CARETTA_NO_CACHE=1 turns the cache off; cr_device_trim() empties it.
+struct BlockCache {
+    static constexpr size_t kLargest = (size_t)16 << 30;
+    std::mutex mu;
+    std::map<size_t, std::vector<void*>> bins;
+    size_t held = 0;
+    // bytes kept per device at most (CARETTA_CACHE_MB overrides the 24 GiB default; the decision scratch of a
+    // 512-structure batch is 8 GiB, and re-allocating blocks of that size from the driver costs 300-400 ms)
+    static size_t limit() {
+        static const size_t v = [] {
+            const char* env = std::getenv("CARETTA_CACHE_MB");
+            const long long mb = env ? std::atoll(env) : 0;
+            return mb > 0 ? (size_t)mb << 20 : (size_t)24 << 30;
+        }();
+        return v;
+    }
+    static size_t size_class(size_t bytes) {          // 8 steps per power of two: at most 12.5 % over
+        size_t c = 256;
+        while (c * 2 < bytes) c *= 2;
+        if (bytes <= c) return c;
+        const size_t q = c / 8;
+        return c + (bytes - c + q - 1) / q * q;
+    }
+    static bool enabled() {
+        static const bool on = std::getenv("CARETTA_NO_CACHE") == nullptr;
+        return on;
+    }
+    void* take(size_t cls) {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = bins.find(cls);
+        if (it == bins.end() || it->second.empty()) return nullptr;
+        void* p = it->second.back();
+        it->second.pop_back();
+        held -= cls;
+        return p;
+    }
+    bool give(void* p, size_t cls) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (cls > kLargest || held + cls > limit()) return false;
+        bins[cls].push_back(p);
+        held += cls;
+        return true;
+    }
+    void trim() {
+        std::lock_guard<std::mutex> lock(mu);
+        for (auto& b : bins)
+            for (void* p : b.second) (void)hipFree(p);
+        bins.clear();
+        held = 0;
+    }
+};
+
+BlockCache& block_cache(int device) {
+    static BlockCache* caches = new BlockCache[64];      // never destroyed: the HIP runtime may be gone by then
+    return caches[device & 63];
+}
+
+// device buffer that releases itself
 template <class T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    size_t cls = 0;      // bytes of the underlying block (0: not from the cache)
+    int dev = 0;
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) {
+            bool kept = false;
+            if (cls) {
+                int cur = 0;
+                (void)hipGetDevice(&cur);
+                if (cur != dev) (void)hipSetDevice(dev);
+                (void)hipDeviceSynchronize();
+                kept = block_cache(dev).give(p, cls);
+                if (cur != dev) (void)hipSetDevice(cur);
+            }
+            if (!kept) (void)hipFree(p);
+        }
         p = nullptr;
         n = 0;
+        cls = 0;
     }
     hipError_t ensure(size_t count) {
         if (count <= n && p) return hipSuccess;
         release();
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T));
+        const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+        if (BlockCache::enabled()) {
+            (void)hipGetDevice(&dev);
+            cls = BlockCache::size_class(bytes);
+            p = static_cast<T*>(block_cache(dev).take(cls));
+            if (p) {
+                n = count;
+                return hipSuccess;
+            }
+            hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), cls);
+            if (e == hipErrorOutOfMemory) {              // give the cached blocks back and try once more
+                block_cache(dev).trim();
+                e = hipMalloc(reinterpret_cast<void**>(&p), cls);
+            }
+            if (e == hipSuccess) n = count;
+            else { p = nullptr; cls = 0; }
+            return e;
+        }
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), bytes);
         if (e == hipSuccess) n = count;
         return e;
     }
@@ -231,6 +326,14 @@ int cr_device_count(int* count) {
         return fail(CR_ERR_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
     }
     *count = n;
+    return CR_OK;
+}
+
+int cr_device_trim(int device) {
+    CR_REQUIRE(device >= 0 && device < 64, "bad device index");
+    CR_HIP(hipSetDevice(device));
+    CR_HIP(hipDeviceSynchronize());
+    block_cache(device).trim();
     return CR_OK;
 }
 

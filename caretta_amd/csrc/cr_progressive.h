@@ -42,6 +42,8 @@ int grow_keep(DevBuf<double>& buf, int64_t rows, int64_t keep_rows, int64_t widt
     CR_HIP(hipStreamSynchronize(stream));
     std::swap(buf.p, bigger.p);
     std::swap(buf.n, bigger.n);
+    std::swap(buf.cls, bigger.cls);
+    std::swap(buf.dev, bigger.dev);
     return CR_OK;
 }
 

@@ -75,6 +75,9 @@ int cr_abi_version(void);
 int cr_device_count(int *count);
 
 /* ---- context ---------------------------------------------------------------------------- */
+/* Device scratch released by batches / drop-ins is kept for reuse (hipMalloc / hipFree dominate short calls);
+ * this returns all of it to the driver.  CARETTA_NO_CACHE=1 in the environment disables the reuse altogether. */
+int cr_device_trim(int device);
 /* `stream` is a hipStream_t to launch on (e.g. torch.cuda.current_stream().cuda_stream) or NULL to
  * create a private stream. */
 int cr_context_create(int device, void *stream, cr_context **out);
