@@ -200,7 +200,7 @@ struct ExplicitRun {
     DevBuf<cr::TraceOut> tout;
 };
 
-constexpr int kExplicitR = 5;
+constexpr int kExplicitR = 2;     // 128 rows per strip: the strip's tile (128 x 129 doubles) fits the LDS
 
 // shared body of the three explicit-matrix drop-ins
 template <int MODE>

@@ -222,31 +222,65 @@ struct RbfNode {
 };
 
 // Explicit score matrix with index sequences: S[seq1[i], seq2[j]] (dynamic_time_warping.py:24-26,79).
+// The strip's 64*R rows x the 128 most recent columns are staged in LDS: every 64 steps all lanes copy the next
+// 64 columns of every row of the strip with row-contiguous (coalesced when seq2 is a range) loads, so the sweep
+// itself never waits on HBM.  A lane reads tile[(lane*R + q) * kStride + (t - lane) mod 128]; kStride makes
+// R * kStride - 1 odd, so the 64 lanes of a step fall into distinct banks.
 template <int R>
 struct Explicit {
     static constexpr bool kNonNegative = false;
+    static constexpr int kStride = kRing + 1 + (R & 1);
     const double* __restrict__ S;
     const int32_t* __restrict__ seq1;
     const int32_t* __restrict__ seq2;
     int64_t s_cols;
-    const double* rowp[R];
-    int64_t colidx;
-    static constexpr int kRingDoubles = 0;
+    int row0, rows;          // first row of the current strip, number of rows of the matrix
+    int lane_;
+    int myrow[R];
+    double val[R];
+    static constexpr int kRingDoubles = kWave * R * kStride + kWave * R / 2 + 1;   // tile + the strip's row indices
     static constexpr bool kMaskRows = true;
 
     CR_D void load_rows(int rowbase, int n) {
+        lane_ = threadIdx.x & (kWave - 1);
+        row0 = __builtin_amdgcn_readfirstlane(rowbase - lane_ * R);
+        rows = n;
 #pragma unroll
-        for (int q = 0; q < R; q++) {
-            int r = rowbase + q;
-            r = r < n ? r : n - 1;
-            rowp[q] = S + (int64_t)seq1[r] * s_cols;
-        }
+        for (int q = 0; q < R; q++) myrow[q] = rowbase + q < n ? seq1[rowbase + q] : 0;   // row indices of this lane
     }
     CR_D void init_ring(double*, int) {}
-    CR_D void load_chunk(double*, int, int, int) {}
-    CR_D void fetch_col(const double*, int) {}
-    CR_D void set_col(int c, int m) { colidx = seq2[c < 0 ? 0 : (c < m ? c : m - 1)]; }
-    CR_D double score(int q, const ExpEntry*) const { return rowp[q][colidx]; }
+    CR_D void load_chunk(double* ring, int chunk, int m, int lane) {
+        // the strip's row indices go through LDS once (LDS operations of one wave execute in order), so that the
+        // copy loop's addresses come from a broadcast ds_read instead of a chain of scalar loads
+        int* rowidx = reinterpret_cast<int*>(ring + kWave * R * kStride);
+        if (chunk == 0) {
+#pragma unroll
+            for (int q = 0; q < R; q++) rowidx[lane * R + q] = myrow[q];
+        }
+        const int c = chunk * kWave + lane;
+        const bool cv = c < m;
+        const int64_t col = cv ? seq2[c] : 0;
+        const int slot = c & (kRing - 1);
+        const int left = rows - row0 < kWave * R ? rows - row0 : kWave * R;
+        // 16 rows at a time: indices, then 16 loads in flight, then the stores (the tile and the index list are
+        // both LDS, so interleaving them would serialise the loads behind the stores)
+        for (int base = 0; base < kWave * R; base += 16) {
+            int idx[16];
+            double v[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) idx[k] = rowidx[base + k];
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = (cv && base + k < left) ? S[(int64_t)idx[k] * s_cols + col] : 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if (cv) ring[(base + k) * kStride + slot] = v[k];   // rows past n: masked in the DP, kept finite
+        }
+    }
+    CR_D void fetch_col(const double* ring, int slot) {
+#pragma unroll
+        for (int q = 0; q < R; q++) val[q] = ring[(lane_ * R + q) * kStride + slot];
+    }
+    CR_D double score(int q, const ExpEntry*) const { return val[q]; }
 };
 
 // Registers a lane carries from column to column of its R rows.
