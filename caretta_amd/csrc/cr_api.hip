@@ -294,6 +294,11 @@ int launch_align(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
     return prm.sw_gap == 0.0 ? launch_align_zg<R, true>(b, ck, prm) : launch_align_zg<R, false>(b, ck, prm);
 }
 
+// The fused kernels feed rows past the end of a structure features of 1e150 so that their RBF score underflows to
+// exactly 0 (they then never win a maximum).  That needs gamma * 1e300 > 745; below 1e-290 every real score is
+// exactly 1.0 anyway, and such a gamma is rejected rather than computed wrongly.
+bool gamma_ok(double g) { return std::isfinite(g) && g >= 1e-290; }
+
 bool all_finite(const double* v, size_t count) {
     for (size_t x = 0; x < count; x++)
         if (!std::isfinite(v[x])) return false;
@@ -543,9 +548,8 @@ int cr_batch_run(cr_batch* b, const cr_params* params, double* d_sw_out) {
     }
     cr_context* ctx = b->ctx;
     const cr_params prm = *params;
-    CR_REQUIRE(std::isfinite(prm.gamma_tensor) && prm.gamma_tensor >= 0.0 && std::isfinite(prm.gamma_coords) &&
-                   prm.gamma_coords >= 0.0,
-               "gamma_tensor and gamma_coords must be finite and >= 0");
+    CR_REQUIRE(gamma_ok(prm.gamma_tensor) && gamma_ok(prm.gamma_coords),
+               "gamma_tensor and gamma_coords must be finite and >= 1e-290 (below that every score is exactly 1.0)");
     CR_REQUIRE(std::isfinite(prm.gap_open) && std::isfinite(prm.gap_extend) && std::isfinite(prm.sw_gap),
                "gap penalties must be finite");
     const bool prof = ctx->slots > 0;

@@ -357,8 +357,8 @@ int cr_protein_score_function(cr_context* ctx, const double* coords_i, const dou
                               double gamma_tensor, double gamma_coords, double* S, uint32_t* flags) {
     CR_REQUIRE(coords_i && tensors_i && coords_j && tensors_j && S, "null array");
     CR_REQUIRE(n >= 1 && m >= 1, "empty structure");
-    CR_REQUIRE(std::isfinite(gamma_tensor) && gamma_tensor >= 0.0 && std::isfinite(gamma_coords) && gamma_coords >= 0.0,
-               "gamma_tensor and gamma_coords must be finite and >= 0");
+    CR_REQUIRE(gamma_ok(gamma_tensor) && gamma_ok(gamma_coords),
+               "gamma_tensor and gamma_coords must be finite and >= 1e-290 (below that every score is exactly 1.0)");
     // a two-structure batch driven through stages 1-2, then the explicit matrix
     std::vector<double> coords((size_t)(n + m) * 3), tensors((size_t)(n + m) * d);
     std::memcpy(coords.data(), coords_i, sizeof(double) * (size_t)n * 3);
@@ -425,10 +425,9 @@ int cr_progressive_node(cr_context* ctx, const double* coords_1, const double* t
     } guard{b};
     if ((rc = cr_batch_set_pairs(b, pair, 1))) return rc;
     const cr_params prm = *params;
-    CR_REQUIRE(std::isfinite(prm.gamma_tensor) && prm.gamma_tensor >= 0.0 && std::isfinite(prm.gamma_coords) &&
-                   prm.gamma_coords >= 0.0 && std::isfinite(prm.gap_open) && std::isfinite(prm.gap_extend) &&
+    CR_REQUIRE(gamma_ok(prm.gamma_tensor) && gamma_ok(prm.gamma_coords) && std::isfinite(prm.gap_open) && std::isfinite(prm.gap_extend) &&
                    std::isfinite(prm.sw_gap),
-               "parameters must be finite, gammas >= 0");
+               "parameters must be finite, gamma_tensor and gamma_coords >= 1e-290 (below that every score is exactly 1.0)");
     const cr_batch::Chunk& ck = b->chunks[0];
     rc = (b->r_seed == 3) ? launch_seed_d<3>(b, ck, prm) : launch_seed_d<5>(b, ck, prm);
     if (rc) return rc;

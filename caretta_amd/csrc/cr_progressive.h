@@ -166,10 +166,9 @@ int cr_progressive_align(cr_context* ctx, const double* coords, const double* te
         CR_REQUIRE(offsets[s + 1] > offsets[s] && offsets[s + 1] - offsets[s] <= cr::kMaxLength,
                    "every structure needs 1 .. 65534 residues");
     const cr_params prm = *params;
-    CR_REQUIRE(std::isfinite(prm.gamma_tensor) && prm.gamma_tensor >= 0.0 && std::isfinite(prm.gamma_coords) &&
-                   prm.gamma_coords >= 0.0 && std::isfinite(prm.gap_open) && std::isfinite(prm.gap_extend) &&
+    CR_REQUIRE(gamma_ok(prm.gamma_tensor) && gamma_ok(prm.gamma_coords) && std::isfinite(prm.gap_open) && std::isfinite(prm.gap_extend) &&
                    std::isfinite(prm.sw_gap),
-               "parameters must be finite, gammas >= 0");
+               "parameters must be finite, gamma_tensor and gamma_coords >= 1e-290 (below that every score is exactly 1.0)");
     CR_REQUIRE(std::isfinite(gamma_weight) && gamma_weight >= 0.0 && std::isfinite(consensus_weight),
                "gamma_weight must be finite and >= 0, consensus_weight finite");
     const int64_t total = offsets[P];

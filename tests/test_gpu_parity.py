@@ -442,6 +442,18 @@ def test_progressive_resident_vs_oracle_and_single_node(oracle, num, length, rag
     assert np.array_equal(np.array([aln[q] for q in order]), rows[-1])
 
 
+def test_gamma_too_small_is_rejected(ctx):
+    """gamma = 0 would make the scores of the padding rows 1.0 instead of 0.0: the fused kernels refuse it."""
+    from caretta_amd import engine, synthetic as syn
+    fam = syn.make_family(3, 30, seed=2, clades=1)
+    batch = engine.PairBatch(ctx, *syn.pack(fam)).set_pairs(engine.all_pairs(3))
+    for bad in (dict(gamma_coords=0.0), dict(gamma_tensor=1e-300)):
+        with pytest.raises(ValueError):
+            batch.run(engine.make_params(**bad))
+    batch.run(engine.make_params(gamma_coords=1e-4))
+    batch.close()
+
+
 def test_progressive_tree_validation(ctx):
     from caretta_amd import multiple_alignment as ma, synthetic
     fam = synthetic.make_family(4, 40, seed=5, clades=2)

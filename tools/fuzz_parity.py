@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""Randomised parity run on one MI355X: the HIP path against the C oracle (TEST infrastructure, oracle/) on many small
+random batches -- ragged lengths from 1 to 700 residues, tensor widths 1..16, all gap / gamma settings, the batched
+pipeline and the device-resident progressive alignment.  Every output must be bit-identical.
+
+    python tools/fuzz_parity.py [seconds] [seed]
+"""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+from caretta_amd import engine, multiple_alignment as ma, neighbor_joining as nj, synthetic  # noqa: E402
+from oracle import pyoracle  # noqa: E402
+
+
+def random_family(rng):
+    kind = rng.integers(0, 4)
+    dim = int(rng.choice([1, 2, 3, 4, 5, 8, 10, 13, 16]))
+    if kind == 0:      # related structures, ragged
+        num, length = int(rng.integers(2, 10)), int(rng.choice([12, 40, 90, 150, 200, 260, 330, 450, 700]))
+        fam = synthetic.make_family(num, length, dim=dim, seed=int(rng.integers(1 << 30)), ragged=True, clades=int(rng.integers(1, 4)))
+    elif kind == 1:    # unrelated random walks of very different lengths
+        fam = []
+        for k in range(int(rng.integers(2, 8))):
+            ln = int(rng.choice([1, 2, 3, 4, 5, 7, 17, 63, 64, 65, 128, 129, 192, 193, 257, 320, 321, 400]))
+            one = synthetic.make_family(1, ln, dim=dim, seed=int(rng.integers(1 << 30)), clades=1)[0]
+            fam.append(one)
+    elif kind == 2:    # tie-heavy: coordinates and tensors on a coarse grid
+        num, length = int(rng.integers(2, 7)), int(rng.choice([20, 70, 140]))
+        fam = synthetic.make_family(num, length, dim=dim, seed=int(rng.integers(1 << 30)), ragged=True, clades=1)
+        for s in fam:
+            s.coordinates[:] = np.round(s.coordinates / 4.0) * 4.0
+            s.tensors[:] = np.round(s.tensors * 2.0) / 2.0
+    else:              # far apart: RBF underflows, seeds of <= 3 positions
+        num, length = int(rng.integers(2, 6)), int(rng.choice([5, 30, 100]))
+        fam = synthetic.make_family(num, length, dim=dim, seed=int(rng.integers(1 << 30)), ragged=True, clades=num)
+        for s in fam:
+            s.tensors[:] = s.tensors * float(rng.choice([1.0, 3.0, 8.0]))
+    return fam, dim
+
+
+def check_batch(ctx, oracle, fam, rng):
+    coords, tensors, offsets = synthetic.pack(fam)
+    num = len(fam)
+    pairs = engine.all_pairs(num)
+    if rng.integers(0, 2):
+        pairs = np.vstack([pairs, pairs[:, ::-1]])                 # both orientations
+    prm = dict(gamma_tensor=float(rng.choice([7.0, 1.0, 0.3])), gamma_coords=float(rng.choice([0.03, 0.1, 1e-4])),
+               gap_open=float(rng.choice([1.0, 0.0, 0.5, 3.0])), gap_extend=float(rng.choice([0.01, 0.0, 0.5])),
+               sw_gap=float(rng.choice([0.0, 0.0, 0.0, 0.1])))
+    batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
+    batch.run(engine.make_params(**prm))
+    res, aln = batch.fetch()
+    batch.close()
+    ref, ref_aln = oracle.pairwise_batch(coords, tensors, offsets, pairs, pyoracle.default_params(**prm), nthreads=8)
+    for key in ("flags", "aln_len", "seed_len", "sw", "dtw_score", "seed_score", "rmsd", "coverage", "tm", "R", "t"):
+        if not np.array_equal(res[key], ref[key]):
+            raise AssertionError(f"{key} differs: params {prm}, lengths {np.diff(offsets)}")
+    for p in range(len(pairs)):
+        ln = int(ref["aln_len"][p])
+        if not np.array_equal(aln[p, :, :ln], ref_aln[p, :, :ln]):
+            raise AssertionError(f"alignment of pair {pairs[p]} differs: params {prm}, lengths {np.diff(offsets)}")
+    return len(pairs), res
+
+
+def check_progressive(oracle, fam, rng):
+    num = len(fam)
+    if num < 3 or min(len(s.coordinates) for s in fam) < 5:
+        return 0
+    prots = [ma.Protein(s.name, s.tensors, s.coordinates, "") for s in fam]
+    msa = ma.MultipleAlignment(prots)
+    prm = dict(flexible=False, gamma_tensor=7.0, gamma_coords=0.03, verbose=False)
+    try:
+        m = msa.make_pairwise_matrix(prm)
+    except TypeError:
+        return 0                                                   # a pair without any positive local alignment
+    tree, _ = nj.neighbor_joining(m.max() - m)
+    go, ge, cw, gw = float(rng.choice([1.0, 0.5])), float(rng.choice([0.01, 0.1])), float(rng.choice([1.0, 0.5])), float(rng.choice([1.0, 0.2]))
+    try:
+        msa.progressive_align(tree, go, ge, cw, gw, prm, dict(flexible=False, verbose=False))
+    except TypeError:
+        return 0                                                   # a node without any positive local alignment
+    tree = np.asarray(tree).astype(np.int64)
+    joins = [(int(tree[x, 0]), int(tree[x + 1, 0])) for x in range(0, tree.shape[0] - 1, 2)] + [(int(tree[-1, 0]), int(tree[-1, 1]))]
+    sizes = [1] * num
+    oprm = pyoracle.default_params(gap_open=go, gap_extend=ge)
+    for k, (n1, n2) in enumerate(joins):
+        tot = sizes[n1] + sizes[n2]
+        s1, s2 = msa.final_sequences[n1], msa.final_sequences[n2]
+        _, _, xn, tn, wn, _ = oracle.progressive_node(s1.coordinates, s1.tensors, msa.final_consensus_weights[n1], s2.coordinates,
+                                                      s2.tensors, msa.final_consensus_weights[n2], sizes[n2] / (2 * tot),
+                                                      sizes[n1] / (2 * tot), oprm, gw)
+        node = msa.final_sequences[num + k]
+        if not (np.array_equal(xn, node.coordinates) and np.array_equal(tn, node.tensors)
+                and np.array_equal(wn, msa.final_consensus_weights[num + k])):
+            raise AssertionError(f"progressive node {k} differs: lengths {[len(p) for p in prots]}")
+        sizes.append(tot)
+    return len(joins)
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    ctx, oracle = engine.Context(0), pyoracle.Oracle()
+    t0, batches, pairs, nodes, flagged = time.time(), 0, 0, 0, 0
+    while time.time() - t0 < seconds:
+        fam, _ = random_family(rng)
+        n, res = check_batch(ctx, oracle, fam, rng)
+        pairs += n
+        flagged += int(np.count_nonzero(res["flags"]))
+        if rng.integers(0, 3) == 0:
+            nodes += check_progressive(oracle, fam, rng)
+        batches += 1
+    print(f"fuzz_parity: seed {seed}, {batches} batches, {pairs} pairs ({flagged} with a soft-condition flag), "
+          f"{nodes} progressive nodes: all bit-identical to the oracle")
+
+
+if __name__ == "__main__":
+    main()
