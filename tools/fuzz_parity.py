@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity run on one MI355X: the HIP path against the C oracle (TEST infrastructure, oracle/) on many small
 random batches -- ragged lengths from 1 to 700 residues, tensor widths 1..16, all gap / gamma settings, the batched
-pipeline and the device-resident progressive alignment.  Every output must be bit-identical.
+pipeline, the device-resident progressive alignment and the explicit-score-matrix drop-ins.  Every output must be bit-identical.
 
     python tools/fuzz_parity.py [seconds] [seed]
 """
@@ -102,12 +102,47 @@ def check_progressive(oracle, fam, rng):
     return len(joins)
 
 
+def check_dropins(oracle, rng):
+    """dtw_align / smith_waterman(_score) on an explicit score matrix, incl. alphabet mode and tie-heavy matrices."""
+    from caretta_amd import dynamic_time_warping as dtw
+    n, m = (int(rng.choice([1, 2, 3, 7, 31, 64, 65, 127, 128, 129, 200, 257, 300, 390])) for _ in range(2))
+    rows, cols = (n, m) if rng.integers(0, 2) else (int(rng.integers(1, 30)), int(rng.integers(1, 30)))   # alphabet mode
+    kind = rng.integers(0, 4)
+    if kind == 0:
+        s = rng.uniform(0.0, 1.0, size=(rows, cols))
+    elif kind == 1:
+        s = np.round(rng.uniform(-1.0, 2.0, size=(rows, cols)))                    # ties, negative scores
+    elif kind == 2:
+        s = np.exp(-rng.uniform(0.0, 800.0, size=(rows, cols)))                    # underflow to 0
+    else:
+        s = np.ones((rows, cols)) * float(rng.choice([0.0, 1.0, 0.25]))            # constant
+    seq1 = np.arange(n) if (rows, cols) == (n, m) else rng.integers(0, rows, size=n)
+    seq2 = np.arange(m) if (rows, cols) == (n, m) else rng.integers(0, cols, size=m)
+    go, ge = float(rng.choice([0.0, 1.0, 0.5, 3.0])), float(rng.choice([0.0, 0.01, 0.5]))
+    a1, a2, sc = dtw.dtw_align(seq1, seq2, s, go, ge)
+    b1, b2, sr = oracle.dtw_align(seq1, seq2, s, go, ge)
+    if not (np.array_equal(a1, b1) and np.array_equal(a2, b2) and sc == sr and dtw.dtw_align_score(seq1, seq2, s, go, ge) == sr):
+        raise AssertionError(f"dtw_align differs: n {n} m {m} kind {kind} gaps {go} {ge} matrix {s.shape}")
+    gap = float(rng.choice([0.0, 0.0, 0.1, 1.0]))
+    if dtw.smith_waterman_score(seq1, seq2, s, gap) != oracle.smith_waterman_score(seq1, seq2, s, gap):
+        raise AssertionError(f"smith_waterman_score differs: n {n} m {m} kind {kind} gap {gap} matrix {s.shape}")
+    b1, b2, sr, none = oracle.smith_waterman(seq1, seq2, s, gap)
+    try:
+        a1, a2, sc = dtw.smith_waterman(seq1, seq2, s, gap)
+        ok = not none and np.array_equal(a1, b1) and np.array_equal(a2, b2) and sc == sr
+    except TypeError:
+        ok = bool(none)
+    if not ok:
+        raise AssertionError(f"smith_waterman differs: n {n} m {m} kind {kind} gap {gap} matrix {s.shape}")
+    return 1
+
+
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
     ctx, oracle = engine.Context(0), pyoracle.Oracle()
-    t0, batches, pairs, nodes, flagged = time.time(), 0, 0, 0, 0
+    t0, batches, pairs, nodes, flagged, dropins = time.time(), 0, 0, 0, 0, 0
     while time.time() - t0 < seconds:
         fam, _ = random_family(rng)
         n, res = check_batch(ctx, oracle, fam, rng)
@@ -115,9 +150,10 @@ def main():
         flagged += int(np.count_nonzero(res["flags"]))
         if rng.integers(0, 3) == 0:
             nodes += check_progressive(oracle, fam, rng)
+        dropins += check_dropins(oracle, rng)
         batches += 1
     print(f"fuzz_parity: seed {seed}, {batches} batches, {pairs} pairs ({flagged} with a soft-condition flag), "
-          f"{nodes} progressive nodes: all bit-identical to the oracle")
+          f"{nodes} progressive nodes, {dropins} explicit-matrix drop-in cases: all bit-identical to the oracle")
 
 
 if __name__ == "__main__":
