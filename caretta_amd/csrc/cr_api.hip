@@ -200,6 +200,7 @@ struct cr_batch {
     // pair list
     int64_t npairs = 0;
     int r_seed = 5, r_align = 5, d_pad = 0;
+    bool team = false;                  // few pairs: one workgroup of kTeamWaves waves per pair (k_seed_team / k_align_team)
     int n_max = 0, m_max = 0;
     int64_t max_aln = 0;
     std::vector<cr::PairDesc> h_pairs;
@@ -297,6 +298,33 @@ int launch_align(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
 // The fused kernels feed rows past the end of a structure features of 1e150 so that their RBF score underflows to
 // exactly 0 (they then never win a maximum).  That needs gamma * 1e300 > 745; below 1e-290 every real score is
 // exactly 1.0 anyway, and such a gamma is rejected rather than computed wrongly.
+template <int R, bool ZG>
+int launch_align_team_zg(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
+    using Src = cr::RbfCoords<R>;
+    const int entries = ck.max_aln;
+    const size_t lds = sizeof(double) * std::max(cr::sweep_team_lds_doubles<R, cr::kSwScore | cr::kDtw, Src>(cr::kTeamWaves),
+                                                 (size_t)cr::kExpDoubles + cr::trace_lds_doubles(R, entries));
+    int rc = allow_lds(cr::k_align_team<R, ZG>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((cr::k_align_team<R, ZG>), dim3((unsigned)ck.count), dim3(cr::kTeamWaves * cr::kWave), lds, b->ctx->stream,
+                       b->pairs.p + ck.first, b->coords.p, b->xf.p + ck.first, b->seed_score.p + ck.first, prm.gamma_coords,
+                       prm.sw_gap, prm.gap_open, prm.gap_extend, entries, b->bits.p, b->aln.p, b->res.p + ck.first);
+    CR_HIP(hipGetLastError());
+    return CR_OK;
+}
+
+int launch_align_team(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
+    const bool zg = prm.sw_gap == 0.0;
+    switch (R) {
+        case 1: return zg ? launch_align_team_zg<1, true>(b, ck, prm) : launch_align_team_zg<1, false>(b, ck, prm);
+        case 2: return zg ? launch_align_team_zg<2, true>(b, ck, prm) : launch_align_team_zg<2, false>(b, ck, prm);
+        default: return zg ? launch_align_team_zg<3, true>(b, ck, prm) : launch_align_team_zg<3, false>(b, ck, prm);
+    }
+}
+
+constexpr int64_t kTeamPairLimit = 128;
+int launch_seed_team(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm);   // cr_dropins.h
+
 bool gamma_ok(double g) { return std::isfinite(g) && g >= 1e-290; }
 
 bool all_finite(const double* v, size_t count) {
@@ -471,6 +499,11 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     }
     // rows per lane: 3 covers 192 rows in one strip, 5 covers 320
     b->r_seed = b->r_align = (b->n_max <= 3 * cr::kWave) ? 3 : 5;
+    // A pair list that cannot even give every CU one wave is latency bound: spread each pair over kTeamWaves waves.
+    // Worth it only when the rows need more than one strip of the single-wave kernels' lag to amortise (n > 64).
+    b->team = npairs > 0 && npairs <= kTeamPairLimit && b->n_max > cr::kWave && b->n_max <= 3 * cr::kTeamWaves * cr::kWave &&
+              !std::getenv("CARETTA_NO_TEAM");
+    if (b->team) b->r_seed = b->r_align = (b->n_max + cr::kTeamWaves * cr::kWave - 1) / (cr::kTeamWaves * cr::kWave);
     // scratch budget per chunk (decision words); CARETTA_SCRATCH_MB overrides the 8 GiB default
     int64_t budget_words = (int64_t)8192 * 1024 * 1024 / 4;
     if (const char* env = std::getenv("CARETTA_SCRATCH_MB")) {
@@ -566,10 +599,12 @@ int cr_batch_run(cr_batch* b, const cr_params* params, double* d_sw_out) {
     }
     size_t evi = 1;
     for (const cr_batch::Chunk& ck : b->chunks) {
-        rc = (b->r_seed == 3) ? launch_seed_d<3>(b, ck, prm) : launch_seed_d<5>(b, ck, prm);
+        rc = b->team ? launch_seed_team(b->r_seed, b, ck, prm)
+                     : (b->r_seed == 3) ? launch_seed_d<3>(b, ck, prm) : launch_seed_d<5>(b, ck, prm);
         if (rc) return rc;
         if (prof) CR_HIP(hipEventRecord((*evl)[evi++], ctx->stream));
-        rc = (b->r_align == 3) ? launch_align<3>(b, ck, prm) : launch_align<5>(b, ck, prm);
+        rc = b->team ? launch_align_team(b->r_align, b, ck, prm)
+                     : (b->r_align == 3) ? launch_align<3>(b, ck, prm) : launch_align<5>(b, ck, prm);
         if (rc) return rc;
         if (prof) CR_HIP(hipEventRecord((*evl)[evi++], ctx->stream));
     }

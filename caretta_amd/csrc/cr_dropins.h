@@ -321,6 +321,12 @@ int launch_seed_team(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_par
     return R == 1 ? launch_seed_team_r<1>(b, ck, prm) : R == 2 ? launch_seed_team_r<2>(b, ck, prm) : launch_seed_team_r<3>(b, ck, prm);
 }
 
+// the seed kernel that matches the batch's layout (cr_batch_set_pairs chose team / rows per lane)
+int launch_seed_auto(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
+    if (b->team) return launch_seed_team(b->r_seed, b, ck, prm);
+    return (b->r_seed == 3) ? launch_seed_d<3>(b, ck, prm) : launch_seed_d<5>(b, ck, prm);
+}
+
 template <class... A>
 int launch_node(int R, A... a) {
     return R == 3 ? launch_node_r<3>(a...) : launch_node_r<5>(a...);
@@ -373,7 +379,7 @@ int cr_protein_score_function(cr_context* ctx, const double* coords_i, const dou
     rc = cr_batch_set_pairs(b, pair, 1);
     if (rc == CR_OK) {
         cr_params prm{gamma_tensor, gamma_coords, 1.0, 0.01, 0.0};
-        rc = (b->r_seed == 3) ? launch_seed_d<3>(b, b->chunks[0], prm) : launch_seed_d<5>(b, b->chunks[0], prm);
+        rc = launch_seed_auto(b, b->chunks[0], prm);
     }
     if (rc == CR_OK) {
         DevBuf<double> ds;
@@ -429,7 +435,7 @@ int cr_progressive_node(cr_context* ctx, const double* coords_1, const double* t
                    std::isfinite(prm.sw_gap),
                "parameters must be finite, gamma_tensor and gamma_coords >= 1e-290 (below that every score is exactly 1.0)");
     const cr_batch::Chunk& ck = b->chunks[0];
-    rc = (b->r_seed == 3) ? launch_seed_d<3>(b, ck, prm) : launch_seed_d<5>(b, ck, prm);
+    rc = launch_seed_auto(b, ck, prm);
     if (rc) return rc;
     const int64_t cap = n + m;
     DevBuf<double> dw, dxn, dtn, dwn;
@@ -444,9 +450,12 @@ int cr_progressive_node(cr_context* ctx, const double* coords_1, const double* t
     const cr::NodeDesc hnd{mult1, mult2, 0};
     DevBuf<cr::NodeDesc> dnd;
     if ((rc = upload(dnd, &hnd, 1, ctx->stream))) return rc;
-    if ((rc = launch_node(R, ctx->stream, 1, (int)n, (int)m, entries, b->pairs.p, b->coords.p, b->tensors.p, (int)d, dw.p,
-                          dnd.p, b->xf.p, prm, gamma_weight, b->bits.p, b->hand.p, b->aln.p, dxn.p, dtn.p, dwn.p, dout.p)))
-        return rc;
+    rc = b->team ? launch_node_team(R, ctx->stream, 1, (int)n, (int)m, entries, b->pairs.p, b->coords.p, b->tensors.p, (int)d,
+                                    dw.p, dnd.p, b->xf.p, prm, gamma_weight, b->bits.p, b->hand.p, b->aln.p, dxn.p, dtn.p, dwn.p,
+                                    dout.p)
+                 : launch_node(R, ctx->stream, 1, (int)n, (int)m, entries, b->pairs.p, b->coords.p, b->tensors.p, (int)d, dw.p,
+                               dnd.p, b->xf.p, prm, gamma_weight, b->bits.p, b->hand.p, b->aln.p, dxn.p, dtn.p, dwn.p, dout.p);
+    if (rc) return rc;
     CR_HIP(hipGetLastError());
     cr::NodeOut no;
     CR_HIP(hipMemcpyAsync(&no, dout.p, sizeof(no), hipMemcpyDeviceToHost, ctx->stream));

@@ -1546,6 +1546,36 @@ __global__ __launch_bounds__(kTeamWaves* kWave) void k_seed_team(const PairDesc*
     }
 }
 
+template <int R, bool ZG>
+__global__ __launch_bounds__(kTeamWaves* kWave) void k_align_team(const PairDesc* __restrict__ pairs,
+                                                                 const double* __restrict__ coords,
+                                                                 const Transform* __restrict__ xf,
+                                                                 const double* __restrict__ seed_score, double gamma,
+                                                                 double sw_gap, double gap_open, double gap_extend,
+                                                                 int max_entries, uint32_t* __restrict__ bits,
+                                                                 int32_t* __restrict__ aln, PairResult* __restrict__ res) {
+    extern __shared__ double lds[];
+    const PairDesc pd = pairs[blockIdx.x];
+    SeedMax unused;
+    AlignEnd e;
+    {
+        RbfCoords<R> src;
+        src.rows_g = coords + pd.off_i * 3;
+        src.cols_g = coords + pd.off_j * 3;
+        src.xf = xf + blockIdx.x;
+        src.neg_gamma = -gamma;
+        SweepParams prm{sw_gap, gap_open, gap_extend};
+        sweep_team<R, kSwScore | kDtw | (ZG ? kZeroGap : 0)>(src, pd.n, pd.m, prm, lds, nullptr, bits + pd.bt_off, unused, e);
+    }
+    if (threadIdx.x >= kWave) return;                  // s_barrier only waits for the waves still running
+    PairResult r;
+    align_trace(pd, R, max_entries, coords, bits, e, lds + kExpDoubles, aln, r);
+    r.seed_score = seed_score[blockIdx.x];
+    r.seed_len = xf[blockIdx.x].seed_len;
+    r.flags |= xf[blockIdx.x].flags;
+    if (threadIdx.x == 0) res[blockIdx.x] = r;
+}
+
 // Pairwise RMSD / coverage / TM matrices of a finished multiple alignment (make_rmsd_coverage_tm_matrix,
 // multiple_alignment.py:1000-1055).  msa: int32 [P][W] residue indices, -1 = gap.  One wave per pair i<j
 // (blockIdx.x enumerates them row-major).  superpose != 0: Kabsch per pair first (superpose_first=False);

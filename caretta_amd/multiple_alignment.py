@@ -437,6 +437,15 @@ class MultipleAlignment:
         """multiple_alignment.py:255-285"""
         mean_function_params = mean_function_params or {}
         score_function_params = score_function_params or {}
+        if len(self.sequences) == 2 and self._all_proteins() and not score_function_params.get("flexible", False):
+            # :263-275 is pipeline H of this one pair: both score matrices, the seed and dtw_align in two launches
+            out = self.pairwise(score_function_params, gap_open_penalty, gap_extend_penalty)
+            if score_function_params.get("verbose", True) and out.results["flags"][0] & _capi.FLAG_SEED_SKIPPED:
+                print(f"Too few aligning positions for {self.sequences[0].name} and {self.sequences[1].name}, "
+                      "continuing without superposition")
+            aln_1, aln_2 = out.alignment(0)
+            self.alignment = {self.sequences[0].name: aln_1.copy(), self.sequences[1].name: aln_2.copy()}
+            return self.alignment
         if len(self.sequences) == 2:
             score_matrix = self.sequences[0].score_function(self.sequences[1], **score_function_params)
             aln_1, aln_2, _ = dtw.dtw_align(np.arange(score_matrix.shape[0]), np.arange(score_matrix.shape[1]),
