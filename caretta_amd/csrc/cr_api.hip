@@ -236,7 +236,7 @@ int set_device(cr_context* ctx) {
 
 template <class K>
 int allow_lds(K kernel, size_t bytes) {
-    if (bytes > 160 * 1024) return fail(CR_ERR_ARGUMENT, "sequence too long: strip hand-off rows exceed the 160 KiB LDS");
+    if (bytes > 160 * 1024) return fail(CR_ERR_ARGUMENT, "pair too long: the alignment columns of one pair (n + m <= 39000) must fit the 160 KiB LDS");
     if (bytes > 48 * 1024)
         CR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)bytes));
