@@ -18,6 +18,15 @@
 #include <vector>
 
 #include "cr_kernels.h"
+#include "cr_ilp_instances.h"
+
+// compiled in cr_kernels_ilp.hip with another instruction scheduler
+#define CR_X(R, D, ZG) extern template CR_SEED_SIGNATURE(R, D, ZG)
+CR_ILP_SEED_INSTANCES(CR_X)
+#undef CR_X
+#define CR_X(R, ZG) extern template CR_ALIGN_SIGNATURE(R, ZG)
+CR_ILP_ALIGN_INSTANCES(CR_X)
+#undef CR_X
 
 namespace {
 

@@ -1,0 +1,18 @@
+// Kernels that are compiled in their own translation unit (cr_kernels_ilp.hip) with
+// -mllvm -amdgpu-sched-strategy=iterative-ilp.  Measured on MI355X against the default scheduler: k_seed -5 %
+// (128 x 300), -9 % (32 x 150); k_align<3> -13 %; k_align<5> +57 % (it loses its 4 waves per SIMD), so that one
+// and everything else stay in cr_api.hip.  cr_api.hip declares these instances `extern template`.
+#pragma once
+
+#define CR_ILP_SEED_INSTANCES(X) \
+    X(3, 4, true) X(3, 4, false) X(3, 8, true) X(3, 8, false) X(3, 10, true) X(3, 10, false) X(3, 16, true) X(3, 16, false) \
+    X(5, 4, true) X(5, 4, false) X(5, 8, true) X(5, 8, false) X(5, 10, true) X(5, 10, false) X(5, 16, true) X(5, 16, false)
+
+#define CR_ILP_ALIGN_INSTANCES(X) X(3, true) X(3, false)
+
+#define CR_SEED_SIGNATURE(R, D, ZG)                                                                                  \
+    __global__ void cr::k_seed<R, D, ZG>(const cr::PairDesc*, const double*, int, const double*, double, double, int, \
+                                         uint32_t*, double*, cr::Transform*, double*);
+#define CR_ALIGN_SIGNATURE(R, ZG)                                                                                      \
+    __global__ void cr::k_align<R, ZG>(const cr::PairDesc*, const double*, const cr::Transform*, const double*, double, \
+                                       double, double, double, int, uint32_t*, double*, int32_t*, cr::PairResult*);

@@ -1576,6 +1576,7 @@ __global__ __launch_bounds__(kTeamWaves* kWave) void k_align_team(const PairDesc
     if (threadIdx.x == 0) res[blockIdx.x] = r;
 }
 
+#ifndef CR_KERNELS_TEMPLATES_ONLY   // the one non-template kernel: defined in cr_api.hip's translation unit only
 // Pairwise RMSD / coverage / TM matrices of a finished multiple alignment (make_rmsd_coverage_tm_matrix,
 // multiple_alignment.py:1000-1055).  msa: int32 [P][W] residue indices, -1 = gap.  One wave per pair i<j
 // (blockIdx.x enumerates them row-major).  superpose != 0: Kabsch per pair first (superpose_first=False);
@@ -1619,5 +1620,6 @@ __global__ __launch_bounds__(kWave) void k_msa_metrics(const double* __restrict_
         out[4 * (int64_t)blockIdx.x + 3] = (double)k;
     }
 }
+#endif
 
 }  // namespace cr

@@ -1,0 +1,16 @@
+// Explicit instantiations of the kernels that gain from the iterative-ILP instruction scheduler (cr_ilp_instances.h).
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -mllvm -amdgpu-sched-strategy=iterative-ilp -c
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#define CR_KERNELS_TEMPLATES_ONLY
+#include "cr_kernels.h"
+#include "cr_ilp_instances.h"
+
+#define CR_X(R, D, ZG) template CR_SEED_SIGNATURE(R, D, ZG)
+CR_ILP_SEED_INSTANCES(CR_X)
+#undef CR_X
+#define CR_X(R, ZG) template CR_ALIGN_SIGNATURE(R, ZG)
+CR_ILP_ALIGN_INSTANCES(CR_X)
+#undef CR_X
