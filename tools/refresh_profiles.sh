@@ -11,4 +11,4 @@ bash tools/pmc_profile.sh r01b_pmc
 python tools/bench_msa.py 128 300 > gpurun_out/r01b/msa_128.txt 2>&1
 python tools/bench_msa.py 512 300 > gpurun_out/r01b/msa_512.txt 2>&1
 python tools/host_overheads.py 128 300 > gpurun_out/r01b/host_128.txt 2>&1
-tail -2 gpurun_out/r01b/msa_*.txt
+tail -n 2 gpurun_out/r01b/msa_128.txt gpurun_out/r01b/msa_512.txt
