@@ -3,7 +3,7 @@
 random batches -- ragged lengths from 1 to 700 residues, tensor widths 1..16, all gap / gamma settings, the batched
 pipeline, the device-resident progressive alignment and the explicit-score-matrix drop-ins.  Every output must be bit-identical.
 
-    python tools/fuzz_parity.py [seconds] [seed]
+    python tests/fuzz_parity.py [seconds] [seed]
 """
 import sys
 import time

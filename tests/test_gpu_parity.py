@@ -573,3 +573,15 @@ def test_integration_md_binding_snippet(golden):
     pairs = g["famA_pairs"]
     for p, (i, j) in enumerate(pairs):
         assert abs(m[i, j] - float(g[f"famA_p{p}_sw"])) <= 1e-9 * max(1.0, abs(m[i, j])) and m[i, j] == m[j, i]
+
+
+def test_randomised_parity_run():
+    """tests/fuzz_parity.py for a few seconds: random ragged batches, all parameter settings, the resident progressive
+    alignment and the explicit-matrix drop-ins, everything bit-identical to the oracle (longer runs: profiles/)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    script = Path(__file__).resolve().parent / "fuzz_parity.py"
+    out = subprocess.run([sys.executable, str(script), "8", "99"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "all bit-identical to the oracle" in out.stdout
