@@ -212,7 +212,10 @@ struct cr_batch {
     bool team = false;                  // few pairs: one workgroup of kTeamWaves waves per pair (k_seed_team / k_align_team)
     int n_max = 0, m_max = 0;
     int64_t max_aln = 0;
-    std::vector<cr::PairDesc> h_pairs;
+    std::vector<cr::PairDesc> h_pairs;  // in LAUNCH order: most cells first (order[k] = index in the caller's list)
+    std::vector<int32_t> order;
+    bool reordered = false;             // false: order is the identity (equal costs), no un-permuting needed
+    DevBuf<int32_t> d_order;
     DevBuf<cr::PairDesc> pairs;
     DevBuf<uint32_t> dirs, bits;
     DevBuf<double> hand;                // strip hand-off rows of multi-strip pairs (per chunk)
@@ -519,12 +522,30 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
         const long long mb = std::atoll(env);
         if (mb > 0) budget_words = (int64_t)mb * 1024 * 1024 / 4;
     }
+    // Launch order: the pairs with the most DP cells first, so that the last wave slots to drain hold short pairs
+    // (waves are dispatched in block order; with ragged structures the caller's order would leave long pairs for
+    // the tail).  Stable, so equal-length inputs keep the caller's order and nothing is permuted.
+    b->order.resize((size_t)npairs);
+    for (int64_t p = 0; p < npairs; p++) b->order[(size_t)p] = (int32_t)p;
+    auto cost = [&](int32_t p) {
+        const int64_t i = pairs[2 * (int64_t)p], j = pairs[2 * (int64_t)p + 1];
+        return (b->offsets[i + 1] - b->offsets[i]) * (b->offsets[j + 1] - b->offsets[j]);
+    };
+    if (!std::getenv("CARETTA_KEEP_ORDER"))          // (for measurements: launch in the caller's order)
+        std::stable_sort(b->order.begin(), b->order.end(), [&](int32_t a, int32_t c) { return cost(a) > cost(c); });
+    b->reordered = false;
+    for (int64_t k = 0; k < npairs; k++)
+        if (b->order[(size_t)k] != k) {
+            b->reordered = true;
+            break;
+        }
     int64_t dirs_off = 0, bt_off = 0, aln_off = 0, max_aln = 0, dirs_max = 0, bits_max = 0, hand_off = 0, hand_max = 0;
     double bytes = 0.0, cells = 0.0;
     b->chunks.clear();
     cr_batch::Chunk ck{0, 0, 0, 0, 0};
-    for (int64_t p = 0; p < npairs; p++) {
-        int64_t i = pairs[2 * p], j = pairs[2 * p + 1];
+    for (int64_t p = 0; p < npairs; p++) {                     // p: position in launch order
+        const int64_t orig = b->order[(size_t)p];
+        int64_t i = pairs[2 * orig], j = pairs[2 * orig + 1];
         cr::PairDesc& pd = b->h_pairs[(size_t)p];
         pd.n = (int)(b->offsets[i + 1] - b->offsets[i]);
         pd.m = (int)(b->offsets[j + 1] - b->offsets[j]);
@@ -570,6 +591,9 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     if (e == hipSuccess) e = b->xf.ensure((size_t)npairs);
     if (e == hipSuccess) e = b->seed_score.ensure((size_t)npairs);
     if (e == hipSuccess) e = b->res.ensure((size_t)npairs);
+    if (e == hipSuccess && b->reordered) e = b->d_order.ensure((size_t)npairs);
+    if (e == hipSuccess && b->reordered)
+        e = hipMemcpyAsync(b->d_order.p, b->order.data(), sizeof(int32_t) * (size_t)npairs, hipMemcpyHostToDevice, b->ctx->stream);
     if (e == hipSuccess && npairs)
         e = hipMemcpyAsync(b->pairs.p, b->h_pairs.data(), sizeof(cr::PairDesc) * (size_t)npairs, hipMemcpyHostToDevice,
                            b->ctx->stream);
@@ -617,7 +641,11 @@ int cr_batch_run(cr_batch* b, const cr_params* params, double* d_sw_out) {
         if (rc) return rc;
         if (prof) CR_HIP(hipEventRecord((*evl)[evi++], ctx->stream));
     }
-    if (d_sw_out) {
+    if (d_sw_out && b->reordered) {
+        hipLaunchKernelGGL(cr::k_scatter_sw, dim3((unsigned)((b->npairs + 255) / 256)), dim3(256), 0, ctx->stream, b->res.p,
+                           b->d_order.p, d_sw_out, (int)b->npairs);
+        CR_HIP(hipGetLastError());
+    } else if (d_sw_out) {
         // strided device-to-device copy of the first field of every PairResult
         CR_HIP(hipMemcpy2DAsync(d_sw_out, sizeof(double), b->res.p, sizeof(cr::PairResult), sizeof(double),
                                 (size_t)b->npairs, hipMemcpyDeviceToDevice, ctx->stream));
@@ -671,13 +699,16 @@ int cr_batch_fetch(cr_batch* b, cr_pair_result* results, int64_t* aln, int64_t a
     if (rc) return rc;
     CR_HIP(hipStreamSynchronize(b->ctx->stream));
     if (b->npairs == 0) return CR_OK;
+    // `res` is in launch order; the caller's arrays are in the order of its pair list
     std::vector<cr_pair_result> local;
     cr_pair_result* res = results;
-    if (!res && aln) {
+    if ((!res && aln) || (res && b->reordered)) {
         local.resize((size_t)b->npairs);
         res = local.data();
     }
     if (res) CR_HIP(hipMemcpy(res, b->res.p, sizeof(cr_pair_result) * (size_t)b->npairs, hipMemcpyDeviceToHost));
+    if (results && b->reordered)
+        for (int64_t k = 0; k < b->npairs; k++) results[b->order[(size_t)k]] = res[k];
     if (aln) {
         CR_REQUIRE(aln_stride >= b->max_aln, "aln_stride smaller than the longest possible alignment");
         std::vector<int32_t> h((size_t)b->aln_elems);
@@ -687,7 +718,7 @@ int cr_batch_fetch(cr_batch* b, cr_pair_result* results, int64_t* aln, int64_t a
             const int cap = pd.n + pd.m;
             const int32_t* a1 = h.data() + pd.aln_off + res[p].aln_start;
             const int32_t* a2 = a1 + cap;
-            int64_t* o1 = aln + (size_t)p * 2 * (size_t)aln_stride;
+            int64_t* o1 = aln + (size_t)b->order[(size_t)p] * 2 * (size_t)aln_stride;
             int64_t* o2 = o1 + aln_stride;
             const int len = res[p].aln_len;
             for (int x = 0; x < len; x++) {
@@ -714,6 +745,11 @@ int cr_batch_fetch_scores(cr_batch* b, double* sw, uint32_t* flags) {
         CR_HIP(hipMemcpy2DAsync(b->sw_stage.p, sizeof(double), reinterpret_cast<const char*>(b->res.p) + offsetof(cr_pair_result, sw),
                                 sizeof(cr::PairResult), sizeof(double), np, hipMemcpyDeviceToDevice, st));
         CR_HIP(hipMemcpyAsync(sw, b->sw_stage.p, sizeof(double) * np, hipMemcpyDeviceToHost, st));
+        if (b->reordered) {                           // launch order -> the caller's order
+            CR_HIP(hipStreamSynchronize(st));
+            std::vector<double> tmp(sw, sw + np);
+            for (size_t k = 0; k < np; k++) sw[b->order[k]] = tmp[k];
+        }
     }
     if (flags) {
         DevBuf<uint32_t> stage;
@@ -722,6 +758,10 @@ int cr_batch_fetch_scores(cr_batch* b, double* sw, uint32_t* flags) {
                                 sizeof(cr::PairResult), sizeof(uint32_t), np, hipMemcpyDeviceToDevice, st));
         CR_HIP(hipMemcpyAsync(flags, stage.p, sizeof(uint32_t) * np, hipMemcpyDeviceToHost, st));
         CR_HIP(hipStreamSynchronize(st));
+        if (b->reordered) {
+            std::vector<uint32_t> tmp(flags, flags + np);
+            for (size_t k = 0; k < np; k++) flags[b->order[k]] = tmp[k];
+        }
     }
     CR_HIP(hipStreamSynchronize(st));
     return CR_OK;

@@ -1513,6 +1513,15 @@ __global__ __launch_bounds__(kTeamWaves* kWave) void k_node_team(const PairDesc*
                         max_entries, bits_base, hand_base, aln_base, Xn_base, Tn_base, Wn_base, outs);
 }
 
+// out[order[k]] = res[k].sw: the scores of a batch whose launch order differs from the caller's pair order
+template <class Dummy = void>
+__global__ void k_scatter_sw_t(const PairResult* __restrict__ res, const int32_t* __restrict__ order,
+                               double* __restrict__ out, int n) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[order[k]] = res[k].sw;
+}
+constexpr auto k_scatter_sw = k_scatter_sw_t<>;
+
 // Team versions of k_seed and k_node for launches with few blocks (progressive alignment levels, small pair
 // lists): kTeamWaves waves sweep the strips of one pair concurrently (sweep_team); wave 0 then runs the same
 // traceback / Kabsch / mean code as the single-wave kernels.  Requires strips_of(n, R) <= kTeamWaves.
