@@ -232,6 +232,7 @@ struct cr_batch {
     struct Chunk {
         int64_t first, count;
         int n_max, m_max, max_aln;
+        int r = 0;                       // rows per lane of this chunk's kernels (pairs are grouped by it)
     };
     std::vector<Chunk> chunks;
 };
@@ -336,6 +337,37 @@ int launch_align_team(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_pa
 
 constexpr int64_t kTeamPairLimit = 128;
 int launch_seed_team(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm);   // cr_dropins.h
+
+// Rows per lane for a structure of n rows: the R in {2, 3, 5} with the cheapest strips.  A strip walks all m
+// columns; its measured cost per column (tools/calibrate_rows_per_lane.py, 4095 equal pairs per length, both
+// kernels) is 1 : 1.175 : 1.77 for R = 2 : 3 : 5 -- not proportional to R, because the narrower kernels keep more
+// waves per SIMD.  Ties go to the larger R.  300 rows -> 5 (one strip), 150 -> 3, 100 -> 2, 350 -> 3 (two strips).
+int rows_per_lane(int n) {
+    if (const char* env = std::getenv("CARETTA_FORCE_R")) {       // calibration runs
+        const int r = std::atoi(env);
+        if (r == 2 || r == 3 || r == 5) return r;
+    }
+    const int rs[3] = {5, 3, 2};
+    const double weight[3] = {1.77, 1.175, 1.0};
+    int best = 5;
+    double best_cost = 1e300;
+    for (int k = 0; k < 3; k++) {
+        const double c = cr::strips_of(n, rs[k]) * weight[k];
+        if (c < best_cost - 1e-9) {
+            best_cost = c;
+            best = rs[k];
+        }
+    }
+    return best;
+}
+
+int launch_seed_r(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
+    return R == 2 ? launch_seed_d<2>(b, ck, prm) : R == 3 ? launch_seed_d<3>(b, ck, prm) : launch_seed_d<5>(b, ck, prm);
+}
+
+int launch_align_r(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
+    return R == 2 ? launch_align<2>(b, ck, prm) : R == 3 ? launch_align<3>(b, ck, prm) : launch_align<5>(b, ck, prm);
+}
 
 bool gamma_ok(double g) { return std::isfinite(g) && g >= 1e-290; }
 
@@ -509,8 +541,7 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
         b->n_max = std::max(b->n_max, n);
         b->m_max = std::max(b->m_max, m);
     }
-    // rows per lane: 3 covers 192 rows in one strip, 5 covers 320
-    b->r_seed = b->r_align = (b->n_max <= 3 * cr::kWave) ? 3 : 5;
+    b->r_seed = b->r_align = rows_per_lane(b->n_max);
     // A pair list that cannot even give every CU one wave is latency bound: spread each pair over kTeamWaves waves.
     // Worth it only when the rows need more than one strip of the single-wave kernels' lag to amortise (n > 64).
     b->team = npairs > 0 && npairs <= kTeamPairLimit && b->n_max > cr::kWave && b->n_max <= 3 * cr::kTeamWaves * cr::kWave &&
@@ -531,8 +562,16 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
         const int64_t i = pairs[2 * (int64_t)p], j = pairs[2 * (int64_t)p + 1];
         return (b->offsets[i + 1] - b->offsets[i]) * (b->offsets[j + 1] - b->offsets[j]);
     };
-    if (!std::getenv("CARETTA_KEEP_ORDER"))          // (for measurements: launch in the caller's order)
-        std::stable_sort(b->order.begin(), b->order.end(), [&](int32_t a, int32_t c) { return cost(a) > cost(c); });
+    // Pairs are also grouped by the rows per lane that suit their row count (one launch pair per group, long rows
+    // first): a 90-residue structure in a 5-rows-per-lane kernel would use 18 of 64 lanes.
+    auto rows_of = [&](int32_t p) { return (int)(b->offsets[pairs[2 * (int64_t)p] + 1] - b->offsets[pairs[2 * (int64_t)p]]); };
+    auto group = [&](int32_t p) { return b->team ? b->r_seed : rows_per_lane(rows_of(p)); };
+    if (!std::getenv("CARETTA_KEEP_ORDER"))          // (for measurements: one group, the caller's order)
+        std::stable_sort(b->order.begin(), b->order.end(), [&](int32_t a, int32_t c) {
+            const int ga = group(a), gc = group(c);
+            return ga != gc ? ga > gc : cost(a) > cost(c);
+        });
+    const bool grouped = !std::getenv("CARETTA_KEEP_ORDER");
     b->reordered = false;
     for (int64_t k = 0; k < npairs; k++)
         if (b->order[(size_t)k] != k) {
@@ -551,18 +590,20 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
         pd.m = (int)(b->offsets[j + 1] - b->offsets[j]);
         pd.off_i = b->offsets[i];
         pd.off_j = b->offsets[j];
-        const int64_t dw = (int64_t)cr::strips_of(pd.n, b->r_seed) * cr::tblocks(pd.m, 16) * b->r_seed * cr::kWave;
-        const int64_t bw = (int64_t)cr::strips_of(pd.n, b->r_align) * cr::tblocks(pd.m, 8) * b->r_align * cr::kWave;
-        if (ck.count > 0 && dirs_off + bt_off + dw + bw > budget_words) {
+        const int R = grouped ? group((int32_t)orig) : b->r_seed;
+        const int64_t dw = (int64_t)cr::strips_of(pd.n, R) * cr::tblocks(pd.m, 16) * R * cr::kWave;
+        const int64_t bw = (int64_t)cr::strips_of(pd.n, R) * cr::tblocks(pd.m, 8) * R * cr::kWave;
+        if (ck.count > 0 && (R != ck.r || dirs_off + bt_off + dw + bw > budget_words)) {
             b->chunks.push_back(ck);
             ck = cr_batch::Chunk{p, 0, 0, 0, 0};
             dirs_off = bt_off = hand_off = 0;
         }
+        ck.r = R;
         pd.dirs_off = dirs_off;
         pd.bt_off = bt_off;
         pd.aln_off = aln_off;
         pd.hand_off = hand_off;
-        if (cr::strips_of(pd.n, std::min(b->r_seed, b->r_align)) > 1) hand_off += 3 * (int64_t)pd.m;
+        if (cr::strips_of(pd.n, R) > 1) hand_off += 3 * (int64_t)pd.m;
         hand_max = std::max(hand_max, hand_off);
         dirs_off += dw;
         bt_off += bw;
@@ -579,6 +620,7 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
         cells += nm;
     }
     if (ck.count > 0) b->chunks.push_back(ck);
+    if (!b->chunks.empty()) b->r_seed = b->r_align = b->chunks[0].r;     // single-chunk callers (drop-ins) read these
     b->max_aln = max_aln;
     b->aln_elems = aln_off;
     b->alg_bytes = bytes;
@@ -632,12 +674,10 @@ int cr_batch_run(cr_batch* b, const cr_params* params, double* d_sw_out) {
     }
     size_t evi = 1;
     for (const cr_batch::Chunk& ck : b->chunks) {
-        rc = b->team ? launch_seed_team(b->r_seed, b, ck, prm)
-                     : (b->r_seed == 3) ? launch_seed_d<3>(b, ck, prm) : launch_seed_d<5>(b, ck, prm);
+        rc = b->team ? launch_seed_team(ck.r, b, ck, prm) : launch_seed_r(ck.r, b, ck, prm);
         if (rc) return rc;
         if (prof) CR_HIP(hipEventRecord((*evl)[evi++], ctx->stream));
-        rc = b->team ? launch_align_team(b->r_align, b, ck, prm)
-                     : (b->r_align == 3) ? launch_align<3>(b, ck, prm) : launch_align<5>(b, ck, prm);
+        rc = b->team ? launch_align_team(ck.r, b, ck, prm) : launch_align_r(ck.r, b, ck, prm);
         if (rc) return rc;
         if (prof) CR_HIP(hipEventRecord((*evl)[evi++], ctx->stream));
     }

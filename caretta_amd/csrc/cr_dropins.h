@@ -324,12 +324,12 @@ int launch_seed_team(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_par
 // the seed kernel that matches the batch's layout (cr_batch_set_pairs chose team / rows per lane)
 int launch_seed_auto(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
     if (b->team) return launch_seed_team(b->r_seed, b, ck, prm);
-    return (b->r_seed == 3) ? launch_seed_d<3>(b, ck, prm) : launch_seed_d<5>(b, ck, prm);
+    return launch_seed_r(b->r_seed, b, ck, prm);
 }
 
 template <class... A>
 int launch_node(int R, A... a) {
-    return R == 3 ? launch_node_r<3>(a...) : launch_node_r<5>(a...);
+    return R == 2 ? launch_node_r<2>(a...) : R == 3 ? launch_node_r<3>(a...) : launch_node_r<5>(a...);
 }
 
 }  // namespace
