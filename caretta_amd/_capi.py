@@ -83,6 +83,31 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so (SONAME libamdhip64.so.7) and looks it
+    up as "libamdhip64.so"; libcaretta_hip.so needs "libamdhip64.so.7".  If ROCm's copy is loaded first, torch later
+    loads its own as well and its runtime finds no GPU ("No HIP GPUs are available").  Loading torch's copy first
+    (when a torch installation is present; torch itself is not imported) lets both resolve to the same object.
+    CARETTA_SYSTEM_HIP=1 keeps the system runtime."""
+    if os.environ.get("CARETTA_SYSTEM_HIP") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    libdir = Path(spec.origin).parent / "lib"
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        cand = libdir / name
+        if cand.exists():
+            try:
+                C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def load() -> C.CDLL:
     """Load the shared library (once).  Raises if it has not been built."""
     global _lib
@@ -93,6 +118,7 @@ def load() -> C.CDLL:
         raise CarettaHipError(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  caretta_amd has no CPU fallback.")
+    _share_torch_hip_runtime()
     lib = C.CDLL(str(path))
     lib.cr_last_error.restype = C.c_char_p
     lib.cr_last_error.argtypes = []

@@ -575,6 +575,19 @@ def test_integration_md_binding_snippet(golden):
         assert abs(m[i, j] - float(g[f"famA_p{p}_sw"])) <= 1e-9 * max(1.0, abs(m[i, j])) and m[i, j] == m[j, i]
 
 
+def test_sharded_matrix_single_rank_ragged():
+    """caretta_amd.distributed.pairwise_matrix_sharded on one rank: the kernels write the scores straight into a torch
+    tensor; a ragged family sends them through the scatter kernel (tests/sharded_single_rank_check.py; its own process,
+    because torch has to initialise its HIP runtime before libcaretta_hip does)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    script = Path(__file__).resolve().parent / "sharded_single_rank_check.py"
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "sharded matrix ok" in out.stdout
+
+
 def test_randomised_parity_run():
     """tests/fuzz_parity.py for a few seconds: random ragged batches, all parameter settings, the resident progressive
     alignment and the explicit-matrix drop-ins, everything bit-identical to the oracle (longer runs: profiles/)."""
