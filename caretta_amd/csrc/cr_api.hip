@@ -338,20 +338,21 @@ int launch_align_team(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_pa
 constexpr int64_t kTeamPairLimit = 128;
 int launch_seed_team(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm);   // cr_dropins.h
 
-// Rows per lane for a structure of n rows: the R in {2, 3, 5} with the cheapest strips.  A strip walks all m
+// Rows per lane for a structure of n rows: the R in {2, 3, 4, 5} with the cheapest strips.  A strip walks all m
 // columns; its measured cost per column (tools/calibrate_rows_per_lane.py, 4095 equal pairs per length, both
-// kernels) is 1 : 1.175 : 1.77 for R = 2 : 3 : 5 -- not proportional to R, because the narrower kernels keep more
-// waves per SIMD.  Ties go to the larger R.  300 rows -> 5 (one strip), 150 -> 3, 100 -> 2, 350 -> 3 (two strips).
+// kernels) is 1 : 1.175 : 1.534 : 1.77 for R = 2 : 3 : 4 : 5 -- not proportional to R, because the narrower kernels
+// keep more waves per SIMD.  Ties go to the larger R.  300 rows -> 5 (one strip), 230 -> 4, 150 -> 3, 100 -> 2,
+// 350 -> 3 (two strips), 450 -> 4 (two strips).
 int rows_per_lane(int n) {
     if (const char* env = std::getenv("CARETTA_FORCE_R")) {       // calibration runs
         const int r = std::atoi(env);
-        if (r == 2 || r == 3 || r == 5) return r;
+        if (r >= 2 && r <= 5) return r;
     }
-    const int rs[3] = {5, 3, 2};
-    const double weight[3] = {1.77, 1.175, 1.0};
+    const int rs[4] = {5, 4, 3, 2};
+    const double weight[4] = {1.77, 1.534, 1.175, 1.0};
     int best = 5;
     double best_cost = 1e300;
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < 4; k++) {
         const double c = cr::strips_of(n, rs[k]) * weight[k];
         if (c < best_cost - 1e-9) {
             best_cost = c;
@@ -362,11 +363,13 @@ int rows_per_lane(int n) {
 }
 
 int launch_seed_r(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
-    return R == 2 ? launch_seed_d<2>(b, ck, prm) : R == 3 ? launch_seed_d<3>(b, ck, prm) : launch_seed_d<5>(b, ck, prm);
+    return R == 2 ? launch_seed_d<2>(b, ck, prm) : R == 3 ? launch_seed_d<3>(b, ck, prm)
+         : R == 4 ? launch_seed_d<4>(b, ck, prm) : launch_seed_d<5>(b, ck, prm);
 }
 
 int launch_align_r(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
-    return R == 2 ? launch_align<2>(b, ck, prm) : R == 3 ? launch_align<3>(b, ck, prm) : launch_align<5>(b, ck, prm);
+    return R == 2 ? launch_align<2>(b, ck, prm) : R == 3 ? launch_align<3>(b, ck, prm)
+         : R == 4 ? launch_align<4>(b, ck, prm) : launch_align<5>(b, ck, prm);
 }
 
 bool gamma_ok(double g) { return std::isfinite(g) && g >= 1e-290; }

@@ -329,7 +329,7 @@ int launch_seed_auto(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& pr
 
 template <class... A>
 int launch_node(int R, A... a) {
-    return R == 2 ? launch_node_r<2>(a...) : R == 3 ? launch_node_r<3>(a...) : launch_node_r<5>(a...);
+    return R == 2 ? launch_node_r<2>(a...) : R == 3 ? launch_node_r<3>(a...) : R == 4 ? launch_node_r<4>(a...) : launch_node_r<5>(a...);
 }
 
 }  // namespace

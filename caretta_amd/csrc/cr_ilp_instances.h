@@ -7,9 +7,10 @@
 #define CR_ILP_SEED_INSTANCES(X) \
     X(2, 4, true) X(2, 4, false) X(2, 8, true) X(2, 8, false) X(2, 10, true) X(2, 10, false) X(2, 16, true) X(2, 16, false) \
     X(3, 4, true) X(3, 4, false) X(3, 8, true) X(3, 8, false) X(3, 10, true) X(3, 10, false) X(3, 16, true) X(3, 16, false) \
+    X(4, 4, true) X(4, 4, false) X(4, 8, true) X(4, 8, false) X(4, 10, true) X(4, 10, false) X(4, 16, true) X(4, 16, false) \
     X(5, 4, true) X(5, 4, false) X(5, 8, true) X(5, 8, false) X(5, 10, true) X(5, 10, false) X(5, 16, true) X(5, 16, false)
 
-#define CR_ILP_ALIGN_INSTANCES(X) X(2, true) X(2, false) X(3, true) X(3, false)
+#define CR_ILP_ALIGN_INSTANCES(X) X(2, true) X(2, false) X(3, true) X(3, false) X(4, true) X(4, false)
 
 #define CR_SEED_SIGNATURE(R, D, ZG)                                                                                  \
     __global__ void cr::k_seed<R, D, ZG>(const cr::PairDesc*, const double*, int, const double*, double, double, int, \
