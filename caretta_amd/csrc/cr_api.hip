@@ -199,6 +199,10 @@ struct cr_context {
     std::vector<std::vector<hipEvent_t>> ev;
     int slots = 0;
     int64_t runs_recorded = 0;
+    // Side streams for batches whose pairs fall into several rows-per-lane groups: the groups are independent, and
+    // run side by side they fill each other's partial last rounds (created on first use).
+    std::vector<hipStream_t> side;
+    std::vector<hipEvent_t> sync_ev;
 };
 
 struct cr_batch {
@@ -222,6 +226,7 @@ struct cr_batch {
     DevBuf<int32_t> aln;
     DevBuf<cr::Transform> xf;
     DevBuf<double> seed_score;
+    hipStream_t launch_stream = nullptr;  // stream of the next launch_seed / launch_align (null: the context's)
     DevBuf<double> sw_stage;            // cr_batch_fetch_scores: the sw field gathered on the device
     DevBuf<cr::PairResult> res;
     int64_t aln_elems = 0;
@@ -233,6 +238,7 @@ struct cr_batch {
         int64_t first, count;
         int n_max, m_max, max_aln;
         int r = 0;                       // rows per lane of this chunk's kernels (pairs are grouped by it)
+        int lane = 0;                    // 0: the context's stream; k > 0: side stream k-1 (one lane per group)
     };
     std::vector<Chunk> chunks;
 };
@@ -264,7 +270,7 @@ int launch_seed_zg(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm)
     const size_t lds = sizeof(double) * std::max(fill, (size_t)cr::kExpDoubles + cr::trace_lds_doubles(R, entries));
     int rc = allow_lds(cr::k_seed<R, D, ZG>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((cr::k_seed<R, D, ZG>), dim3((unsigned)ck.count), dim3(cr::kWave), lds, b->ctx->stream,
+    hipLaunchKernelGGL((cr::k_seed<R, D, ZG>), dim3((unsigned)ck.count), dim3(cr::kWave), lds, b->launch_stream ? b->launch_stream : b->ctx->stream,
                        b->pairs.p + ck.first, b->tensors.p, (int)b->d, b->coords.p, prm.gamma_tensor, prm.sw_gap,
                        entries, b->dirs.p, b->hand.p, b->xf.p + ck.first, b->seed_score.p + ck.first);
     CR_HIP(hipGetLastError());
@@ -295,7 +301,7 @@ int launch_align_zg(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm
     const size_t lds = sizeof(double) * std::max(fill, (size_t)cr::kExpDoubles + cr::trace_lds_doubles(R, entries));
     int rc = allow_lds(cr::k_align<R, ZG>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((cr::k_align<R, ZG>), dim3((unsigned)ck.count), dim3(cr::kWave), lds, b->ctx->stream,
+    hipLaunchKernelGGL((cr::k_align<R, ZG>), dim3((unsigned)ck.count), dim3(cr::kWave), lds, b->launch_stream ? b->launch_stream : b->ctx->stream,
                        b->pairs.p + ck.first, b->coords.p, b->xf.p + ck.first, b->seed_score.p + ck.first,
                        prm.gamma_coords, prm.sw_gap, prm.gap_open, prm.gap_extend, entries, b->bits.p, b->hand.p, b->aln.p,
                        b->res.p + ck.first);
@@ -336,6 +342,7 @@ int launch_align_team(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_pa
 }
 
 constexpr int64_t kTeamPairLimit = 128;
+constexpr int kGroupLanes = 4;             // streams that row-per-lane groups are spread over
 int launch_seed_team(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm);   // cr_dropins.h
 
 // Rows per lane for a structure of n rows: the R in {2, 3, 4, 5} with the cheapest strips.  A strip walks all m
@@ -451,6 +458,8 @@ int cr_context_destroy(cr_context* ctx) {
     (void)hipSetDevice(ctx->device);
     for (auto& l : ctx->ev)
         for (auto& e : l) (void)hipEventDestroy(e);
+    for (auto& e : ctx->sync_ev) (void)hipEventDestroy(e);
+    for (auto& st : ctx->side) (void)hipStreamDestroy(st);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return CR_OK;
@@ -582,6 +591,20 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
             break;
         }
     int64_t dirs_off = 0, bt_off = 0, aln_off = 0, max_aln = 0, dirs_max = 0, bits_max = 0, hand_off = 0, hand_max = 0;
+    // Each group owns a region of the decision scratch (its chunks run in order on the group's stream and reuse the
+    // region; different groups run side by side); the budget is shared equally between the groups.
+    int ngroups = 0;
+    {
+        int last = -1;
+        for (int64_t p = 0; p < npairs; p++) {
+            const int g = grouped ? group(b->order[(size_t)p]) : b->r_seed;
+            if (g != last) ngroups++;
+            last = g;
+        }
+    }
+    budget_words /= std::max(ngroups, 1);
+    int64_t dirs_base = 0, bt_base = 0, hand_base = 0;
+    int lane = 0;
     double bytes = 0.0, cells = 0.0;
     b->chunks.clear();
     cr_batch::Chunk ck{0, 0, 0, 0, 0};
@@ -596,12 +619,22 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
         const int R = grouped ? group((int32_t)orig) : b->r_seed;
         const int64_t dw = (int64_t)cr::strips_of(pd.n, R) * cr::tblocks(pd.m, 16) * R * cr::kWave;
         const int64_t bw = (int64_t)cr::strips_of(pd.n, R) * cr::tblocks(pd.m, 8) * R * cr::kWave;
-        if (ck.count > 0 && (R != ck.r || dirs_off + bt_off + dw + bw > budget_words)) {
+        if (ck.count > 0 && R != ck.r) {                       // next group: its own region and stream
             b->chunks.push_back(ck);
             ck = cr_batch::Chunk{p, 0, 0, 0, 0};
-            dirs_off = bt_off = hand_off = 0;
+            dirs_base = dirs_off = dirs_max;
+            bt_base = bt_off = bits_max;
+            hand_base = hand_off = hand_max;
+            lane = (lane + 1) % kGroupLanes;
+        } else if (ck.count > 0 && (dirs_off - dirs_base) + (bt_off - bt_base) + dw + bw > budget_words) {
+            b->chunks.push_back(ck);                           // same group, scratch budget used up: reuse the region
+            ck = cr_batch::Chunk{p, 0, 0, 0, 0};
+            dirs_off = dirs_base;
+            bt_off = bt_base;
+            hand_off = hand_base;
         }
         ck.r = R;
+        ck.lane = lane;
         pd.dirs_off = dirs_off;
         pd.bt_off = bt_off;
         pd.aln_off = aln_off;
@@ -665,24 +698,46 @@ int cr_batch_run(cr_batch* b, const cr_params* params, double* d_sw_out) {
                "gap penalties must be finite");
     const bool prof = ctx->slots > 0;
     std::vector<hipEvent_t>* evl = nullptr;
-    if (prof) {
+    if (prof) {                                                   // three events per chunk: start, seed done, align done
         evl = &ctx->ev[(size_t)(ctx->runs_recorded % ctx->slots)];
-        const size_t need = 1 + 2 * b->chunks.size();
+        const size_t need = 3 * b->chunks.size();
         while (evl->size() < need) {
             hipEvent_t e;
             CR_HIP(hipEventCreate(&e));
             evl->push_back(e);
         }
-        CR_HIP(hipEventRecord((*evl)[0], ctx->stream));
     }
-    size_t evi = 1;
+    int lanes_used = 1;
+    for (const cr_batch::Chunk& ck : b->chunks) lanes_used = std::max(lanes_used, ck.lane + 1);
+    if (lanes_used > 1) {                                         // fork: the side streams start after the work queued so far
+        while ((int)ctx->side.size() < lanes_used - 1) {
+            hipStream_t st;
+            CR_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            ctx->side.push_back(st);
+        }
+        while ((int)ctx->sync_ev.size() < lanes_used) {
+            hipEvent_t e;
+            CR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->sync_ev.push_back(e);
+        }
+        CR_HIP(hipEventRecord(ctx->sync_ev[0], ctx->stream));
+        for (int k = 1; k < lanes_used; k++) CR_HIP(hipStreamWaitEvent(ctx->side[(size_t)k - 1], ctx->sync_ev[0], 0));
+    }
+    size_t evi = 0;
     for (const cr_batch::Chunk& ck : b->chunks) {
+        hipStream_t st = ck.lane == 0 ? ctx->stream : ctx->side[(size_t)ck.lane - 1];
+        b->launch_stream = st;
+        if (prof) (void)hipEventRecord((*evl)[evi++], st);
         rc = b->team ? launch_seed_team(ck.r, b, ck, prm) : launch_seed_r(ck.r, b, ck, prm);
+        if (!rc && prof) (void)hipEventRecord((*evl)[evi++], st);
+        if (!rc) rc = b->team ? launch_align_team(ck.r, b, ck, prm) : launch_align_r(ck.r, b, ck, prm);
+        if (!rc && prof) (void)hipEventRecord((*evl)[evi++], st);
+        b->launch_stream = nullptr;
         if (rc) return rc;
-        if (prof) CR_HIP(hipEventRecord((*evl)[evi++], ctx->stream));
-        rc = b->team ? launch_align_team(ck.r, b, ck, prm) : launch_align_r(ck.r, b, ck, prm);
-        if (rc) return rc;
-        if (prof) CR_HIP(hipEventRecord((*evl)[evi++], ctx->stream));
+    }
+    for (int k = 1; k < lanes_used; k++) {                         // join
+        CR_HIP(hipEventRecord(ctx->sync_ev[(size_t)k], ctx->side[(size_t)k - 1]));
+        CR_HIP(hipStreamWaitEvent(ctx->stream, ctx->sync_ev[(size_t)k], 0));
     }
     if (d_sw_out && b->reordered) {
         hipLaunchKernelGGL(cr::k_scatter_sw, dim3((unsigned)((b->npairs + 255) / 256)), dim3(256), 0, ctx->stream, b->res.p,
@@ -709,10 +764,10 @@ int cr_batch_stage_ms(cr_batch* b, float ms[CR_NUM_STAGES], int* runs_averaged) 
     double acc[CR_NUM_STAGES] = {};
     for (int64_t r = 0; r < n; r++) {
         const std::vector<hipEvent_t>& ev = ctx->ev[(size_t)r];
-        for (size_t c = 0; c < b->chunks.size() && 2 * c + 2 < ev.size(); c++) {
+        for (size_t c = 0; c < b->chunks.size() && 3 * c + 2 < ev.size(); c++) {
             for (int s = 0; s < CR_NUM_STAGES; s++) {
                 float t = 0.f;
-                CR_HIP(hipEventElapsedTime(&t, ev[2 * c + s], ev[2 * c + s + 1]));
+                CR_HIP(hipEventElapsedTime(&t, ev[3 * c + s], ev[3 * c + s + 1]));
                 acc[s] += t;
             }
         }
