@@ -570,20 +570,31 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     // the tail).  Stable, so equal-length inputs keep the caller's order and nothing is permuted.
     b->order.resize((size_t)npairs);
     for (int64_t p = 0; p < npairs; p++) b->order[(size_t)p] = (int32_t)p;
-    auto cost = [&](int32_t p) {
-        const int64_t i = pairs[2 * (int64_t)p], j = pairs[2 * (int64_t)p + 1];
-        return (b->offsets[i + 1] - b->offsets[i]) * (b->offsets[j + 1] - b->offsets[j]);
-    };
+    std::vector<int64_t> cost_of((size_t)npairs);               // sort keys, computed once per pair
+    std::vector<int8_t> group_of((size_t)npairs);
+    {
+        std::vector<int8_t> r_of_len;                             // rows_per_lane by row count (it reads the environment)
+        for (int64_t p = 0; p < npairs; p++) {
+            const int64_t i = pairs[2 * p], j = pairs[2 * p + 1];
+            const int64_t n = b->offsets[i + 1] - b->offsets[i], m = b->offsets[j + 1] - b->offsets[j];
+            cost_of[(size_t)p] = n * m;
+            if ((int64_t)r_of_len.size() <= n) r_of_len.resize((size_t)n + 1, 0);
+            if (!r_of_len[(size_t)n]) r_of_len[(size_t)n] = (int8_t)rows_per_lane((int)n);
+            group_of[(size_t)p] = r_of_len[(size_t)n];
+        }
+    }
+    auto cost = [&](int32_t p) { return cost_of[(size_t)p]; };
     // Pairs are also grouped by the rows per lane that suit their row count (one launch pair per group, long rows
     // first): a 90-residue structure in a 5-rows-per-lane kernel would use 18 of 64 lanes.
-    auto rows_of = [&](int32_t p) { return (int)(b->offsets[pairs[2 * (int64_t)p] + 1] - b->offsets[pairs[2 * (int64_t)p]]); };
-    auto group = [&](int32_t p) { return b->team ? b->r_seed : rows_per_lane(rows_of(p)); };
-    if (!std::getenv("CARETTA_KEEP_ORDER"))          // (for measurements: one group, the caller's order)
+    const bool team_batch = b->team;
+    const int team_r = b->r_seed;
+    auto group = [&](int32_t p) { return team_batch ? team_r : (int)group_of[(size_t)p]; };
+    const bool grouped = !std::getenv("CARETTA_KEEP_ORDER");
+    if (grouped)                                     // (CARETTA_KEEP_ORDER, for measurements: one group, the caller's order)
         std::stable_sort(b->order.begin(), b->order.end(), [&](int32_t a, int32_t c) {
             const int ga = group(a), gc = group(c);
             return ga != gc ? ga > gc : cost(a) > cost(c);
         });
-    const bool grouped = !std::getenv("CARETTA_KEEP_ORDER");
     b->reordered = false;
     for (int64_t k = 0; k < npairs; k++)
         if (b->order[(size_t)k] != k) {

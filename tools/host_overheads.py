@@ -22,7 +22,7 @@ def main():
     msa = ma.MultipleAlignment(prots)
     ctx = default_context()
     params = make_params(gamma_tensor=7.0, gamma_coords=0.03)
-    for rep in range(3):
+    for rep in range(int(sys.argv[3]) if len(sys.argv) > 3 else 3):
         t = [time.perf_counter()]
         coords, tensors, offsets = ma.pack_proteins(msa.sequences)
         t.append(time.perf_counter())
