@@ -590,7 +590,10 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     const int team_r = b->r_seed;
     auto group = [&](int32_t p) { return team_batch ? team_r : (int)group_of[(size_t)p]; };
     const bool grouped = !std::getenv("CARETTA_KEEP_ORDER");
-    if (grouped)                                     // (CARETTA_KEEP_ORDER, for measurements: one group, the caller's order)
+    bool uniform = true;                             // equal keys everywhere (all BASELINE configs): nothing to sort
+    for (int64_t p = 1; p < npairs && uniform; p++)
+        uniform = cost_of[(size_t)p] == cost_of[0] && group_of[(size_t)p] == group_of[0];
+    if (grouped && !uniform)                         // (CARETTA_KEEP_ORDER, for measurements: one group, the caller's order)
         std::stable_sort(b->order.begin(), b->order.end(), [&](int32_t a, int32_t c) {
             const int ga = group(a), gc = group(c);
             return ga != gc ? ga > gc : cost(a) > cost(c);
