@@ -341,7 +341,7 @@ int launch_align_team(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_pa
     }
 }
 
-constexpr int64_t kTeamPairLimit = 128;
+constexpr int64_t kTeamPairLimit = 256;
 constexpr int kGroupLanes = 4;             // streams that row-per-lane groups are spread over
 int launch_seed_team(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm);   // cr_dropins.h
 
@@ -555,8 +555,12 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     }
     b->r_seed = b->r_align = rows_per_lane(b->n_max);
     // A pair list that cannot even give every CU one wave is latency bound: spread each pair over kTeamWaves waves.
-    // Worth it only when the rows need more than one strip of the single-wave kernels' lag to amortise (n > 64).
-    b->team = npairs > 0 && npairs <= kTeamPairLimit && b->n_max > cr::kWave && b->n_max <= 3 * cr::kTeamWaves * cr::kWave &&
+    // Measured (tools/calibrate_team_limit.py): with 300 rows the team kernels win up to ~250 pairs (0.66 vs 0.76 ms
+    // per pass) and lose from ~450 on; with 150 rows (three 64-row strips against one 192-row strip of the
+    // single-wave kernels) they never win.  Hence: at most 256 pairs, more than 192 rows.
+    int64_t team_limit = kTeamPairLimit;
+    if (const char* env = std::getenv("CARETTA_TEAM_PAIRS")) team_limit = std::atoll(env);   // calibration
+    b->team = npairs > 0 && npairs <= team_limit && b->n_max > 3 * cr::kWave && b->n_max <= 3 * cr::kTeamWaves * cr::kWave &&
               !std::getenv("CARETTA_NO_TEAM");
     if (b->team) b->r_seed = b->r_align = (b->n_max + cr::kTeamWaves * cr::kWave - 1) / (cr::kTeamWaves * cr::kWave);
     // scratch budget per chunk (decision words); CARETTA_SCRATCH_MB overrides the 8 GiB default

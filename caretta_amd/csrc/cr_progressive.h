@@ -70,9 +70,9 @@ int run_level(cr_progressive* h, const std::vector<int64_t>& ids, const cr_param
     int n_max = 0, m_max = 0, cap_max = 0;
     for (int64_t id : ids) n_max = std::max<int>(n_max, (int)h->len[(size_t)h->child1[(size_t)id]]);
     // few blocks per launch: the team kernels (kTeamWaves waves per node) whenever the rows fit their strips
-    const bool team = n_max <= 3 * cr::kTeamWaves * cr::kWave && !std::getenv("CARETTA_NO_TEAM");
-    const int R = team ? (n_max + cr::kTeamWaves * cr::kWave - 1) / (cr::kTeamWaves * cr::kWave)
-                       : (n_max <= 3 * cr::kWave ? 3 : 5);
+    // (with at most 192 rows one strip of a single-wave kernel beats three 64-row strips of the team, cr_batch_set_pairs)
+    const bool team = n_max > 3 * cr::kWave && n_max <= 3 * cr::kTeamWaves * cr::kWave && !std::getenv("CARETTA_NO_TEAM");
+    const int R = team ? (n_max + cr::kTeamWaves * cr::kWave - 1) / (cr::kTeamWaves * cr::kWave) : rows_per_lane(n_max);
     int64_t dirs_off = 0, bt_off = 0, aln_off = 0, hand_off = 0, rows = h->used;
     for (size_t x = 0; x < count; x++) {
         const int64_t id = ids[x], c1 = h->child1[(size_t)id], c2 = h->child2[(size_t)id];
@@ -114,7 +114,7 @@ int run_level(cr_progressive* h, const std::vector<int64_t>& ids, const cr_param
     CR_HIP(hipMemcpyAsync(h->d_nodes.p, nodes, sizeof(cr::NodeDesc) * count, hipMemcpyHostToDevice, stream));
     b.r_seed = b.r_align = R;
     const cr_batch::Chunk ck{0, (int64_t)count, n_max, m_max, cap_max};
-    rc = team ? launch_seed_team(R, &b, ck, prm) : (R == 3) ? launch_seed_d<3>(&b, ck, prm) : launch_seed_d<5>(&b, ck, prm);
+    rc = team ? launch_seed_team(R, &b, ck, prm) : launch_seed_r(R, &b, ck, prm);
     if (rc) return rc;
     rc = team ? launch_node_team(R, stream, (int)count, n_max, m_max, cap_max, b.pairs.p, b.coords.p, b.tensors.p, (int)h->d,
                                  h->weights.p, h->d_nodes.p, b.xf.p, prm, gamma_weight, b.bits.p, b.hand.p, b.aln.p, b.coords.p,
