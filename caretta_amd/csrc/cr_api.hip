@@ -3,8 +3,12 @@
 #include "../../include/caretta_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <algorithm>
+#include <thread>
+#include <functional>
+#include <atomic>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>

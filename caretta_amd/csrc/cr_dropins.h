@@ -725,6 +725,95 @@ int cr_assemble_matrix(const int32_t* pairs, const double* scores, int64_t npair
     return CR_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+// Helper threads for the two row-parallel passes of neighbor joining (row sums, Q search) on large matrices.
+// Every row is still summed / searched by ONE thread in the reference's order, so results do not depend on the
+// thread count.  run(f) executes f(t) for t = 0 .. threads-1 (t = 0 on the caller); helpers poll for the next
+// pass (passes of one call are microseconds apart) and yield between polls.
+struct NjTeam {
+    int threads = 1;
+    std::vector<std::thread> helpers;
+    std::atomic<int64_t> generation{0};
+    std::atomic<int> done{0};
+    std::atomic<bool> quit{false};
+    const std::function<void(int)>* job = nullptr;
+    explicit NjTeam(int t) : threads(t) {
+        for (int x = 1; x < threads; x++) helpers.emplace_back([this, x] { work(x); });
+    }
+    ~NjTeam() { stop(); }
+    void work(int t) {
+        int64_t seen = 0;
+        for (;;) {
+            int spins = 0;
+            while (generation.load(std::memory_order_acquire) == seen) {
+                if (quit.load(std::memory_order_acquire)) return;
+                if (++spins > 256) {
+                    std::this_thread::yield();
+                    spins = 0;
+                } else {
+                    __builtin_ia32_pause();
+                }
+            }
+            seen++;
+            (*job)(t);
+            done.fetch_add(1, std::memory_order_release);
+        }
+    }
+    void run(const std::function<void(int)>& f) {
+        job = &f;
+        done.store(0, std::memory_order_relaxed);
+        generation.fetch_add(1, std::memory_order_release);
+        f(0);
+        const int need = (int)helpers.size();
+        int spins = 0;
+        while (done.load(std::memory_order_acquire) < need) {
+            if (++spins > 256) {
+                std::this_thread::yield();
+                spins = 0;
+            } else {
+                __builtin_ia32_pause();
+            }
+        }
+    }
+    void stop() {
+        if (helpers.empty()) return;
+        quit.store(true, std::memory_order_release);
+        for (std::thread& h : helpers) h.join();
+        helpers.clear();
+        threads = 1;
+    }
+};
+
+// CPUs this process may really use: the cgroup quota (cpu.max) when there is one -- spinning helpers beyond the
+// quota get the whole process throttled --, else the affinity mask.  CARETTA_NJ_THREADS overrides.
+int nj_threads() {
+    if (const char* env = std::getenv("CARETTA_NJ_THREADS")) {
+        const int t = std::atoi(env);
+        if (t >= 1) return std::min(t, 64);
+    }
+    int cpus = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = std::min(cpus, CPU_COUNT(&set));
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32] = {0};
+        long long period = 0;
+        if (std::fscanf(f, "%31s %lld", quota, &period) == 2 && std::strcmp(quota, "max") != 0 && period > 0)
+            cpus = std::min<long long>(cpus, std::max<long long>(1, std::atoll(quota) / period));
+        std::fclose(f);
+    }
+    // half of what is there, at most 16: the passes are memory bound well before that
+    return std::max(1, std::min(16, cpus / 2));
+}
+
+constexpr int64_t kNjParallelNodes = 640;      // below this one thread is as fast (the matrix sits in its L2)
+
+}  // namespace
+
+extern "C" {
+
 // neighbor_joining.py:19-157.  The reference recomputes both row sums for every (i, j) (O(P^4));
 // here each row sum is formed once per iteration with the same sequential left-to-right order
 // (numba's np.sum), so every Q value, hence every decision, is bit-identical to the reference's.
@@ -773,10 +862,10 @@ int cr_neighbor_joining(const double* D0, int64_t P, uint64_t* tree, double* bl)
     }
     // Row sums of 8 rows at a time: each row is still summed left to right, but the 8 add chains are
     // independent, so the loop runs at the adder's throughput, not its latency.
-    auto rowsums = [&](int64_t lo) {
+    auto rowsums = [&](int64_t lo, int64_t row_begin, int64_t row_end) {
         const int64_t cnt = W - lo;
-        int64_t i = lo;
-        for (; i + 8 <= W; i += 8) {
+        int64_t i = row_begin;
+        for (; i + 8 <= row_end; i += 8) {
             const double* r = &A[(size_t)(i * W + lo)];
             double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
             for (int64_t k = 0; k < cnt; k++) {
@@ -792,7 +881,7 @@ int cr_neighbor_joining(const double* D0, int64_t P, uint64_t* tree, double* bl)
             rs[(size_t)i] = s0; rs[(size_t)i + 1] = s1; rs[(size_t)i + 2] = s2; rs[(size_t)i + 3] = s3;
             rs[(size_t)i + 4] = s4; rs[(size_t)i + 5] = s5; rs[(size_t)i + 6] = s6; rs[(size_t)i + 7] = s7;
         }
-        for (; i < W; i++) {
+        for (; i < row_end; i++) {
             const double* r = &A[(size_t)(i * W + lo)];
             double s = 0.0;
             for (int64_t k = 0; k < cnt; k++) s += r[k];
@@ -800,6 +889,7 @@ int cr_neighbor_joining(const double* D0, int64_t P, uint64_t* tree, double* bl)
         }
     };
     typedef double v4 __attribute__((ext_vector_type(4)));
+    NjTeam team(P >= kNjParallelNodes ? nj_threads() : 1);
     int64_t index = 0, nint = 0;
     while (n > 3) {
         if (left < 0) {
@@ -815,50 +905,93 @@ int cr_neighbor_joining(const double* D0, int64_t P, uint64_t* tree, double* bl)
             compact(old.data(), sw, slots, ids);
         }
         const int64_t lo = left + 1;
-        rowsums(lo);
-        for (int64_t x = lo; x < W; x++) rsx[(size_t)x] = alive[(size_t)x] ? rs[(size_t)x] : -inf;
-        // first minimum of Q in row-major order (neighbor_joining.py:98-121, strict <): per row the minimum
-        // value (min is exact, so four interleaved chains give the same value) and, only when it beats the
-        // running minimum, the first column that attains it.
+        const double nm2 = (double)(n - 2);
+        struct Best {
+            double q;
+            int64_t i, j;
+        };
+        // first minimum of Q in row-major order (neighbor_joining.py:98-121, strict <) over the rows [row_begin, row_end)
+        auto search = [&](int64_t row_begin, int64_t row_end) {
+            double min_q = inf;
+            int64_t mi = 0, mj = 0;
+            for (int64_t i = row_begin; i < row_end; i++) {
+                if (!alive[(size_t)i]) continue;
+                const double* r = &A[(size_t)(i * W)];
+                const double ri = rs[(size_t)i];
+                auto qv = [&](int64_t j) { return (nm2 * r[j] - ri) - rsx[(size_t)j]; };
+                double m = inf;
+                v4 mv = {inf, inf, inf, inf};
+                int64_t j = lo;
+                for (; j + 4 <= W; j += 4) {
+                    if (i >= j && i < j + 4) {                       // the block holding the diagonal: i != j
+                        for (int64_t c = j; c < j + 4; c++)
+                            if (c != i) {
+                                const double q = qv(c);
+                                m = q < m ? q : m;
+                            }
+                        continue;
+                    }
+                    v4 rv, sv;
+                    std::memcpy(&rv, r + j, sizeof(rv));
+                    std::memcpy(&sv, &rsx[(size_t)j], sizeof(sv));
+                    const v4 q = (rv * nm2 - ri) - sv;
+                    mv = q < mv ? q : mv;
+                }
+                for (; j < W; j++)
+                    if (j != i) {
+                        const double q = qv(j);
+                        m = q < m ? q : m;
+                    }
+                for (int c = 0; c < 4; c++) m = mv[c] < m ? mv[c] : m;
+                if (m < min_q) {
+                    int64_t c = lo;
+                    while (c == i || qv(c) != m) c++;
+                    mi = i;
+                    mj = c;
+                    min_q = m;
+                }
+            }
+            return Best{min_q, mi, mj};
+        };
         double min_q = inf;
         int64_t mi = 0, mj = 0;
-        const double nm2 = (double)(n - 2);
-        for (int64_t i = lo; i < W; i++) {
-            if (!alive[(size_t)i]) continue;
-            const double* r = &A[(size_t)(i * W)];
-            const double ri = rs[(size_t)i];
-            auto qv = [&](int64_t j) { return (nm2 * r[j] - ri) - rsx[(size_t)j]; };
-            double m = inf;
-            v4 mv = {inf, inf, inf, inf};
-            int64_t j = lo;
-            for (; j + 4 <= W; j += 4) {
-                if (i >= j && i < j + 4) {                       // the block holding the diagonal: i != j
-                    for (int64_t c = j; c < j + 4; c++)
-                        if (c != i) {
-                            const double q = qv(c);
-                            m = q < m ? q : m;
-                        }
-                    continue;
+        if (team.threads > 1 && n >= kNjParallelNodes) {
+            // contiguous row ranges, one per thread; the per-range minima combined in range order with a strict <
+            // give the first minimum in row-major order again
+            const int T = team.threads;
+            const int64_t chunk = (((W - lo) + T - 1) / T + 7) / 8 * 8;
+            auto range = [&](int t, int64_t& b0, int64_t& b1) {
+                b0 = std::min(W, lo + t * chunk);
+                b1 = std::min(W, b0 + chunk);
+            };
+            const std::function<void(int)> sums = [&](int t) {
+                int64_t b0, b1;
+                range(t, b0, b1);
+                rowsums(lo, b0, b1);
+            };
+            team.run(sums);
+            for (int64_t x = lo; x < W; x++) rsx[(size_t)x] = alive[(size_t)x] ? rs[(size_t)x] : -inf;
+            std::vector<Best> best((size_t)T);
+            const std::function<void(int)> find = [&](int t) {
+                int64_t b0, b1;
+                range(t, b0, b1);
+                best[(size_t)t] = search(b0, b1);
+            };
+            team.run(find);
+            for (int t = 0; t < T; t++)
+                if (best[(size_t)t].q < min_q) {
+                    min_q = best[(size_t)t].q;
+                    mi = best[(size_t)t].i;
+                    mj = best[(size_t)t].j;
                 }
-                v4 rv, sv;
-                std::memcpy(&rv, r + j, sizeof(rv));
-                std::memcpy(&sv, &rsx[(size_t)j], sizeof(sv));
-                const v4 q = (rv * nm2 - ri) - sv;
-                mv = q < mv ? q : mv;
-            }
-            for (; j < W; j++)
-                if (j != i) {
-                    const double q = qv(j);
-                    m = q < m ? q : m;
-                }
-            for (int c = 0; c < 4; c++) m = mv[c] < m ? mv[c] : m;
-            if (m < min_q) {
-                int64_t c = lo;
-                while (c == i || qv(c) != m) c++;
-                mi = i;
-                mj = c;
-                min_q = m;
-            }
+        } else {
+            team.stop();
+            rowsums(lo, lo, W);
+            for (int64_t x = lo; x < W; x++) rsx[(size_t)x] = alive[(size_t)x] ? rs[(size_t)x] : -inf;
+            const Best bst = search(lo, W);
+            min_q = bst.q;
+            mi = bst.i;
+            mj = bst.j;
         }
         const double dij = A[(size_t)(mi * W + mj)];
         const double di = 0.5 * dij + (0.5 / (double)(n - 2)) * (rs[(size_t)mi] - rs[(size_t)mj]);
