@@ -81,6 +81,23 @@ def test_neighbor_joining_matches_oracle_sequential(oracle):
         assert np.array_equal(tree, otree) and np.array_equal(bl, obl)
 
 
+def test_neighbor_joining_threaded_matches_oracle(oracle, monkeypatch):
+    """Above 640 taxa the two O(n^2) passes are shared between helper threads; the tree must not depend on the thread
+    count (every row is summed and searched by one thread in the reference's order), incl. tie-heavy matrices and the
+    compaction / switch back to one thread below 640 live nodes."""
+    from caretta_amd import neighbor_joining as nj
+    rng = np.random.default_rng(4)
+    x = rng.normal(size=(700, 4))
+    d = np.sqrt(((x[:, None] - x[None]) ** 2).sum(-1))
+    ties = np.round(d * 2) / 2
+    for mat in (d, ties):
+        otree, obl = oracle.neighbor_joining(mat, hoist=True)
+        for threads in ("1", "3", "8"):
+            monkeypatch.setenv("CARETTA_NJ_THREADS", threads)
+            tree, bl = nj.neighbor_joining(mat)
+            assert np.array_equal(tree, otree) and np.array_equal(bl, obl), threads
+
+
 def test_common_positions_and_assembly(golden):
     from caretta_amd import engine, helper
     g = golden("f1_misc.npz")
