@@ -341,7 +341,9 @@ int launch_align_team(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_pa
     switch (R) {
         case 1: return zg ? launch_align_team_zg<1, true>(b, ck, prm) : launch_align_team_zg<1, false>(b, ck, prm);
         case 2: return zg ? launch_align_team_zg<2, true>(b, ck, prm) : launch_align_team_zg<2, false>(b, ck, prm);
-        default: return zg ? launch_align_team_zg<3, true>(b, ck, prm) : launch_align_team_zg<3, false>(b, ck, prm);
+        case 3: return zg ? launch_align_team_zg<3, true>(b, ck, prm) : launch_align_team_zg<3, false>(b, ck, prm);
+        case 4: return zg ? launch_align_team_zg<4, true>(b, ck, prm) : launch_align_team_zg<4, false>(b, ck, prm);
+        default: return zg ? launch_align_team_zg<5, true>(b, ck, prm) : launch_align_team_zg<5, false>(b, ck, prm);
     }
 }
 
@@ -564,7 +566,7 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     // single-wave kernels) they never win.  Hence: at most 256 pairs, more than 192 rows.
     int64_t team_limit = kTeamPairLimit;
     if (const char* env = std::getenv("CARETTA_TEAM_PAIRS")) team_limit = std::atoll(env);   // calibration
-    b->team = npairs > 0 && npairs <= team_limit && b->n_max > 3 * cr::kWave && b->n_max <= 3 * cr::kTeamWaves * cr::kWave &&
+    b->team = npairs > 0 && npairs <= team_limit && b->n_max > 3 * cr::kWave && b->n_max <= 5 * cr::kTeamWaves * cr::kWave &&
               !std::getenv("CARETTA_NO_TEAM");
     if (b->team) b->r_seed = b->r_align = (b->n_max + cr::kTeamWaves * cr::kWave - 1) / (cr::kTeamWaves * cr::kWave);
     // scratch budget per chunk (decision words); CARETTA_SCRATCH_MB overrides the 8 GiB default

@@ -268,7 +268,7 @@ int launch_node_r(hipStream_t stream, int count, int n_max, int m_max, int entri
     return CR_OK;
 }
 
-// team kernels (kTeamWaves waves per node): R rows per lane, strips_of(n_max, R) <= kTeamWaves
+// team kernels (kTeamWaves waves per node): R = 1 .. 5 rows per lane, strips_of(n_max, R) <= kTeamWaves (n_max <= 1280)
 template <int R>
 int launch_node_team_r(hipStream_t stream, int count, int n_max, int m_max, int entries, const cr::PairDesc* pairs,
                        const double* coords, const double* tensors, int d, const double* weights,
@@ -287,7 +287,8 @@ int launch_node_team_r(hipStream_t stream, int count, int n_max, int m_max, int 
 
 template <class... A>
 int launch_node_team(int R, A... a) {
-    return R == 1 ? launch_node_team_r<1>(a...) : R == 2 ? launch_node_team_r<2>(a...) : launch_node_team_r<3>(a...);
+    return R == 1 ? launch_node_team_r<1>(a...) : R == 2 ? launch_node_team_r<2>(a...) : R == 3 ? launch_node_team_r<3>(a...)
+         : R == 4 ? launch_node_team_r<4>(a...) : launch_node_team_r<5>(a...);
 }
 
 template <int R, int D, bool ZG>
@@ -318,7 +319,8 @@ int launch_seed_team_r(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& 
 }
 
 int launch_seed_team(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
-    return R == 1 ? launch_seed_team_r<1>(b, ck, prm) : R == 2 ? launch_seed_team_r<2>(b, ck, prm) : launch_seed_team_r<3>(b, ck, prm);
+    return R == 1 ? launch_seed_team_r<1>(b, ck, prm) : R == 2 ? launch_seed_team_r<2>(b, ck, prm)
+         : R == 3 ? launch_seed_team_r<3>(b, ck, prm) : R == 4 ? launch_seed_team_r<4>(b, ck, prm) : launch_seed_team_r<5>(b, ck, prm);
 }
 
 // the seed kernel that matches the batch's layout (cr_batch_set_pairs chose team / rows per lane)

@@ -71,7 +71,7 @@ int run_level(cr_progressive* h, const std::vector<int64_t>& ids, const cr_param
     for (int64_t id : ids) n_max = std::max<int>(n_max, (int)h->len[(size_t)h->child1[(size_t)id]]);
     // few blocks per launch: the team kernels (kTeamWaves waves per node) whenever the rows fit their strips
     // (with at most 192 rows one strip of a single-wave kernel beats three 64-row strips of the team, cr_batch_set_pairs)
-    const bool team = n_max > 3 * cr::kWave && n_max <= 3 * cr::kTeamWaves * cr::kWave && !std::getenv("CARETTA_NO_TEAM");
+    const bool team = n_max > 3 * cr::kWave && n_max <= 5 * cr::kTeamWaves * cr::kWave && !std::getenv("CARETTA_NO_TEAM");
     const int R = team ? (n_max + cr::kTeamWaves * cr::kWave - 1) / (cr::kTeamWaves * cr::kWave) : rows_per_lane(n_max);
     int64_t dirs_off = 0, bt_off = 0, aln_off = 0, hand_off = 0, rows = h->used;
     for (size_t x = 0; x < count; x++) {

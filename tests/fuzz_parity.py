@@ -22,7 +22,7 @@ def random_family(rng):
     dim = int(rng.choice([1, 2, 3, 4, 5, 8, 10, 13, 16]))
     if kind == 0:      # related structures, ragged
         # up to 18 structures: with both orientations more than 128 pairs, i.e. the grouped single-wave kernels too
-        num, length = int(rng.integers(2, 19)), int(rng.choice([12, 40, 90, 150, 200, 260, 330, 450, 700]))
+        num, length = int(rng.integers(2, 19)), int(rng.choice([12, 40, 90, 150, 200, 260, 330, 450, 700, 1000]))
         fam = synthetic.make_family(num, length, dim=dim, seed=int(rng.integers(1 << 30)), ragged=True, clades=int(rng.integers(1, 4)))
     elif kind == 1:    # unrelated random walks of very different lengths
         fam = []
