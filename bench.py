@@ -209,6 +209,16 @@ def main():
                          "achieved_tflops": (59 + 49) * cells_rank / ((stage_ms[0] + stage_ms[1]) * 1e-3) / 1e12,
                          "peak_tflops": FP64_VALU_PEAK_TFLOPS},
         }
+        # the binding resource, from the committed PMC summary of this workload (tools/pmc_profile.sh): share of all
+        # cycles in which a SIMD issues a VALU instruction = SQ_INSTS_VALU / 1024 SIMDs x 4 cycles / (GRBM_GUI_ACTIVE / 8 XCDs)
+        try:
+            if args.workload == "headline" and args.gpus == 1:
+                pmc = json.load(open(ROOT / "profiles" / "r01" / "pmc_summary.json"))
+                out["valu_f64"]["issue_frac_pmc"] = {
+                    ("k_seed" if "k_seed" in k else "k_align"): round(v["SQ_INSTS_VALU"] / 1024 * 4 / (v["GRBM_GUI_ACTIVE"] / 8), 4)
+                    for k, v in pmc.items() if "SQ_INSTS_VALU" in v and "GRBM_GUI_ACTIVE" in v}
+        except (OSError, ValueError, KeyError):
+            pass
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(coords, tensors, offsets, pairs, res, aln)
             out["speedup_vs_cpu_1thread"] = out["value"] / out["cpu_baseline"]["value"]
