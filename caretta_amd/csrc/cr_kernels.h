@@ -8,7 +8,9 @@
 // materialised: the RBF is evaluated in the sweep from row features held in registers and column
 // features streamed through a 128-column LDS ring filled by coalesced HBM reads.  Backtrack
 // decisions are packed (2 bit/cell SW, 4 bit/cell DTW) in the same skewed order and written with
-// 256-byte coalesced stores; the tracebacks run afterwards, one lane per pair.
+// 256-byte coalesced stores; the traceback, Kabsch and metric phase follows in the same wave (wave-uniform
+// walk through an LDS window of the decision words, ordered cooperative sums).  Launches with few pairs use
+// the team variants: one workgroup of four waves per pair, one wave per strip (sweep_team).
 //
 // Reference semantics: dynamic_time_warping.py (fills, tie-breaks), score_functions.py (RBF),
 // superposition_functions.py (Kabsch), multiple_alignment.py:321-349, 1028-1054.
