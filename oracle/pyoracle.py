@@ -6,6 +6,7 @@ Nothing under caretta_amd/ may import this module.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import subprocess
 from pathlib import Path
 
@@ -50,9 +51,13 @@ def build(force: bool = False) -> None:
 
 class Oracle:
     def __init__(self, libm_exp: bool = False):
-        build()
         name = "libcaretta_oracle_libm.so" if libm_exp else "libcaretta_oracle.so"
-        self.lib = lib = C.CDLL(str(HERE / name))
+        override = os.environ.get("CARETTA_ORACLE_DIR")          # e.g. a sanitizer build of the same sources
+        if override:
+            self.lib = lib = C.CDLL(str(Path(override) / name))
+        else:
+            build()
+            self.lib = lib = C.CDLL(str(HERE / name))
         lib.cro_exp.restype = C.c_double
         lib.cro_exp.argtypes = [C.c_double]
         lib.cro_make_score_matrix.argtypes = [_f64p, C.c_int64, _f64p, C.c_int64, C.c_int64, C.c_double, _f64p]

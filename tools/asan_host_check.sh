@@ -15,3 +15,13 @@ RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
 cd "$ROOT"
 ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 LD_PRELOAD=$RT CARETTA_HIP_LIB="$OUT/libcaretta_hip_asan.so" CARETTA_SYSTEM_HIP=1 \
     python -m pytest tests/test_capi_cpu.py -x -q
+
+# The oracle (test infrastructure) under gcc's ASan + UBSan against the golden vectors
+cp "$ROOT"/oracle/caretta_oracle.c "$ROOT"/oracle/caretta_oracle.h "$ROOT"/oracle/exp_table.inc "$OUT"/
+cd "$OUT"
+OFLAGS="-O1 -g -ffp-contract=off -mfma -fopenmp -fPIC -std=gnu11 -fsanitize=address,undefined -fno-omit-frame-pointer -shared"
+gcc $OFLAGS -o libcaretta_oracle.so caretta_oracle.c -lm
+gcc $OFLAGS -DCRO_LIBM_EXP -o libcaretta_oracle_libm.so caretta_oracle.c -lm
+cd "$ROOT"
+ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 LD_PRELOAD=$(gcc -print-file-name=libasan.so) CARETTA_ORACLE_DIR="$OUT" \
+    python -m pytest tests/test_oracle_golden.py -x -q
