@@ -1524,6 +1524,72 @@ __global__ void k_scatter_sw_t(const PairResult* __restrict__ res, const int32_t
 }
 constexpr auto k_scatter_sw = k_scatter_sw_t<>;
 
+// ---------------------------------------------------------------------------------------------
+// Device-side planning of one level of the guide tree (cr_progressive.h, the launch sequence without host
+// round trips).  One thread: (1) commits the previous level -- length and arena offset of every node it produced --,
+// (2) lays out this level: PairDesc / NodeDesc of every node from its children's lengths, decision-scratch offsets by
+// running sums, output rows appended to the arena.  Lengths beyond the bound the launches were sized for set
+// *overflow and are clamped (the host then repeats the tree with the level-by-level path).
+// ---------------------------------------------------------------------------------------------
+struct PlanNode {
+    int32_t c1, c2, id, pad;     // children and own node id
+    double mult1, mult2;
+};
+
+template <class Dummy = void>
+__global__ void k_plan_level_t(const PlanNode* __restrict__ prev, int prev_count, const NodeDesc* __restrict__ prev_desc,
+                               const NodeOut* __restrict__ prev_out, const PlanNode* __restrict__ cur, int count, int R,
+                               int bound, int64_t aln_base, int64_t* __restrict__ len, int64_t* __restrict__ off,
+                               int64_t* __restrict__ used, PairDesc* __restrict__ pairs, NodeDesc* __restrict__ nodes,
+                               int32_t* __restrict__ overflow) {
+    // one workgroup: the global reads and writes are spread over the threads, the running sums are taken by thread 0
+    // over LDS copies of the lengths
+    extern __shared__ int32_t plan_nm[];                     // [count][2]
+    for (int x = threadIdx.x; x < prev_count; x += blockDim.x) {
+        len[prev[x].id] = prev_out[x].len;
+        off[prev[x].id] = prev_desc[x].out_off + prev_out[x].first;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int x = threadIdx.x; x < count; x += blockDim.x) {
+        int64_t n = len[cur[x].c1], m = len[cur[x].c2];
+        if (n > bound || m > bound || n < 1 || m < 1) {
+            *overflow = 1;
+            n = n > bound ? bound : (n < 1 ? 1 : n);
+            m = m > bound ? bound : (m < 1 ? 1 : m);
+        }
+        plan_nm[2 * x] = (int32_t)n;
+        plan_nm[2 * x + 1] = (int32_t)m;
+        PairDesc pd;
+        pd.n = (int32_t)n;
+        pd.m = (int32_t)m;
+        pd.off_i = off[cur[x].c1];
+        pd.off_j = off[cur[x].c2];
+        pd.dirs_off = pd.bt_off = pd.aln_off = pd.hand_off = 0;
+        pairs[x] = pd;
+        nodes[x].mult1 = cur[x].mult1;
+        nodes[x].mult2 = cur[x].mult2;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t dirs_off = 0, bt_off = 0, aln_off = aln_base, rows = *used;
+        for (int x = 0; x < count; x++) {
+            const int n = plan_nm[2 * x], m = plan_nm[2 * x + 1];
+            pairs[x].dirs_off = dirs_off;
+            pairs[x].bt_off = bt_off;
+            pairs[x].aln_off = aln_off;
+            nodes[x].out_off = rows;
+            dirs_off += (int64_t)strips_of(n, R) * tblocks(m, 16) * R * kWave;
+            bt_off += (int64_t)strips_of(n, R) * tblocks(m, 8) * R * kWave;
+            aln_off += 2 * (int64_t)(n + m);
+            rows += n + m;
+        }
+        *used = rows;
+    }
+}
+constexpr auto k_plan_level = k_plan_level_t<>;
+
 // Team versions of k_seed and k_node for launches with few blocks (progressive alignment levels, small pair
 // lists): kTeamWaves waves sweep the strips of one pair concurrently (sweep_team); wave 0 then runs the same
 // traceback / Kabsch / mean code as the single-wave kernels.  Requires strips_of(n, R) <= kTeamWaves.

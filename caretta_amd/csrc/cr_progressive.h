@@ -147,6 +147,118 @@ int run_level(cr_progressive* h, const std::vector<int64_t>& ids, const cr_param
     return CR_OK;
 }
 
+// The whole tree without host round trips.  Launch shapes (rows per lane, LDS, scratch) are sized for a length
+// bound of 1.5 x the longest leaf; a one-thread planning kernel per level (cr::k_plan_level) turns the lengths the
+// previous level produced into this level's descriptors on the device.  Returns 1 when the bound does not apply
+// (team kernels need 192 < bound <= 1280) or a node outgrew it: the caller then runs the level-by-level path.
+int run_tree_planned(cr_progressive* h, const std::vector<std::vector<int64_t>>& by_level, const cr_params& prm,
+                     double gamma_weight) {
+    cr_batch& b = h->scratch;
+    hipStream_t stream = h->ctx->stream;
+    const int64_t P = h->P, total = h->used, num_nodes = P - 1;
+    int64_t longest = 0;
+    for (int64_t s = 0; s < P; s++) longest = std::max(longest, h->len[(size_t)s]);
+    const int bound = (int)std::min<int64_t>(5 * cr::kTeamWaves * cr::kWave, (longest * 3 + 1) / 2 + 8);
+    if (bound <= 3 * cr::kWave || longest > bound || std::getenv("CARETTA_NO_TEAM")) return 1;
+    const int R = (bound + cr::kTeamWaves * cr::kWave - 1) / (cr::kTeamWaves * cr::kWave);
+
+    // static plan: every internal node in level order
+    std::vector<cr::PlanNode> plan;
+    std::vector<int64_t> start((size_t)h->levels + 2, 0), aln_base((size_t)h->levels + 2, 0);
+    int64_t max_count = 0;
+    for (int64_t lv = 1; lv <= h->levels; lv++) {
+        start[(size_t)lv] = (int64_t)plan.size();
+        for (int64_t id : by_level[(size_t)lv]) {
+            const int64_t c1 = h->child1[(size_t)id], c2 = h->child2[(size_t)id];
+            const double tot = (double)(h->members[(size_t)c1] + h->members[(size_t)c2]);
+            plan.push_back(cr::PlanNode{(int32_t)c1, (int32_t)c2, (int32_t)id, 0, (double)h->members[(size_t)c2] / (2.0 * tot),
+                                        (double)h->members[(size_t)c1] / (2.0 * tot)});
+        }
+        const int64_t count = (int64_t)by_level[(size_t)lv].size();
+        max_count = std::max(max_count, count);
+        aln_base[(size_t)lv + 1] = aln_base[(size_t)lv] + count * 4 * (int64_t)bound;
+    }
+    start[(size_t)h->levels + 1] = (int64_t)plan.size();
+    const int64_t aln_total = aln_base[(size_t)h->levels + 1];
+    int rc = arena_reserve(h, total + num_nodes * 2 * (int64_t)bound);
+    if (rc) return rc;
+    const int64_t dirs_words = max_count * cr::strips_of(bound, R) * cr::tblocks(bound, 16) * R * cr::kWave;
+    const int64_t bits_words = max_count * cr::strips_of(bound, R) * cr::tblocks(bound, 8) * R * cr::kWave;
+    DevBuf<cr::PlanNode> d_plan;
+    DevBuf<int64_t> d_len, d_off, d_used;
+    DevBuf<int32_t> d_overflow;
+    CR_HIP(d_plan.ensure(plan.size()));
+    CR_HIP(d_len.ensure((size_t)(2 * P - 1)));
+    CR_HIP(d_off.ensure((size_t)(2 * P - 1)));
+    CR_HIP(d_used.ensure(1));
+    CR_HIP(d_overflow.ensure(1));
+    CR_HIP(b.pairs.ensure((size_t)num_nodes));
+    CR_HIP(b.xf.ensure((size_t)num_nodes));
+    CR_HIP(b.seed_score.ensure((size_t)num_nodes));
+    CR_HIP(h->d_nodes.ensure((size_t)num_nodes));
+    CR_HIP(h->d_outs.ensure((size_t)num_nodes));
+    CR_HIP(b.dirs.ensure((size_t)dirs_words));
+    CR_HIP(b.bits.ensure((size_t)bits_words));
+    CR_HIP(b.aln.ensure((size_t)aln_total));
+    CR_HIP(hipMemcpyAsync(d_plan.p, plan.data(), sizeof(cr::PlanNode) * plan.size(), hipMemcpyHostToDevice, stream));
+    CR_HIP(hipMemcpyAsync(d_len.p, h->len.data(), sizeof(int64_t) * (size_t)(2 * P - 1), hipMemcpyHostToDevice, stream));
+    CR_HIP(hipMemcpyAsync(d_off.p, h->off.data(), sizeof(int64_t) * (size_t)(2 * P - 1), hipMemcpyHostToDevice, stream));
+    CR_HIP(hipMemcpyAsync(d_used.p, &total, sizeof(int64_t), hipMemcpyHostToDevice, stream));
+    CR_HIP(hipMemsetAsync(d_overflow.p, 0, sizeof(int32_t), stream));
+    b.r_seed = b.r_align = R;
+    for (int64_t lv = 1; lv <= h->levels + 1; lv++) {
+        const int64_t first = start[(size_t)lv], count = lv <= h->levels ? start[(size_t)lv + 1] - first : 0;
+        const int64_t pfirst = lv > 1 ? start[(size_t)lv - 1] : 0, pcount = lv > 1 ? first - pfirst : 0;
+        hipLaunchKernelGGL(cr::k_plan_level, dim3(1), dim3(256), sizeof(int32_t) * 2 * (size_t)std::max<int64_t>(count, 1), stream, d_plan.p + pfirst, (int)pcount, h->d_nodes.p + pfirst,
+                           h->d_outs.p + pfirst, d_plan.p + first, (int)count, R, bound, aln_base[(size_t)std::min(lv, h->levels)],
+                           d_len.p, d_off.p, d_used.p, b.pairs.p + first, h->d_nodes.p + first, d_overflow.p);
+        CR_HIP(hipGetLastError());
+        if (count == 0) break;
+        const cr_batch::Chunk ck{first, count, bound, bound, 2 * bound};
+        if ((rc = launch_seed_team(R, &b, ck, prm))) return rc;
+        if ((rc = launch_node_team(R, stream, (int)count, bound, bound, 2 * bound, b.pairs.p + first, b.coords.p, b.tensors.p,
+                                   (int)h->d, h->weights.p, h->d_nodes.p + first, b.xf.p + first, prm, gamma_weight, b.bits.p,
+                                   b.hand.p, b.aln.p, b.coords.p, b.tensors.p, h->weights.p, h->d_outs.p + first)))
+            return rc;
+    }
+    // one read-back for the whole tree
+    std::vector<cr::NodeOut> outs((size_t)num_nodes);
+    std::vector<cr::NodeDesc> descs((size_t)num_nodes);
+    std::vector<int64_t> len((size_t)(2 * P - 1)), off((size_t)(2 * P - 1));
+    std::vector<int32_t> rows_host((size_t)aln_total);
+    int32_t overflow = 0;
+    int64_t used = 0;
+    CR_HIP(hipMemcpyAsync(outs.data(), h->d_outs.p, sizeof(cr::NodeOut) * (size_t)num_nodes, hipMemcpyDeviceToHost, stream));
+    CR_HIP(hipMemcpyAsync(descs.data(), h->d_nodes.p, sizeof(cr::NodeDesc) * (size_t)num_nodes, hipMemcpyDeviceToHost, stream));
+    CR_HIP(hipMemcpyAsync(len.data(), d_len.p, sizeof(int64_t) * len.size(), hipMemcpyDeviceToHost, stream));
+    CR_HIP(hipMemcpyAsync(off.data(), d_off.p, sizeof(int64_t) * off.size(), hipMemcpyDeviceToHost, stream));
+    CR_HIP(hipMemcpyAsync(rows_host.data(), b.aln.p, sizeof(int32_t) * (size_t)aln_total, hipMemcpyDeviceToHost, stream));
+    CR_HIP(hipMemcpyAsync(&overflow, d_overflow.p, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    CR_HIP(hipMemcpyAsync(&used, d_used.p, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    CR_HIP(hipStreamSynchronize(stream));
+    if (overflow) return 1;
+    h->len = len;
+    h->off = off;
+    h->used = used;
+    for (int64_t lv = 1; lv <= h->levels; lv++) {
+        int64_t aln_off = aln_base[(size_t)lv];                 // the planning kernel's running offsets, replayed
+        for (int64_t x = start[(size_t)lv]; x < start[(size_t)lv + 1]; x++) {
+            const cr::PlanNode& pn = plan[(size_t)x];
+            const int64_t k = pn.id - P, cap = len[(size_t)pn.c1] + len[(size_t)pn.c2];
+            const cr::NodeOut& no = outs[(size_t)x];
+            h->flags[(size_t)k] = no.flags;
+            h->any_flags |= no.flags;
+            std::vector<int32_t>& a = h->aln[(size_t)k];
+            a.resize((size_t)(2 * no.len));
+            const int32_t* src = rows_host.data() + aln_off;
+            std::copy(src + no.first, src + no.first + no.len, a.begin());
+            std::copy(src + cap + no.first, src + cap + no.first + no.len, a.begin() + no.len);
+            aln_off += 2 * cap;
+        }
+    }
+    return CR_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -242,8 +354,14 @@ int cr_progressive_align(cr_context* ctx, const double* coords, const double* te
     }
     std::vector<std::vector<int64_t>> by_level((size_t)h->levels + 1);
     for (int64_t id = P; id < num_ids; id++) by_level[(size_t)h->level[(size_t)id]].push_back(id);
-    for (int64_t lv = 1; lv <= h->levels; lv++)
-        if ((rc = run_level(h, by_level[(size_t)lv], prm, gamma_weight))) return rc;
+    rc = std::getenv("CARETTA_SYNC_LEVELS") ? 1 : run_tree_planned(h, by_level, prm, gamma_weight);
+    if (rc < 0) return rc;
+    if (rc == 1) {                                  // not applicable, or a node outgrew the bound: level by level
+        h->used = total;
+        h->any_flags = 0;
+        for (int64_t lv = 1; lv <= h->levels; lv++)
+            if ((rc = run_level(h, by_level[(size_t)lv], prm, gamma_weight))) return rc;
+    }
     guard.h = nullptr;
     *out = h;
     return CR_OK;

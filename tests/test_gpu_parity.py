@@ -454,6 +454,35 @@ def test_gamma_too_small_is_rejected(ctx):
     batch.close()
 
 
+def test_progressive_unrelated_structures_outgrow_the_bound(oracle):
+    """With rewarded gaps every alignment is all gaps, so tree nodes grow past 1.5 x the longest leaf: the planned
+    (host-round-trip-free) launch sequence reports the overflow and the level-by-level path takes over.  Every node
+    still has to match the oracle."""
+    from caretta_amd import multiple_alignment as ma, neighbor_joining as nj
+    fam = [synthetic.make_family(1, ln, seed=500 + k, clades=1)[0] for k, ln in enumerate((300, 280, 260, 310, 295))]
+    prots = [ma.Protein(f"u{k}", s.tensors, s.coordinates, "") for k, s in enumerate(fam)]
+    msa = ma.MultipleAlignment(prots)
+    prm = dict(flexible=False, gamma_tensor=7.0, gamma_coords=0.03, verbose=False)
+    m = msa.make_pairwise_matrix(prm)
+    tree, _ = nj.neighbor_joining(m.max() - m)
+    aln = msa.progressive_align(tree, -0.5, -0.5, 1.0, 1.0, prm, dict(flexible=False, verbose=False))
+    width = len(aln["u0"])
+    assert width > 1.5 * 310                                 # the case this test is about
+    from oracle.pyoracle import default_params
+    oprm = default_params(gap_open=-0.5, gap_extend=-0.5)
+    sizes = [1] * 5
+    for k, (n1, n2) in enumerate(_replay_tree(msa, tree, 5)):
+        tot = sizes[n1] + sizes[n2]
+        s1, s2 = msa.final_sequences[n1], msa.final_sequences[n2]
+        _, _, xn, tn, wn, _ = oracle.progressive_node(s1.coordinates, s1.tensors, msa.final_consensus_weights[n1], s2.coordinates,
+                                                      s2.tensors, msa.final_consensus_weights[n2], sizes[n2] / (2 * tot),
+                                                      sizes[n1] / (2 * tot), oprm)
+        node = msa.final_sequences[5 + k]
+        assert np.array_equal(xn, node.coordinates) and np.array_equal(tn, node.tensors)
+        assert np.array_equal(wn, msa.final_consensus_weights[5 + k])
+        sizes.append(tot)
+
+
 def test_progressive_tree_validation(ctx):
     from caretta_amd import multiple_alignment as ma, synthetic
     fam = synthetic.make_family(4, 40, seed=5, clades=2)
