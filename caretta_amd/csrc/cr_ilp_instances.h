@@ -18,3 +18,20 @@
 #define CR_ALIGN_SIGNATURE(R, ZG)                                                                                      \
     __global__ void cr::k_align<R, ZG>(const cr::PairDesc*, const double*, const cr::Transform*, const double*, double, \
                                        double, double, double, int, uint32_t*, double*, int32_t*, cr::PairResult*);
+
+// the team kernels of the progressive alignment levels (+4 % under the same scheduler)
+#define CR_ILP_SEED_TEAM_INSTANCES(X)                                                                                  \
+    X(1, 4, true) X(1, 4, false) X(1, 8, true) X(1, 8, false) X(1, 10, true) X(1, 10, false) X(1, 16, true) X(1, 16, false) \
+    X(2, 4, true) X(2, 4, false) X(2, 8, true) X(2, 8, false) X(2, 10, true) X(2, 10, false) X(2, 16, true) X(2, 16, false) \
+    X(3, 4, true) X(3, 4, false) X(3, 8, true) X(3, 8, false) X(3, 10, true) X(3, 10, false) X(3, 16, true) X(3, 16, false) \
+    X(4, 4, true) X(4, 4, false) X(4, 8, true) X(4, 8, false) X(4, 10, true) X(4, 10, false) X(4, 16, true) X(4, 16, false) \
+    X(5, 4, true) X(5, 4, false) X(5, 8, true) X(5, 8, false) X(5, 10, true) X(5, 10, false) X(5, 16, true) X(5, 16, false)
+#define CR_ILP_NODE_TEAM_INSTANCES(X) X(1) X(2) X(3) X(4) X(5)
+
+#define CR_SEED_TEAM_SIGNATURE(R, D, ZG)                                                                                   \
+    __global__ void cr::k_seed_team<R, D, ZG>(const cr::PairDesc*, const double*, int, const double*, double, double, int, \
+                                              uint32_t*, cr::Transform*, double*);
+#define CR_NODE_TEAM_SIGNATURE(R)                                                                                            \
+    __global__ void cr::k_node_team<R>(const cr::PairDesc*, const double*, const double*, int, const double*,                \
+                                       const cr::NodeDesc*, const cr::Transform*, double, double, double, double, int,       \
+                                       uint32_t*, double*, int32_t*, double*, double*, double*, cr::NodeOut*);

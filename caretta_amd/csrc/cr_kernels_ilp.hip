@@ -14,3 +14,9 @@ CR_ILP_SEED_INSTANCES(CR_X)
 #define CR_X(R, ZG) template CR_ALIGN_SIGNATURE(R, ZG)
 CR_ILP_ALIGN_INSTANCES(CR_X)
 #undef CR_X
+#define CR_X(R, D, ZG) template CR_SEED_TEAM_SIGNATURE(R, D, ZG)
+CR_ILP_SEED_TEAM_INSTANCES(CR_X)
+#undef CR_X
+#define CR_X(R) template CR_NODE_TEAM_SIGNATURE(R)
+CR_ILP_NODE_TEAM_INSTANCES(CR_X)
+#undef CR_X
