@@ -617,6 +617,17 @@ def test_sharded_matrix_single_rank_ragged():
     assert "sharded matrix ok" in out.stdout
 
 
+def test_very_long_pairs_match_the_oracle():
+    """3000 x 2500 residues: ten 320-row strips per sweep with their hand-off rows through HBM (tests/long_pair_oracle_check.py)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    script = Path(__file__).resolve().parent / "long_pair_oracle_check.py"
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "long pairs ok" in out.stdout
+
+
 def test_randomised_parity_run():
     """tests/fuzz_parity.py for a few seconds: random ragged batches, all parameter settings, the resident progressive
     alignment and the explicit-matrix drop-ins, everything bit-identical to the oracle (longer runs: profiles/)."""
