@@ -48,6 +48,16 @@ def stage_bytes(lengths, pairs, d):
     return float(seed.sum()), float(align.sum())
 
 
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(coords, tensors, offsets, pairs, gpu_res, gpu_aln, budget_s=12.0):
     """Time the C oracle (reference-shaped CPU restatement) on a bounded sample of the same pairs and
     use its outputs as the correctness gate for the GPU results."""
@@ -80,6 +90,7 @@ def cpu_baseline(coords, tensors, offsets, pairs, gpu_res, gpu_aln, budget_s=12.
         "sample": f"{count} of {len(pairs)} pairs (random, seed 0), C oracle -O2 -ffp-contract=off, reference-shaped "
                   f"(dense f64 DP matrices + int64 backtrack per pair), 1 thread as the reference's pair loop",
         "all_cores": {"value": len(big) / tall, "cores": cores, "pairs": int(len(big))},
+        "cpu_model": cpu_model(),
         "parity_mismatches": mism, "parity_checked": int(count),
     }
 
