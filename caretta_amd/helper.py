@@ -117,3 +117,15 @@ def local_shape_descriptor(coordinates, width: int = 10):
         dist = np.linalg.norm(x - x[idx], axis=1)
         out[:, col] = dist / (dist + 10.0)
     return out
+
+
+def nb_std_axis_0(array) -> np.ndarray:
+    """Column standard deviations (helper.py:57-64)."""
+    return np.std(np.asarray(array, dtype=np.float64), axis=0)
+
+
+def normalize(numbers) -> np.ndarray:
+    """Min-max scaling to [0, 1] (helper.py:67-70)."""
+    numbers = np.asarray(numbers, dtype=np.float64)
+    lo, hi = np.min(numbers), np.max(numbers)
+    return (numbers - lo) / (hi - lo)

@@ -477,6 +477,22 @@ class MultipleAlignment:
                 f.write(f">{p.name}\n{aligned}\n")
 
 
+def alignment_to_numpy(alignment: typing.Dict[str, str]) -> typing.Dict[str, np.ndarray]:
+    """Gapped sequences ("AC-D") -> index arrays ([0, 1, -1, 2]) (multiple_alignment.py:30-42)."""
+    out = {}
+    for name, gapped in alignment.items():
+        present = np.frombuffer(str(gapped).encode("ascii", "replace"), dtype=np.uint8) != ord("-")
+        out[name] = np.where(present, np.cumsum(present) - 1, -1)
+    return out
+
+
+def trigger_numba_compilation():
+    """The reference warms up its njit functions here (multiple_alignment.py:1058-1076).  Nothing is compiled at run
+    time in this package; the call loads libcaretta_hip.so and creates the device context, so that the first
+    alignment does not pay for it."""
+    default_context()
+
+
 def make_rmsd_coverage_tm_matrix(alignment, proteins, superpose_first: bool = True):
     """multiple_alignment.py:1000-1055 (see caretta_amd.msa_superposition)."""
     from .msa_superposition import make_rmsd_coverage_tm_matrix as impl

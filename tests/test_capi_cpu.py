@@ -154,3 +154,11 @@ def test_c1_fixture(golden):
     assert list(g["names"]) == ["1kdu", "1pk4", "1pkr"]
     assert [g[f"{n}_coords"].shape[0] for n in g["names"]] == [85, 79, 80]
     assert all(len(str(g[f"{n}_sequence"])) == g[f"{n}_coords"].shape[0] for n in g["names"])
+
+
+def test_small_host_helpers():
+    from caretta_amd import helper, multiple_alignment as ma
+    got = ma.alignment_to_numpy({"a": "AC-D-", "b": "--XYZ", "c": ""})
+    assert got["a"].tolist() == [0, 1, -1, 2, -1] and got["b"].tolist() == [-1, -1, 0, 1, 2] and len(got["c"]) == 0
+    x = np.array([[1.0, 4.0], [3.0, 4.0], [5.0, 10.0]])
+    assert np.allclose(helper.nb_std_axis_0(x), np.std(x, axis=0)) and helper.normalize([2.0, 4.0, 6.0]).tolist() == [0.0, 0.5, 1.0]
