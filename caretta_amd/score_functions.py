@@ -28,15 +28,19 @@ def make_score_matrix(coords_1, coords_2, score_function, gamma, normalized: boo
     """(n, m) matrix of ``score_function`` between all rows (score_functions.py:23-51).
 
     Only ``get_gaussian_score`` is ever passed by the reference (and is the only function the
-    kernels implement); ``normalized=True`` has no caller in the reference and is rejected.
+    kernels implement).  ``normalized=True`` (no caller in the reference) z-scores both inputs with the
+    mean / standard deviation of their concatenation first (score_functions.py:43-47).
     """
     if score_function is not get_gaussian_score:
         raise ValueError("only caretta_amd.score_functions.get_gaussian_score is supported")
-    if normalized:
-        raise ValueError("normalized=True is not supported (no caller in the reference)")
     a, b = f64(coords_1), f64(coords_2)
     if a.ndim != 2 or b.ndim != 2 or a.shape[1] != b.shape[1]:
         raise ValueError("coords_1 and coords_2 must be 2-D with equal width")
+    if normalized:
+        from . import helper
+        both = np.concatenate((a, b))
+        mean, std = helper.nb_mean_axis_0(both), helper.nb_std_axis_0(both)
+        a, b = f64((a - mean) / std), f64((b - mean) / std)
     s = np.zeros((a.shape[0], b.shape[0]))
     check(_capi.load().cr_make_score_matrix(default_context()._h, ptr(a), a.shape[0], ptr(b), b.shape[0], a.shape[1],
                                             float(gamma), ptr(s)))

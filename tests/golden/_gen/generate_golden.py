@@ -430,6 +430,30 @@ def gen_c1_inputs():
     save("c1_kringle_calpha.npz", out)
 
 
+def gen_extras(rng):
+    """Small helpers next to the path: the normalized=True branch of make_score_matrix (no caller in the reference),
+    alignment_to_numpy, helper.normalize / nb_std_axis_0."""
+    out = {}
+    c = 0
+    for n, m, k, gamma in [(7, 5, 3, 0.03), (20, 31, 10, 7.0), (1, 4, 1, 1.0)]:
+        a = rng.normal(scale=3.0, size=(n, k)) + 2.0
+        b = rng.normal(scale=3.0, size=(m, k)) - 1.0
+        out[f"ns{c}_a"], out[f"ns{c}_b"], out[f"ns{c}_gamma"] = a, b, np.float64(gamma)
+        out[f"ns{c}_S"] = score_functions.make_score_matrix(a, b, score_functions.get_gaussian_score, gamma, normalized=True)
+        c += 1
+    out["nns"] = np.int64(c)
+    gapped = {"a": "AC-D-", "b": "--XYZ", "c": "-----", "d": "MKV"}
+    got = multiple_alignment.alignment_to_numpy(gapped)
+    for key, seq in gapped.items():
+        out[f"a2n_{key}_in"] = np.frombuffer(seq.encode(), dtype=np.uint8)
+        out[f"a2n_{key}_out"] = np.asarray(got[key], dtype=np.int64)
+    x = rng.normal(size=(11, 4))
+    out["std_x"], out["std_out"] = x, helper.nb_std_axis_0(x)
+    v = rng.uniform(-3, 9, size=13)
+    out["norm_x"], out["norm_out"] = v, helper.normalize(v)
+    save("f6_extras.npz", out)
+
+
 def main():
     only = set(sys.argv[1:])
     rng = np.random.default_rng(20230)
@@ -445,7 +469,8 @@ def main():
               ("tree", lambda: gen_tree(np.random.default_rng(20224))),
               ("progressive", gen_progressive),
               ("c1", gen_c1_inputs),
-              ("postmsa", gen_post_msa)]
+              ("postmsa", gen_post_msa),
+              ("extras", lambda: gen_extras(np.random.default_rng(20223)))]
     for name, fn in steps:
         if only and name not in only:
             continue

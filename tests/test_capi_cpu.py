@@ -156,9 +156,13 @@ def test_c1_fixture(golden):
     assert all(len(str(g[f"{n}_sequence"])) == g[f"{n}_coords"].shape[0] for n in g["names"])
 
 
-def test_small_host_helpers():
+def test_small_host_helpers(golden):
+    """alignment_to_numpy, helper.normalize / nb_std_axis_0 against vectors from the reference's own source."""
     from caretta_amd import helper, multiple_alignment as ma
-    got = ma.alignment_to_numpy({"a": "AC-D-", "b": "--XYZ", "c": ""})
-    assert got["a"].tolist() == [0, 1, -1, 2, -1] and got["b"].tolist() == [-1, -1, 0, 1, 2] and len(got["c"]) == 0
-    x = np.array([[1.0, 4.0], [3.0, 4.0], [5.0, 10.0]])
-    assert np.allclose(helper.nb_std_axis_0(x), np.std(x, axis=0)) and helper.normalize([2.0, 4.0, 6.0]).tolist() == [0.0, 0.5, 1.0]
+    g = golden("f6_extras.npz")
+    for key in "abcd":
+        gapped = bytes(g[f"a2n_{key}_in"]).decode()
+        assert np.array_equal(ma.alignment_to_numpy({key: gapped})[key], g[f"a2n_{key}_out"])
+    assert len(ma.alignment_to_numpy({"e": ""})["e"]) == 0
+    np.testing.assert_allclose(helper.nb_std_axis_0(g["std_x"]), g["std_out"], rtol=1e-14)
+    np.testing.assert_allclose(helper.normalize(g["norm_x"]), g["norm_out"], rtol=0, atol=1e-15)

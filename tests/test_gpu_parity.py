@@ -67,6 +67,15 @@ def test_make_score_matrix_golden(oracle, golden):
 
 
 # ------------------------------------------------------------------------------- DP drop-ins
+def test_make_score_matrix_normalized_golden(golden):
+    """The normalized=True branch (score_functions.py:43-47; no caller in the reference) against the reference's output."""
+    from caretta_amd import score_functions as sf
+    g = golden("f6_extras.npz")
+    for c in range(int(g["nns"])):
+        s = sf.make_score_matrix(g[f"ns{c}_a"], g[f"ns{c}_b"], sf.get_gaussian_score, float(g[f"ns{c}_gamma"]), normalized=True)
+        np.testing.assert_allclose(s, g[f"ns{c}_S"], rtol=1e-11, atol=1e-300)
+
+
 def test_dtw_align_golden(golden):
     from caretta_amd import dynamic_time_warping as dtw
     g = golden("f1_dtw.npz")
