@@ -203,7 +203,7 @@ def main():
         out = {
             "metric": "pairwise alignments/sec", "value": total_pairs / (elapsed / args.steps), "unit": "pairs/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak" if args.workload == "headline" else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {num} structures x {length} residues, d={dim}, all {total_pairs} "
                                    f"pairs i<j sharded over {args.gpus} GPU(s), pipeline H (tensor-RBF SW seed -> Kabsch -> "
                                    f"coord-RBF SW score + affine DTW(1.0,0.01) -> Kabsch/RMSD/TM)",
