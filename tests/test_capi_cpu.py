@@ -40,6 +40,20 @@ def test_no_cpu_fallback(lib):
         engine.Context(0)
     with pytest.raises(_capi.CarettaHipError):
         score_functions.make_score_matrix(np.zeros((2, 3)), np.zeros((2, 3)), score_functions.get_gaussian_score, 1.0)
+    # the reference's own entry points: every compute path of the mirror needs the device
+    from caretta_amd import dynamic_time_warping as dtw, multiple_alignment as ma, superposition_functions as sup, synthetic
+    fam = synthetic.make_family(3, 20, seed=1, clades=1)
+    msa = ma.MultipleAlignment([ma.Protein(s.name, s.tensors, s.coordinates, "") for s in fam])
+    tree = np.array([[0, 3], [1, 3], [3, 2]], dtype=np.uint64)
+    for call in (lambda: msa.make_pairwise_matrix(dict(gamma_tensor=7.0, gamma_coords=0.03)),
+                 lambda: msa.progressive_align(tree, 1.0, 0.01, 1.0, 1.0, dict(verbose=False), dict(verbose=False)),
+                 lambda: msa.sequences[0].score_function(msa.sequences[1], verbose=False),
+                 lambda: dtw.dtw_align(np.arange(3), np.arange(3), np.ones((3, 3)), 1.0, 0.01),
+                 lambda: dtw.smith_waterman_score(np.arange(3), np.arange(3), np.ones((3, 3))),
+                 lambda: sup.paired_svd_superpose(np.eye(3), np.eye(3)),
+                 lambda: ma.tm_score(np.eye(3), np.eye(3), 3, 3)):
+        with pytest.raises(_capi.CarettaHipError):
+            call()
 
 
 def test_product_does_not_touch_oracle():
