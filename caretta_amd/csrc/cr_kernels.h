@@ -59,6 +59,16 @@ struct AlignEnd {            // result of the coordinate fill
     int32_t pad;
 };
 
+// __syncthreads() for code that one wave runs on its own (every traceback / Kabsch / metric phase): the same
+// fences, but a wave barrier instead of s_barrier.  In a 64-thread workgroup the compiler lowers __syncthreads() to
+// exactly this; in the team kernels, where the other waves of the workgroup have already exited, it keeps wave 0 off
+// the hardware barrier altogether instead of relying on s_barrier ignoring terminated waves.
+CR_D void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 // value of `v` in lane `src_lane` (wave-uniform index), broadcast to every lane
 CR_D double lane_value(double v, int src_lane) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_lane),
@@ -948,7 +958,7 @@ struct BitWindow {
     uint32_t* win;        // LDS, kWinBlocks * R * 64 words
     int s, lo, hi;        // strip and word-block range held; hi < lo: empty
     CR_D void load(const uint32_t* __restrict__ words, int R, int TB, int strip, int tb_hi, int lane) {
-        __syncthreads();
+        wave_sync();
         const int tb_lo = tb_hi - (kWinBlocks - 1) > 0 ? tb_hi - (kWinBlocks - 1) : 0;
         const uint32_t* src = words + ((int64_t)(strip * TB + tb_lo) * R) * kWave;
         const int total = (tb_hi - tb_lo + 1) * R * kWave;
@@ -957,7 +967,7 @@ struct BitWindow {
         s = strip;
         lo = tb_lo;
         hi = tb_hi;
-        __syncthreads();
+        wave_sync();
     }
     CR_D bool holds(int strip, int tb) const { return strip == s && tb >= lo && tb <= hi; }
     CR_D uint32_t word(int R, int tb, int q, int l) const {
@@ -1020,13 +1030,13 @@ CR_D double ordered_sums(int count, int lane, double* scratch, TermFn term) {
 #pragma unroll
             for (int a = 0; a < NACC; a++) scratch[lane * NACC + a] = tv[a];
         }
-        __syncthreads();
+        wave_sync();
         const int cnt = count - base < kWave ? count - base : kWave;
         if (lane < NACC) {
 #pragma unroll 8
             for (int x = 0; x < cnt; x++) acc += scratch[x * NACC + lane];
         }
-        __syncthreads();
+        wave_sync();
     }
     return acc;
 }
@@ -1122,7 +1132,7 @@ CR_D void seed_trace(const PairDesc& pd, int R, int max_entries, const double* _
             }
         }
     }
-    __syncthreads();
+    wave_sync();
 #pragma unroll
     for (int x = 0; x < 3; x++) tr.c1[x] = tr.c2[x] = 0.0;
 #pragma unroll
@@ -1172,7 +1182,7 @@ CR_D void rmsd_tm_ordered(const double* __restrict__ Xi, const double* __restric
             scratch[lane * 5 + 3] = pair ? 1.0 / (1.0 + q1 * q1) : 0.0;
             scratch[lane * 5 + 4] = pair ? 1.0 / (1.0 + q2 * q2) : 0.0;
         }
-        __syncthreads();
+        wave_sync();
         const int cnt = count - base < kWave ? count - base : kWave;
         if (lane == 0) {
             for (int y = 0; y < cnt; y++) {
@@ -1184,7 +1194,7 @@ CR_D void rmsd_tm_ordered(const double* __restrict__ Xi, const double* __restric
 #pragma unroll 8
             for (int y = 0; y < cnt; y++) acc += scratch[y * 5 + 2 + lane];
         }
-        __syncthreads();
+        wave_sync();
     }
     const double ss = lane_value(acc, 0), sum1 = lane_value(acc, 1), sum2 = lane_value(acc, 2);
     rmsd = sqrt(ss / (double)k);
@@ -1244,7 +1254,7 @@ CR_D void dtw_walk(int n0, int m0, int R, int max_entries, const uint32_t* __res
     for (int x = lane; x < n; x += kWave) arow[cap - idx - 1 - x] = pack_entry(n - 1 - x, -1);
     for (int x = lane; x < m; x += kWave) arow[cap - idx - 1 - x] = pack_entry(-1, m - 1 - x);
     idx += n + m;
-    __syncthreads();
+    wave_sync();
     const int first = cap - idx;
     int32_t* a1 = aln;                                           // alignment rows -> HBM, coalesced
     int32_t* a2 = a1 + cap;
@@ -1303,7 +1313,7 @@ CR_D void align_trace(const PairDesc& pd, int R, int max_entries, const double* 
 CR_D void drain_stores() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
+    wave_sync();
 }
 
 // Stages 1+2: tensor RBF + SW fill (multiple_alignment.py:328-335), then traceback + seed Kabsch.
@@ -1431,7 +1441,7 @@ CR_D void node_body(const PairDesc* __restrict__ pairs, const double* coords,
         else sweep<R, kDtw>(src, pd.n, pd.m, prm, lds, nullptr, bits, hand, unused, e);
     }
     if constexpr (TEAM) {
-        if (threadIdx.x >= kWave) return;              // s_barrier only waits for the waves still running
+        if (threadIdx.x >= kWave) return;              // wave 0 goes on alone (wave_sync, no s_barrier from here on)
     } else {
         drain_stores();
     }
@@ -1550,7 +1560,7 @@ __global__ void k_plan_level_t(const PlanNode* __restrict__ prev, int prev_count
         off[prev[x].id] = prev_desc[x].out_off + prev_out[x].first;
     }
     __threadfence_block();
-    __syncthreads();
+    wave_sync();
     for (int x = threadIdx.x; x < count; x += blockDim.x) {
         int64_t n = len[cur[x].c1], m = len[cur[x].c2];
         if (n > bound || m > bound || n < 1 || m < 1) {
@@ -1571,7 +1581,7 @@ __global__ void k_plan_level_t(const PlanNode* __restrict__ prev, int prev_count
         nodes[x].mult2 = cur[x].mult2;
     }
     __threadfence_block();
-    __syncthreads();
+    wave_sync();
     if (threadIdx.x == 0) {
         int64_t dirs_off = 0, bt_off = 0, aln_off = aln_base, rows = *used;
         for (int x = 0; x < count; x++) {
@@ -1614,7 +1624,7 @@ __global__ __launch_bounds__(kTeamWaves* kWave) void k_seed_team(const PairDesc*
         SweepParams prm{sw_gap, 0.0, 0.0};
         sweep_team<R, kSwTrace | (ZG ? kZeroGap : 0)>(src, pd.n, pd.m, prm, lds, dirs + pd.dirs_off, nullptr, sm, unused);
     }
-    if (threadIdx.x >= kWave) return;                  // s_barrier only waits for the waves still running
+    if (threadIdx.x >= kWave) return;                  // wave 0 goes on alone (wave_sync, no s_barrier from here on)
     Transform tr;
     seed_trace(pd, R, max_entries, coords, dirs, sm, lds + kExpDoubles, tr);
     if (threadIdx.x == 0) {
@@ -1644,7 +1654,7 @@ __global__ __launch_bounds__(kTeamWaves* kWave) void k_align_team(const PairDesc
         SweepParams prm{sw_gap, gap_open, gap_extend};
         sweep_team<R, kSwScore | kDtw | (ZG ? kZeroGap : 0)>(src, pd.n, pd.m, prm, lds, nullptr, bits + pd.bt_off, unused, e);
     }
-    if (threadIdx.x >= kWave) return;                  // s_barrier only waits for the waves still running
+    if (threadIdx.x >= kWave) return;                  // wave 0 goes on alone (wave_sync, no s_barrier from here on)
     PairResult r;
     align_trace(pd, R, max_entries, coords, bits, e, lds + kExpDoubles, aln, r);
     r.seed_score = seed_score[blockIdx.x];
@@ -1675,7 +1685,7 @@ __global__ __launch_bounds__(kWave) void k_msa_metrics(const double* __restrict_
         kloc += pair ? 1 : 0;
     }
     for (int off = 32; off > 0; off >>= 1) kloc += __shfl_xor(kloc, off);
-    __syncthreads();
+    wave_sync();
     const int k = kloc;
     const double* Xi = coords + offsets[i] * 3;
     const double* Xj = coords + offsets[j] * 3;
