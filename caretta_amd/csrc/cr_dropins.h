@@ -168,6 +168,100 @@ __global__ void k_rmsd_tm(const double* __restrict__ x1, const double* __restric
     out[1] = t1 > t2 ? t1 : t2;
 }
 
+// superpose_core (multiple_alignment.py:914-950): every structure fitted onto the reference over the gap-free
+// columns of the alignment.  k_core_reference (one wave): centroid of the reference's core coordinates (sequential
+// mean, helper.py:46-53) and the centred core coordinates x1[e].  k_core_superpose (one wave per structure):
+// paired_svd_superpose(x1, own core coordinates) with every sum in column order, then apply_rotran to the whole
+// structure; the reference itself is only shifted by the centroid.
+__global__ __launch_bounds__(kWave) void k_core_reference(const double* __restrict__ ref_coords,
+                                                         const int32_t* __restrict__ ref_row,
+                                                         const int32_t* __restrict__ core, int ncore,
+                                                         double* __restrict__ x1, double* __restrict__ centroid) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const double s = ordered_sums<3>(ncore, lane, lds, [&](int e, double* out) {
+        const double* v = ref_coords + (int64_t)ref_row[core[e]] * 3;
+        out[0] = v[0];
+        out[1] = v[1];
+        out[2] = v[2];
+    });
+    const double mean = s / (double)ncore;
+    const double c[3] = {lane_value(mean, 0), lane_value(mean, 1), lane_value(mean, 2)};
+    for (int e = lane; e < ncore; e += kWave) {
+        const double* v = ref_coords + (int64_t)ref_row[core[e]] * 3;
+        for (int a = 0; a < 3; a++) x1[(int64_t)e * 3 + a] = v[a] - c[a];
+    }
+    if (lane < 3) centroid[lane] = c[lane];
+}
+
+__global__ __launch_bounds__(kWave) void k_core_superpose(const double* __restrict__ coords,
+                                                         const int64_t* __restrict__ offsets,
+                                                         const int32_t* __restrict__ msa, int W,
+                                                         const int32_t* __restrict__ core, int ncore, int ref,
+                                                         const double* __restrict__ x1,
+                                                         const double* __restrict__ centroid, double* __restrict__ out) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x, s = blockIdx.x;
+    const int64_t off = offsets[s], len = offsets[s + 1] - off;
+    const double* X = coords + off * 3;
+    double* O = out + off * 3;
+    if (s == ref) {
+        for (int64_t r = lane; r < len; r += kWave)
+            for (int a = 0; a < 3; a++) O[r * 3 + a] = X[r * 3 + a] - centroid[a];
+        return;
+    }
+    uint32_t* ent = reinterpret_cast<uint32_t*>(lds);
+    double* scratch = lds + ((size_t)ncore + 3) / 4 * 2;
+    for (int e = lane; e < ncore; e += kWave) ent[e] = pack_entry(e, msa[(int64_t)s * W + core[e]]);
+    wave_sync();
+    double c1[3], c2[3], Rm[9], t[3];
+    kabsch_ordered(x1, X, ent, ncore, ncore, lane, scratch, c1, c2, Rm, t);
+    for (int64_t r = lane; r < len; r += kWave) {              // apply_rotran (superposition_functions.py:64-80)
+        const double v[3] = {X[r * 3], X[r * 3 + 1], X[r * 3 + 2]};
+        double o[3];
+        rot3(v, Rm, o);
+        for (int a = 0; a < 3; a++) O[r * 3 + a] = o[a] + t[a];
+    }
+}
+
+// superpose_reference (multiple_alignment.py:953-972): the structures listed in `which` fitted onto the reference
+// over the alignment columns the two share.  `ref_coords` are the reference's coordinates to fit on (the loop of the
+// reference refits the reference structure itself when it reaches it, so later structures see the refitted copy).
+// counts[b] = number of shared columns (the caller checks > 3, :965).
+__global__ __launch_bounds__(kWave) void k_reference_superpose(const double* __restrict__ coords,
+                                                              const int64_t* __restrict__ offsets,
+                                                              const int32_t* __restrict__ msa, int W, int ref,
+                                                              const double* __restrict__ ref_coords,
+                                                              const int32_t* __restrict__ which, double* __restrict__ out,
+                                                              int32_t* __restrict__ counts) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x, s = which[blockIdx.x];
+    const int64_t off = offsets[s], len = offsets[s + 1] - off;
+    const double* X = coords + off * 3;
+    double* O = out + off * 3;
+    uint32_t* ent = reinterpret_cast<uint32_t*>(lds);
+    double* scratch = lds + ((size_t)W + 3) / 4 * 2;
+    int kloc = 0;
+    for (int x = lane; x < W; x += kWave) {
+        const int a = msa[(int64_t)ref * W + x], b = msa[(int64_t)s * W + x];
+        const bool pair = a != -1 && b != -1;
+        ent[x] = pair ? pack_entry(a, b) : pack_entry(-1, -1);
+        kloc += pair ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) kloc += __shfl_xor(kloc, o);
+    wave_sync();
+    if (lane == 0) counts[blockIdx.x] = kloc;
+    if (kloc <= 3) return;
+    double c1[3], c2[3], Rm[9], t[3];
+    kabsch_ordered(ref_coords, X, ent, W, kloc, lane, scratch, c1, c2, Rm, t);
+    for (int64_t r = lane; r < len; r += kWave) {
+        const double v[3] = {X[r * 3], X[r * 3 + 1], X[r * 3 + 2]};
+        double o[3];
+        rot3(v, Rm, o);
+        for (int a = 0; a < 3; a++) O[r * 3 + a] = o[a] + t[a];
+    }
+}
+
 }  // namespace cr
 
 namespace {
@@ -700,6 +794,89 @@ int cr_mean_axis0(const double* x, int64_t rows, int64_t cols, double* out) {
         for (int64_t r = 0; r < rows; r++) s += x[r * cols + c];
         out[c] = s / (double)rows;
     }
+    return CR_OK;
+}
+
+int cr_superpose_core(cr_context* ctx, const double* coords, const int64_t* offsets, int64_t P, const int32_t* msa,
+                      int64_t W, const int32_t* core, int64_t ncore, int64_t ref, double* coords_out) {
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    CR_REQUIRE(coords && offsets && msa && core && coords_out, "null argument");
+    CR_REQUIRE(P >= 1 && W >= 1 && W <= 65534 && ref >= 0 && ref < P, "bad alignment shape");
+    CR_REQUIRE(ncore >= 1 && ncore <= 65534, "superpose_core needs at least one gap-free column");
+    const int64_t total = offsets[P];
+    CR_REQUIRE(all_finite(coords, (size_t)total * 3), "coordinates contain NaN or infinity");
+    for (int64_t e = 0; e < ncore; e++) {
+        CR_REQUIRE(core[e] >= 0 && core[e] < W, "core column outside the alignment");
+        for (int64_t s = 0; s < P; s++) {
+            const int32_t r = msa[s * W + core[e]];
+            CR_REQUIRE(r >= 0 && r < offsets[s + 1] - offsets[s], "a core column holds a gap or an index outside its structure");
+        }
+    }
+    DevBuf<double> dc, dout, dx1, dcen;
+    DevBuf<int64_t> doff;
+    DevBuf<int32_t> dmsa, dcore;
+    if ((rc = upload(dc, coords, (size_t)total * 3, ctx->stream))) return rc;
+    if ((rc = upload(doff, offsets, (size_t)P + 1, ctx->stream))) return rc;
+    if ((rc = upload(dmsa, msa, (size_t)P * W, ctx->stream))) return rc;
+    if ((rc = upload(dcore, core, (size_t)ncore, ctx->stream))) return rc;
+    CR_HIP(dout.ensure((size_t)total * 3));
+    CR_HIP(dx1.ensure((size_t)ncore * 3));
+    CR_HIP(dcen.ensure(3));
+    const size_t lds1 = sizeof(double) * (size_t)cr::kWave * 3;
+    hipLaunchKernelGGL(cr::k_core_reference, dim3(1), dim3(cr::kWave), lds1, ctx->stream, dc.p + offsets[ref] * 3,
+                       dmsa.p + ref * W, dcore.p, (int)ncore, dx1.p, dcen.p);
+    CR_HIP(hipGetLastError());
+    const size_t lds2 = sizeof(double) * (((size_t)ncore + 3) / 4 * 2 + (size_t)cr::kWave * cr::kMaxAcc);
+    if ((rc = allow_lds(cr::k_core_superpose, lds2))) return rc;
+    hipLaunchKernelGGL(cr::k_core_superpose, dim3((unsigned)P), dim3(cr::kWave), lds2, ctx->stream, dc.p, doff.p, dmsa.p, (int)W,
+                       dcore.p, (int)ncore, (int)ref, dx1.p, dcen.p, dout.p);
+    CR_HIP(hipGetLastError());
+    CR_HIP(hipMemcpyAsync(coords_out, dout.p, sizeof(double) * (size_t)total * 3, hipMemcpyDeviceToHost, ctx->stream));
+    CR_HIP(hipStreamSynchronize(ctx->stream));
+    return CR_OK;
+}
+
+int cr_superpose_reference(cr_context* ctx, const double* coords, const int64_t* offsets, int64_t P, const int32_t* msa,
+                           int64_t W, int64_t ref, double* coords_out) {
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    CR_REQUIRE(coords && offsets && msa && coords_out, "null argument");
+    CR_REQUIRE(P >= 1 && W >= 1 && W <= 65534 && ref >= 0 && ref < P, "bad alignment shape");
+    const int64_t total = offsets[P];
+    CR_REQUIRE(all_finite(coords, (size_t)total * 3), "coordinates contain NaN or infinity");
+    for (int64_t s = 0; s < P; s++)
+        for (int64_t x = 0; x < W; x++)
+            CR_REQUIRE(msa[s * W + x] >= -1 && msa[s * W + x] < offsets[s + 1] - offsets[s], "alignment index outside its structure");
+    DevBuf<double> dc, dout;
+    DevBuf<int64_t> doff;
+    DevBuf<int32_t> dmsa, dwhich, dcounts;
+    // list order of the reference's loop: structures before the reference, the reference itself, the rest
+    std::vector<int32_t> which((size_t)P);
+    for (int64_t s = 0; s < P; s++) which[(size_t)s] = (int32_t)s;
+    if ((rc = upload(dc, coords, (size_t)total * 3, ctx->stream))) return rc;
+    if ((rc = upload(doff, offsets, (size_t)P + 1, ctx->stream))) return rc;
+    if ((rc = upload(dmsa, msa, (size_t)P * W, ctx->stream))) return rc;
+    if ((rc = upload(dwhich, which.data(), (size_t)P, ctx->stream))) return rc;
+    CR_HIP(dout.ensure((size_t)total * 3));
+    CR_HIP(dcounts.ensure((size_t)P));
+    const size_t lds = sizeof(double) * (((size_t)W + 3) / 4 * 2 + (size_t)cr::kWave * cr::kMaxAcc);
+    if ((rc = allow_lds(cr::k_reference_superpose, lds))) return rc;
+    auto launch = [&](int64_t first, int64_t count, const double* ref_coords) {
+        if (count <= 0) return;
+        hipLaunchKernelGGL(cr::k_reference_superpose, dim3((unsigned)count), dim3(cr::kWave), lds, ctx->stream, dc.p, doff.p, dmsa.p,
+                           (int)W, (int)ref, ref_coords, dwhich.p + first, dout.p, dcounts.p + first);
+    };
+    launch(0, ref, dc.p + offsets[ref] * 3);                       // before the reference: its original coordinates
+    launch(ref, 1, dc.p + offsets[ref] * 3);                       // the reference onto itself (:966-968)
+    launch(ref + 1, P - ref - 1, dout.p + offsets[ref] * 3);       // after it: the refitted reference
+    CR_HIP(hipGetLastError());
+    std::vector<int32_t> counts((size_t)P);
+    CR_HIP(hipMemcpyAsync(counts.data(), dcounts.p, sizeof(int32_t) * (size_t)P, hipMemcpyDeviceToHost, ctx->stream));
+    CR_HIP(hipMemcpyAsync(coords_out, dout.p, sizeof(double) * (size_t)total * 3, hipMemcpyDeviceToHost, ctx->stream));
+    CR_HIP(hipStreamSynchronize(ctx->stream));
+    for (int64_t s = 0; s < P; s++)
+        CR_REQUIRE(counts[(size_t)s] > 3, "a structure shares 3 or fewer alignment columns with the reference (reference: assert len(pos_1) > 3)");
     return CR_OK;
 }
 

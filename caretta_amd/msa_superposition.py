@@ -24,7 +24,10 @@ def make_coverage_gap_distance_matrix(alignment_array):
     """For rows i, j: fraction of i's residues that face a gap in j, and the number that face a residue."""
     present = np.asarray(alignment_array) != GAP
     counts = present.sum(axis=1)
-    aligning = (present[:, None, :] & present[None, :, :]).sum(axis=2).astype(np.int32)
+    # columns where both rows hold a residue: an exact small-integer matrix product (counts < 2**24 in float32)
+    p32 = present.astype(np.float32)
+    aligning = np.rint(p32 @ p32.T).astype(np.int32) if present.shape[1] < (1 << 24) else \
+        (present[:, None, :] & present[None, :, :]).sum(axis=2).astype(np.int32)
     distance = (counts[:, None] - aligning) / counts[:, None]
     return distance.astype(np.float64), aligning
 
@@ -73,16 +76,18 @@ def superpose_core(alignment, proteins, reference_name, core_indices=None, gap=G
         core_indices = np.where((rows != gap).all(axis=0))[0]
     core_indices = np.asarray(core_indices, dtype=np.int64)
     ref = _index_of(proteins, reference_name)
-    ref_coords = f64(proteins[ref].coordinates)[np.asarray(alignment[reference_name])[core_indices]]
-    centroid = helper.nb_mean_axis_0(ref_coords)
-    ref_coords = ref_coords - centroid
+    # all structures in one launch (cr_superpose_core): paired_svd_superpose on the core columns + apply_rotran
+    lens = [len(p) for p in proteins]
+    offsets = np.zeros(len(proteins) + 1, dtype=np.int64)
+    offsets[1:] = np.cumsum(lens)
+    coords = np.ascontiguousarray(np.vstack([f64(p.coordinates) for p in proteins]))
+    msa = np.ascontiguousarray(np.array([alignment[p.name] for p in proteins]), dtype=np.int32)
+    core = np.ascontiguousarray(core_indices, dtype=np.int32)
+    moved = np.empty_like(coords)
+    check(_capi.load().cr_superpose_core(default_context()._h, ptr(coords), ptr(offsets), len(proteins), ptr(msa), msa.shape[1],
+                                         ptr(core), len(core), ref, ptr(moved)))
     for i, protein in enumerate(proteins):
-        if i == ref:
-            protein.coordinates = f64(protein.coordinates) - centroid
-        else:
-            own = f64(protein.coordinates)[np.asarray(alignment[protein.name])[core_indices]]
-            rot, tran = sup.paired_svd_superpose(ref_coords, own)
-            protein.coordinates = sup.apply_rotran(protein.coordinates, rot, tran)
+        protein.coordinates = moved[offsets[i]:offsets[i + 1]].copy()
     return proteins
 
 
@@ -90,12 +95,21 @@ def superpose_reference(alignment, proteins, reference_name):
     """Fit every structure onto the reference over the positions the two share (multiple_alignment.py:953-972).
     The reference itself is refitted in turn, exactly as the reference's loop does."""
     ref = _index_of(proteins, reference_name)
-    aln_ref = alignment[reference_name]
-    for protein in proteins:
-        pos_1, pos_2 = helper.get_common_positions(aln_ref, alignment[protein.name])
-        assert len(pos_1) > 3
-        rot, tran = sup.paired_svd_superpose(f64(proteins[ref].coordinates)[pos_1], f64(protein.coordinates)[pos_2])
-        protein.coordinates = sup.apply_rotran(protein.coordinates, rot, tran)
+    lens = [len(p) for p in proteins]
+    offsets = np.zeros(len(proteins) + 1, dtype=np.int64)
+    offsets[1:] = np.cumsum(lens)
+    coords = np.ascontiguousarray(np.vstack([f64(p.coordinates) for p in proteins]))
+    msa = np.ascontiguousarray(np.array([alignment[p.name] for p in proteins]), dtype=np.int32)
+    moved = np.empty_like(coords)
+    try:
+        check(_capi.load().cr_superpose_reference(default_context()._h, ptr(coords), ptr(offsets), len(proteins), ptr(msa),
+                                                  msa.shape[1], ref, ptr(moved)))
+    except ValueError as e:
+        if "3 or fewer" in str(e):
+            raise AssertionError(str(e)) from None
+        raise
+    for i, protein in enumerate(proteins):
+        protein.coordinates = moved[offsets[i]:offsets[i + 1]].copy()
     return proteins
 
 

@@ -193,6 +193,18 @@ int cr_tm_score(cr_context *ctx, const double *x1, const double *x2, int64_t k, 
  * common positions (the reference asserts) get rmsd = tm = NaN. */
 int cr_msa_metrics(cr_context *ctx, const double *coords, const int64_t *offsets, int64_t P, const int32_t *msa,
                    int64_t W, int superpose, double *rmsd, double *coverage, double *tm);
+/* superpose_core (multiple_alignment.py:914-950): all P structures fitted onto structure `ref` over the gap-free
+ * alignment columns core[ncore] (msa int32 [P, W], -1 = gap): one launch, one wave per structure.  coords_out
+ * (sum of lengths, 3): the moved coordinates; the reference is shifted by the centroid of its core positions. */
+int cr_superpose_core(cr_context *ctx, const double *coords, const int64_t *offsets, int64_t num_structures,
+                      const int32_t *msa, int64_t width, const int32_t *core, int64_t ncore, int64_t ref,
+                      double *coords_out);
+/* superpose_reference (multiple_alignment.py:953-972): every structure fitted onto structure `ref` over the columns
+ * the two share, in list order -- the reference is refitted onto itself when its turn comes and later structures are
+ * fitted onto that copy, as in the reference's loop.  Three launches (before / the reference / after), one wave per
+ * structure.  CR_ERR_ARGUMENT if a structure shares 3 or fewer columns with the reference (:965). */
+int cr_superpose_reference(cr_context *ctx, const double *coords, const int64_t *offsets, int64_t num_structures,
+                           const int32_t *msa, int64_t width, int64_t ref, double *coords_out);
 /* helper.nb_mean_axis_0 (sequential column means, as numba computes them)   helper.py:46-53 */
 int cr_mean_axis0(const double *x, int64_t rows, int64_t cols, double *out);
 

@@ -584,6 +584,55 @@ def test_post_msa_products_golden(golden, tag):
     assert ma.superpose is post.superpose                      # reachable under the reference's module name too
 
 
+def test_superpose_core_batched_equals_the_per_structure_calls(golden):
+    """superpose_core as one launch (cr_superpose_core) against the reference's own formulation with the single-call
+    drop-ins: paired_svd_superpose on the core columns, then apply_rotran, structure by structure -- bit-identical."""
+    from caretta_amd import helper, multiple_alignment as ma, msa_superposition as msup, superposition_functions as sup
+    f = golden("f4_progressive.npz")
+    coords, tensors, offsets = f["famP8_coords"], f["famP8_tensors"], f["famP8_offsets"]
+    p = len(offsets) - 1
+    names = [f"s{i:04d}" for i in range(p)]
+    aln = {n: f["famP8_msa"][i] for i, n in enumerate(names)}
+    prots = [ma.Protein(n, tensors[offsets[i]:offsets[i + 1]], coords[offsets[i]:offsets[i + 1]].copy(), "") for i, n in enumerate(names)]
+    rows = np.array([aln[n] for n in names])
+    core = np.where((rows != -1).all(axis=0))[0]
+    assert len(core) > 3
+    ref = 2
+    moved = msup.superpose_core(aln, [ma.Protein(q.name, q.tensors, q.coordinates.copy(), "") for q in prots], names[ref], core)
+    ref_core = prots[ref].coordinates[aln[names[ref]][core]]
+    centroid = helper.nb_mean_axis_0(ref_core)
+    ref_core = ref_core - centroid
+    for i, q in enumerate(prots):
+        if i == ref:
+            want = q.coordinates - centroid
+        else:
+            rot, tran = sup.paired_svd_superpose(ref_core, q.coordinates[aln[q.name][core]])
+            want = sup.apply_rotran(q.coordinates, rot, tran)
+        assert np.array_equal(moved[i].coordinates, want), i
+
+
+def test_superpose_reference_batched_equals_the_loop(golden):
+    """superpose_reference as three launches (cr_superpose_reference) against the reference's loop written with the
+    single-call drop-ins, incl. the refit of the reference onto itself half way through -- bit-identical."""
+    from caretta_amd import helper, multiple_alignment as ma, msa_superposition as msup, superposition_functions as sup
+    f = golden("f4_progressive.npz")
+    coords, tensors, offsets = f["famP8_coords"], f["famP8_tensors"], f["famP8_offsets"]
+    p = len(offsets) - 1
+    names = [f"s{i:04d}" for i in range(p)]
+    aln = {n: f["famP8_msa"][i] for i, n in enumerate(names)}
+    make = lambda: [ma.Protein(n, tensors[offsets[i]:offsets[i + 1]], coords[offsets[i]:offsets[i + 1]].copy(), "")  # noqa: E731
+                    for i, n in enumerate(names)]
+    ref = 3
+    moved = msup.superpose_reference(aln, make(), names[ref])
+    want = make()
+    for q in want:
+        pos_1, pos_2 = helper.get_common_positions(aln[names[ref]], aln[q.name])
+        rot, tran = sup.paired_svd_superpose(want[ref].coordinates[pos_1], q.coordinates[pos_2])
+        q.coordinates = sup.apply_rotran(q.coordinates, rot, tran)
+    for i in range(p):
+        assert np.array_equal(moved[i].coordinates, want[i].coordinates), i
+
+
 def test_integration_md_binding_snippet(golden):
     """The hand-written ctypes binding shown in INTEGRATION.md section 2 runs as printed and reproduces the reference's
     pairwise matrix (golden family A)."""
