@@ -24,10 +24,7 @@ def make_coverage_gap_distance_matrix(alignment_array):
     """For rows i, j: fraction of i's residues that face a gap in j, and the number that face a residue."""
     present = np.asarray(alignment_array) != GAP
     counts = present.sum(axis=1)
-    # columns where both rows hold a residue: an exact small-integer matrix product (counts < 2**24 in float32)
-    p32 = present.astype(np.float32)
-    aligning = np.rint(p32 @ p32.T).astype(np.int32) if present.shape[1] < (1 << 24) else \
-        (present[:, None, :] & present[None, :, :]).sum(axis=2).astype(np.int32)
+    aligning = (present[:, None, :] & present[None, :, :]).sum(axis=2).astype(np.int32)
     distance = (counts[:, None] - aligning) / counts[:, None]
     return distance.astype(np.float64), aligning
 
