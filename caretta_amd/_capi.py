@@ -76,6 +76,7 @@ SIGNATURES = {
     "cr_msa_metrics": [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp],
     "cr_superpose_core": [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp],
     "cr_superpose_reference": [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp],
+    "cr_superpose_members": [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64],
     "cr_mean_axis0": [_vp, _i64, _i64, _vp],
     "cr_get_common_positions": [_vp, _vp, _i64, _vp, _vp, C.POINTER(C.c_int64)],
     "cr_neighbor_joining": [_vp, _i64, _vp, _vp],

@@ -880,6 +880,45 @@ int cr_superpose_reference(cr_context* ctx, const double* coords, const int64_t*
     return CR_OK;
 }
 
+int cr_superpose_members(cr_context* ctx, double* coords, const int64_t* offsets, int64_t P, const int32_t* msa, int64_t W,
+                         int64_t ref, const int32_t* which, int64_t nwhich) {
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    CR_REQUIRE(coords && offsets && msa && (which || nwhich == 0), "null argument");
+    CR_REQUIRE(P >= 1 && W >= 1 && W <= 65534 && ref >= 0 && ref < P && nwhich >= 0, "bad alignment shape");
+    if (nwhich == 0) return CR_OK;
+    const int64_t total = offsets[P];
+    CR_REQUIRE(all_finite(coords, (size_t)total * 3), "coordinates contain NaN or infinity");
+    for (int64_t b = 0; b < nwhich; b++) CR_REQUIRE(which[b] >= 0 && which[b] < P, "structure index out of range");
+    for (int64_t s = 0; s < P; s++)
+        for (int64_t x = 0; x < W; x++)
+            CR_REQUIRE(msa[s * W + x] >= -1 && msa[s * W + x] < offsets[s + 1] - offsets[s], "alignment index outside its structure");
+    DevBuf<double> dc, dout;
+    DevBuf<int64_t> doff;
+    DevBuf<int32_t> dmsa, dwhich, dcounts;
+    if ((rc = upload(dc, coords, (size_t)total * 3, ctx->stream))) return rc;
+    if ((rc = upload(doff, offsets, (size_t)P + 1, ctx->stream))) return rc;
+    if ((rc = upload(dmsa, msa, (size_t)P * W, ctx->stream))) return rc;
+    if ((rc = upload(dwhich, which, (size_t)nwhich, ctx->stream))) return rc;
+    CR_HIP(dout.ensure((size_t)total * 3));
+    CR_HIP(dcounts.ensure((size_t)nwhich));
+    CR_HIP(hipMemcpyAsync(dout.p, dc.p, sizeof(double) * (size_t)total * 3, hipMemcpyDeviceToDevice, ctx->stream));
+    const size_t lds = sizeof(double) * (((size_t)W + 3) / 4 * 2 + (size_t)cr::kWave * cr::kMaxAcc);
+    if ((rc = allow_lds(cr::k_reference_superpose, lds))) return rc;
+    hipLaunchKernelGGL(cr::k_reference_superpose, dim3((unsigned)nwhich), dim3(cr::kWave), lds, ctx->stream, dc.p, doff.p, dmsa.p,
+                       (int)W, (int)ref, dc.p + offsets[ref] * 3, dwhich.p, dout.p, dcounts.p);
+    CR_HIP(hipGetLastError());
+    std::vector<int32_t> counts((size_t)nwhich);
+    std::vector<double> moved((size_t)total * 3);
+    CR_HIP(hipMemcpyAsync(counts.data(), dcounts.p, sizeof(int32_t) * (size_t)nwhich, hipMemcpyDeviceToHost, ctx->stream));
+    CR_HIP(hipMemcpyAsync(moved.data(), dout.p, sizeof(double) * (size_t)total * 3, hipMemcpyDeviceToHost, ctx->stream));
+    CR_HIP(hipStreamSynchronize(ctx->stream));
+    for (int64_t b = 0; b < nwhich; b++)
+        CR_REQUIRE(counts[(size_t)b] > 3, "a structure shares 3 or fewer alignment columns with the reference (reference: assert len(pos_1) > 3)");
+    std::memcpy(coords, moved.data(), sizeof(double) * (size_t)total * 3);
+    return CR_OK;
+}
+
 int cr_get_common_positions(const int64_t* a1, const int64_t* a2, int64_t len, int64_t* p1, int64_t* p2, int64_t* k) {
     CR_REQUIRE(len >= 0 && (len == 0 || (a1 && a2 && p1 && p2)) && k, "bad argument");
     int64_t c = 0;

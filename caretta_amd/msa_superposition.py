@@ -113,16 +113,42 @@ def superpose_reference(alignment, proteins, reference_name):
 def superpose_references(alignment, proteins, minimum_coverage=50):
     """Fit every structure onto the reference structure chosen for it (multiple_alignment.py:975-997)."""
     order = [p.name for p in proteins]
-    by_name = {p.name: p for p in proteins}
+    index = {name: i for i, name in enumerate(order)}
     _, groups, _ = get_reference_structures(alignment, minimum_coverage)
+    lens = [len(p) for p in proteins]
+    offsets = np.zeros(len(proteins) + 1, dtype=np.int64)
+    offsets[1:] = np.cumsum(lens)
+    coords = np.ascontiguousarray(np.vstack([f64(p.coordinates) for p in proteins]))
+    msa = np.ascontiguousarray(np.array([alignment[name] for name in order]), dtype=np.int32)
+    lib, ctx = _capi.load(), default_context()._h
+
+    def fit(ref, members):
+        which = np.ascontiguousarray([index[name] for name in members], dtype=np.int32)
+        if len(which):
+            try:
+                check(lib.cr_superpose_members(ctx, ptr(coords), ptr(offsets), len(proteins), ptr(msa), msa.shape[1], ref,
+                                               ptr(which), len(which)))
+            except ValueError as e:
+                if "3 or fewer" in str(e):
+                    raise AssertionError(str(e)) from None
+                raise
+
+    # the groups in order; inside a group the members are independent, except that a reference listed among its own
+    # members is refitted onto itself when its turn comes and the members after it see the refitted copy (:985-995)
     for reference_name, members in groups.items():
-        for name in members:
-            pos_1, pos_2 = helper.get_common_positions(alignment[reference_name], alignment[name])
-            assert len(pos_1) > 3
-            rot, tran = sup.paired_svd_superpose(f64(by_name[reference_name].coordinates)[pos_1],
-                                                 f64(by_name[name].coordinates)[pos_2])
-            by_name[name].coordinates = sup.apply_rotran(by_name[name].coordinates, rot, tran)
-    return [by_name[name] for name in order]
+        ref = index[reference_name]
+        if reference_name in members:
+            at = members.index(reference_name)
+            fit(ref, members[:at])
+            fit_self = np.ascontiguousarray([ref], dtype=np.int32)
+            check(lib.cr_superpose_members(ctx, ptr(coords), ptr(offsets), len(proteins), ptr(msa), msa.shape[1], ref,
+                                           ptr(fit_self), 1))
+            fit(ref, members[at + 1:])
+        else:
+            fit(ref, members)
+    for i, protein in enumerate(proteins):
+        protein.coordinates = coords[offsets[i]:offsets[i + 1]].copy()
+    return proteins
 
 
 def superpose(alignment, proteins, gap=GAP, verbose=False):

@@ -205,6 +205,12 @@ int cr_superpose_core(cr_context *ctx, const double *coords, const int64_t *offs
  * structure.  CR_ERR_ARGUMENT if a structure shares 3 or fewer columns with the reference (:965). */
 int cr_superpose_reference(cr_context *ctx, const double *coords, const int64_t *offsets, int64_t num_structures,
                            const int32_t *msa, int64_t width, int64_t ref, double *coords_out);
+/* One group of superpose_references (multiple_alignment.py:975-997): the structures which[nwhich] fitted onto
+ * structure `ref` as it currently is in coords (in place).  All listed structures see the same copy of `ref`: where the
+ * reference's loop refits `ref` onto itself in the middle of a group, the caller splits the list there and lists `ref`
+ * alone.  One wave per listed structure. */
+int cr_superpose_members(cr_context *ctx, double *coords, const int64_t *offsets, int64_t num_structures,
+                         const int32_t *msa, int64_t width, int64_t ref, const int32_t *which, int64_t nwhich);
 /* helper.nb_mean_axis_0 (sequential column means, as numba computes them)   helper.py:46-53 */
 int cr_mean_axis0(const double *x, int64_t rows, int64_t cols, double *out);
 

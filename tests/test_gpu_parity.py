@@ -633,6 +633,30 @@ def test_superpose_reference_batched_equals_the_loop(golden):
         assert np.array_equal(moved[i].coordinates, want[i].coordinates), i
 
 
+def test_superpose_references_batched_equals_the_loop(golden):
+    """superpose_references group by group (cr_superpose_members) against the reference's loop written with the
+    single-call drop-ins -- bit-identical, for two coverage thresholds (one and several groups)."""
+    from caretta_amd import helper, multiple_alignment as ma, msa_superposition as msup, superposition_functions as sup
+    f = golden("f4_progressive.npz")
+    coords, tensors, offsets = f["famP8_coords"], f["famP8_tensors"], f["famP8_offsets"]
+    p = len(offsets) - 1
+    names = [f"s{i:04d}" for i in range(p)]
+    aln = {n: f["famP8_msa"][i] for i, n in enumerate(names)}
+    make = lambda: [ma.Protein(n, tensors[offsets[i]:offsets[i + 1]], coords[offsets[i]:offsets[i + 1]].copy(), "")  # noqa: E731
+                    for i, n in enumerate(names)]
+    for coverage in (50, 97):
+        moved = msup.superpose_references(aln, make(), coverage)
+        want = {q.name: q for q in make()}
+        _, groups, _ = msup.get_reference_structures(aln, coverage)
+        for reference_name, members in groups.items():
+            for name in members:
+                pos_1, pos_2 = helper.get_common_positions(aln[reference_name], aln[name])
+                rot, tran = sup.paired_svd_superpose(want[reference_name].coordinates[pos_1], want[name].coordinates[pos_2])
+                want[name].coordinates = sup.apply_rotran(want[name].coordinates, rot, tran)
+        for q in moved:
+            assert np.array_equal(q.coordinates, want[q.name].coordinates), (coverage, q.name)
+
+
 def test_integration_md_binding_snippet(golden):
     """The hand-written ctypes binding shown in INTEGRATION.md section 2 runs as printed and reproduces the reference's
     pairwise matrix (golden family A)."""
