@@ -70,7 +70,7 @@ static double sum_strided(const double *a, int64_t n, int64_t stride) {
  * Constants: tools/gen_exp_constants.py.
  * ---------------------------------------------------------------------------------------- */
 #include "exp_table.inc"
-static const double EXP_TAB[CR_EXP_N][2] = {CR_EXP_TABLE};
+static const double EXP_TAB[CR_EXP_N][2] __attribute__((unused)) = {CR_EXP_TABLE};   /* unused with -DCRO_LIBM_EXP */
 
 static inline double pow2i(int e) { /* 2^e for -1022 <= e <= 1023 */
     uint64_t bits = (uint64_t)(e + 1023) << 52;
