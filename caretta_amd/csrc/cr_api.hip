@@ -24,7 +24,9 @@
 #include "cr_kernels.h"
 #include "cr_ilp_instances.h"
 
-// compiled in cr_kernels_ilp.hip with another instruction scheduler
+// compiled in cr_kernels_ilp.hip with another instruction scheduler (the diagnostic stamps build is one translation
+// unit: its stamp buffer is a static __device__ array)
+#ifndef CR_STAMPS
 #define CR_X(R, D, ZG) extern template CR_SEED_SIGNATURE(R, D, ZG)
 CR_ILP_SEED_INSTANCES(CR_X)
 #undef CR_X
@@ -37,6 +39,7 @@ CR_ILP_SEED_TEAM_INSTANCES(CR_X)
 #define CR_X(R) extern template CR_NODE_TEAM_SIGNATURE(R)
 CR_ILP_NODE_TEAM_INSTANCES(CR_X)
 #undef CR_X
+#endif
 
 namespace {
 
@@ -224,6 +227,7 @@ struct cr_batch {
     int64_t npairs = 0;
     int r_seed = 5, r_align = 5, d_pad = 0;
     bool team = false;                  // few pairs: one workgroup of kTeamWaves waves per pair (k_seed_team / k_align_team)
+    int wide_sync = 0;                  // > 0: the wide kernels (one wave per strip, up to 16 waves per pair) with a barrier every wide_sync steps
     int n_max = 0, m_max = 0;
     int64_t max_aln = 0;
     std::vector<cr::PairDesc> h_pairs;  // in LAUNCH order: most cells first (order[k] = index in the caller's list)
@@ -351,6 +355,78 @@ int launch_align_team(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_pa
         case 4: return zg ? launch_align_team_zg<4, true>(b, ck, prm) : launch_align_team_zg<4, false>(b, ck, prm);
         default: return zg ? launch_align_team_zg<5, true>(b, ck, prm) : launch_align_team_zg<5, false>(b, ck, prm);
     }
+}
+
+// ---- wide kernels: one wave per strip, up to kWideMaxWaves waves per pair, columns resident in LDS ----------
+template <int R, int D, bool ZG>
+int launch_seed_wide_zg(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
+    using Src = cr::RbfTensor<R, D>;
+    const int entries = std::min(ck.n_max, ck.m_max);
+    const int waves = cr::strips_of(ck.n_max, R);
+    const size_t lds = sizeof(double) * std::max(cr::sweep_wide_lds_doubles<cr::kSwTrace, Src>(waves, ck.m_max),
+                                                 (size_t)cr::kExpDoubles + cr::trace_lds_doubles(R, entries));
+    int rc = allow_lds(cr::k_seed_wide<R, D, ZG>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((cr::k_seed_wide<R, D, ZG>), dim3((unsigned)ck.count), dim3(waves * cr::kWave), lds,
+                       b->launch_stream ? b->launch_stream : b->ctx->stream, b->pairs.p + ck.first, b->tensors.p, (int)b->d,
+                       b->coords.p, prm.gamma_tensor, prm.sw_gap, entries, b->wide_sync, b->dirs.p, b->xf.p + ck.first,
+                       b->seed_score.p + ck.first);
+    CR_HIP(hipGetLastError());
+    return CR_OK;
+}
+
+template <int R>
+int launch_seed_wide_r(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
+    const bool zg = prm.sw_gap == 0.0;
+    switch (b->d_pad) {
+        case 4: return zg ? launch_seed_wide_zg<R, 4, true>(b, ck, prm) : launch_seed_wide_zg<R, 4, false>(b, ck, prm);
+        case 8: return zg ? launch_seed_wide_zg<R, 8, true>(b, ck, prm) : launch_seed_wide_zg<R, 8, false>(b, ck, prm);
+        case 10: return zg ? launch_seed_wide_zg<R, 10, true>(b, ck, prm) : launch_seed_wide_zg<R, 10, false>(b, ck, prm);
+        case 16: return zg ? launch_seed_wide_zg<R, 16, true>(b, ck, prm) : launch_seed_wide_zg<R, 16, false>(b, ck, prm);
+        default: return fail(CR_ERR_ARGUMENT, "unsupported tensor width");
+    }
+}
+
+int launch_seed_wide(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
+    return R == 1 ? launch_seed_wide_r<1>(b, ck, prm) : R == 2 ? launch_seed_wide_r<2>(b, ck, prm) : launch_seed_wide_r<3>(b, ck, prm);
+}
+
+template <int R, bool ZG>
+int launch_align_wide_zg(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
+    using Src = cr::RbfCoords<R>;
+    const int entries = ck.max_aln;
+    const int waves = cr::strips_of(ck.n_max, R);
+    const size_t lds = sizeof(double) * std::max(cr::sweep_wide_lds_doubles<cr::kSwScore | cr::kDtw, Src>(waves, ck.m_max),
+                                                 (size_t)cr::kExpDoubles + cr::trace_lds_doubles(R, entries));
+    int rc = allow_lds(cr::k_align_wide<R, ZG>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((cr::k_align_wide<R, ZG>), dim3((unsigned)ck.count), dim3(waves * cr::kWave), lds,
+                       b->launch_stream ? b->launch_stream : b->ctx->stream, b->pairs.p + ck.first, b->coords.p, b->xf.p + ck.first,
+                       b->seed_score.p + ck.first, prm.gamma_coords, prm.sw_gap, prm.gap_open, prm.gap_extend, entries,
+                       b->wide_sync, b->bits.p, b->aln.p, b->res.p + ck.first);
+    CR_HIP(hipGetLastError());
+    return CR_OK;
+}
+
+int launch_align_wide(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
+    const bool zg = prm.sw_gap == 0.0;
+    switch (R) {
+        case 1: return zg ? launch_align_wide_zg<1, true>(b, ck, prm) : launch_align_wide_zg<1, false>(b, ck, prm);
+        case 2: return zg ? launch_align_wide_zg<2, true>(b, ck, prm) : launch_align_wide_zg<2, false>(b, ck, prm);
+        default: return zg ? launch_align_wide_zg<3, true>(b, ck, prm) : launch_align_wide_zg<3, false>(b, ck, prm);
+    }
+}
+
+// Can a pair list with these maxima run on the wide kernels with R rows per lane?  (strips <= 16 waves, the columns
+// of the tensor sweep -- the larger of the two -- resident in LDS next to the edge rings)
+bool wide_fits(int R, int n_max, int m_max, int d_pad) {
+    if (R < 1 || R > 3) return false;
+    const int waves = cr::strips_of(n_max, R);
+    if (waves > cr::kWideMaxWaves) return false;
+    const size_t seed = cr::kExpDoubles + (size_t)d_pad * m_max + (size_t)waves * (cr::kWideEdge + 8);
+    const size_t align = cr::kExpDoubles + (size_t)3 * m_max + (size_t)waves * (3 * cr::kWideEdge + 8);
+    const size_t trace = cr::kExpDoubles + cr::trace_lds_doubles(R, n_max + m_max);
+    return sizeof(double) * std::max(std::max(seed, align), trace) <= 160 * 1024;
 }
 
 constexpr int64_t kTeamPairLimit = 256;
@@ -575,6 +651,16 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     b->team = npairs > 0 && npairs <= team_limit && b->n_max > 3 * cr::kWave && b->n_max <= 5 * cr::kTeamWaves * cr::kWave &&
               !std::getenv("CARETTA_NO_TEAM");
     if (b->team) b->r_seed = b->r_align = (b->n_max + cr::kTeamWaves * cr::kWave - 1) / (cr::kTeamWaves * cr::kWave);
+    b->wide_sync = 0;
+    if (const char* env = std::getenv("CARETTA_WIDE")) {           // calibration: "R,B" forces the wide kernels
+        int r = 0, sync = 0;
+        if (std::sscanf(env, "%d,%d", &r, &sync) == 2 && npairs > 0 && sync >= 1 && sync <= cr::kWideMaxSync &&
+            wide_fits(r, b->n_max, b->m_max, b->d_pad)) {
+            b->team = true;                                         // same layout rules as the team kernels: one group, one R
+            b->wide_sync = sync;
+            b->r_seed = b->r_align = r;
+        }
+    }
     // scratch budget per chunk (decision words); CARETTA_SCRATCH_MB overrides the 8 GiB default
     int64_t budget_words = (int64_t)8192 * 1024 * 1024 / 4;
     if (const char* env = std::getenv("CARETTA_SCRATCH_MB")) {
@@ -758,9 +844,9 @@ int cr_batch_run(cr_batch* b, const cr_params* params, double* d_sw_out) {
         hipStream_t st = ck.lane == 0 ? ctx->stream : ctx->side[(size_t)ck.lane - 1];
         b->launch_stream = st;
         if (prof) (void)hipEventRecord((*evl)[evi++], st);
-        rc = b->team ? launch_seed_team(ck.r, b, ck, prm) : launch_seed_r(ck.r, b, ck, prm);
+        rc = b->wide_sync ? launch_seed_wide(ck.r, b, ck, prm) : b->team ? launch_seed_team(ck.r, b, ck, prm) : launch_seed_r(ck.r, b, ck, prm);
         if (!rc && prof) (void)hipEventRecord((*evl)[evi++], st);
-        if (!rc) rc = b->team ? launch_align_team(ck.r, b, ck, prm) : launch_align_r(ck.r, b, ck, prm);
+        if (!rc) rc = b->wide_sync ? launch_align_wide(ck.r, b, ck, prm) : b->team ? launch_align_team(ck.r, b, ck, prm) : launch_align_r(ck.r, b, ck, prm);
         if (!rc && prof) (void)hipEventRecord((*evl)[evi++], st);
         b->launch_stream = nullptr;
         if (rc) return rc;
@@ -894,6 +980,15 @@ int cr_batch_fetch_scores(cr_batch* b, double* sw, uint32_t* flags) {
     CR_HIP(hipStreamSynchronize(st));
     return CR_OK;
 }
+
+#ifdef CR_STAMPS
+// diagnostic build only: copy out (and clear) the phase stamps of the first `blocks` blocks
+int cr_debug_stamps(unsigned long long* out, int blocks) {
+    CR_HIP(hipDeviceSynchronize());
+    CR_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8 * (size_t)blocks));
+    return CR_OK;
+}
+#endif
 
 int cr_batch_destroy(cr_batch* b) {
     if (!b) return CR_OK;

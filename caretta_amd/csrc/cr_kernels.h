@@ -18,6 +18,20 @@
 
 #include "cr_math.h"
 
+// Diagnostic build only (-DCR_STAMPS, tools/stamps.py): shader-clock stamps of the phases of the batch kernels,
+// 8 slots per block (0-3 seed kernel: start, fill done, walk done, end; 4-7 the same for the align kernel).
+#ifdef CR_STAMPS
+static __device__ unsigned long long g_stamps[8192 * 8];
+#define CR_STAMP(k)                                                                                  \
+    do {                                                                                             \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define CR_STAMP(k) \
+    do {            \
+    } while (0)
+#endif
+
 namespace cr {
 
 constexpr int kWave = 64;
@@ -124,6 +138,21 @@ struct RbfTensor {
 #pragma unroll
         for (int k = 0; k < D; k++) col[k] = ring[k * kRing + slot];
     }
+    // wide sweep: all m columns resident in LDS, feature-major planes of `stride` doubles (consecutive lanes read
+    // consecutive doubles of a plane: conflict-free ds_read_b64)
+    static constexpr int kColDoubles = D;
+    CR_D void load_resident(double* res, int stride, int m, int tid, int nth) {
+        const int total = m * d;
+        for (int e = tid; e < total; e += nth) {
+            const int c = e / d, k = e - c * d;
+            res[k * stride + c] = cols_g[e];
+        }
+        for (int e = tid; e < (D - d) * stride; e += nth) res[d * stride + e] = 0.0;   // padded features
+    }
+    CR_D void fetch_resident(const double* res, int stride, int c) {
+#pragma unroll
+        for (int k = 0; k < D; k++) col[k] = res[k * stride + c];
+    }
     CR_D double score(int q, const ExpEntry* tab) const {
         double df = row[q][0] - col[0];
         double acc = df * df;
@@ -189,6 +218,28 @@ struct RbfCoords {
         col[1] = ring[kRing + slot];
         col[2] = ring[2 * kRing + slot];
     }
+    static constexpr int kColDoubles = 3;
+    CR_D void load_resident(double* res, int stride, int m, int tid, int nth) {
+        const bool raw = xf->flags & kFlagSeedSkipped;
+        for (int c = tid; c < m; c += nth) {
+            const double v[3] = {cols_g[(int64_t)c * 3], cols_g[(int64_t)c * 3 + 1], cols_g[(int64_t)c * 3 + 2]};
+            double o[3];
+            if (raw) {
+                o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+            } else {
+                const double w[3] = {v[0] - xf->c2[0], v[1] - xf->c2[1], v[2] - xf->c2[2]};
+                rot3(w, xf->R, o);
+            }
+            res[c] = o[0];
+            res[stride + c] = o[1];
+            res[2 * stride + c] = o[2];
+        }
+    }
+    CR_D void fetch_resident(const double* res, int stride, int c) {
+        col[0] = res[c];
+        col[1] = res[stride + c];
+        col[2] = res[2 * stride + c];
+    }
     CR_D double score(int q, const ExpEntry* tab) const {
         double dx = row[q][0] - col[0], dy = row[q][1] - col[1], dz = row[q][2] - col[2];
         double acc = (dx * dx + dy * dy) + dz * dz;
@@ -226,6 +277,15 @@ struct RbfNode {
     CR_D void fetch_col(const double* ring, int slot) {
         xyz.fetch_col(ring, slot);
         wcol = ring[3 * kRing + slot];
+    }
+    static constexpr int kColDoubles = 4;
+    CR_D void load_resident(double* res, int stride, int m, int tid, int nth) {
+        xyz.load_resident(res, stride, m, tid, nth);
+        for (int c = tid; c < m; c += nth) res[3 * stride + c] = w_cols[c] * mult2;
+    }
+    CR_D void fetch_resident(const double* res, int stride, int c) {
+        xyz.fetch_resident(res, stride, c);
+        wcol = res[3 * stride + c];
     }
     CR_D double score(int q, const ExpEntry* tab) const {
         const double dw = wrow[q] - wcol;
@@ -829,6 +889,218 @@ __host__ __device__ inline size_t sweep_team_lds_doubles(int waves) {
     return kExpDoubles + (size_t)waves * (Src::kRingDoubles + NB * kEdgeRing + 8);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The wide sweep: one WORKGROUP of up to kWideMaxWaves waves per pair, one wave per strip, for pair lists that
+// cannot fill the chip with one or four waves per pair (one GPU's share of a sharded long-chain family: 252 pairs
+// of 1200 x 1200 on 256 CUs).  Differences from sweep_team:
+//   * all m columns of the pair are RESIDENT in LDS (feature-major planes, loaded once by the whole workgroup with
+//     coalesced reads): no per-wave column rings, no chunk loads, no chunk barriers, and the LDS cost does not
+//     grow with the number of waves;
+//   * strip s runs lag = 63 + B steps behind strip s-1 and the waves meet at a barrier every B steps only
+//     (B = sync_every): a value written by strip s-1's last lane in global step g is read by strip s in step g + B,
+//     and every window of B consecutive steps holds one barrier.  B = 1 is sweep_team's lock step; larger B lets the
+//     waves of one SIMD drift and fill each other's issue gaps at the price of a (S - 1) * (B - 1) steps longer
+//     pipeline.  Edge rings of kWideEdge entries per value: the writer is at most 2B - 1 columns ahead (B <= 32).
+// Decision words use the same (strip, time block, row, lane) layout as the other sweeps (shared traceback).
+// LDS (doubles): exp table | Src::kColDoubles planes of `stride` | NW edge rings of NB * kWideEdge | NW * 8.
+// ---------------------------------------------------------------------------------------------
+constexpr int kWideEdge = 64;
+constexpr int kWideMaxWaves = 16;
+constexpr int kWideMaxSync = 32;
+
+template <int R, int MODE, class Src>
+CR_D void sweep_wide(Src& src, const int n, const int m, const SweepParams prm, double* lds, const int sync_every,
+                     uint32_t* __restrict__ sw_dirs, uint32_t* __restrict__ dtw_bits, SeedMax& seed_out,
+                     AlignEnd& end_out) {
+    constexpr bool SW = (MODE & (kSwTrace | kSwScore)) != 0;
+    constexpr bool TRACE = (MODE & kSwTrace) != 0;
+    constexpr bool DTW = (MODE & kDtw) != 0;
+    constexpr int NB = (SW ? 1 : 0) + (DTW ? 2 : 0);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int NW = (int)(blockDim.x >> 6);
+    const int stride = m;
+    const ExpEntry* tab = reinterpret_cast<const ExpEntry*>(lds);
+    double* res = lds + kExpDoubles;
+    double* edges = res + (size_t)Src::kColDoubles * stride;
+    double* edge_out = edges + w * (NB * kWideEdge);
+    const double* edge_in = edges + (w > 0 ? w - 1 : 0) * (NB * kWideEdge);
+    double* red = edges + NW * (NB * kWideEdge);
+
+    load_exp_table(lds, threadIdx.x);
+    src.load_resident(res, stride, m, (int)threadIdx.x, (int)blockDim.x);
+
+    const int nstrips = strips_of(n, R);                 // <= NW, guaranteed by the launcher
+    const int TB_SW = tblocks(m, 16), TB_DTW = tblocks(m, 8);
+    const double col0_m2 = kMinF64 - prm.gap_open;
+    const bool mine = w < nstrips;
+    const int rowbase = (w * kWave + lane) * R;
+    const int rows_here = n - w * kWave * R;
+    const int lanes_here = rows_here >= kWave * R ? kWave : (rows_here + R - 1) / R;
+    const int T = mine ? m + lanes_here - 1 : 0;
+    const int lag = kWave - 1 + sync_every;
+
+    DpState<R> st;
+    st.sw_max = 0.0;
+    if (mine) src.load_rows(rowbase, n);
+    st.reset_column0(col0_m2);
+#pragma unroll
+    for (int q = 0; q < R; q++) st.swbits[q] = st.dtbits[q] = 0;
+    st.h_bot = st.m0_bot = st.m1_bot = 0.0;
+
+    const int G = lag * (nstrips - 1) + m + kWave - 1;
+    int until_sync = 0;
+    for (int g = 0; g < G; g++) {
+        if (until_sync == 0) {
+            __syncthreads();                               // edge values of the last B steps visible to the next strip
+            until_sync = sync_every;
+        }
+        until_sync--;
+        const int t = g - lag * w;
+        const bool live = mine && t >= 0 && t < T;
+        if (!live) continue;
+        const int c = t - lane;
+        const bool active = (unsigned)c < (unsigned)m;
+
+        double h_top0 = 0.0, m0_top0 = col0_m2, m1_top0 = 0.0;
+        if (w > 0 && lane == 0 && active) {
+            if constexpr (SW) h_top0 = edge_in[c & (kWideEdge - 1)];
+            if constexpr (DTW) {
+                m0_top0 = edge_in[(NB - 2) * kWideEdge + (c & (kWideEdge - 1))];
+                m1_top0 = edge_in[(NB - 1) * kWideEdge + (c & (kWideEdge - 1))];
+            }
+        }
+        double h_top = 0.0, m0_top = 0.0, m1_top = 0.0;
+        if constexpr (SW) h_top = wave_shr1(st.h_bot, h_top0);
+        if constexpr (DTW) {
+            m0_top = wave_shr1(st.m0_bot, m0_top0);
+            m1_top = wave_shr1(st.m1_bot, m1_top0);
+        }
+        const int sh2 = (t & 15) * 2, sh4 = (t & 7) * 4;
+
+        if (active) {
+            src.fetch_resident(res, stride, c);
+            dp_column<R, MODE>(src, st, prm, tab, c, rowbase, n, sh2, sh4, h_top, m0_top, m1_top);
+            if (w + 1 < nstrips && lane == kWave - 1) {
+                if constexpr (SW) edge_out[c & (kWideEdge - 1)] = st.h_bot;
+                if constexpr (DTW) {
+                    edge_out[(NB - 2) * kWideEdge + (c & (kWideEdge - 1))] = st.m0_bot;
+                    edge_out[(NB - 1) * kWideEdge + (c & (kWideEdge - 1))] = st.m1_bot;
+                }
+            }
+        }
+        if constexpr (TRACE) {
+            if ((t & 15) == 15 || t == T - 1) {
+                const int64_t base = ((int64_t)(w * TB_SW + (t >> 4)) * R) * kWave + lane;
+#pragma unroll
+                for (int q = 0; q < R; q++) {
+                    sw_dirs[base + q * kWave] = st.swbits[q];
+                    st.swbits[q] = 0;
+                }
+            }
+        }
+        if constexpr (DTW) {
+            if ((t & 7) == 7 || t == T - 1) {
+                const int64_t base = ((int64_t)(w * TB_DTW + (t >> 3)) * R) * kWave + lane;
+#pragma unroll
+                for (int q = 0; q < R; q++) {
+                    dtw_bits[base + q * kWave] = st.dtbits[q];
+                    st.dtbits[q] = 0;
+                }
+            }
+        }
+    }
+
+    // ---- per-wave results, then across the waves through LDS (as sweep_team) -------------------------
+    double best_v = 0.0;
+    int best_i = 0x7fffffff, best_j = 0x7fffffff;
+    if constexpr (TRACE) {
+        if (mine) {
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const bool gt = st.rowmax[q] > best_v;
+                best_v = gt ? st.rowmax[q] : best_v;
+                best_i = gt ? rowbase + q : best_i;
+                best_j = gt ? st.rowarg[q] : best_j;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            double ov = __shfl_xor(best_v, off);
+            int oi = __shfl_xor(best_i, off), oj = __shfl_xor(best_j, off);
+            bool take = ov > best_v || (ov == best_v && (oi < best_i || (oi == best_i && oj < best_j)));
+            best_v = take ? ov : best_v;
+            best_i = take ? oi : best_i;
+            best_j = take ? oj : best_j;
+        }
+    }
+    double sw_max = mine ? st.sw_max : 0.0;
+    if constexpr ((MODE & kSwScore) != 0) {
+        for (int off = 32; off > 0; off >>= 1) sw_max = __builtin_fmax(sw_max, __shfl_xor(sw_max, off));
+    }
+    const int owner_wave = (n - 1) / (kWave * R);
+    if (lane == 0) {
+        red[w * 8 + 0] = best_v;
+        red[w * 8 + 1] = (double)best_i;
+        red[w * 8 + 2] = (double)best_j;
+        red[w * 8 + 3] = sw_max;
+    }
+    if constexpr (DTW) {
+        if (w == owner_wave) {
+            const int owner = ((n - 1) / R) % kWave;
+            const int qo = (n - 1) % R;
+            double fin0 = 0.0, fin1 = 0.0, fin2 = 0.0;
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                fin0 = (q == qo) ? st.m0_left[q] : fin0;
+                fin1 = (q == qo) ? st.m1_left[q] : fin1;
+                fin2 = (q == qo) ? st.m2_left[q] : fin2;
+            }
+            if (lane == owner) {
+                red[w * 8 + 4] = fin0;
+                red[w * 8 + 5] = fin1;
+                red[w * 8 + 6] = fin2;
+            }
+        }
+    }
+    __threadfence();                                   // decision words of every wave visible to wave 0's walk
+    __syncthreads();
+    if constexpr (TRACE) {
+        best_v = 0.0;
+        best_i = best_j = 0x7fffffff;
+        for (int x = 0; x < nstrips; x++) {
+            const double ov = red[x * 8 + 0];
+            const int oi = (int)red[x * 8 + 1], oj = (int)red[x * 8 + 2];
+            const bool take = ov > best_v || (ov == best_v && (oi < best_i || (oi == best_i && oj < best_j)));
+            best_v = take ? ov : best_v;
+            best_i = take ? oi : best_i;
+            best_j = take ? oj : best_j;
+        }
+        seed_out.score = best_v;
+        seed_out.i = best_v > 0.0 ? best_i + 1 : 0;
+        seed_out.j = best_v > 0.0 ? best_j + 1 : 0;
+    }
+    if constexpr ((MODE & kSwScore) != 0 || DTW) {
+        double smax = 0.0;
+        for (int x = 0; x < nstrips; x++) smax = __builtin_fmax(smax, red[x * 8 + 3]);
+        const double fin0 = red[owner_wave * 8 + 4], fin1 = red[owner_wave * 8 + 5], fin2 = red[owner_wave * 8 + 6];
+        end_out.sw = smax;
+        int idx = 0;
+        double best = fin0;
+        if (fin1 > best) { best = fin1; idx = 1; }
+        if (fin2 > best) { best = fin2; idx = 2; }
+        end_out.dtw_score = DTW ? best : 0.0;
+        end_out.start_layer = idx;
+        end_out.pad = 0;
+    }
+    __syncthreads();
+}
+
+template <int MODE, class Src>
+__host__ __device__ inline size_t sweep_wide_lds_doubles(int waves, int m_max) {
+    constexpr int NB = ((MODE & (kSwTrace | kSwScore)) ? 1 : 0) + ((MODE & kDtw) ? 2 : 0);
+    return kExpDoubles + (size_t)Src::kColDoubles * m_max + (size_t)waves * (NB * kWideEdge + 8);
+}
+
 CR_D uint32_t lookup_bits(const uint32_t* __restrict__ words, int R, int TB, int per_word_log2, int bits,
                           int row, int col) {
     const int s = row / (kWave * R);
@@ -911,33 +1183,66 @@ struct PairResult {          // per-pair scalar outputs, device and host layout
 // Traceback + superposition stages.  ONE WAVE PER PAIR.
 //
 // The walk is a single logical thread, so it is written wave-uniform (every lane carries the same
-// state; the compiler keeps it in SGPRs) and never touches HBM directly: the packed decisions of
-// the current strip are streamed back through an LDS window of kWinBlocks word-blocks with 256-byte
-// coalesced loads issued by all 64 lanes, newest time step first, and the walk reads its 2/4 bits
-// from LDS.  Emitted alignment columns go to LDS as packed (i, j) 16-bit pairs and are written to
+// state; the compiler keeps it in SGPRs); its decision lookups come out of a register-resident block of words
+// (Walker, below).  Emitted alignment columns go to LDS as packed (i, j) 16-bit pairs and are written to
 // HBM at the end with coalesced stores.  The aligned positions are then gathered 64 at a time by
 // all lanes, per-position terms are computed in parallel, and the sums are taken by one lane per
 // accumulator IN POSITION ORDER out of LDS, so every sum has the reference's (numba's) sequential
 // rounding.  Gap columns contribute +0.0 terms, which never change a running sum that started at
 // +0.0 (such a sum can not be -0.0).
 // ---------------------------------------------------------------------------------------------
-constexpr int kWinBlocks = 4;           // word-blocks (of 16 SW steps / 8 DTW steps) per LDS window
 constexpr int kMaxAcc = 9;              // accumulators summed in order (3x3 correlation matrix)
 constexpr uint32_t kGap16 = 0xffffu;    // -1 in a packed 16-bit alignment entry
 constexpr int kMaxLength = 65534;       // longest structure the packed entries can index
 
 CR_D uint32_t pack_entry(int i, int j) { return ((uint32_t)i & 0xffffu) | ((uint32_t)j << 16); }
 
-// lane -> (strip, lane-in-strip, row slot) bookkeeping of a DP row, updated incrementally
-struct RowPos {
-    int s, l, q;
-    CR_D void set(int row, int R) {
+// ---------------------------------------------------------------------------------------------
+// Walk-side view of the packed decisions of one pair (BITS = 2: SW, 16 steps per word; BITS = 4: DTW, 8 per word).
+//
+// A walk is one logical thread chasing a chain of dependent lookups, so everything that can be taken off that
+// chain is: the wave keeps, in ONE VGPR, the decision words of a block of kBlockRows consecutive DP rows x kBlockWords
+// consecutive words per row (lane 4a + w: row r0 - a, word (c0 + lane_of_row) / steps_per_word - w), gathered straight
+// from L2/HBM with a single global load; a lookup inside the block is one v_readlane (no memory access), and the block
+// covers every path that leaves the anchor cell (r0, c0) going up, diagonally, or up to ~25 (DTW) / ~50 (SW) columns
+// to the left per row.  Whole DIAGONAL RUNS are resolved at once: every lane tests the cell of its row on the diagonal
+// through the current cell, one ballot gives the run length, and the run's alignment entries are emitted by the lanes
+// in parallel -- on structural alignments most columns are aligned pairs, so the walk advances by up to 16 cells per
+// iteration.  Row bookkeeping (strip, fill lane, row slot) is wave-uniform and lives in SGPRs.
+// ---------------------------------------------------------------------------------------------
+template <int R, int BITS>
+struct Walker {
+    static constexpr int kLog = BITS == 2 ? 4 : 3;                 // log2(steps per word)
+    static constexpr int kStepMask = (1 << kLog) - 1;
+    static constexpr uint32_t kFieldMask = (1u << BITS) - 1u;
+    static constexpr int kBlockRows = 16, kBlockWords = 4;
+    const uint32_t* __restrict__ words;
+    int TB;
+    int ax, wx;               // per lane: row offset and word slot held by this lane
+    uint32_t blk;             // per lane: the word
+    int lax;                  // per lane: fill lane of this lane's row
+    int r0, c0, bs, amax;     // block key (wave-uniform): anchor cell, strip (-1: empty), deepest row offset held
+    int s, l, q;              // position of the current row (wave-uniform): strip, fill lane, row slot
+
+    CR_D void init(const uint32_t* __restrict__ w, int tb, int lane) {
+        words = w;
+        TB = tb;
+        ax = lane >> 2;
+        wx = lane & 3;
+        blk = 0;
+        lax = 0;
+        r0 = c0 = 0;
+        bs = -1;                  // no strip: the first lookup fills the block
+        amax = -1;
+        s = l = q = 0;
+    }
+    CR_D void set_row(int row) {
         s = row / (kWave * R);
-        const int rem = row - s * kWave * R;
+        const int rem = row - s * (kWave * R);
         l = rem / R;
         q = rem - l * R;
     }
-    CR_D void up(int R) {              // row -> row - 1
+    CR_D void row_up() {
         if (q > 0) {
             q--;
         } else {
@@ -950,69 +1255,48 @@ struct RowPos {
             }
         }
     }
-};
-
-// LDS window over the packed decisions of one strip: word-blocks [lo, hi], a contiguous range of
-// the strip's words, copied with coalesced loads that are all in flight together.
-struct BitWindow {
-    uint32_t* win;        // LDS, kWinBlocks * R * 64 words
-    int s, lo, hi;        // strip and word-block range held; hi < lo: empty
-    CR_D void load(const uint32_t* __restrict__ words, int R, int TB, int strip, int tb_hi, int lane) {
-        wave_sync();
-        const int tb_lo = tb_hi - (kWinBlocks - 1) > 0 ? tb_hi - (kWinBlocks - 1) : 0;
-        const uint32_t* src = words + ((int64_t)(strip * TB + tb_lo) * R) * kWave;
-        const int total = (tb_hi - tb_lo + 1) * R * kWave;
-#pragma unroll 8
-        for (int x = lane; x < total; x += kWave) win[x] = src[x];
-        s = strip;
-        lo = tb_lo;
-        hi = tb_hi;
-        wave_sync();
+    CR_D void refill(int r, int c) {
+        r0 = r;
+        c0 = c;
+        bs = s;
+        const int base = s * (kWave * R);
+        amax = r - base < kBlockRows - 1 ? r - base : kBlockRows - 1;
+        const int rel = r - ax - base;                    // this lane's row, relative to the strip
+        const bool rv = rel >= 0;
+        const int relc = rv ? rel : 0;
+        const int la = relc / R, qa = relc - la * R;
+        lax = la;
+        const int tb = ((c + la) >> kLog) - wx;
+        blk = (rv && tb >= 0) ? words[((int64_t)(s * TB + tb) * R + qa) * kWave + la] : 0u;
     }
-    CR_D bool holds(int strip, int tb) const { return strip == s && tb >= lo && tb <= hi; }
-    CR_D uint32_t word(int R, int tb, int q, int l) const {
-        return (uint32_t)__builtin_amdgcn_readfirstlane((int)win[((tb - lo) * R + q) * kWave + l]);
-    }
-};
-
-// Decision lookup for the walk.  On top of the LDS window it keeps, in ONE VGPR, the words of a block of
-// cells around the walk: kDeep consecutive fill lanes (row blocks) x 2 word-blocks x R rows, one word per
-// lane of this wave.  A lookup inside the block is a v_readlane (no memory access); the block is refilled
-// with a single ds_read when the walk leaves it, about once per kDeep * R steps on a diagonal path.
-struct DecisionReader {
-    BitWindow bw;
-    uint32_t blk;             // lane x holds the word (fill lane bl - ls, word-block bhi - tsel, row qq)
-    int ls, tsel, qq;         // this lane's slot in the block
-    int deep;                 // fill lanes per block = 32 / R
-    int bs, bl, bhi, blo;     // block key: strip, top fill lane, word-block range
-    CR_D void init(uint32_t* win, int R, int lane) {
-        bw.win = win;
-        bw.s = -1;
-        bw.lo = 0;
-        bw.hi = -1;
-        deep = 32 / R;
-        ls = lane / (2 * R);
-        const int rest = lane - ls * 2 * R;
-        tsel = rest / R;
-        qq = rest - tsel * R;
-        bs = -1;
-        bl = bhi = blo = 0;
-        blk = 0;
-    }
-    CR_D uint32_t get(const uint32_t* __restrict__ words, int R, int TB, int strip, int l, int q, int tb, int lane) {
-        const bool hit = strip == bs && l <= bl && l > bl - deep && tb <= bhi && tb >= blo;
-        if (!hit) {
-            if (!bw.holds(strip, tb)) bw.load(words, R, TB, strip, tb, lane);
-            bs = strip;
-            bl = l;
-            bhi = tb;
-            blo = tb - 1 > bw.lo ? tb - 1 : bw.lo;
-            const int fl = bl - ls, tbx = bhi - tsel;
-            const bool valid = ls < deep && fl >= 0 && tbx >= blo;
-            blk = valid ? bw.win[((tbx - bw.lo) * R + qq) * kWave + fl] : 0u;
+    // decision field of cell (r, c); (s, l, q) must be the position of row r
+    CR_D uint32_t get(int r, int c) {
+        int a = r0 - r;
+        int w = ((c0 + l) >> kLog) - ((c + l) >> kLog);
+        if (!(s == bs && a <= amax && w < kBlockWords)) {
+            refill(r, c);
+            a = 0;
+            w = 0;
         }
-        const int idx = __builtin_amdgcn_readfirstlane(((bl - l) * 2 + (bhi - tb)) * R + q);
-        return (uint32_t)__builtin_amdgcn_readlane((int)blk, idx);
+        const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)blk, a * 4 + w);
+        return (word >> (((c + l) & kStepMask) * BITS)) & kFieldMask;
+    }
+    // Number of consecutive cells (r - k, c - k), k = 0, 1, ..., whose decision field satisfies `diag`, as far as the
+    // block holds them (at least 1 when the caller has just seen diag(get(r, c))).
+    template <class Pred>
+    CR_D int diag_run(int r, int c, Pred diag) {
+        const int a_cur = r0 - r;
+        const int k = ax - a_cur;
+        const int col = c - k;
+        const int t = col + lax;
+        const int wneed = ((c0 + lax) >> kLog) - (t >> kLog);
+        const uint32_t f = (blk >> ((t & kStepMask) * BITS)) & kFieldMask;
+        const bool cont = k >= 0 && ax <= amax && col >= 0 && wneed == wx && diag(f);
+        uint64_t mk = __ballot(cont);
+        mk = (mk | (mk >> 1) | (mk >> 2) | (mk >> 3)) & 0x1111111111111111ull;     // bit 4a: row a continues
+        const uint64_t stop = ~(mk >> (4 * a_cur)) & 0x1111111111111111ull;
+        const int rows = stop ? (__builtin_ctzll(stop) >> 2) : 16;
+        return __builtin_amdgcn_readfirstlane(rows);
     }
 };
 
@@ -1084,55 +1368,55 @@ CR_D void kabsch_ordered(const double* __restrict__ Xi, const double* __restrict
     kabsch_from_correlation(C, c1, c2, R, t);     // every lane computes the same 3x3 SVD
 }
 
-// LDS carve-up of a traceback stage: [entries: max_entries words][window / sum scratch (aliased)]
-__host__ __device__ inline size_t trace_lds_doubles(int R, int max_entries) {
-    const size_t win = (sizeof(uint32_t) * kWinBlocks * R * kWave) / 8, scr = (size_t)kWave * kMaxAcc;
-    return ((size_t)max_entries + 3) / 4 * 2 + (win > scr ? win : scr);
+// LDS carve-up of a traceback stage: [entries: max_entries words][sum scratch]
+__host__ __device__ inline size_t trace_lds_doubles(int /*R*/, int max_entries) {
+    return ((size_t)max_entries + 3) / 4 * 2 + (size_t)kWave * kMaxAcc;
 }
 
 // Stage 2: SW traceback on the stored decisions, common positions, seed Kabsch
 // (dynamic_time_warping.py:249-278, helper.py:13-42, superposition_functions.py:39-60).
 // Wave-uniform; `lds` is this stage's LDS.  Returns the transform in every lane.
-CR_D void seed_trace(const PairDesc& pd, int R, int max_entries, const double* __restrict__ coords,
+template <int R>
+CR_D void seed_trace(const PairDesc& pd, int max_entries, const double* __restrict__ coords,
                      const uint32_t* __restrict__ dirs, const SeedMax sm, double* lds, Transform& tr) {
     const int lane = threadIdx.x;
     uint32_t* plist = reinterpret_cast<uint32_t*>(lds);          // aligned pairs, filled back-to-front
     double* scratch = lds + ((size_t)max_entries + 3) / 4 * 2;   // 16-byte aligned, after the list
-    DecisionReader rd;
-    rd.init(reinterpret_cast<uint32_t*>(scratch), R, lane);
     const int cap = pd.n < pd.m ? pd.n : pd.m;
     uint32_t flags = 0;
     int k = 0, len = 0;
     if (sm.i == 0) {
         flags |= kFlagSeedAllZero;
     } else {
-        const uint32_t* w = dirs + pd.dirs_off;
-        const int TB = tblocks(pd.m, 16);
+        Walker<R, 2> wk;
+        wk.init(dirs + pd.dirs_off, tblocks(pd.m, 16), lane);
         // the walk is wave-uniform: pin its state to SGPRs so that it compiles to scalar code
         int i = __builtin_amdgcn_readfirstlane(sm.i), j = __builtin_amdgcn_readfirstlane(sm.j);
-        RowPos rp;
-        rp.set(i - 1, R);
+        wk.set_row(i - 1);
 #pragma unroll 1
         while (i > 0 && j > 0) {
-            const int t = (j - 1) + rp.l;
-            const int tb = t >> 4;
-            const uint32_t code = (rd.get(w, R, TB, rp.s, rp.l, rp.q, tb, lane) >> ((t & 15) * 2)) & 3u;
+            const uint32_t code = wk.get(i - 1, j - 1);
             if (code == 0) break;
-            len++;
-            if (code == 2) {
+            if (code == 1) {                                     // a run of aligned pairs: all of it at once
+                const int run = wk.diag_run(i - 1, j - 1, [](uint32_t f) { return f == 1u; });
+                if (lane < run) plist[cap - k - 1 - lane] = pack_entry(i - 1 - lane, j - 1 - lane);
+                k += run;
+                len += run;
+                i -= run;
+                j -= run;
+                if (i > 0) wk.set_row(i - 1);
+            } else if (code == 2) {
+                len++;
                 j--;
             } else {
+                len++;
                 i--;
-                rp.up(R);
-                if (code == 1) {
-                    j--;
-                    k++;
-                    plist[cap - k] = pack_entry(i, j);
-                }
+                wk.row_up();
             }
         }
     }
     wave_sync();
+    CR_STAMP(2);
 #pragma unroll
     for (int x = 0; x < 3; x++) tr.c1[x] = tr.c2[x] = 0.0;
 #pragma unroll
@@ -1206,49 +1490,48 @@ CR_D void rmsd_tm_ordered(const double* __restrict__ Xi, const double* __restric
 // DTW traceback (dynamic_time_warping.py:90-144) on the packed decisions: leaves the alignment columns
 // as packed entries in lds[first .. cap) (cap = n + m), writes the rows to HBM (back-to-front in
 // [aln, aln + 2*cap)), returns the number of columns and of aligned pairs.  Wave-uniform.
-CR_D void dtw_walk(int n0, int m0, int R, int max_entries, const uint32_t* __restrict__ w, int start_layer,
+template <int R>
+CR_D void dtw_walk(int n0, int m0, int max_entries, const uint32_t* __restrict__ w, int start_layer,
                    double* lds, int32_t* __restrict__ aln, int& len_out, int& pairs_out) {
     const int lane = threadIdx.x;
     uint32_t* arow = reinterpret_cast<uint32_t*>(lds);           // packed alignment columns, back-to-front
-    double* scratch = lds + ((size_t)max_entries + 3) / 4 * 2;
-    DecisionReader rd;
-    rd.init(reinterpret_cast<uint32_t*>(scratch), R, lane);
     const int cap = n0 + m0;
-    const int TB = tblocks(m0, 8);
+    Walker<R, 4> wk;
+    wk.init(w, tblocks(m0, 8), lane);
     // the walk is wave-uniform: pin its state to SGPRs so that it compiles to scalar code
     int n = __builtin_amdgcn_readfirstlane(n0), m = __builtin_amdgcn_readfirstlane(m0);
     int dir = __builtin_amdgcn_readfirstlane(start_layer), idx = 0, k = 0;
-    RowPos rp;
-    rp.set(n - 1, R);
+    wk.set_row(n - 1);
 #pragma unroll 1
     while (n > 0 && m > 0) {
-        const int t = (m - 1) + rp.l;
-        const int tb = t >> 3;
-        const uint32_t nib = (rd.get(w, R, TB, rp.s, rp.l, rp.q, tb, lane) >> ((t & 7) * 4)) & 15u;
+        const uint32_t nib = wk.get(n - 1, m - 1);
         // dynamic_time_warping.py:118-143.  In layer 1 the stored decision either keeps the walk on
         // the diagonal or switches layer at the SAME cell; the switch and the move it then makes in
         // layer 0 / 2 (which reads the same cell's decisions) are done in one iteration.
         int layer = dir;
         if (layer == 1) layer = (int)((nib >> 1) & 3u);
-        uint32_t entry;
         if (layer == 1) {
-            n--; m--;
-            rp.up(R);
-            k++;
+            // every following cell of the diagonal whose layer-1 decision is "diagonal" belongs to the same run
+            const int run = wk.diag_run(n - 1, m - 1, [](uint32_t f) { return ((f >> 1) & 3u) == 1u; });
+            if (lane < run) arow[cap - idx - 1 - lane] = pack_entry(n - 1 - lane, m - 1 - lane);
+            idx += run;
+            k += run;
+            n -= run;
+            m -= run;
             dir = 1;
-            entry = pack_entry(n, m);
+            if (n > 0) wk.set_row(n - 1);
         } else if (layer == 0) {
             dir = (int)(nib & 1u);
             n--;
-            rp.up(R);
-            entry = pack_entry(n, -1);
+            wk.row_up();
+            idx++;
+            if (lane == 0) arow[cap - idx] = pack_entry(n, -1);
         } else {
             dir = (int)((nib >> 3) & 1u) + 1;
             m--;
-            entry = pack_entry(-1, m);
+            idx++;
+            if (lane == 0) arow[cap - idx] = pack_entry(-1, m);
         }
-        idx++;
-        arow[cap - idx] = entry;
     }
     // border runs (dynamic_time_warping.py:108-117): only one of n, m is still positive
     for (int x = lane; x < n; x += kWave) arow[cap - idx - 1 - x] = pack_entry(n - 1 - x, -1);
@@ -1270,7 +1553,8 @@ CR_D void dtw_walk(int n0, int m0, int R, int max_entries, const uint32_t* __res
 
 // Stage 4: DTW traceback, common positions, Kabsch on the original coordinates, RMSD / coverage / TM
 // (multiple_alignment.py:1033-1054, :59-70).  Wave-uniform.
-CR_D void align_trace(const PairDesc& pd, int R, int max_entries, const double* __restrict__ coords,
+template <int R>
+CR_D void align_trace(const PairDesc& pd, int max_entries, const double* __restrict__ coords,
                       const uint32_t* __restrict__ bits, const AlignEnd e, double* lds,
                       int32_t* __restrict__ aln, PairResult& r) {
     const int lane = threadIdx.x;
@@ -1278,7 +1562,8 @@ CR_D void align_trace(const PairDesc& pd, int R, int max_entries, const double* 
     double* scratch = lds + ((size_t)max_entries + 3) / 4 * 2;
     const int cap = pd.n + pd.m;
     int idx, k;
-    dtw_walk(pd.n, pd.m, R, max_entries, bits + pd.bt_off, e.start_layer, lds, aln + pd.aln_off, idx, k);
+    dtw_walk<R>(pd.n, pd.m, max_entries, bits + pd.bt_off, e.start_layer, lds, aln + pd.aln_off, idx, k);
+    CR_STAMP(6);
     const int first = cap - idx;
     r.sw = e.sw;
     r.dtw_score = e.dtw_score;
@@ -1325,6 +1610,7 @@ __global__ __launch_bounds__(kWave, 2) void k_seed(const PairDesc* __restrict__ 
                                                double* __restrict__ hand, Transform* __restrict__ xf,
                                                double* __restrict__ seed_score) {
     extern __shared__ double lds[];
+    CR_STAMP(0);
     const PairDesc pd = pairs[blockIdx.x];
     SeedMax sm;
     AlignEnd unused;
@@ -1339,12 +1625,14 @@ __global__ __launch_bounds__(kWave, 2) void k_seed(const PairDesc* __restrict__ 
                                                   hand + pd.hand_off, sm, unused);
     }
     drain_stores();
+    CR_STAMP(1);
     Transform tr;
-    seed_trace(pd, R, max_entries, coords, dirs, sm, lds + kExpDoubles, tr);
+    seed_trace<R>(pd, max_entries, coords, dirs, sm, lds + kExpDoubles, tr);
     if (threadIdx.x == 0) {
         xf[blockIdx.x] = tr;
         seed_score[blockIdx.x] = sm.score;
     }
+    CR_STAMP(3);
 }
 
 // Stages 3+4: coordinate RBF on the seed-superposed frames + SW score + affine DTW fill
@@ -1359,6 +1647,7 @@ __global__ __launch_bounds__(kWave, 4) void k_align(const PairDesc* __restrict__
                                                 double* __restrict__ hand, int32_t* __restrict__ aln,
                                                 PairResult* __restrict__ res) {
     extern __shared__ double lds[];
+    CR_STAMP(4);
     const PairDesc pd = pairs[blockIdx.x];
     SeedMax unused;
     AlignEnd e;
@@ -1373,12 +1662,14 @@ __global__ __launch_bounds__(kWave, 4) void k_align(const PairDesc* __restrict__
                                                          hand + pd.hand_off, unused, e);
     }
     drain_stores();
+    CR_STAMP(5);
     PairResult r;
-    align_trace(pd, R, max_entries, coords, bits, e, lds + kExpDoubles, aln, r);
+    align_trace<R>(pd, max_entries, coords, bits, e, lds + kExpDoubles, aln, r);
     r.seed_score = seed_score[blockIdx.x];
     r.seed_len = xf[blockIdx.x].seed_len;
     r.flags |= xf[blockIdx.x].flags;
     if (threadIdx.x == 0) res[blockIdx.x] = r;
+    CR_STAMP(7);
 }
 
 // One node of progressive alignment (multiple_alignment.py:193-234), after k_seed has produced the seed
@@ -1448,7 +1739,7 @@ CR_D void node_body(const PairDesc* __restrict__ pairs, const double* coords,
     double* tl = lds + kExpDoubles;
     const int cap = pd.n + pd.m;
     int idx, k;
-    dtw_walk(pd.n, pd.m, R, max_entries, bits, e.start_layer, tl, aln, idx, k);
+    dtw_walk<R>(pd.n, pd.m, max_entries, bits, e.start_layer, tl, aln, idx, k);
     const int first = cap - idx;
     const uint32_t* ent = reinterpret_cast<const uint32_t*>(tl) + first;
     double* scratch = tl + ((size_t)max_entries + 3) / 4 * 2;
@@ -1612,6 +1903,7 @@ __global__ __launch_bounds__(kTeamWaves* kWave) void k_seed_team(const PairDesc*
                                                                 Transform* __restrict__ xf,
                                                                 double* __restrict__ seed_score) {
     extern __shared__ double lds[];
+    CR_STAMP(0);
     const PairDesc pd = pairs[blockIdx.x];
     SeedMax sm;
     AlignEnd unused;
@@ -1625,12 +1917,14 @@ __global__ __launch_bounds__(kTeamWaves* kWave) void k_seed_team(const PairDesc*
         sweep_team<R, kSwTrace | (ZG ? kZeroGap : 0)>(src, pd.n, pd.m, prm, lds, dirs + pd.dirs_off, nullptr, sm, unused);
     }
     if (threadIdx.x >= kWave) return;                  // wave 0 goes on alone (wave_sync, no s_barrier from here on)
+    CR_STAMP(1);
     Transform tr;
-    seed_trace(pd, R, max_entries, coords, dirs, sm, lds + kExpDoubles, tr);
+    seed_trace<R>(pd, max_entries, coords, dirs, sm, lds + kExpDoubles, tr);
     if (threadIdx.x == 0) {
         xf[blockIdx.x] = tr;
         seed_score[blockIdx.x] = sm.score;
     }
+    CR_STAMP(3);
 }
 
 template <int R, bool ZG>
@@ -1642,6 +1936,7 @@ __global__ __launch_bounds__(kTeamWaves* kWave) void k_align_team(const PairDesc
                                                                  int max_entries, uint32_t* __restrict__ bits,
                                                                  int32_t* __restrict__ aln, PairResult* __restrict__ res) {
     extern __shared__ double lds[];
+    CR_STAMP(4);
     const PairDesc pd = pairs[blockIdx.x];
     SeedMax unused;
     AlignEnd e;
@@ -1655,12 +1950,83 @@ __global__ __launch_bounds__(kTeamWaves* kWave) void k_align_team(const PairDesc
         sweep_team<R, kSwScore | kDtw | (ZG ? kZeroGap : 0)>(src, pd.n, pd.m, prm, lds, nullptr, bits + pd.bt_off, unused, e);
     }
     if (threadIdx.x >= kWave) return;                  // wave 0 goes on alone (wave_sync, no s_barrier from here on)
+    CR_STAMP(5);
     PairResult r;
-    align_trace(pd, R, max_entries, coords, bits, e, lds + kExpDoubles, aln, r);
+    align_trace<R>(pd, max_entries, coords, bits, e, lds + kExpDoubles, aln, r);
     r.seed_score = seed_score[blockIdx.x];
     r.seed_len = xf[blockIdx.x].seed_len;
     r.flags |= xf[blockIdx.x].flags;
     if (threadIdx.x == 0) res[blockIdx.x] = r;
+    CR_STAMP(7);
+}
+
+// Wide versions (sweep_wide): up to kWideMaxWaves waves per pair, columns resident in LDS, a barrier every
+// `sync_every` steps.  Requires strips_of(n, R) <= blockDim.x / 64 and the resident columns to fit the LDS.
+template <int R, int D, bool ZG>
+__global__ __launch_bounds__(kWideMaxWaves* kWave) void k_seed_wide(const PairDesc* __restrict__ pairs,
+                                                                   const double* __restrict__ tensors, int d,
+                                                                   const double* __restrict__ coords, double gamma,
+                                                                   double sw_gap, int max_entries, int sync_every,
+                                                                   uint32_t* __restrict__ dirs,
+                                                                   Transform* __restrict__ xf,
+                                                                   double* __restrict__ seed_score) {
+    extern __shared__ double lds[];
+    CR_STAMP(0);
+    const PairDesc pd = pairs[blockIdx.x];
+    SeedMax sm;
+    AlignEnd unused;
+    {
+        RbfTensor<R, D> src;
+        src.rows_g = tensors + pd.off_i * d;
+        src.cols_g = tensors + pd.off_j * d;
+        src.d = d;
+        src.neg_gamma = -gamma;
+        SweepParams prm{sw_gap, 0.0, 0.0};
+        sweep_wide<R, kSwTrace | (ZG ? kZeroGap : 0)>(src, pd.n, pd.m, prm, lds, sync_every, dirs + pd.dirs_off, nullptr, sm, unused);
+    }
+    if (threadIdx.x >= kWave) return;                  // wave 0 goes on alone (wave_sync, no s_barrier from here on)
+    CR_STAMP(1);
+    Transform tr;
+    seed_trace<R>(pd, max_entries, coords, dirs, sm, lds + kExpDoubles, tr);
+    if (threadIdx.x == 0) {
+        xf[blockIdx.x] = tr;
+        seed_score[blockIdx.x] = sm.score;
+    }
+    CR_STAMP(3);
+}
+
+template <int R, bool ZG>
+__global__ __launch_bounds__(kWideMaxWaves* kWave) void k_align_wide(const PairDesc* __restrict__ pairs,
+                                                                    const double* __restrict__ coords,
+                                                                    const Transform* __restrict__ xf,
+                                                                    const double* __restrict__ seed_score, double gamma,
+                                                                    double sw_gap, double gap_open, double gap_extend,
+                                                                    int max_entries, int sync_every,
+                                                                    uint32_t* __restrict__ bits,
+                                                                    int32_t* __restrict__ aln, PairResult* __restrict__ res) {
+    extern __shared__ double lds[];
+    CR_STAMP(4);
+    const PairDesc pd = pairs[blockIdx.x];
+    SeedMax unused;
+    AlignEnd e;
+    {
+        RbfCoords<R> src;
+        src.rows_g = coords + pd.off_i * 3;
+        src.cols_g = coords + pd.off_j * 3;
+        src.xf = xf + blockIdx.x;
+        src.neg_gamma = -gamma;
+        SweepParams prm{sw_gap, gap_open, gap_extend};
+        sweep_wide<R, kSwScore | kDtw | (ZG ? kZeroGap : 0)>(src, pd.n, pd.m, prm, lds, sync_every, nullptr, bits + pd.bt_off, unused, e);
+    }
+    if (threadIdx.x >= kWave) return;                  // wave 0 goes on alone (wave_sync, no s_barrier from here on)
+    CR_STAMP(5);
+    PairResult r;
+    align_trace<R>(pd, max_entries, coords, bits, e, lds + kExpDoubles, aln, r);
+    r.seed_score = seed_score[blockIdx.x];
+    r.seed_len = xf[blockIdx.x].seed_len;
+    r.flags |= xf[blockIdx.x].flags;
+    if (threadIdx.x == 0) res[blockIdx.x] = r;
+    CR_STAMP(7);
 }
 
 #ifndef CR_KERNELS_TEMPLATES_ONLY   // the one non-template kernel: defined in cr_api.hip's translation unit only

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Wide kernels (one wave per strip, up to 16 waves per pair) against the default kernel choice.
+
+    python tools/calibrate_wide.py [workload ...]      workloads: c5share c2 c5 one300 p64x300 p120x600
+
+For every workload: time the default path, then every feasible (rows per lane R, barrier cadence B) of the wide
+kernels (CARETTA_WIDE=R,B is read by cr_batch_set_pairs), and demand bit-identical results (all PairResult fields and
+the alignment rows) against the default path, which tests/test_gpu_parity.py pins to the oracle.
+"""
+import os
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import numpy as np  # noqa: E402
+
+from caretta_amd import engine, synthetic  # noqa: E402
+
+WORKLOADS = {
+    "c5share": (64, 1200, 20244, 8),      # 252 pairs: one GPU's share of BASELINE config 5 on 8 GPUs
+    "c5": (64, 1200, 20244, 1),
+    "c2": (32, 150, 20241, 1),
+    "one300": (2, 300, 7, 1),
+    "p64x300": (12, 300, 11, 1),          # 66 pairs
+    "p120x600": (16, 600, 12, 1),         # 120 pairs
+    "c4share": (512, 300, 20243, 8),      # 16352 pairs: one GPU's share of config 4
+}
+GRID = [(r, b) for r in (1, 2, 3) for b in (1, 4, 8, 16)]
+
+
+def timed(batch, ctx, prm, reps):
+    for _ in range(2):
+        batch.run(prm)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        batch.run(prm)
+    ctx.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+def same(a, b):
+    ra, aa = a
+    rb, ab = b
+    for name in ra.dtype.names:
+        if not np.array_equal(ra[name], rb[name]):
+            return f"field {name} differs"
+    for p in range(len(ra)):
+        ln = int(ra["aln_len"][p])
+        if not np.array_equal(aa[p, :, :ln], ab[p, :, :ln]):
+            return f"alignment of pair {p} differs"
+    return None
+
+
+def main():
+    names = sys.argv[1:] or ["c5share", "c2"]
+    ctx = engine.Context(0)
+    prm = engine.make_params()
+    for name in names:
+        num, length, seed, stride = WORKLOADS[name]
+        fam = synthetic.make_family(num, length, seed=seed)
+        coords, tensors, offsets = synthetic.pack(fam)
+        pairs = engine.all_pairs(num)[::stride]
+        reps = 5 if length >= 600 else 20
+        os.environ.pop("CARETTA_WIDE", None)
+        b = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
+        base_ms = timed(b, ctx, prm, reps)
+        ctx.set_profiling(reps)
+        for _ in range(reps):
+            b.run(prm)
+        st, _ = b.stage_ms()
+        ctx.set_profiling(0)
+        base = b.fetch()
+        print(f"{name}: {len(pairs)} pairs of {length}: default {base_ms:.3f} ms (k_seed {st[0]:.3f} k_align {st[1]:.3f})", flush=True)
+        for r, sync in GRID:
+            os.environ["CARETTA_WIDE"] = f"{r},{sync}"
+            b.set_pairs(pairs)
+            ms = timed(b, ctx, prm, reps)
+            ctx.set_profiling(reps)
+            for _ in range(reps):
+                b.run(prm)
+            st, _ = b.stage_ms()
+            ctx.set_profiling(0)
+            verdict = same(base, b.fetch())
+            waves = -(-length // (64 * r))
+            print(f"  R={r} B={sync:2d} ({waves:2d} waves): {ms:.3f} ms (k_seed {st[0]:.3f} k_align {st[1]:.3f})  "
+                  f"{'bit-identical' if verdict is None else 'MISMATCH: ' + verdict}", flush=True)
+        os.environ.pop("CARETTA_WIDE", None)
+        b.close()
+
+
+if __name__ == "__main__":
+    main()

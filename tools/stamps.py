@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""In-kernel phase timing of the batch kernels (diagnostic build, never shipped).
+
+    python tools/stamps.py build                      hipcc -DCR_STAMPS -> caretta_amd/csrc/libcaretta_hip_stamps.so (run HERE)
+    python tools/stamps.py run [workload ...]         on the GPU box: medians of fill / walk / rest per kernel, in shader cycles and us
+
+The stamped library is ONE translation unit with the default instruction scheduler, so its absolute times differ a
+little from the product's; it tells which PHASE dominates a launch.  CARETTA_WIDE=R,B is honoured.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+CSRC = ROOT / "caretta_amd" / "csrc"
+LIB = CSRC / "libcaretta_hip_stamps.so"
+
+
+def build():
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-pthread", "-DCR_STAMPS",
+           "-shared", str(CSRC / "cr_api.hip"), "-o", str(LIB)]
+    print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=str(CSRC))
+
+
+def run(names):
+    os.environ["CARETTA_HIP_LIB"] = str(LIB)
+    sys.path.insert(0, str(ROOT))
+    import numpy as np
+    from caretta_amd import _capi, engine, synthetic
+    sys.path.insert(0, str(ROOT / "tools"))
+    from calibrate_wide import WORKLOADS
+    lib = _capi.load()
+    lib.cr_debug_stamps.restype = C.c_int
+    lib.cr_debug_stamps.argtypes = [C.c_void_p, C.c_int]
+    ctx = engine.Context(0)
+    prm = engine.make_params()
+    for name in names:
+        num, length, seed, stride = WORKLOADS[name]
+        fam = synthetic.make_family(num, length, seed=seed)
+        coords, tensors, offsets = synthetic.pack(fam)
+        pairs = engine.all_pairs(num)[::stride]
+        b = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
+        for _ in range(3):
+            b.run(prm)
+        ctx.synchronize()
+        blocks = min(len(pairs), 8192)
+        st = np.zeros((blocks, 8), dtype=np.uint64)
+        _capi.check(lib.cr_debug_stamps(st.ctypes.data_as(C.c_void_p), blocks))
+        st = st.astype(np.int64)
+        d = np.diff(st, axis=1)
+        med = lambda x: float(np.median(x))
+        span_seed = st[:, 3].max() - st[:, 0].min()
+        span_align = st[:, 7].max() - st[:, 4].min()
+        print(f"{name} ({len(pairs)} pairs of {length}, CARETTA_WIDE={os.environ.get('CARETTA_WIDE', '-')}): shader-clock cycles (s_memtime; ~2.4 GHz)\n"
+              f"  seed : fill {med(d[:, 0]):9.0f}  walk {med(d[:, 1]):9.0f}  kabsch/rest {med(d[:, 2]):9.0f}   launch span {span_seed}\n"
+              f"  align: fill {med(d[:, 4]):9.0f}  walk {med(d[:, 5]):9.0f}  kabsch/metrics {med(d[:, 6]):9.0f}   launch span {span_align}", flush=True)
+        b.close()
+
+
+if __name__ == "__main__":
+    if len(sys.argv) < 2 or sys.argv[1] not in ("build", "run"):
+        raise SystemExit(__doc__)
+    if sys.argv[1] == "build":
+        build()
+    else:
+        run(sys.argv[2:] or ["c5share", "c2"])
