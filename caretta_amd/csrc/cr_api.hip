@@ -39,6 +39,14 @@ CR_ILP_SEED_TEAM_INSTANCES(CR_X)
 #define CR_X(R) extern template CR_NODE_TEAM_SIGNATURE(R)
 CR_ILP_NODE_TEAM_INSTANCES(CR_X)
 #undef CR_X
+#ifdef CR_WIDE_ILP
+#define CR_X(R, D, ZG) extern template CR_SEED_WIDE_SIGNATURE(R, D, ZG)
+CR_ILP_SEED_WIDE_INSTANCES(CR_X)
+#undef CR_X
+#define CR_X(R, ZG) extern template CR_ALIGN_WIDE_SIGNATURE(R, ZG)
+CR_ILP_ALIGN_WIDE_INSTANCES(CR_X)
+#undef CR_X
+#endif
 #endif
 
 namespace {
@@ -609,7 +617,8 @@ int cr_batch_create(cr_context* ctx, const double* coords, const double* tensors
     b->total = offsets[num_structures];
     b->offsets.assign(offsets, offsets + num_structures + 1);
     hipError_t e = b->coords.ensure((size_t)b->total * 3);
-    if (e == hipSuccess) e = b->tensors.ensure((size_t)b->total * d);
+    // (+ d_pad doubles of slack: the column sweep always reads a padded row of features, cr_kernels.h sweep_cols)
+    if (e == hipSuccess) e = b->tensors.ensure((size_t)b->total * d + (size_t)b->d_pad);
     if (e == hipSuccess)
         e = hipMemcpyAsync(b->coords.p, coords, sizeof(double) * b->total * 3, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess)

@@ -670,6 +670,146 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
     __syncthreads();                                   // the caller may reuse the LDS from here on
 }
 
+// ---------------------------------------------------------------------------------------------
+// The column sweep: Smith-Waterman with gap 0 on non-negative scores (the reference's only use of smith_waterman in
+// the pipeline, multiple_alignment.py:332-335) WITHOUT the time skew.
+//
+// With gap = 0 and S >= 0 the recurrence H = max(0, diag + S, left, up) (dynamic_time_warping.py:234-238) makes H
+// non-decreasing along rows and columns, and max is exact and associative, so for one column j
+//     H[i][j] = max over i' <= i of B[i'][j],      B[i][j] = max(H[i-1][j-1] + S[i][j], H[i][j-1]),
+// i.e. the `up` dependency is a PREFIX MAXIMUM down the column.  All 64 lanes (R rows each) therefore work on the SAME
+// column in every step: B from the previous column's values (registers), a sequential scan down the lane's R rows, a
+// 6-step DPP max-scan across the lanes (row_shr 1/2/4/8, row_bcast 15/31), one more max per cell.  A strip takes m
+// steps instead of m + 63, no lane ever idles in a ramp, and the column's features are wave-uniform: they are read
+// with scalar loads into SGPRs (no LDS ring, no per-step ds_reads).  Every value is bit-identical to the
+// cell-by-cell evaluation; the decisions (h == diag + S, then h == left, else up; 0 when h == 0) and the row-major
+// first maximum are taken from the same values: a row's maximum is its last value and its first position is the column
+// of the row's last strict increase (h != left).
+// Decision words: ((strip * TB + (j >> 4)) * R + q) * 64 + lane, TB = ceil(m / 16), bits (j & 15) * 2: the layout of
+// the skewed sweeps with time step = column (Walker<R, 2, 0>).
+// Strips after the first take the row above them (the previous strip's last row, one value per column) from `hand_g`,
+// 64 columns per coalesced load.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+CR_D double scan_step(double v) {
+    // lanes without a source lane read +0.0 (bound_ctrl), rows outside ROW_MASK keep the +0.0 they are given:
+    // max(v, 0) = v for v >= 0
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, ROW_MASK == 0xf);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, ROW_MASK == 0xf);
+    return vmax(v, __hiloint2double(hi, lo));
+}
+
+// inclusive prefix maximum over the 64 lanes of non-negative doubles
+CR_D double wave_scan_max(double v) {
+    v = scan_step<0x111, 0xf>(v);      // row_shr:1
+    v = scan_step<0x112, 0xf>(v);      // row_shr:2
+    v = scan_step<0x114, 0xf>(v);      // row_shr:4
+    v = scan_step<0x118, 0xf>(v);      // row_shr:8
+    v = scan_step<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+    v = scan_step<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+template <int R, int D>
+CR_D void sweep_cols(RbfTensor<R, D>& src, const int n, const int m, double* lds, uint32_t* __restrict__ sw_dirs,
+                     double* __restrict__ hand_g, SeedMax& seed_out) {
+    const int lane = threadIdx.x;
+    const ExpEntry* tab = reinterpret_cast<const ExpEntry*>(lds);
+    load_exp_table(lds, lane);
+    __syncthreads();
+
+    const int nstrips = strips_of(n, R);
+    const int TB = (m + 15) >> 4;
+    const int d = src.d;
+    double best_v = 0.0;
+    int best_i = 0x7fffffff, best_j = 0x7fffffff;
+
+    for (int s = 0; s < nstrips; s++) {
+        const int rowbase = (s * kWave + lane) * R;
+        src.load_rows(rowbase, n);
+        double hprev[R], eprev = 0.0;        // H of this lane's rows / of the row above them, previous column
+        int rowfirst[R];
+        uint32_t bits[R];
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            hprev[q] = 0.0;
+            rowfirst[q] = 0;
+            bits[q] = 0;
+        }
+        double cin_vec = 0.0;                // row above the strip, 64 columns per load (lane x: column j0 + x)
+        const double* __restrict__ cg = src.cols_g;
+#pragma unroll 1
+        for (int j = 0; j < m; j++) {
+            if (s > 0 && (j & (kWave - 1)) == 0) cin_vec = (j + lane < m) ? hand_g[j + lane] : 0.0;
+            // the column's features: wave-uniform -> scalar loads
+            // (always D loads: the tensor array is allocated with D doubles of slack, the padded features are zeroed
+            // by scalar selects -- conditional loads would cost a branch each)
+#pragma unroll
+            for (int k = 0; k < D; k++) {
+                const double v = cg[(int64_t)j * d + k];
+                src.col[k] = (k < d) ? v : 0.0;
+            }
+            double dg[R], p[R];
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const double sc = src.score(q, tab);
+                dg[q] = (q == 0 ? eprev : hprev[q - 1]) + sc;
+                const double b = vmax(dg[q], hprev[q]);
+                p[q] = q == 0 ? b : vmax(p[q - 1], b);
+            }
+            double e = wave_shr1(wave_scan_max(p[R - 1]), 0.0);
+            if (s > 0) e = vmax(e, lane_value(cin_vec, j & (kWave - 1)));
+            const int sh2 = (j & 15) * 2;
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const double h = vmax(p[q], e);
+                // decision replayed by the traceback's equality tests (:255-277): diag, then left, else up
+                const bool same = h == hprev[q];
+                uint32_t code = (h == dg[q]) ? 1u : same ? 2u : 3u;
+                code = (h > 0.0) ? code : 0u;
+                bits[q] |= code << sh2;
+                rowfirst[q] = same ? rowfirst[q] : j;          // column of the row's last strict increase
+                hprev[q] = h;
+            }
+            eprev = e;
+            if (s + 1 < nstrips && lane == kWave - 1) hand_g[j] = hprev[R - 1];
+            if ((j & 15) == 15 || j == m - 1) {
+                const int64_t base = ((int64_t)(s * TB + (j >> 4)) * R) * kWave + lane;
+#pragma unroll
+                for (int q = 0; q < R; q++) {
+                    sw_dirs[base + q * kWave] = bits[q];
+                    bits[q] = 0;
+                }
+            }
+        }
+        if (s + 1 < nstrips) {                 // the hand-off row: visible to this wave's loads in the next strip
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+        }
+        // fold the rows' maxima (= last values) into the lane's running best, rows ascending
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const bool gt = hprev[q] > best_v;
+            best_v = gt ? hprev[q] : best_v;
+            best_i = gt ? rowbase + q : best_i;
+            best_j = gt ? rowfirst[q] : best_j;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        double ov = __shfl_xor(best_v, off);
+        int oi = __shfl_xor(best_i, off), oj = __shfl_xor(best_j, off);
+        bool take = ov > best_v || (ov == best_v && (oi < best_i || (oi == best_i && oj < best_j)));
+        best_v = take ? ov : best_v;
+        best_i = take ? oi : best_i;
+        best_j = take ? oj : best_j;
+    }
+    seed_out.score = best_v;
+    seed_out.i = best_v > 0.0 ? best_i + 1 : 0;
+    seed_out.j = best_v > 0.0 ? best_j + 1 : 0;
+    __syncthreads();                                   // the caller may reuse the LDS from here on
+}
+
 // LDS doubles needed by a sweep of the given provider/mode for column count m and row count n
 template <int R, int MODE, class Src>
 __host__ __device__ inline size_t sweep_lds_doubles(int n_max, int m_max) {
@@ -1209,8 +1349,10 @@ CR_D uint32_t pack_entry(int i, int j) { return ((uint32_t)i & 0xffffu) | ((uint
 // through the current cell, one ballot gives the run length, and the run's alignment entries are emitted by the lanes
 // in parallel -- on structural alignments most columns are aligned pairs, so the walk advances by up to 16 cells per
 // iteration.  Row bookkeeping (strip, fill lane, row slot) is wave-uniform and lives in SGPRs.
+// SKEW = 1: words written by the time-skewed sweeps (time step of a cell = column + fill lane); SKEW = 0: words of
+// the column sweep (time step = column).
 // ---------------------------------------------------------------------------------------------
-template <int R, int BITS>
+template <int R, int BITS, int SKEW = 1>
 struct Walker {
     static constexpr int kLog = BITS == 2 ? 4 : 3;                 // log2(steps per word)
     static constexpr int kStepMask = (1 << kLog) - 1;
@@ -1266,20 +1408,20 @@ struct Walker {
         const int relc = rv ? rel : 0;
         const int la = relc / R, qa = relc - la * R;
         lax = la;
-        const int tb = ((c + la) >> kLog) - wx;
+        const int tb = ((c + la * SKEW) >> kLog) - wx;
         blk = (rv && tb >= 0) ? words[((int64_t)(s * TB + tb) * R + qa) * kWave + la] : 0u;
     }
     // decision field of cell (r, c); (s, l, q) must be the position of row r
     CR_D uint32_t get(int r, int c) {
         int a = r0 - r;
-        int w = ((c0 + l) >> kLog) - ((c + l) >> kLog);
+        int w = ((c0 + l * SKEW) >> kLog) - ((c + l * SKEW) >> kLog);
         if (!(s == bs && a <= amax && w < kBlockWords)) {
             refill(r, c);
             a = 0;
             w = 0;
         }
         const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)blk, a * 4 + w);
-        return (word >> (((c + l) & kStepMask) * BITS)) & kFieldMask;
+        return (word >> (((c + l * SKEW) & kStepMask) * BITS)) & kFieldMask;
     }
     // Number of consecutive cells (r - k, c - k), k = 0, 1, ..., whose decision field satisfies `diag`, as far as the
     // block holds them (at least 1 when the caller has just seen diag(get(r, c))).
@@ -1288,8 +1430,8 @@ struct Walker {
         const int a_cur = r0 - r;
         const int k = ax - a_cur;
         const int col = c - k;
-        const int t = col + lax;
-        const int wneed = ((c0 + lax) >> kLog) - (t >> kLog);
+        const int t = col + lax * SKEW;
+        const int wneed = ((c0 + lax * SKEW) >> kLog) - (t >> kLog);
         const uint32_t f = (blk >> ((t & kStepMask) * BITS)) & kFieldMask;
         const bool cont = k >= 0 && ax <= amax && col >= 0 && wneed == wx && diag(f);
         uint64_t mk = __ballot(cont);
@@ -1376,7 +1518,7 @@ __host__ __device__ inline size_t trace_lds_doubles(int /*R*/, int max_entries) 
 // Stage 2: SW traceback on the stored decisions, common positions, seed Kabsch
 // (dynamic_time_warping.py:249-278, helper.py:13-42, superposition_functions.py:39-60).
 // Wave-uniform; `lds` is this stage's LDS.  Returns the transform in every lane.
-template <int R>
+template <int R, int SKEW = 1>
 CR_D void seed_trace(const PairDesc& pd, int max_entries, const double* __restrict__ coords,
                      const uint32_t* __restrict__ dirs, const SeedMax sm, double* lds, Transform& tr) {
     const int lane = threadIdx.x;
@@ -1388,8 +1530,8 @@ CR_D void seed_trace(const PairDesc& pd, int max_entries, const double* __restri
     if (sm.i == 0) {
         flags |= kFlagSeedAllZero;
     } else {
-        Walker<R, 2> wk;
-        wk.init(dirs + pd.dirs_off, tblocks(pd.m, 16), lane);
+        Walker<R, 2, SKEW> wk;
+        wk.init(dirs + pd.dirs_off, SKEW ? tblocks(pd.m, 16) : (pd.m + 15) >> 4, lane);
         // the walk is wave-uniform: pin its state to SGPRs so that it compiles to scalar code
         int i = __builtin_amdgcn_readfirstlane(sm.i), j = __builtin_amdgcn_readfirstlane(sm.j);
         wk.set_row(i - 1);
@@ -1621,13 +1763,13 @@ __global__ __launch_bounds__(kWave, 2) void k_seed(const PairDesc* __restrict__ 
         src.d = d;
         src.neg_gamma = -gamma;
         SweepParams prm{sw_gap, 0.0, 0.0};
-        sweep<R, kSwTrace | (ZG ? kZeroGap : 0)>(src, pd.n, pd.m, prm, lds, dirs + pd.dirs_off, nullptr,
-                                                  hand + pd.hand_off, sm, unused);
+        if constexpr (ZG) sweep_cols<R, D>(src, pd.n, pd.m, lds, dirs + pd.dirs_off, hand + pd.hand_off, sm);
+        else sweep<R, kSwTrace>(src, pd.n, pd.m, prm, lds, dirs + pd.dirs_off, nullptr, hand + pd.hand_off, sm, unused);
     }
     drain_stores();
     CR_STAMP(1);
     Transform tr;
-    seed_trace<R>(pd, max_entries, coords, dirs, sm, lds + kExpDoubles, tr);
+    seed_trace<R, ZG ? 0 : 1>(pd, max_entries, coords, dirs, sm, lds + kExpDoubles, tr);
     if (threadIdx.x == 0) {
         xf[blockIdx.x] = tr;
         seed_score[blockIdx.x] = sm.score;

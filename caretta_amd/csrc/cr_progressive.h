@@ -36,7 +36,7 @@ namespace {
 // grow a device array to `rows * width` elements, keeping its first `keep_rows * width`
 int grow_keep(DevBuf<double>& buf, int64_t rows, int64_t keep_rows, int64_t width, hipStream_t stream) {
     DevBuf<double> bigger;
-    CR_HIP(bigger.ensure((size_t)(rows * width)));
+    CR_HIP(bigger.ensure((size_t)(rows * width) + 64));      // slack: sweep_cols reads padded feature rows
     if (keep_rows > 0 && buf.p)
         CR_HIP(hipMemcpyAsync(bigger.p, buf.p, sizeof(double) * (size_t)(keep_rows * width), hipMemcpyDeviceToDevice, stream));
     CR_HIP(hipStreamSynchronize(stream));

@@ -26,7 +26,7 @@ WORKLOADS = {
     "p120x600": (16, 600, 12, 1),         # 120 pairs
     "c4share": (512, 300, 20243, 8),      # 16352 pairs: one GPU's share of config 4
 }
-GRID = [(r, b) for r in (1, 2, 3) for b in (1, 4, 8, 16)]
+GRID = [(r, b) for r in (1, 2, 3) for b in (2, 4, 8)]
 
 
 def timed(batch, ctx, prm, reps):
