@@ -39,7 +39,6 @@ CR_ILP_SEED_TEAM_INSTANCES(CR_X)
 #define CR_X(R) extern template CR_NODE_TEAM_SIGNATURE(R)
 CR_ILP_NODE_TEAM_INSTANCES(CR_X)
 #undef CR_X
-#ifdef CR_WIDE_ILP
 #define CR_X(R, D, ZG) extern template CR_SEED_WIDE_SIGNATURE(R, D, ZG)
 CR_ILP_SEED_WIDE_INSTANCES(CR_X)
 #undef CR_X
@@ -47,11 +46,11 @@ CR_ILP_SEED_WIDE_INSTANCES(CR_X)
 CR_ILP_ALIGN_WIDE_INSTANCES(CR_X)
 #undef CR_X
 #endif
-#endif
 
 namespace {
 
 thread_local std::string g_err;
+thread_local bool g_no_wide = false;     // set around cr_batch_set_pairs by callers whose second kernel has no wide version (cr_progressive_node)
 
 int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -371,8 +370,9 @@ int launch_seed_wide_zg(cr_batch* b, const cr_batch::Chunk& ck, const cr_params&
     using Src = cr::RbfTensor<R, D>;
     const int entries = std::min(ck.n_max, ck.m_max);
     const int waves = cr::strips_of(ck.n_max, R);
-    const size_t lds = sizeof(double) * std::max(cr::sweep_wide_lds_doubles<cr::kSwTrace, Src>(waves, ck.m_max),
-                                                 (size_t)cr::kExpDoubles + cr::trace_lds_doubles(R, entries));
+    // gap 0: the column sweep (scalar column loads, no resident columns)
+    const size_t fill = ZG ? cr::sweep_cols_team_lds_doubles(waves) : cr::sweep_wide_lds_doubles<cr::kSwTrace, Src>(waves, ck.m_max);
+    const size_t lds = sizeof(double) * std::max(fill, (size_t)cr::kExpDoubles + cr::trace_lds_doubles(R, entries));
     int rc = allow_lds(cr::k_seed_wide<R, D, ZG>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL((cr::k_seed_wide<R, D, ZG>), dim3((unsigned)ck.count), dim3(waves * cr::kWave), lds,
@@ -431,6 +431,7 @@ bool wide_fits(int R, int n_max, int m_max, int d_pad) {
     if (R < 1 || R > 3) return false;
     const int waves = cr::strips_of(n_max, R);
     if (waves > cr::kWideMaxWaves) return false;
+    // (sized for sw_gap != 0, where the tensor sweep needs its columns resident too; the parameters come with cr_batch_run)
     const size_t seed = cr::kExpDoubles + (size_t)d_pad * m_max + (size_t)waves * (cr::kWideEdge + 8);
     const size_t align = cr::kExpDoubles + (size_t)3 * m_max + (size_t)waves * (3 * cr::kWideEdge + 8);
     const size_t trace = cr::kExpDoubles + cr::trace_lds_doubles(R, n_max + m_max);
@@ -660,10 +661,21 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     b->team = npairs > 0 && npairs <= team_limit && b->n_max > 3 * cr::kWave && b->n_max <= 5 * cr::kTeamWaves * cr::kWave &&
               !std::getenv("CARETTA_NO_TEAM");
     if (b->team) b->r_seed = b->r_align = (b->n_max + cr::kTeamWaves * cr::kWave - 1) / (cr::kTeamWaves * cr::kWave);
+    // Above 384 rows the wide kernels (one wave per strip of 2 or 3 rows per lane, up to 16 waves per pair, a barrier
+    // every 8 steps) beat the four-wave teams: two waves per SIMD issue FP64 at the full rate where a lone wave gets
+    // about 60 % of it.  Measured (tools/calibrate_wide.py): 120 pairs of 600: 1.14 -> 1.05 ms (R = 2), 252 pairs of
+    // 1200 (one GPU's share of BASELINE config 5 on 8 GPUs): 2.95 -> 2.72 ms (R = 3); 66 pairs of 300: no gain.
     b->wide_sync = 0;
+    if (b->team && b->n_max > 6 * cr::kWave && !g_no_wide && !std::getenv("CARETTA_NO_WIDE")) {
+        const int r = b->n_max <= 12 * cr::kWave ? 2 : 3;
+        if (wide_fits(r, b->n_max, b->m_max, b->d_pad)) {
+            b->wide_sync = 8;
+            b->r_seed = b->r_align = r;
+        }
+    }
     if (const char* env = std::getenv("CARETTA_WIDE")) {           // calibration: "R,B" forces the wide kernels
         int r = 0, sync = 0;
-        if (std::sscanf(env, "%d,%d", &r, &sync) == 2 && npairs > 0 && sync >= 1 && sync <= cr::kWideMaxSync &&
+        if (std::sscanf(env, "%d,%d", &r, &sync) == 2 && npairs > 0 && sync >= 1 && sync <= cr::kWideMaxSync && !g_no_wide &&
             wide_fits(r, b->n_max, b->m_max, b->d_pad)) {
             b->team = true;                                         // same layout rules as the team kernels: one group, one R
             b->wide_sync = sync;

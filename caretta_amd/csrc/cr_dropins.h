@@ -526,7 +526,10 @@ int cr_progressive_node(cr_context* ctx, const double* coords_1, const double* t
         cr_batch* b;
         ~Guard() { cr_batch_destroy(b); }
     } guard{b};
-    if ((rc = cr_batch_set_pairs(b, pair, 1))) return rc;
+    g_no_wide = true;                        // the node kernel exists as a single-wave and a four-wave team kernel only
+    rc = cr_batch_set_pairs(b, pair, 1);
+    g_no_wide = false;
+    if (rc) return rc;
     const cr_params prm = *params;
     CR_REQUIRE(gamma_ok(prm.gamma_tensor) && gamma_ok(prm.gamma_coords) && std::isfinite(prm.gap_open) && std::isfinite(prm.gap_extend) &&
                    std::isfinite(prm.sw_gap),

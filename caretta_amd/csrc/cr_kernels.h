@@ -16,6 +16,8 @@
 // superposition_functions.py (Kabsch), multiple_alignment.py:321-349, 1028-1054.
 #pragma once
 
+#include <type_traits>
+
 #include "cr_math.h"
 
 // Diagnostic build only (-DCR_STAMPS, tools/stamps.py): shader-clock stamps of the phases of the batch kernels,
@@ -710,6 +712,92 @@ CR_D double wave_scan_max(double v) {
     return v;
 }
 
+// Per-lane state of the column sweep and one column step.
+template <int R, int D>
+struct ColSweep {
+    double hprev[R];          // H of this lane's rows, previous column
+    double eprev;             // H of the row above them, previous column
+    int rowfirst[R];          // column of each row's last strict increase
+    uint32_t bits[R];         // decisions of the current word
+
+    CR_D void reset() {
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            hprev[q] = 0.0;
+            rowfirst[q] = 0;
+            bits[q] = 0;
+        }
+        eprev = 0.0;
+    }
+    // Column j.  FULL: the stored tensor width equals D (no padded features).  `top`: H of the row above the strip in
+    // this column (wave-uniform; only read when TOP).
+    template <bool FULL, bool TOP>
+    CR_D void step(RbfTensor<R, D>& src, const ExpEntry* tab, int j, double top) {
+        const double* __restrict__ cg = src.cols_g;
+        const int d = FULL ? D : src.d;
+        // the column's features are wave-uniform: scalar loads.  (Always D loads: the tensor array is allocated with
+        // D doubles of slack and the padded features are zeroed by scalar selects -- conditional loads would cost a
+        // branch each.)
+#pragma unroll
+        for (int k = 0; k < D; k++) {
+            const double v = cg[(int64_t)j * d + k];
+            src.col[k] = (FULL || k < d) ? v : 0.0;
+        }
+        double dg[R], p[R];
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const double sc = src.score(q, tab);
+            dg[q] = (q == 0 ? eprev : hprev[q - 1]) + sc;
+            const double b = vmax(dg[q], hprev[q]);
+            p[q] = q == 0 ? b : vmax(p[q - 1], b);
+        }
+        double e = wave_shr1(wave_scan_max(p[R - 1]), 0.0);
+        if constexpr (TOP) e = vmax(e, top);
+        const int sh2 = (j & 15) * 2;
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const double h = vmax(p[q], e);
+            // decision replayed by the traceback's equality tests (:255-277): diag, then left, else up
+            const bool same = h == hprev[q];
+            uint32_t code = (h == dg[q]) ? 1u : same ? 2u : 3u;
+            code = (h > 0.0) ? code : 0u;
+            bits[q] |= code << sh2;
+            rowfirst[q] = same ? rowfirst[q] : j;          // column of the row's last strict increase
+            hprev[q] = h;
+        }
+        eprev = e;
+    }
+    CR_D void flush(uint32_t* __restrict__ sw_dirs, int64_t base) {
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            sw_dirs[base + q * kWave] = bits[q];
+            bits[q] = 0;
+        }
+    }
+    // fold the rows' maxima (= last values) into a running best, rows ascending
+    CR_D void fold(int rowbase, double& best_v, int& best_i, int& best_j) const {
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const bool gt = hprev[q] > best_v;
+            best_v = gt ? hprev[q] : best_v;
+            best_i = gt ? rowbase + q : best_i;
+            best_j = gt ? rowfirst[q] : best_j;
+        }
+    }
+};
+
+CR_D void wave_first_max(double& best_v, int& best_i, int& best_j) {
+    for (int off = 32; off > 0; off >>= 1) {
+        double ov = __shfl_xor(best_v, off);
+        int oi = __shfl_xor(best_i, off), oj = __shfl_xor(best_j, off);
+        bool take = ov > best_v || (ov == best_v && (oi < best_i || (oi == best_i && oj < best_j)));
+        best_v = take ? ov : best_v;
+        best_i = take ? oi : best_i;
+        best_j = take ? oj : best_j;
+    }
+}
+
+// One wave, strips one after the other.
 template <int R, int D>
 CR_D void sweep_cols(RbfTensor<R, D>& src, const int n, const int m, double* lds, uint32_t* __restrict__ sw_dirs,
                      double* __restrict__ hand_g, SeedMax& seed_out) {
@@ -720,86 +808,125 @@ CR_D void sweep_cols(RbfTensor<R, D>& src, const int n, const int m, double* lds
 
     const int nstrips = strips_of(n, R);
     const int TB = (m + 15) >> 4;
-    const int d = src.d;
+    const bool full = src.d == D;
     double best_v = 0.0;
     int best_i = 0x7fffffff, best_j = 0x7fffffff;
+    ColSweep<R, D> st;
 
     for (int s = 0; s < nstrips; s++) {
         const int rowbase = (s * kWave + lane) * R;
         src.load_rows(rowbase, n);
-        double hprev[R], eprev = 0.0;        // H of this lane's rows / of the row above them, previous column
-        int rowfirst[R];
-        uint32_t bits[R];
-#pragma unroll
-        for (int q = 0; q < R; q++) {
-            hprev[q] = 0.0;
-            rowfirst[q] = 0;
-            bits[q] = 0;
-        }
-        double cin_vec = 0.0;                // row above the strip, 64 columns per load (lane x: column j0 + x)
-        const double* __restrict__ cg = src.cols_g;
+        st.reset();
+        const bool hand_out = s + 1 < nstrips;
+        auto run = [&](auto full_tag, auto top_tag) {
+            constexpr bool FULL = decltype(full_tag)::value, TOP = decltype(top_tag)::value;
+            double top_vec = 0.0;                // row above the strip, 64 columns per load (lane x: column j0 + x)
 #pragma unroll 1
-        for (int j = 0; j < m; j++) {
-            if (s > 0 && (j & (kWave - 1)) == 0) cin_vec = (j + lane < m) ? hand_g[j + lane] : 0.0;
-            // the column's features: wave-uniform -> scalar loads
-            // (always D loads: the tensor array is allocated with D doubles of slack, the padded features are zeroed
-            // by scalar selects -- conditional loads would cost a branch each)
-#pragma unroll
-            for (int k = 0; k < D; k++) {
-                const double v = cg[(int64_t)j * d + k];
-                src.col[k] = (k < d) ? v : 0.0;
+            for (int j = 0; j < m; j++) {
+                if (TOP && (j & (kWave - 1)) == 0) top_vec = (j + lane < m) ? hand_g[j + lane] : 0.0;
+                st.template step<FULL, TOP>(src, tab, j, TOP ? lane_value(top_vec, j & (kWave - 1)) : 0.0);
+                if (hand_out && lane == kWave - 1) hand_g[j] = st.hprev[R - 1];
+                if ((j & 15) == 15 || j == m - 1) st.flush(sw_dirs, ((int64_t)(s * TB + (j >> 4)) * R) * kWave + lane);
             }
-            double dg[R], p[R];
-#pragma unroll
-            for (int q = 0; q < R; q++) {
-                const double sc = src.score(q, tab);
-                dg[q] = (q == 0 ? eprev : hprev[q - 1]) + sc;
-                const double b = vmax(dg[q], hprev[q]);
-                p[q] = q == 0 ? b : vmax(p[q - 1], b);
-            }
-            double e = wave_shr1(wave_scan_max(p[R - 1]), 0.0);
-            if (s > 0) e = vmax(e, lane_value(cin_vec, j & (kWave - 1)));
-            const int sh2 = (j & 15) * 2;
-#pragma unroll
-            for (int q = 0; q < R; q++) {
-                const double h = vmax(p[q], e);
-                // decision replayed by the traceback's equality tests (:255-277): diag, then left, else up
-                const bool same = h == hprev[q];
-                uint32_t code = (h == dg[q]) ? 1u : same ? 2u : 3u;
-                code = (h > 0.0) ? code : 0u;
-                bits[q] |= code << sh2;
-                rowfirst[q] = same ? rowfirst[q] : j;          // column of the row's last strict increase
-                hprev[q] = h;
-            }
-            eprev = e;
-            if (s + 1 < nstrips && lane == kWave - 1) hand_g[j] = hprev[R - 1];
-            if ((j & 15) == 15 || j == m - 1) {
-                const int64_t base = ((int64_t)(s * TB + (j >> 4)) * R) * kWave + lane;
-#pragma unroll
-                for (int q = 0; q < R; q++) {
-                    sw_dirs[base + q * kWave] = bits[q];
-                    bits[q] = 0;
-                }
-            }
+        };
+        if (s == 0) {
+            if (full) run(std::true_type{}, std::false_type{});
+            else run(std::false_type{}, std::false_type{});
+        } else {
+            if (full) run(std::true_type{}, std::true_type{});
+            else run(std::false_type{}, std::true_type{});
         }
-        if (s + 1 < nstrips) {                 // the hand-off row: visible to this wave's loads in the next strip
+        if (hand_out) {                        // the hand-off row: visible to this wave's loads in the next strip
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
         }
-        // fold the rows' maxima (= last values) into the lane's running best, rows ascending
-#pragma unroll
-        for (int q = 0; q < R; q++) {
-            const bool gt = hprev[q] > best_v;
-            best_v = gt ? hprev[q] : best_v;
-            best_i = gt ? rowbase + q : best_i;
-            best_j = gt ? rowfirst[q] : best_j;
-        }
+        st.fold(rowbase, best_v, best_i, best_j);
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        double ov = __shfl_xor(best_v, off);
-        int oi = __shfl_xor(best_i, off), oj = __shfl_xor(best_j, off);
-        bool take = ov > best_v || (ov == best_v && (oi < best_i || (oi == best_i && oj < best_j)));
+    wave_first_max(best_v, best_i, best_j);
+    seed_out.score = best_v;
+    seed_out.i = best_v > 0.0 ? best_i + 1 : 0;
+    seed_out.j = best_v > 0.0 ? best_j + 1 : 0;
+    __syncthreads();                                   // the caller may reuse the LDS from here on
+}
+
+// One WORKGROUP per pair, one wave per strip, all strips in flight: strip s works on columns [c * B, (c + 1) * B) in
+// phase c + s (B = kColChunk), i.e. only B columns behind the strip above it -- against 64 + in the skewed team sweeps.
+// The row above a strip arrives through an LDS ring written by the previous strip's last lane (one double per column,
+// two chunks deep); the waves meet at one barrier per phase.  LDS (doubles): exp table | NW rings of 2 * kColChunk |
+// NW * 4 reduction slots.  Results in every lane of every wave.
+constexpr int kColChunk = 16;
+
+template <int R, int D>
+CR_D void sweep_cols_team(RbfTensor<R, D>& src, const int n, const int m, double* lds,
+                          uint32_t* __restrict__ sw_dirs, SeedMax& seed_out) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int NW = (int)(blockDim.x >> 6);
+    const ExpEntry* tab = reinterpret_cast<const ExpEntry*>(lds);
+    double* rings = lds + kExpDoubles;
+    double* ring_out = rings + w * (2 * kColChunk);
+    const double* ring_in = rings + (w > 0 ? w - 1 : 0) * (2 * kColChunk);
+    double* red = rings + NW * (2 * kColChunk);
+    load_exp_table(lds, threadIdx.x);
+
+    const int nstrips = strips_of(n, R);                 // <= NW, guaranteed by the launcher
+    const int TB = (m + 15) >> 4;
+    const bool mine = w < nstrips;
+    const bool full = src.d == D;
+    const int rowbase = (w * kWave + lane) * R;
+    const bool hand_out = w + 1 < nstrips;
+    ColSweep<R, D> st;
+    st.reset();
+    if (mine) src.load_rows(rowbase, n);
+    const int chunks = (m + kColChunk - 1) / kColChunk;
+    const int phases = chunks + nstrips - 1;
+
+    auto run = [&](auto full_tag, auto top_tag) {
+        constexpr bool FULL = decltype(full_tag)::value, TOP = decltype(top_tag)::value;
+#pragma unroll 1
+        for (int g = 0; g < phases; g++) {
+            __syncthreads();                           // the chunk written in phase g - 1 is visible to the strip below
+            const int c = g - w;
+            if (!mine || c < 0 || c >= chunks) continue;
+            const int j0 = c * kColChunk;
+            const int jend = j0 + kColChunk < m ? j0 + kColChunk : m;
+            // the row above the strip for this chunk: lane x holds column j0 + x
+            double top_vec = 0.0;
+            if (TOP && lane < kColChunk) top_vec = ring_in[(c & 1) * kColChunk + lane];
+#pragma unroll 1
+            for (int j = j0; j < jend; j++) {
+                st.template step<FULL, TOP>(src, tab, j, TOP ? lane_value(top_vec, j - j0) : 0.0);
+                if (hand_out && lane == kWave - 1) ring_out[(c & 1) * kColChunk + (j - j0)] = st.hprev[R - 1];
+            }
+            st.flush(sw_dirs, ((int64_t)(w * TB + c) * R) * kWave + lane);      // one chunk = one decision word per row
+        }
+    };
+    if (w == 0) {
+        if (full) run(std::true_type{}, std::false_type{});
+        else run(std::false_type{}, std::false_type{});
+    } else {
+        if (full) run(std::true_type{}, std::true_type{});
+        else run(std::false_type{}, std::true_type{});
+    }
+
+    double best_v = 0.0;
+    int best_i = 0x7fffffff, best_j = 0x7fffffff;
+    if (mine) st.fold(rowbase, best_v, best_i, best_j);
+    wave_first_max(best_v, best_i, best_j);
+    if (lane == 0) {
+        red[w * 4 + 0] = best_v;
+        red[w * 4 + 1] = (double)best_i;
+        red[w * 4 + 2] = (double)best_j;
+    }
+    __threadfence();                                   // decision words of every wave visible to wave 0's walk
+    __syncthreads();
+    best_v = 0.0;
+    best_i = best_j = 0x7fffffff;
+    for (int x = 0; x < nstrips; x++) {
+        const double ov = red[x * 4 + 0];
+        const int oi = (int)red[x * 4 + 1], oj = (int)red[x * 4 + 2];
+        const bool take = ov > best_v || (ov == best_v && (oi < best_i || (oi == best_i && oj < best_j)));
         best_v = take ? ov : best_v;
         best_i = take ? oi : best_i;
         best_j = take ? oj : best_j;
@@ -807,7 +934,11 @@ CR_D void sweep_cols(RbfTensor<R, D>& src, const int n, const int m, double* lds
     seed_out.score = best_v;
     seed_out.i = best_v > 0.0 ? best_i + 1 : 0;
     seed_out.j = best_v > 0.0 ? best_j + 1 : 0;
-    __syncthreads();                                   // the caller may reuse the LDS from here on
+    __syncthreads();
+}
+
+__host__ __device__ inline size_t sweep_cols_team_lds_doubles(int waves) {
+    return kExpDoubles + (size_t)waves * (2 * kColChunk + 4);
 }
 
 // LDS doubles needed by a sweep of the given provider/mode for column count m and row count n
@@ -1744,8 +1875,9 @@ CR_D void drain_stores() {
 }
 
 // Stages 1+2: tensor RBF + SW fill (multiple_alignment.py:328-335), then traceback + seed Kabsch.
+// (the column sweep holds R * D row features and little else: three waves per SIMD -- 168 VGPRs -- up to 50 of them)
 template <int R, int D, bool ZG>
-__global__ __launch_bounds__(kWave, 2) void k_seed(const PairDesc* __restrict__ pairs,
+__global__ __launch_bounds__(kWave, (ZG && R * D <= 50) ? 3 : 2) void k_seed(const PairDesc* __restrict__ pairs,
                                                const double* __restrict__ tensors, int d,
                                                const double* __restrict__ coords, double gamma, double sw_gap,
                                                int max_entries, uint32_t* __restrict__ dirs,
@@ -2056,12 +2188,13 @@ __global__ __launch_bounds__(kTeamWaves* kWave) void k_seed_team(const PairDesc*
         src.d = d;
         src.neg_gamma = -gamma;
         SweepParams prm{sw_gap, 0.0, 0.0};
-        sweep_team<R, kSwTrace | (ZG ? kZeroGap : 0)>(src, pd.n, pd.m, prm, lds, dirs + pd.dirs_off, nullptr, sm, unused);
+        if constexpr (ZG) sweep_cols_team<R, D>(src, pd.n, pd.m, lds, dirs + pd.dirs_off, sm);
+        else sweep_team<R, kSwTrace>(src, pd.n, pd.m, prm, lds, dirs + pd.dirs_off, nullptr, sm, unused);
     }
     if (threadIdx.x >= kWave) return;                  // wave 0 goes on alone (wave_sync, no s_barrier from here on)
     CR_STAMP(1);
     Transform tr;
-    seed_trace<R>(pd, max_entries, coords, dirs, sm, lds + kExpDoubles, tr);
+    seed_trace<R, ZG ? 0 : 1>(pd, max_entries, coords, dirs, sm, lds + kExpDoubles, tr);
     if (threadIdx.x == 0) {
         xf[blockIdx.x] = tr;
         seed_score[blockIdx.x] = sm.score;
@@ -2124,12 +2257,13 @@ __global__ __launch_bounds__(kWideMaxWaves* kWave) void k_seed_wide(const PairDe
         src.d = d;
         src.neg_gamma = -gamma;
         SweepParams prm{sw_gap, 0.0, 0.0};
-        sweep_wide<R, kSwTrace | (ZG ? kZeroGap : 0)>(src, pd.n, pd.m, prm, lds, sync_every, dirs + pd.dirs_off, nullptr, sm, unused);
+        if constexpr (ZG) sweep_cols_team<R, D>(src, pd.n, pd.m, lds, dirs + pd.dirs_off, sm);
+        else sweep_wide<R, kSwTrace>(src, pd.n, pd.m, prm, lds, sync_every, dirs + pd.dirs_off, nullptr, sm, unused);
     }
     if (threadIdx.x >= kWave) return;                  // wave 0 goes on alone (wave_sync, no s_barrier from here on)
     CR_STAMP(1);
     Transform tr;
-    seed_trace<R>(pd, max_entries, coords, dirs, sm, lds + kExpDoubles, tr);
+    seed_trace<R, ZG ? 0 : 1>(pd, max_entries, coords, dirs, sm, lds + kExpDoubles, tr);
     if (threadIdx.x == 0) {
         xf[blockIdx.x] = tr;
         seed_score[blockIdx.x] = sm.score;

@@ -20,11 +20,9 @@ CR_ILP_SEED_TEAM_INSTANCES(CR_X)
 #define CR_X(R) template CR_NODE_TEAM_SIGNATURE(R)
 CR_ILP_NODE_TEAM_INSTANCES(CR_X)
 #undef CR_X
-#ifdef CR_WIDE_ILP
 #define CR_X(R, D, ZG) template CR_SEED_WIDE_SIGNATURE(R, D, ZG)
 CR_ILP_SEED_WIDE_INSTANCES(CR_X)
 #undef CR_X
 #define CR_X(R, ZG) template CR_ALIGN_WIDE_SIGNATURE(R, ZG)
 CR_ILP_ALIGN_WIDE_INSTANCES(CR_X)
 #undef CR_X
-#endif
