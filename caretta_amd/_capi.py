@@ -40,6 +40,7 @@ SIGNATURES = {
     "cr_device_count": [C.POINTER(C.c_int)],
     "cr_device_trim": [_i32],
     "cr_context_create": [_i32, _vp, _pp],
+    "cr_context_create_on_stream": [_i32, _vp, _pp],
     "cr_context_destroy": [_vp],
     "cr_context_synchronize": [_vp],
     "cr_context_stream": [_vp, _pp],

@@ -50,6 +50,9 @@ CR_ILP_ALIGN_WIDE_INSTANCES(CR_X)
 namespace {
 
 thread_local std::string g_err;
+// Work may be in flight on the device since the last device-wide wait of this thread (set by every API entry and every
+// kernel launch; DevBuf::release waits once and clears it, instead of once per buffer).
+thread_local bool g_dirty = true;
 thread_local bool g_no_wide = false;     // set around cr_batch_set_pairs by callers whose second kernel has no wide version (cr_progressive_node)
 
 int fail(int code, const std::string& msg) {
@@ -149,7 +152,10 @@ struct DevBuf {
                 int cur = 0;
                 (void)hipGetDevice(&cur);
                 if (cur != dev) (void)hipSetDevice(dev);
-                (void)hipDeviceSynchronize();
+                if (g_dirty || cur != dev) {             // one wait for all the buffers a call releases
+                    (void)hipDeviceSynchronize();
+                    g_dirty = false;
+                }
                 kept = block_cache(dev).give(p, cls);
                 if (cur != dev) (void)hipSetDevice(cur);
             }
@@ -271,8 +277,16 @@ namespace {
 int set_device(cr_context* ctx) {
     CR_REQUIRE(ctx != nullptr, "null context");
     CR_HIP(hipSetDevice(ctx->device));
+    g_dirty = true;
     return CR_OK;
 }
+
+// every kernel launch of the library goes through this (see g_dirty)
+#define CR_LAUNCH(...)                   \
+    do {                                 \
+        g_dirty = true;                  \
+        hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)
 
 template <class K>
 int allow_lds(K kernel, size_t bytes) {
@@ -291,7 +305,7 @@ int launch_seed_zg(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm)
     const size_t lds = sizeof(double) * std::max(fill, (size_t)cr::kExpDoubles + cr::trace_lds_doubles(R, entries));
     int rc = allow_lds(cr::k_seed<R, D, ZG>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((cr::k_seed<R, D, ZG>), dim3((unsigned)ck.count), dim3(cr::kWave), lds, b->launch_stream ? b->launch_stream : b->ctx->stream,
+    CR_LAUNCH((cr::k_seed<R, D, ZG>), dim3((unsigned)ck.count), dim3(cr::kWave), lds, b->launch_stream ? b->launch_stream : b->ctx->stream,
                        b->pairs.p + ck.first, b->tensors.p, (int)b->d, b->coords.p, prm.gamma_tensor, prm.sw_gap,
                        entries, b->dirs.p, b->hand.p, b->xf.p + ck.first, b->seed_score.p + ck.first);
     CR_HIP(hipGetLastError());
@@ -322,7 +336,7 @@ int launch_align_zg(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm
     const size_t lds = sizeof(double) * std::max(fill, (size_t)cr::kExpDoubles + cr::trace_lds_doubles(R, entries));
     int rc = allow_lds(cr::k_align<R, ZG>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((cr::k_align<R, ZG>), dim3((unsigned)ck.count), dim3(cr::kWave), lds, b->launch_stream ? b->launch_stream : b->ctx->stream,
+    CR_LAUNCH((cr::k_align<R, ZG>), dim3((unsigned)ck.count), dim3(cr::kWave), lds, b->launch_stream ? b->launch_stream : b->ctx->stream,
                        b->pairs.p + ck.first, b->coords.p, b->xf.p + ck.first, b->seed_score.p + ck.first,
                        prm.gamma_coords, prm.sw_gap, prm.gap_open, prm.gap_extend, entries, b->bits.p, b->hand.p, b->aln.p,
                        b->res.p + ck.first);
@@ -346,7 +360,7 @@ int launch_align_team_zg(cr_batch* b, const cr_batch::Chunk& ck, const cr_params
                                                  (size_t)cr::kExpDoubles + cr::trace_lds_doubles(R, entries));
     int rc = allow_lds(cr::k_align_team<R, ZG>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((cr::k_align_team<R, ZG>), dim3((unsigned)ck.count), dim3(cr::kTeamWaves * cr::kWave), lds, b->ctx->stream,
+    CR_LAUNCH((cr::k_align_team<R, ZG>), dim3((unsigned)ck.count), dim3(cr::kTeamWaves * cr::kWave), lds, b->ctx->stream,
                        b->pairs.p + ck.first, b->coords.p, b->xf.p + ck.first, b->seed_score.p + ck.first, prm.gamma_coords,
                        prm.sw_gap, prm.gap_open, prm.gap_extend, entries, b->bits.p, b->aln.p, b->res.p + ck.first);
     CR_HIP(hipGetLastError());
@@ -375,7 +389,7 @@ int launch_seed_wide_zg(cr_batch* b, const cr_batch::Chunk& ck, const cr_params&
     const size_t lds = sizeof(double) * std::max(fill, (size_t)cr::kExpDoubles + cr::trace_lds_doubles(R, entries));
     int rc = allow_lds(cr::k_seed_wide<R, D, ZG>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((cr::k_seed_wide<R, D, ZG>), dim3((unsigned)ck.count), dim3(waves * cr::kWave), lds,
+    CR_LAUNCH((cr::k_seed_wide<R, D, ZG>), dim3((unsigned)ck.count), dim3(waves * cr::kWave), lds,
                        b->launch_stream ? b->launch_stream : b->ctx->stream, b->pairs.p + ck.first, b->tensors.p, (int)b->d,
                        b->coords.p, prm.gamma_tensor, prm.sw_gap, entries, b->wide_sync, b->dirs.p, b->xf.p + ck.first,
                        b->seed_score.p + ck.first);
@@ -408,7 +422,7 @@ int launch_align_wide_zg(cr_batch* b, const cr_batch::Chunk& ck, const cr_params
                                                  (size_t)cr::kExpDoubles + cr::trace_lds_doubles(R, entries));
     int rc = allow_lds(cr::k_align_wide<R, ZG>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((cr::k_align_wide<R, ZG>), dim3((unsigned)ck.count), dim3(waves * cr::kWave), lds,
+    CR_LAUNCH((cr::k_align_wide<R, ZG>), dim3((unsigned)ck.count), dim3(waves * cr::kWave), lds,
                        b->launch_stream ? b->launch_stream : b->ctx->stream, b->pairs.p + ck.first, b->coords.p, b->xf.p + ck.first,
                        b->seed_score.p + ck.first, prm.gamma_coords, prm.sw_gap, prm.gap_open, prm.gap_extend, entries,
                        b->wide_sync, b->bits.p, b->aln.p, b->res.p + ck.first);
@@ -521,7 +535,7 @@ int cr_device_trim(int device) {
     return CR_OK;
 }
 
-int cr_context_create(int device, void* stream, cr_context** out) {
+static int context_create(int device, void* stream, bool borrow, cr_context** out) {
     CR_REQUIRE(out != nullptr, "null out");
     *out = nullptr;
     int n = 0;
@@ -536,10 +550,12 @@ int cr_context_create(int device, void* stream, cr_context** out) {
     cr_context* ctx = new (std::nothrow) cr_context();
     if (!ctx) return fail(CR_ERR_MEMORY, "out of host memory");
     ctx->device = device;
-    if (stream) {
-        ctx->stream = reinterpret_cast<hipStream_t>(stream);
+    if (borrow) {
+        ctx->stream = reinterpret_cast<hipStream_t>(stream);     // may be 0: the legacy default stream
     } else {
-        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        // a blocking stream: ordered with the legacy default stream that PyTorch and RCCL use (a non-blocking one
+        // would let a collective queued after cr_batch_run read the scores while the kernels still write them)
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamDefault);
         if (e != hipSuccess) {
             delete ctx;
             return fail(CR_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
@@ -549,6 +565,10 @@ int cr_context_create(int device, void* stream, cr_context** out) {
     *out = ctx;
     return CR_OK;
 }
+
+int cr_context_create(int device, void* stream, cr_context** out) { return context_create(device, stream, stream != nullptr, out); }
+
+int cr_context_create_on_stream(int device, void* stream, cr_context** out) { return context_create(device, stream, true, out); }
 
 int cr_context_destroy(cr_context* ctx) {
     if (!ctx) return CR_OK;
@@ -877,7 +897,7 @@ int cr_batch_run(cr_batch* b, const cr_params* params, double* d_sw_out) {
         CR_HIP(hipStreamWaitEvent(ctx->stream, ctx->sync_ev[(size_t)k], 0));
     }
     if (d_sw_out && b->reordered) {
-        hipLaunchKernelGGL(cr::k_scatter_sw, dim3((unsigned)((b->npairs + 255) / 256)), dim3(256), 0, ctx->stream, b->res.p,
+        CR_LAUNCH(cr::k_scatter_sw, dim3((unsigned)((b->npairs + 255) / 256)), dim3(256), 0, ctx->stream, b->res.p,
                            b->d_order.p, d_sw_out, (int)b->npairs);
         CR_HIP(hipGetLastError());
     } else if (d_sw_out) {

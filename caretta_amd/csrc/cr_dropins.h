@@ -99,8 +99,9 @@ __global__ void k_sw_trace_full(int n, int m, int R, const uint32_t* __restrict_
     out->start = cap - len;
 }
 
-// paired_svd_superpose (superposition_functions.py:7-35), sequential sums as under numba.
-CR_D void kabsch_seq(const double* __restrict__ x1, const double* __restrict__ x2, int k, double* R, double* t,
+// paired_svd_superpose (superposition_functions.py:7-35), sequential sums as under numba.  Host and device: the
+// single-call drop-ins run it on the host for small inputs (small_on_host()), the kernels for the rest.
+CR_HD void kabsch_seq(const double* __restrict__ x1, const double* __restrict__ x2, int k, double* R, double* t,
                      double* c1, double* c2) {
     for (int a = 0; a < 3; a++) {
         double s1 = 0.0, s2 = 0.0;
@@ -144,9 +145,8 @@ __global__ void k_transform(const double* __restrict__ x, int k, const double* _
 }
 
 // get_rmsd (score_functions.py:15-19) and tm_score (multiple_alignment.py:59-70); out[0]=rmsd, out[1]=tm
-__global__ void k_rmsd_tm(const double* __restrict__ x1, const double* __restrict__ x2, int k, int64_t l1, int64_t l2,
-                          double* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+CR_HD void rmsd_tm_seq(const double* __restrict__ x1, const double* __restrict__ x2, int k, int64_t l1, int64_t l2,
+                       double* __restrict__ out) {
     const double d1 = 1.24 * (double)(l1 - 15) / 3.0 - 1.8;
     const double d2 = 1.24 * (double)(l2 - 15) / 3.0 - 1.8;
     double ss = 0.0, sum1 = 0.0, sum2 = 0.0;
@@ -166,6 +166,12 @@ __global__ void k_rmsd_tm(const double* __restrict__ x1, const double* __restric
     const double t1 = (1.0 / (double)l1) * sum1;
     const double t2 = (1.0 / (double)l2) * sum2;
     out[1] = t1 > t2 ? t1 : t2;
+}
+
+__global__ void k_rmsd_tm(const double* __restrict__ x1, const double* __restrict__ x2, int k, int64_t l1, int64_t l2,
+                          double* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    rmsd_tm_seq(x1, x2, k, l1, l2, out);
 }
 
 // superpose_core (multiple_alignment.py:914-950): every structure fitted onto the reference over the gap-free
@@ -323,7 +329,7 @@ int run_explicit(cr_context* ctx, const int64_t* seq1, int64_t n, const int64_t*
     CR_HIP(r.aln.ensure(2 * (size_t)(n + m)));
     const size_t lds = cr::sweep_lds_doubles<R, MODE, cr::Explicit<R>>((int)n, (int)m) * sizeof(double);
     if ((rc = allow_lds(cr::k_explicit<R, MODE>, lds))) return rc;
-    hipLaunchKernelGGL((cr::k_explicit<R, MODE>), dim3(1), dim3(cr::kWave), lds, ctx->stream, r.s1.p, (int)n, r.s2.p,
+    CR_LAUNCH((cr::k_explicit<R, MODE>), dim3(1), dim3(cr::kWave), lds, ctx->stream, r.s1.p, (int)n, r.s2.p,
                        (int)m, r.S.p, s_cols, prm, r.dirs.p, r.bits.p, r.hand.p, r.seed.p, r.end.p);
     CR_HIP(hipGetLastError());
     return CR_OK;
@@ -355,7 +361,7 @@ int launch_node_r(hipStream_t stream, int count, int n_max, int m_max, int entri
                                                  (size_t)cr::kExpDoubles + cr::trace_lds_doubles(R, entries));
     int rc = allow_lds(cr::k_node<R>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(cr::k_node<R>, dim3((unsigned)count), dim3(cr::kWave), lds, stream, pairs, coords, tensors, d, weights,
+    CR_LAUNCH(cr::k_node<R>, dim3((unsigned)count), dim3(cr::kWave), lds, stream, pairs, coords, tensors, d, weights,
                        nodes, xf, prm.gamma_coords, gamma_weight, prm.gap_open, prm.gap_extend, entries, bits, hand, aln, xn,
                        tn, wn, out);
     CR_HIP(hipGetLastError());
@@ -372,7 +378,7 @@ int launch_node_team_r(hipStream_t stream, int count, int n_max, int m_max, int 
                                                  (size_t)cr::kExpDoubles + cr::trace_lds_doubles(R, entries));
     int rc = allow_lds(cr::k_node_team<R>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(cr::k_node_team<R>, dim3((unsigned)count), dim3(cr::kTeamWaves * cr::kWave), lds, stream, pairs, coords,
+    CR_LAUNCH(cr::k_node_team<R>, dim3((unsigned)count), dim3(cr::kTeamWaves * cr::kWave), lds, stream, pairs, coords,
                        tensors, d, weights, nodes, xf, prm.gamma_coords, gamma_weight, prm.gap_open, prm.gap_extend, entries,
                        bits, hand, aln, xn, tn, wn, out);
     CR_HIP(hipGetLastError());
@@ -393,7 +399,7 @@ int launch_seed_team_zg(cr_batch* b, const cr_batch::Chunk& ck, const cr_params&
                                                  (size_t)cr::kExpDoubles + cr::trace_lds_doubles(R, entries));
     int rc = allow_lds(cr::k_seed_team<R, D, ZG>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((cr::k_seed_team<R, D, ZG>), dim3((unsigned)ck.count), dim3(cr::kTeamWaves * cr::kWave), lds,
+    CR_LAUNCH((cr::k_seed_team<R, D, ZG>), dim3((unsigned)ck.count), dim3(cr::kTeamWaves * cr::kWave), lds,
                        b->ctx->stream, b->pairs.p + ck.first, b->tensors.p, (int)b->d, b->coords.p, prm.gamma_tensor,
                        prm.sw_gap, entries, b->dirs.p, b->xf.p + ck.first, b->seed_score.p + ck.first);
     CR_HIP(hipGetLastError());
@@ -448,7 +454,7 @@ int cr_make_score_matrix(cr_context* ctx, const double* a, int64_t n, const doub
     if ((rc = upload(db, b, (size_t)m * k, ctx->stream))) return rc;
     CR_HIP(ds.ensure((size_t)n * m));
     dim3 block(64, 4), grid((unsigned)((m + 63) / 64), (unsigned)((n + 3) / 4));
-    hipLaunchKernelGGL(cr::k_score_matrix, grid, block, 0, ctx->stream, da.p, (int)n, db.p, (int)m, (int)k, -gamma, ds.p);
+    CR_LAUNCH(cr::k_score_matrix, grid, block, 0, ctx->stream, da.p, (int)n, db.p, (int)m, (int)k, -gamma, ds.p);
     CR_HIP(hipGetLastError());
     CR_HIP(hipMemcpyAsync(S, ds.p, sizeof(double) * (size_t)n * m, hipMemcpyDeviceToHost, ctx->stream));
     CR_HIP(hipStreamSynchronize(ctx->stream));
@@ -483,7 +489,7 @@ int cr_protein_score_function(cr_context* ctx, const double* coords_i, const dou
         hipError_t e = ds.ensure((size_t)n * m);
         if (e == hipSuccess) {
             dim3 block(64, 4), grid((unsigned)((m + 63) / 64), (unsigned)((n + 3) / 4));
-            hipLaunchKernelGGL(cr::k_score_matrix_xf, grid, block, 0, ctx->stream, b->coords.p, (int)n,
+            CR_LAUNCH(cr::k_score_matrix_xf, grid, block, 0, ctx->stream, b->coords.p, (int)n,
                                b->coords.p + n * 3, (int)m, b->xf.p, -gamma_coords, ds.p);
             e = hipGetLastError();
         }
@@ -583,7 +589,7 @@ int cr_dtw_align(cr_context* ctx, const int64_t* seq1, int64_t n, const int64_t*
     if (rc) return rc;
     cr::AlignEnd e;
     if (aln1 && aln2) {
-        hipLaunchKernelGGL(cr::k_dtw_trace_full, dim3(1), dim3(1), 0, ctx->stream, (int)n, (int)m, kExplicitR, r.bits.p,
+        CR_LAUNCH(cr::k_dtw_trace_full, dim3(1), dim3(1), 0, ctx->stream, (int)n, (int)m, kExplicitR, r.bits.p,
                            r.end.p, r.aln.p, r.tout.p);
         CR_HIP(hipGetLastError());
     }
@@ -621,7 +627,7 @@ int cr_smith_waterman(cr_context* ctx, const int64_t* seq1, int64_t n, const int
     cr::SweepParams prm{gap, 0.0, 0.0};
     int rc = run_explicit<cr::kSwTrace>(ctx, seq1, n, seq2, m, S, s_rows, s_cols, prm, r);
     if (rc) return rc;
-    hipLaunchKernelGGL(cr::k_sw_trace_full, dim3(1), dim3(1), 0, ctx->stream, (int)n, (int)m, kExplicitR, r.dirs.p,
+    CR_LAUNCH(cr::k_sw_trace_full, dim3(1), dim3(1), 0, ctx->stream, (int)n, (int)m, kExplicitR, r.dirs.p,
                        r.seed.p, r.aln.p, r.tout.p);
     CR_HIP(hipGetLastError());
     cr::SeedMax sm;
@@ -632,15 +638,29 @@ int cr_smith_waterman(cr_context* ctx, const int64_t* seq1, int64_t n, const int
     return fetch_alignment(ctx, r, n, m, aln1, aln2, aln_len);
 }
 
+// The single-call Kabsch / RMSD / TM drop-ins work on a 3 x 3 problem fed by sequential sums: one launch and two
+// copies (0.1 ms) for what the reference's numba does in microseconds.  Up to this many positions they run the SAME
+// CR_HD code on the host (bit-identical: FP64 +, -, *, /, sqrt are correctly rounded on both sides, the library is
+// built without FMA contraction); CARETTA_HOST_SMALL_K=0 sends everything to the kernels (the parity test does).
+static bool small_on_host(int64_t k) {
+    const char* env = std::getenv("CARETTA_HOST_SMALL_K");
+    return k <= (env ? (int64_t)std::atoll(env) : (int64_t)4096);
+}
+
 int cr_paired_svd_superpose(cr_context* ctx, const double* x1, const double* x2, int64_t k, double* R, double* t) {
     int rc = set_device(ctx);
     if (rc) return rc;
     CR_REQUIRE(x1 && x2 && R && t && k >= 1 && k < (1 << 28), "bad argument");
+    if (small_on_host(k)) {
+        double c1[3], c2[3];
+        cr::kabsch_seq(x1, x2, (int)k, R, t, c1, c2);
+        return CR_OK;
+    }
     DevBuf<double> d1, d2, out;
     if ((rc = upload(d1, x1, (size_t)k * 3, ctx->stream))) return rc;
     if ((rc = upload(d2, x2, (size_t)k * 3, ctx->stream))) return rc;
     CR_HIP(out.ensure(18));
-    hipLaunchKernelGGL(cr::k_kabsch, dim3(1), dim3(1), 0, ctx->stream, d1.p, d2.p, (int)k, out.p);
+    CR_LAUNCH(cr::k_kabsch, dim3(1), dim3(1), 0, ctx->stream, d1.p, d2.p, (int)k, out.p);
     CR_HIP(hipGetLastError());
     double h[18];
     CR_HIP(hipMemcpyAsync(h, out.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
@@ -665,13 +685,13 @@ int cr_paired_svd_superpose_with_subset(cr_context* ctx, const double* c1, int64
     CR_HIP(r1.ensure((size_t)n * 3));
     CR_HIP(r2.ensure((size_t)m * 3));
     CR_HIP(r3.ensure((size_t)k * 3));
-    hipLaunchKernelGGL(cr::k_kabsch, dim3(1), dim3(1), 0, ctx->stream, ds1.p, ds2.p, (int)k, kab.p);
+    CR_LAUNCH(cr::k_kabsch, dim3(1), dim3(1), 0, ctx->stream, ds1.p, ds2.p, (int)k, kab.p);
     const int th = 256;
-    hipLaunchKernelGGL(cr::k_transform, dim3((unsigned)((n + th - 1) / th)), dim3(th), 0, ctx->stream, dc1.p, (int)n,
+    CR_LAUNCH(cr::k_transform, dim3((unsigned)((n + th - 1) / th)), dim3(th), 0, ctx->stream, dc1.p, (int)n,
                        (const double*)nullptr, (const double*)nullptr, kab.p + 12, r1.p);
-    hipLaunchKernelGGL(cr::k_transform, dim3((unsigned)((m + th - 1) / th)), dim3(th), 0, ctx->stream, dc2.p, (int)m,
+    CR_LAUNCH(cr::k_transform, dim3((unsigned)((m + th - 1) / th)), dim3(th), 0, ctx->stream, dc2.p, (int)m,
                        kab.p, (const double*)nullptr, kab.p + 15, r2.p);
-    hipLaunchKernelGGL(cr::k_transform, dim3((unsigned)((k + th - 1) / th)), dim3(th), 0, ctx->stream, ds2.p, (int)k,
+    CR_LAUNCH(cr::k_transform, dim3((unsigned)((k + th - 1) / th)), dim3(th), 0, ctx->stream, ds2.p, (int)k,
                        kab.p, kab.p + 9, (const double*)nullptr, r3.p);
     CR_HIP(hipGetLastError());
     CR_HIP(hipMemcpyAsync(o1, r1.p, sizeof(double) * (size_t)n * 3, hipMemcpyDeviceToHost, ctx->stream));
@@ -694,7 +714,7 @@ int cr_apply_rotran(cr_context* ctx, const double* x, int64_t k, const double* R
     if ((rc = upload(dr, rt, 12, ctx->stream))) return rc;
     CR_HIP(dout.ensure((size_t)k * 3));
     const int th = 256;
-    hipLaunchKernelGGL(cr::k_transform, dim3((unsigned)((k + th - 1) / th)), dim3(th), 0, ctx->stream, dx.p, (int)k, dr.p,
+    CR_LAUNCH(cr::k_transform, dim3((unsigned)((k + th - 1) / th)), dim3(th), 0, ctx->stream, dx.p, (int)k, dr.p,
                        dr.p + 9, (const double*)nullptr, dout.p);
     CR_HIP(hipGetLastError());
     CR_HIP(hipMemcpyAsync(out, dout.p, sizeof(double) * (size_t)k * 3, hipMemcpyDeviceToHost, ctx->stream));
@@ -706,11 +726,15 @@ static int rmsd_tm(cr_context* ctx, const double* x1, const double* x2, int64_t 
     int rc = set_device(ctx);
     if (rc) return rc;
     CR_REQUIRE(x1 && x2 && k >= 1, "bad argument");
+    if (small_on_host(k)) {
+        cr::rmsd_tm_seq(x1, x2, (int)k, l1, l2, h);
+        return CR_OK;
+    }
     DevBuf<double> d1, d2, out;
     if ((rc = upload(d1, x1, (size_t)k * 3, ctx->stream))) return rc;
     if ((rc = upload(d2, x2, (size_t)k * 3, ctx->stream))) return rc;
     CR_HIP(out.ensure(2));
-    hipLaunchKernelGGL(cr::k_rmsd_tm, dim3(1), dim3(1), 0, ctx->stream, d1.p, d2.p, (int)k, l1, l2, out.p);
+    CR_LAUNCH(cr::k_rmsd_tm, dim3(1), dim3(1), 0, ctx->stream, d1.p, d2.p, (int)k, l1, l2, out.p);
     CR_HIP(hipGetLastError());
     CR_HIP(hipMemcpyAsync(h, out.p, sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->stream));
     CR_HIP(hipStreamSynchronize(ctx->stream));
@@ -771,7 +795,7 @@ int cr_msa_metrics(cr_context* ctx, const double* coords, const int64_t* offsets
     CR_HIP(dout.ensure((size_t)npairs * 4));
     const size_t lds = sizeof(double) * (((size_t)W + 3) / 4 * 2 + (size_t)cr::kWave * cr::kMaxAcc);
     if ((rc = allow_lds(cr::k_msa_metrics, lds))) return rc;
-    hipLaunchKernelGGL(cr::k_msa_metrics, dim3((unsigned)npairs), dim3(cr::kWave), lds, ctx->stream, dc.p, doff.p, dmsa.p,
+    CR_LAUNCH(cr::k_msa_metrics, dim3((unsigned)npairs), dim3(cr::kWave), lds, ctx->stream, dc.p, doff.p, dmsa.p,
                        (int)P, (int)W, superpose, dpairs.p, dout.p);
     CR_HIP(hipGetLastError());
     std::vector<double> h((size_t)npairs * 4);
@@ -828,12 +852,12 @@ int cr_superpose_core(cr_context* ctx, const double* coords, const int64_t* offs
     CR_HIP(dx1.ensure((size_t)ncore * 3));
     CR_HIP(dcen.ensure(3));
     const size_t lds1 = sizeof(double) * (size_t)cr::kWave * 3;
-    hipLaunchKernelGGL(cr::k_core_reference, dim3(1), dim3(cr::kWave), lds1, ctx->stream, dc.p + offsets[ref] * 3,
+    CR_LAUNCH(cr::k_core_reference, dim3(1), dim3(cr::kWave), lds1, ctx->stream, dc.p + offsets[ref] * 3,
                        dmsa.p + ref * W, dcore.p, (int)ncore, dx1.p, dcen.p);
     CR_HIP(hipGetLastError());
     const size_t lds2 = sizeof(double) * (((size_t)ncore + 3) / 4 * 2 + (size_t)cr::kWave * cr::kMaxAcc);
     if ((rc = allow_lds(cr::k_core_superpose, lds2))) return rc;
-    hipLaunchKernelGGL(cr::k_core_superpose, dim3((unsigned)P), dim3(cr::kWave), lds2, ctx->stream, dc.p, doff.p, dmsa.p, (int)W,
+    CR_LAUNCH(cr::k_core_superpose, dim3((unsigned)P), dim3(cr::kWave), lds2, ctx->stream, dc.p, doff.p, dmsa.p, (int)W,
                        dcore.p, (int)ncore, (int)ref, dx1.p, dcen.p, dout.p);
     CR_HIP(hipGetLastError());
     CR_HIP(hipMemcpyAsync(coords_out, dout.p, sizeof(double) * (size_t)total * 3, hipMemcpyDeviceToHost, ctx->stream));
@@ -868,7 +892,7 @@ int cr_superpose_reference(cr_context* ctx, const double* coords, const int64_t*
     if ((rc = allow_lds(cr::k_reference_superpose, lds))) return rc;
     auto launch = [&](int64_t first, int64_t count, const double* ref_coords) {
         if (count <= 0) return;
-        hipLaunchKernelGGL(cr::k_reference_superpose, dim3((unsigned)count), dim3(cr::kWave), lds, ctx->stream, dc.p, doff.p, dmsa.p,
+        CR_LAUNCH(cr::k_reference_superpose, dim3((unsigned)count), dim3(cr::kWave), lds, ctx->stream, dc.p, doff.p, dmsa.p,
                            (int)W, (int)ref, ref_coords, dwhich.p + first, dout.p, dcounts.p + first);
     };
     launch(0, ref, dc.p + offsets[ref] * 3);                       // before the reference: its original coordinates
@@ -909,7 +933,7 @@ int cr_superpose_members(cr_context* ctx, double* coords, const int64_t* offsets
     CR_HIP(hipMemcpyAsync(dout.p, dc.p, sizeof(double) * (size_t)total * 3, hipMemcpyDeviceToDevice, ctx->stream));
     const size_t lds = sizeof(double) * (((size_t)W + 3) / 4 * 2 + (size_t)cr::kWave * cr::kMaxAcc);
     if ((rc = allow_lds(cr::k_reference_superpose, lds))) return rc;
-    hipLaunchKernelGGL(cr::k_reference_superpose, dim3((unsigned)nwhich), dim3(cr::kWave), lds, ctx->stream, dc.p, doff.p, dmsa.p,
+    CR_LAUNCH(cr::k_reference_superpose, dim3((unsigned)nwhich), dim3(cr::kWave), lds, ctx->stream, dc.p, doff.p, dmsa.p,
                        (int)W, (int)ref, dc.p + offsets[ref] * 3, dwhich.p, dout.p, dcounts.p);
     CR_HIP(hipGetLastError());
     std::vector<int32_t> counts((size_t)nwhich);

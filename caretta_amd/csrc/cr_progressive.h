@@ -209,7 +209,7 @@ int run_tree_planned(cr_progressive* h, const std::vector<std::vector<int64_t>>&
     for (int64_t lv = 1; lv <= h->levels + 1; lv++) {
         const int64_t first = start[(size_t)lv], count = lv <= h->levels ? start[(size_t)lv + 1] - first : 0;
         const int64_t pfirst = lv > 1 ? start[(size_t)lv - 1] : 0, pcount = lv > 1 ? first - pfirst : 0;
-        hipLaunchKernelGGL(cr::k_plan_level, dim3(1), dim3(256), sizeof(int32_t) * 2 * (size_t)std::max<int64_t>(count, 1), stream, d_plan.p + pfirst, (int)pcount, h->d_nodes.p + pfirst,
+        CR_LAUNCH(cr::k_plan_level, dim3(1), dim3(256), sizeof(int32_t) * 2 * (size_t)std::max<int64_t>(count, 1), stream, d_plan.p + pfirst, (int)pcount, h->d_nodes.p + pfirst,
                            h->d_outs.p + pfirst, d_plan.p + first, (int)count, R, bound, aln_base[(size_t)std::min(lv, h->levels)],
                            d_len.p, d_off.p, d_used.p, b.pairs.p + first, h->d_nodes.p + first, d_overflow.p);
         CR_HIP(hipGetLastError());

@@ -71,14 +71,29 @@ def pairwise_matrix_sharded(coords, tensors, offsets, params=None, group=None,
         local = torch.full((size,), float("nan"), dtype=torch.float64)
         local[:len(mine)] = torch.from_numpy(np.asarray(compute_fn(coords, tensors, offsets, pairs[mine]), dtype=np.float64))
     else:
-        from .engine import Context, PairBatch
+        from . import _capi
+        from .engine import Context, PairBatch, make_params
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        # the kernels run on torch's current stream (also when that is the legacy default stream, handle 0): the fill
+        # of `local` before them and the all-gather after them are ordered with them by the stream itself
         ctx = Context(dev.index or 0, stream=torch.cuda.current_stream(dev).cuda_stream)
         local = torch.full((size,), float("nan"), dtype=torch.float64, device=dev)
         batch = PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs[mine])
+        if params is None:       # Protein.score_function's defaults (multiple_alignment.py:321-322), as make_pairwise_matrix
+            params = make_params(gamma_tensor=0.03, gamma_coords=0.03)
         batch.run(params, sw_out_device_ptr=local.data_ptr())
-        ctx.synchronize()
+        _, flags = batch.fetch_scores()
         batch.close()
         ctx.close()
+        # The reference raises at a pair whose tensor score matrix has no positive local alignment (smith_waterman:
+        # max_pos is None).  The owner marks such a pair NaN BEFORE the collective, so every rank takes part in the
+        # all-gather and every rank raises afterwards.
+        bad = np.nonzero(flags & _capi.FLAG_SEED_ALL_ZERO)[0]
+        if len(bad):
+            local[torch.from_numpy(bad).to(dev)] = float("nan")
     gathered = gather_scores(local, world, group)
-    return scatter_to_matrix(gathered.cpu().numpy(), pairs, lengths, num)
+    try:
+        return scatter_to_matrix(gathered.cpu().numpy(), pairs, lengths, num)
+    except RuntimeError as exc:
+        raise TypeError("a pair of the family has no positive local alignment of its tensor score matrix "
+                        "(reference: max_pos is None)") from exc

@@ -36,7 +36,10 @@ class Context:
     def __init__(self, device: int = 0, stream: Optional[int] = None, profiling: int = 0):
         self._lib = _capi.load()
         self._h = C.c_void_p()
-        check(self._lib.cr_context_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        if stream is None:       # a private (blocking) stream
+            check(self._lib.cr_context_create(int(device), None, C.byref(self._h)))
+        else:                    # borrow the caller's stream; 0 is the legacy default stream torch works on
+            check(self._lib.cr_context_create_on_stream(int(device), C.c_void_p(int(stream)), C.byref(self._h)))
         self.device = int(device)
         if profiling:
             self.set_profiling(profiling)

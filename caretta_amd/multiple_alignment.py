@@ -32,15 +32,25 @@ def tm_score(coords_1, coords_2, l1, l2):
     return out.value
 
 
+def _merge_rows(rows_1, rows_2, aln_1, aln_2, combine):
+    """One output row per alignment column: a gap on one side takes the other side's row, an aligned column
+    `combine(row_1, row_2)` -- the element-wise rule shared by the reference's mean functions."""
+    aln_1, aln_2 = np.asarray(aln_1), np.asarray(aln_2)
+    has_1, has_2 = aln_1 != -1, aln_2 != -1
+    rows_1, rows_2 = np.asarray(rows_1, dtype=np.float64), np.asarray(rows_2, dtype=np.float64)
+    out = np.zeros((len(aln_1),) + rows_1.shape[1:])
+    both = has_1 & has_2
+    out[has_1 & ~has_2] = rows_1[aln_1[has_1 & ~has_2]]
+    out[has_2 & ~has_1] = rows_2[aln_2[has_2 & ~has_1]]
+    out[both] = combine(rows_1[aln_1[both]], rows_2[aln_2[both]])
+    return out
+
+
 def get_mean_weights(weights_1, weights_2, aln_1, aln_2) -> np.ndarray:
-    """multiple_alignment.py:73-82"""
-    mean_weights = np.zeros((aln_1.shape[0], 1))
-    for i, (x, y) in enumerate(zip(aln_1, aln_2)):
-        if not x == -1:
-            mean_weights[i] += weights_1[x]
-        if not y == -1:
-            mean_weights[i] += weights_2[y]
-    return mean_weights
+    """multiple_alignment.py:73-82: the consensus weight of a column is the sum of the weights present in it
+    ((len, 1) array; 0 + w is w exactly, so the masked form gives the reference's values bit for bit)."""
+    w1, w2 = np.asarray(weights_1, dtype=np.float64).reshape(-1, 1), np.asarray(weights_2, dtype=np.float64).reshape(-1, 1)
+    return _merge_rows(w1, w2, aln_1, aln_2, lambda a, b: a + b)
 
 
 class SequenceBase(ABC):
@@ -93,34 +103,22 @@ class Protein(SequenceBase):
 
     def mean_function(self, other: "Protein", aln_1: np.ndarray, aln_2: np.ndarray, name_int: str, flexible=False,
                       verbose=True) -> "Protein":
-        """multiple_alignment.py:351-381"""
-        tensors_mean = np.zeros((len(aln_1), self.tensors.shape[1]))
-        for i, (x, y) in enumerate(zip(aln_1, aln_2)):
-            if x == -1:
-                tensors_mean[i] = other.tensors[y]
-            elif y == -1:
-                tensors_mean[i] = self.tensors[x]
-            else:
-                tensors_mean[i] = (self.tensors[x] + other.tensors[y]) / 2
+        """multiple_alignment.py:351-381: column-wise mean of the tensors, and of the coordinates after superposing
+        `other` on `self` over the aligned columns.  (The resident progressive alignment computes the same node on the
+        device, cr_progressive.h; this host form serves callers that hold two Proteins and an alignment.)"""
+        halve = lambda a, b: (a + b) / 2
+        tensors_mean = _merge_rows(self.tensors, other.tensors, aln_1, aln_2, halve)
         if flexible:
             return Protein(name_int, tensors_mean)
         pos_1, pos_2 = helper.get_common_positions(aln_1, aln_2)
-        if len(pos_1) <= 3:
+        if len(pos_1) > 3:
+            frame_1, frame_2, _ = superposition_functions.paired_svd_superpose_with_subset(
+                self.coordinates, other.coordinates, self.coordinates[pos_1], other.coordinates[pos_2])
+        else:
             if verbose:
                 print(f"Too few aligning positions for {self.name} and {other.name}, continuing without superposition")
-            coords_1, coords_2 = np.array(self.coordinates), np.array(other.coordinates)
-        else:
-            coords_1, coords_2, _ = superposition_functions.paired_svd_superpose_with_subset(
-                self.coordinates, other.coordinates, self.coordinates[pos_1], other.coordinates[pos_2])
-        coordinates_mean = np.zeros((len(aln_1), self.coordinates.shape[1]))
-        for i, (x, y) in enumerate(zip(aln_1, aln_2)):
-            if x == -1:
-                coordinates_mean[i] = coords_2[y]
-            elif y == -1:
-                coordinates_mean[i] = coords_1[x]
-            else:
-                coordinates_mean[i] = (coords_1[x] + coords_2[y]) / 2
-        return Protein(name_int, tensors_mean, coordinates_mean)
+            frame_1, frame_2 = np.array(self.coordinates), np.array(other.coordinates)
+        return Protein(name_int, tensors_mean, _merge_rows(frame_1, frame_2, aln_1, aln_2, halve))
 
     def __len__(self) -> int:
         return self.tensors.shape[0]
@@ -193,6 +191,45 @@ class _NodeAttribute:
 
     def __set__(self, obj, value):
         obj.__dict__[self.slot] = value
+
+
+def _tree_joins(tree):
+    """The joins of a neighbor-joining tree in the order progressive_align performs them (multiple_alignment.py:236-246):
+    rows come in pairs (child, parent) sharing the parent, the last row joins the two remaining nodes.
+    Yields (child_1, child_2, label) with label the parent id, or "final" for the root."""
+    tree = np.asarray(tree)
+    for row in range(0, tree.shape[0] - 1, 2):
+        if int(tree[row + 1, 1]) != int(tree[row, 1]):
+            raise AssertionError("rows of the tree do not pair up")
+        yield int(tree[row, 0]), int(tree[row + 1, 0]), int(tree[row, 1])
+    yield int(tree[-1, 0]), int(tree[-1, 1]), "final"
+
+
+class _GuideTreeWalk:
+    """State of a progressive alignment on the host: the nodes built so far, their consensus weights, and for every
+    node the alignment rows of its members (name -> {member name -> index row}), i.e. the reference's
+    final_sequences / final_consensus_weights / final_alignments."""
+
+    def __init__(self, leaves, consensus_weight):
+        self.nodes = list(leaves)
+        self.weights = [np.full((len(s), 1), consensus_weight, dtype=np.float64) for s in leaves]
+        self.members = {s.name: {s.name: np.arange(len(s))} for s in leaves}
+
+    def join(self, left, right, label, align_children):
+        """Append the parent of nodes `left` and `right`; returns the member rows of the new node."""
+        s1, s2 = self.nodes[left], self.nodes[right]
+        name_int = f"int-{label}"
+        aln_1, aln_2, parent, weights = align_children(s1, s2, self.weights[left], self.weights[right], name_int)
+        merged = {}
+        for child, aln in ((s1, aln_1), (s2, aln_2)):
+            # every member row is re-indexed through the node alignment (:218-229); gaps stay -1
+            rows = {name: np.where(aln != -1, np.asarray(row)[aln], -1) for name, row in self.members[child.name].items()}
+            self.members[child.name] = rows
+            merged.update(rows)
+        self.members[name_int] = merged
+        self.nodes.append(parent)
+        self.weights.append(weights)
+        return merged
 
 
 @dataclass
@@ -277,56 +314,33 @@ class MultipleAlignment:
             return self._progressive_align_resident(tree, gap_open_penalty, gap_extend_penalty, consensus_weight,
                                                     gamma_weight, score_function_params, mean_function_params)
         self._drop_pending_nodes()
-        final_sequences = [s for s in self.sequences]
-        final_alignments = {s.name: {s.name: np.arange(len(s))} for s in final_sequences}
-        final_consensus_weights = [np.full((len(s), 1), consensus_weight, dtype=np.float64) for s in final_sequences]
+        walk = _GuideTreeWalk(self.sequences, consensus_weight)
+        fusable = not score_function_params.get("flexible", False) and not mean_function_params.get("flexible", False)
 
-        def make_intermediate_node(n1, n2, n_int):
-            name_1, name_2 = final_sequences[n1].name, final_sequences[n2].name
-            n1_weights, n2_weights = final_consensus_weights[n1], final_consensus_weights[n2]
-            total = len(final_alignments[name_1]) + len(final_alignments[name_2])
-            multiplier_n1 = len(final_alignments[name_2]) / (2 * total)
-            multiplier_n2 = len(final_alignments[name_1]) / (2 * total)
-            name_int = f"int-{n_int}"
-            s1, s2 = final_sequences[n1], final_sequences[n2]
-            fused = (type(s1) is Protein and type(s2) is Protein and s1.coordinates is not None
-                     and s2.coordinates is not None and not score_function_params.get("flexible", False)
-                     and not mean_function_params.get("flexible", False))
-            if fused:
+        def align_children(s1, s2, w1, w2, name_int):
+            """One tree node: (aln_1, aln_2, the new consensus sequence, its consensus weights)."""
+            size_1, size_2 = len(walk.members[s1.name]), len(walk.members[s2.name])
+            mult_1, mult_2 = size_2 / (2 * (size_1 + size_2)), size_1 / (2 * (size_1 + size_2))       # :199-202
+            if (fusable and type(s1) is Protein and type(s2) is Protein and s1.coordinates is not None
+                    and s2.coordinates is not None):
                 # the whole node (score matrices, dtw_align, mean_function, get_mean_weights) in two launches
-                aln_1, aln_2, intermediate, weights = _progressive_node(
-                    s1, s2, n1_weights, n2_weights, multiplier_n1, multiplier_n2, name_int, gap_open_penalty,
-                    gap_extend_penalty, gamma_weight, score_function_params, mean_function_params)
-            else:
-                score_matrix = s1.score_function(s2, **score_function_params)
-                score_matrix += score_functions.make_score_matrix(n1_weights * multiplier_n1,
-                                                                  n2_weights * multiplier_n2,
-                                                                  score_functions.get_gaussian_score, gamma_weight)
-                aln_1, aln_2, _ = dtw.dtw_align(np.arange(score_matrix.shape[0]), np.arange(score_matrix.shape[1]),
-                                                score_matrix, gap_open_penalty=gap_open_penalty,
-                                                gap_extend_penalty=gap_extend_penalty)
-                intermediate = s1.mean_function(s2, aln_1, aln_2, name_int, **mean_function_params)
-                weights = get_mean_weights(n1_weights, n2_weights, aln_1, aln_2)
-            # re-index every member row through the node alignment (:218-229), vectorised
-            final_alignments[name_1] = {name: np.where(aln_1 != -1, np.asarray(seq)[aln_1], -1)
-                                        for name, seq in final_alignments[name_1].items()}
-            final_alignments[name_2] = {name: np.where(aln_2 != -1, np.asarray(seq)[aln_2], -1)
-                                        for name, seq in final_alignments[name_2].items()}
-            final_alignments[name_int] = {**final_alignments[name_1], **final_alignments[name_2]}
-            final_sequences.append(intermediate)
-            final_consensus_weights.append(weights)
+                return _progressive_node(s1, s2, w1, w2, mult_1, mult_2, name_int, gap_open_penalty, gap_extend_penalty,
+                                         gamma_weight, score_function_params, mean_function_params)
+            # third-party SequenceBase plugins: their score / mean functions around the HIP dtw_align (:204-217)
+            scores = s1.score_function(s2, **score_function_params)
+            scores += score_functions.make_score_matrix(w1 * mult_1, w2 * mult_2, score_functions.get_gaussian_score,
+                                                        gamma_weight)
+            aln_1, aln_2, _ = dtw.dtw_align(np.arange(scores.shape[0]), np.arange(scores.shape[1]), scores,
+                                            gap_open_penalty=gap_open_penalty, gap_extend_penalty=gap_extend_penalty)
+            return (aln_1, aln_2, s1.mean_function(s2, aln_1, aln_2, name_int, **mean_function_params),
+                    get_mean_weights(w1, w2, aln_1, aln_2))
 
-        for x in range(0, tree.shape[0] - 1, 2):
-            node_1, node_2, node_int = int(tree[x, 0]), int(tree[x + 1, 0]), int(tree[x, 1])
-            assert int(tree[x + 1, 1]) == node_int
-            make_intermediate_node(node_1, node_2, node_int)
-        node_1, node_2 = int(tree[-1, 0]), int(tree[-1, 1])
-        make_intermediate_node(node_1, node_2, "final")
-        alignment = {**final_alignments[final_sequences[node_1].name], **final_alignments[final_sequences[node_2].name]}
-        self.final_consensus_weights = final_consensus_weights
-        self.final_alignments = final_alignments
-        self.final_sequences = final_sequences
-        return alignment
+        for left, right, label in _tree_joins(tree):
+            top = walk.join(left, right, label, align_children)
+        self.final_consensus_weights = walk.weights
+        self.final_alignments = walk.members
+        self.final_sequences = walk.nodes
+        return top
 
     def _progressive_align_resident(self, tree, gap_open_penalty, gap_extend_penalty, consensus_weight, gamma_weight,
                                     score_function_params, mean_function_params):

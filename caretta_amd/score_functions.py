@@ -27,12 +27,12 @@ def get_rmsd(coords_1, coords_2) -> float:
 def make_score_matrix(coords_1, coords_2, score_function, gamma, normalized: bool = False) -> np.ndarray:
     """(n, m) matrix of ``score_function`` between all rows (score_functions.py:23-51).
 
-    Only ``get_gaussian_score`` is ever passed by the reference (and is the only function the
-    kernels implement).  ``normalized=True`` (no caller in the reference) z-scores both inputs with the
-    mean / standard deviation of their concatenation first (score_functions.py:43-47).
+    ``get_gaussian_score`` -- the only function the reference ever passes -- runs as a HIP kernel.  Any other
+    callable (a third-party plugin's cell score) is applied cell by cell on the host exactly as the reference's loop
+    does (score_functions.py:48-50): that is the plugin's own code, not a fallback of the accelerated path.
+    ``normalized=True`` (no caller in the reference) z-scores both inputs with the mean / standard deviation of their
+    concatenation first (score_functions.py:43-47).
     """
-    if score_function is not get_gaussian_score:
-        raise ValueError("only caretta_amd.score_functions.get_gaussian_score is supported")
     a, b = f64(coords_1), f64(coords_2)
     if a.ndim != 2 or b.ndim != 2 or a.shape[1] != b.shape[1]:
         raise ValueError("coords_1 and coords_2 must be 2-D with equal width")
@@ -41,6 +41,10 @@ def make_score_matrix(coords_1, coords_2, score_function, gamma, normalized: boo
         both = np.concatenate((a, b))
         mean, std = helper.nb_mean_axis_0(both), helper.nb_std_axis_0(both)
         a, b = f64((a - mean) / std), f64((b - mean) / std)
+    if score_function is not get_gaussian_score:
+        if not callable(score_function):
+            raise TypeError("score_function must be callable")
+        return np.array([[score_function(row, col, gamma) for col in b] for row in a], dtype=np.float64).reshape(len(a), len(b))
     s = np.zeros((a.shape[0], b.shape[0]))
     check(_capi.load().cr_make_score_matrix(default_context()._h, ptr(a), a.shape[0], ptr(b), b.shape[0], a.shape[1],
                                             float(gamma), ptr(s)))

@@ -78,9 +78,14 @@ int cr_device_count(int *count);
 /* Device scratch released by batches / drop-ins is kept for reuse (hipMalloc / hipFree dominate short calls);
  * this returns all of it to the driver.  CARETTA_NO_CACHE=1 in the environment disables the reuse altogether. */
 int cr_device_trim(int device);
-/* `stream` is a hipStream_t to launch on (e.g. torch.cuda.current_stream().cuda_stream) or NULL to
- * create a private stream. */
+/* `stream` is a hipStream_t to launch on or NULL to create a private stream.  The private stream is a BLOCKING
+ * stream (hipStreamDefault): it is implicitly ordered with the legacy default stream, on which PyTorch and RCCL
+ * work unless told otherwise, so a collective queued after cr_batch_run sees the finished scores. */
 int cr_context_create(int device, void *stream, cr_context **out);
+/* Borrow `stream` as it is, INCLUDING the legacy default stream (hipStream_t 0 -- what
+ * torch.cuda.current_stream().cuda_stream returns by default, and which cr_context_create cannot tell from
+ * "no stream"). */
+int cr_context_create_on_stream(int device, void *stream, cr_context **out);
 int cr_context_destroy(cr_context *ctx);
 int cr_context_synchronize(cr_context *ctx);
 int cr_context_stream(cr_context *ctx, void **stream_out);

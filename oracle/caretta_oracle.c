@@ -438,7 +438,22 @@ void cro_svd3(const double C[9], double U[9], double Sg[3], double Vt[9]) {
         else
             for (int r = 0; r < 3; r++) Um[3 * r + j] = (r == j) ? 1.0 : 0.0;
     }
-    if (!(Sg[2] > 1e-12 * Sg[0])) { /* rank <= 2: complete the basis */
+    /* rank-deficient C (collinear or coincident positions): LAPACK returns an orthonormal U with an arbitrary basis of
+     * the null space; complete ours so that U @ Vt stays a rotation */
+    const double tol = 1e-12 * Sg[0];
+    if (!(Sg[1] > tol)) { /* rank <= 1: column 1 := the coordinate axis least aligned with column 0, Gram-Schmidt */
+        const double a0 = fabs(Um[0]), a1 = fabs(Um[3]), a2 = fabs(Um[6]);
+        int k = 0;
+        double am = a0;
+        if (a1 < am) { am = a1; k = 1; }
+        if (a2 < am) { am = a2; k = 2; }
+        const double uk = Um[3 * k];
+        double v[3];
+        for (int r = 0; r < 3; r++) v[r] = ((r == k) ? 1.0 : 0.0) - uk * Um[3 * r];
+        const double nv = sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+        for (int r = 0; r < 3; r++) Um[3 * r + 1] = v[r] / nv;
+    }
+    if (!(Sg[2] > tol)) { /* rank <= 2: column 2 := column 0 x column 1 */
         Um[2] = Um[3] * Um[7] - Um[6] * Um[4];
         Um[5] = Um[6] * Um[1] - Um[0] * Um[7];
         Um[8] = Um[0] * Um[4] - Um[3] * Um[1];

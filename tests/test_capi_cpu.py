@@ -180,3 +180,15 @@ def test_small_host_helpers(golden):
     assert len(ma.alignment_to_numpy({"e": ""})["e"]) == 0
     np.testing.assert_allclose(helper.nb_std_axis_0(g["std_x"]), g["std_out"], rtol=1e-14)
     np.testing.assert_allclose(helper.normalize(g["norm_x"]), g["norm_out"], rtol=0, atol=1e-15)
+
+
+def test_make_score_matrix_applies_a_plugin_score_function_on_the_host():
+    """score_functions.py:48-50: any callable is applied cell by cell (a third-party SequenceBase plugin's own code)."""
+    from caretta_amd import score_functions as sf
+    a = np.arange(6.0).reshape(3, 2)
+    b = np.arange(8.0).reshape(4, 2) / 3
+    got = sf.make_score_matrix(a, b, lambda u, v, gamma: gamma * float(np.abs(u - v).sum()), 0.5)
+    want = np.array([[0.5 * np.abs(u - v).sum() for v in b] for u in a])
+    assert got.shape == (3, 4) and np.array_equal(got, want)
+    with pytest.raises(TypeError):
+        sf.make_score_matrix(a, b, "not callable", 0.5)

@@ -135,6 +135,39 @@ def test_dp_multistrip_vs_oracle(oracle):
 
 
 # ------------------------------------------------------------------------------- Kabsch & metrics
+def test_kabsch_rank_deficient(oracle):
+    """Collinear / coincident / planar positions: the device SVD completes U to a rotation exactly as the oracle does."""
+    from caretta_amd import superposition_functions as sup
+    from test_oracle_golden import degenerate_kabsch_cases
+    for tag, x1, x2 in degenerate_kabsch_cases():
+        r, t = sup.paired_svd_superpose(x1, x2)
+        ro, to = oracle.paired_svd_superpose(x1, x2)
+        assert np.array_equal(r, ro) and np.array_equal(t, to), tag
+        np.testing.assert_allclose(r @ r.T, np.eye(3), atol=1e-12, err_msg=tag)
+
+
+def test_small_dropins_host_and_kernel_paths_agree(oracle, monkeypatch):
+    """paired_svd_superpose / get_rmsd / tm_score run the same CR_HD code on the host for small inputs and in a kernel
+    for large ones: both paths, and the oracle, bit for bit."""
+    from caretta_amd import multiple_alignment as ma
+    from caretta_amd import score_functions as sf
+    from caretta_amd import superposition_functions as sup
+    rng = np.random.default_rng(5)
+    for k in (3, 17, 300):
+        x1 = rng.normal(size=(k, 3)) * 10
+        x2 = rng.normal(size=(k, 3)) * 10
+        got = {}
+        for limit in ("4096", "0"):
+            monkeypatch.setenv("CARETTA_HOST_SMALL_K", limit)
+            r, t = sup.paired_svd_superpose(x1, x2)
+            got[limit] = (r, t, sf.get_rmsd(x1, x2), ma.tm_score(x1, x2, k + 20, k + 40))
+        for a, b in zip(got["4096"], got["0"]):
+            assert np.array_equal(a, b)
+        ro, to = oracle.paired_svd_superpose(x1, x2)
+        assert np.array_equal(got["0"][0], ro) and np.array_equal(got["0"][1], to)
+        assert got["0"][2] == oracle.get_rmsd(x1, x2) and got["0"][3] == oracle.tm_score(x1, x2, k + 20, k + 40)
+
+
 def test_kabsch_golden(oracle, golden):
     from caretta_amd import score_functions as sf
     from caretta_amd import superposition_functions as sup

@@ -90,6 +90,50 @@ def test_smith_waterman_all_zero_flag(oracle):
     assert rc == 1 and len(a1) == 0 and sc == 0.0
 
 
+def degenerate_kabsch_cases():
+    """Rank-deficient correlation matrices: collinear positions (rank 1), coincident positions (rank 0), planar (rank 2)."""
+    rng = np.random.default_rng(77)
+    cases = []
+    for _ in range(6):
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        ts = rng.normal(size=(12, 1)) * 5
+        line1 = rng.normal(size=3) + ts * d
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        if np.linalg.det(q) < 0:
+            q[:, 0] = -q[:, 0]
+        line2 = (line1 - line1.mean(0)) @ q + rng.normal(size=3)
+        cases.append(("collinear", line1, line2))
+    axis = np.zeros((9, 3))
+    axis[:, 0] = np.arange(9.0)
+    cases.append(("collinear on x", axis, axis[::-1].copy()))
+    cases.append(("coincident", np.ones((7, 3)) * 2.5, np.ones((7, 3)) * -1.0))
+    plane = rng.normal(size=(15, 3))
+    plane[:, 2] = 0.0
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    cases.append(("planar", plane, plane @ q + 1.0))
+    return cases
+
+
+def test_kabsch_rank_deficient(oracle):
+    """The reference's LAPACK SVD returns an orthonormal U for any input; so must the Jacobi SVD (collinear seeds)."""
+    for tag, x1, x2 in degenerate_kabsch_cases():
+        r, t = oracle.paired_svd_superpose(x1, x2)
+        assert np.all(np.isfinite(r)) and np.all(np.isfinite(t)), tag
+        np.testing.assert_allclose(r @ r.T, np.eye(3), atol=1e-12, err_msg=tag)
+        assert abs(np.linalg.det(r) - 1.0) < 1e-12, tag
+        moved = oracle.apply_rotran(x2, r, t)
+        # the superposition is optimal: same RMSD as numpy's LAPACK-based Kabsch
+        c1, c2 = x1.mean(0), x2.mean(0)
+        u, sv, vh = np.linalg.svd((x2 - c2).T @ (x1 - c1))
+        if np.linalg.det(u) * np.linalg.det(vh) < 0:
+            u[:, -1] = -u[:, -1]
+        ref = (x2 - c2) @ (u @ vh) + c1
+        assert abs(oracle.get_rmsd(x1, moved) - oracle.get_rmsd(x1, ref)) < 1e-9, tag
+
+
 def test_kabsch(oracle, golden):
     g = golden("f1_kabsch.npz")
     for c in range(int(g["ncases"])):
