@@ -30,6 +30,10 @@ PAIR_RESULT_DTYPE = np.dtype([("sw", "f8"), ("dtw_score", "f8"), ("R", "f8", (9,
                               ("rmsd", "f8"), ("coverage", "f8"), ("tm", "f8"), ("seed_score", "f8"),
                               ("aln_len", "i4"), ("aln_start", "i4"), ("seed_len", "i4"), ("flags", "u4")])
 assert PAIR_RESULT_DTYPE.itemsize == 160
+# cr_explicit_problem (include/caretta_hip.h)
+EXPLICIT_PROBLEM_DTYPE = np.dtype([("s_off", "i8"), ("seq1_off", "i8"), ("seq2_off", "i8"), ("s_rows", "i4"), ("s_cols", "i4"),
+                                   ("n", "i4"), ("m", "i4")])
+assert EXPLICIT_PROBLEM_DTYPE.itemsize == 40
 
 _vp, _i64, _i32, _f64 = C.c_void_p, C.c_int64, C.c_int, C.c_double
 _pp = C.POINTER(C.c_void_p)
@@ -69,6 +73,11 @@ SIGNATURES = {
     "cr_smith_waterman_score": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _f64, C.POINTER(C.c_double)],
     "cr_smith_waterman": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _f64, _vp, _vp, C.POINTER(C.c_int64),
                           C.POINTER(C.c_double), C.POINTER(C.c_int)],
+    "cr_explicit_batch_create": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _pp],
+    "cr_explicit_batch_destroy": [_vp],
+    "cr_explicit_batch_last_ms": [_vp, C.POINTER(C.c_float)],
+    "cr_smith_waterman_score_batch": [_vp, _f64, _vp],
+    "cr_dtw_align_batch": [_vp, _f64, _f64, _vp, _i64, _vp, _vp],
     "cr_paired_svd_superpose": [_vp, _vp, _vp, _i64, _vp, _vp],
     "cr_paired_svd_superpose_with_subset": [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp],
     "cr_apply_rotran": [_vp, _vp, _i64, _vp, _vp, _vp],

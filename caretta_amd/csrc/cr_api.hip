@@ -1043,3 +1043,4 @@ int cr_batch_destroy(cr_batch* b) {
 
 #include "cr_dropins.h"
 #include "cr_progressive.h"
+#include "cr_explicit_batch.h"

@@ -67,3 +67,91 @@ def smith_waterman(seq1, seq2, score_matrix, gap: float = 0.0):
     if az.value:
         raise TypeError("cannot unpack non-iterable NoneType object (score matrix has no positive local alignment)")
     return a1[:ln.value].copy(), a2[:ln.value].copy(), sc.value
+
+
+class ExplicitBatch:
+    """A list of (seq1, seq2, score_matrix) problems resident in HBM: ``smith_waterman_scores`` / ``dtw_align`` run the
+    reference's function over the whole list in one launch sequence (C ABI: cr_explicit_batch).  This is how
+    ``MultipleAlignment.make_pairwise_matrix`` serves third-party ``SequenceBase`` plugins (multiple_alignment.py:158-170):
+    the plugin's score matrices are computed by its own Python code, the O(P^2) smith_waterman_score calls are not."""
+
+    def __init__(self, problems, context=None):
+        problems = list(problems)
+        if not problems:
+            raise ValueError("need at least one problem")
+        self._lib = _capi.load()
+        self._ctx = context or default_context()
+        mats, seqs = [], []
+        desc = np.zeros(len(problems), dtype=_capi.EXPLICIT_PROBLEM_DTYPE)
+        s_off = q_off = 0
+        for k, (seq1, seq2, matrix) in enumerate(problems):
+            s1, s2, s = _prep(seq1, seq2, matrix)
+            desc[k] = (s_off, q_off, q_off + len(s1), s.shape[0], s.shape[1], len(s1), len(s2))
+            mats.append(s.ravel())
+            seqs.extend((s1, s2))
+            s_off += s.size
+            q_off += len(s1) + len(s2)
+        self.shapes = [(int(d["n"]), int(d["m"])) for d in desc]
+        self.cells = int(sum(int(d["s_rows"]) * int(d["s_cols"]) for d in desc))
+        S = np.concatenate(mats) if len(mats) > 1 else np.ascontiguousarray(mats[0])
+        Q = np.concatenate(seqs)
+        self._h = C.c_void_p()
+        check(self._lib.cr_explicit_batch_create(self._ctx._h, ptr(S), S.size, ptr(Q), Q.size, ptr(desc), len(desc),
+                                                 C.byref(self._h)))
+
+    def __len__(self):
+        return len(self.shapes)
+
+    def smith_waterman_scores(self, gap: float = 0.0) -> np.ndarray:
+        """smith_waterman_score (dynamic_time_warping.py:205-222) of every problem."""
+        out = np.zeros(len(self))
+        check(self._lib.cr_smith_waterman_score_batch(self._h, float(gap), ptr(out)))
+        return out
+
+    def dtw_align(self, gap_open_penalty: float = 0.0, gap_extend_penalty: float = 0.0, want_alignments: bool = True):
+        """dtw_align (dynamic_time_warping.py:148-184) of every problem -> list of (aln_1, aln_2, score), or the scores."""
+        scores = np.zeros(len(self))
+        if not want_alignments:
+            check(self._lib.cr_dtw_align_batch(self._h, float(gap_open_penalty), float(gap_extend_penalty), None, 0, None,
+                                               ptr(scores)))
+            return scores
+        stride = max(n + m for n, m in self.shapes)
+        aln = np.empty((len(self), 2, stride), dtype=np.int64)
+        lens = np.zeros(len(self), dtype=np.int64)
+        check(self._lib.cr_dtw_align_batch(self._h, float(gap_open_penalty), float(gap_extend_penalty), ptr(aln), stride,
+                                           ptr(lens), ptr(scores)))
+        return [(aln[k, 0, :lens[k]].copy(), aln[k, 1, :lens[k]].copy(), float(scores[k])) for k in range(len(self))]
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float(0.0)
+        check(self._lib.cr_explicit_batch_last_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def close(self):
+        if self._h:
+            self._lib.cr_explicit_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def smith_waterman_score_batch(problems, gap: float = 0.0) -> np.ndarray:
+    """[smith_waterman_score(seq1, seq2, matrix, gap) for (seq1, seq2, matrix) in problems] in one launch."""
+    batch = ExplicitBatch(problems)
+    try:
+        return batch.smith_waterman_scores(gap)
+    finally:
+        batch.close()
+
+
+def dtw_align_batch(problems, gap_open_penalty: float = 0.0, gap_extend_penalty: float = 0.0):
+    """[dtw_align(seq1, seq2, matrix, gap_open_penalty, gap_extend_penalty) for ... in problems] in one launch sequence."""
+    batch = ExplicitBatch(problems)
+    try:
+        return batch.dtw_align(gap_open_penalty, gap_extend_penalty)
+    finally:
+        batch.close()

@@ -193,6 +193,9 @@ class _NodeAttribute:
         obj.__dict__[self.slot] = value
 
 
+_PLUGIN_BATCH_BYTES = 1 << 30      # score matrices of plugin sequences gathered on the host per batched launch
+
+
 def _tree_joins(tree):
     """The joins of a neighbor-joining tree in the order progressive_align performs them (multiple_alignment.py:236-246):
     rows come in pairs (child, parent) sharing the parent, the last row joins the two remaining nodes.
@@ -290,13 +293,29 @@ class MultipleAlignment:
         if self._all_proteins() and not score_function_params.get("flexible", False):
             out = self.pairwise(score_function_params, want_alignments=False, scores_only=True)
             return assemble_matrix(out.pairs, out.results["sw"], num)
-        # third-party SequenceBase plugins: their own score_function, our smith_waterman_score
+        # third-party SequenceBase plugins: the score matrices come from the plugin's own score_function (its Python),
+        # the O(P^2) smith_waterman_score calls run many matrices per launch (dtw.ExplicitBatch), flushed whenever
+        # the matrices held on the host reach _PLUGIN_BATCH_BYTES
         matrix = np.zeros((num, num))
+        held, where, held_bytes = [], [], 0
+
+        def flush():
+            nonlocal held, where, held_bytes
+            if held:
+                for (i, j), score in zip(where, dtw.smith_waterman_score_batch(held)):
+                    matrix[i, j] = matrix[j, i] = score
+            held, where, held_bytes = [], [], 0
+
         for i in range(num - 1):
             for j in range(i + 1, num):
-                matrix[i, j] = matrix[j, i] = dtw.smith_waterman_score(
-                    np.arange(len(self.sequences[i])), np.arange(len(self.sequences[j])),
-                    self.sequences[i].score_function(self.sequences[j], **score_function_params))
+                scores = np.ascontiguousarray(self.sequences[i].score_function(self.sequences[j], **score_function_params),
+                                              dtype=np.float64)
+                held.append((np.arange(len(self.sequences[i])), np.arange(len(self.sequences[j])), scores))
+                where.append((i, j))
+                held_bytes += scores.nbytes
+                if held_bytes >= _PLUGIN_BATCH_BYTES:
+                    flush()
+        flush()
         return matrix
 
     # -- guide tree + progressive alignment ---------------------------------------------------

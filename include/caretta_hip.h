@@ -172,6 +172,30 @@ int cr_dtw_align(cr_context *ctx, const int64_t *seq1, int64_t n, const int64_t 
 /* dynamic_time_warping.smith_waterman_score                            dynamic_time_warping.py:205-222 */
 int cr_smith_waterman_score(cr_context *ctx, const int64_t *seq1, int64_t n, const int64_t *seq2, int64_t m,
                             const double *S, int64_t s_rows, int64_t s_cols, double gap, double *score);
+/* ---- many explicit score matrices per launch --------------------------------------------------------
+ * MultipleAlignment.make_pairwise_matrix calls smith_waterman_score once per pair on the matrix a SequenceBase
+ * plugin's score_function returned (multiple_alignment.py:158-170), progressive_align calls dtw_align once per tree
+ * node (:204-217).  A cr_explicit_batch holds a list of such problems -- matrices packed in S, index sequences packed
+ * in seqs (int64, as the reference's np.arange) -- resident in HBM; the two entry points below run
+ * dynamic_time_warping.py:205-222 / :148-184 over the whole list in one launch sequence. */
+typedef struct {
+    int64_t s_off;              /* element offset of the s_rows x s_cols matrix in S */
+    int64_t seq1_off, seq2_off; /* element offsets of the index sequences in seqs */
+    int32_t s_rows, s_cols;
+    int32_t n, m;               /* sequence lengths */
+} cr_explicit_problem;
+typedef struct cr_explicit_batch cr_explicit_batch;
+int cr_explicit_batch_create(cr_context *ctx, const double *S, int64_t s_elems, const int64_t *seqs, int64_t seq_elems,
+                             const cr_explicit_problem *problems, int64_t count, cr_explicit_batch **out);
+int cr_explicit_batch_destroy(cr_explicit_batch *b);
+/* device time (ms, HIP events on the context's stream) of the kernels of the last batch call */
+int cr_explicit_batch_last_ms(cr_explicit_batch *b, float *ms);
+/* scores[count] = smith_waterman_score(seq1_k, seq2_k, S_k, gap)      dynamic_time_warping.py:205-222 */
+int cr_smith_waterman_score_batch(cr_explicit_batch *b, double gap, double *scores);
+/* dtw_align(seq1_k, seq2_k, S_k, gap_open, gap_extend) for every k     dynamic_time_warping.py:148-184
+ * aln: int64 [count][2][aln_stride] (aln_stride >= longest n + m), rows padded with -2; aln may be NULL (scores only). */
+int cr_dtw_align_batch(cr_explicit_batch *b, double gap_open, double gap_extend, int64_t *aln, int64_t aln_stride,
+                       int64_t *aln_len, double *scores);
 /* dynamic_time_warping.smith_waterman; *all_zero = 1 where the reference raises (no maximum)
  *                                                                      dynamic_time_warping.py:226-278 */
 int cr_smith_waterman(cr_context *ctx, const int64_t *seq1, int64_t n, const int64_t *seq2, int64_t m,

@@ -118,6 +118,88 @@ def test_smith_waterman_edge_cases():
         dtw.dtw_align(np.array([0, 7]), np.arange(3), np.ones((2, 3)))
 
 
+def _explicit_problems(rng):
+    """Ragged list of (seq1, seq2, S): identity sequences, alphabet mode, negative scores, a -1 in seq2, columns
+    beyond one strip of every width, a 1 x 1 matrix."""
+    problems = []
+    for n, m in [(1, 1), (5, 64), (64, 65), (37, 128), (150, 150), (300, 300), (90, 321), (33, 700), (257, 513), (12, 1100)]:
+        problems.append((np.arange(n), np.arange(m), rng.uniform(size=(n, m)) ** 3 - 0.2))
+    sub = rng.normal(size=(20, 20))                      # alphabet mode: a substitution matrix indexed by residue type
+    for n, m in [(40, 55), (200, 333), (7, 600)]:
+        problems.append((rng.integers(0, 20, size=n), rng.integers(0, 20, size=m), sub))
+    big = rng.uniform(size=(50, 400))                    # a window of a larger matrix: contiguous columns from 17 on
+    problems.append((np.arange(10, 40), np.arange(17, 317), big))
+    problems.append((np.arange(50)[::-1].copy(), np.arange(400)[::2].copy(), big))     # strided columns: gathers
+    return problems
+
+
+def test_smith_waterman_score_batch_vs_oracle(oracle):
+    """Many matrices per launch: the row sweep (gap 0) and the skewed sweep (gap != 0) against the oracle, cell-exact."""
+    from caretta_amd import dynamic_time_warping as dtw
+    rng = np.random.default_rng(11)
+    problems = _explicit_problems(rng)
+    batch = dtw.ExplicitBatch(problems)
+    for gap in (0.0, 0.3):
+        got = batch.smith_waterman_scores(gap)
+        want = np.array([oracle.smith_waterman_score(a, b, s, gap) for a, b, s in problems])
+        assert np.array_equal(got, want), (gap, np.nonzero(got != want)[0])
+    batch.close()
+    # a row stops at the first -1 of seq2 (dynamic_time_warping.py:214-215), also in a batch; an all-(-1) row scores 0
+    s = np.ones((3, 6))
+    cut = [(np.arange(3), np.array([0, 1, 2, -1, 4, 5]), s), (np.arange(3), np.arange(6), s),
+           (np.arange(3), np.array([-1, 1, 2, 3, 4, 5]), s)]
+    assert np.array_equal(dtw.smith_waterman_score_batch(cut), [3.0, 3.0, 0.0])
+    assert np.array_equal(dtw.smith_waterman_score_batch(cut, 0.25), [oracle.smith_waterman_score(*c, 0.25) for c in cut[:2]] + [0.0])
+    # equal to the single-call drop-in
+    one = problems[5]
+    assert dtw.smith_waterman_score_batch([one])[0] == dtw.smith_waterman_score(*one)
+
+
+def test_dtw_align_batch_vs_oracle(oracle):
+    from caretta_amd import dynamic_time_warping as dtw
+    rng = np.random.default_rng(12)
+    problems = _explicit_problems(rng)
+    got = dtw.dtw_align_batch(problems, 1.0, 0.01)
+    for (a, b, s), (a1, a2, score) in zip(problems, got):
+        o1, o2, osc = oracle.dtw_align(a, b, s, 1.0, 0.01)
+        assert np.array_equal(a1, o1) and np.array_equal(a2, o2) and score == osc, (len(a), len(b))
+    batch = dtw.ExplicitBatch(problems[:6])
+    assert np.array_equal(batch.dtw_align(0.5, 0.1, want_alignments=False),
+                          [oracle.dtw_align_score(a, b, s, 0.5, 0.1) for a, b, s in problems[:6]])
+    batch.close()
+    with pytest.raises(ValueError):
+        dtw.dtw_align_batch([(np.arange(3), np.array([0, -1, 2]), np.ones((3, 3)))])
+
+
+def test_plugin_pairwise_matrix_runs_batched(oracle):
+    """A third-party SequenceBase plugin (multiple_alignment.py:109-127): make_pairwise_matrix = the reference's loop of
+    smith_waterman_score over the plugin's own score matrices, computed many matrices per launch."""
+    from caretta_amd import multiple_alignment as ma
+
+    class Letters(ma.SequenceBase):
+        def __init__(self, name, codes):
+            self.name, self.codes = name, np.asarray(codes)
+
+        def score_function(self, other, match=1.0, mismatch=-0.5):
+            return np.where(self.codes[:, None] == other.codes[None, :], match, mismatch)
+
+        def __len__(self):
+            return len(self.codes)
+
+        def __str__(self):
+            return "".join(chr(65 + c) for c in self.codes)
+
+    rng = np.random.default_rng(3)
+    seqs = [Letters(f"s{k}", rng.integers(0, 4, size=int(rng.integers(30, 400)))) for k in range(9)]
+    got = ma.MultipleAlignment(seqs).make_pairwise_matrix({"match": 2.0, "mismatch": -1.0})
+    want = np.zeros((9, 9))
+    for i in range(8):
+        for j in range(i + 1, 9):
+            want[i, j] = want[j, i] = oracle.smith_waterman_score(
+                np.arange(len(seqs[i])), np.arange(len(seqs[j])), seqs[i].score_function(seqs[j], 2.0, -1.0), 0.0)
+    assert np.array_equal(got, want)
+
+
 def test_dp_multistrip_vs_oracle(oracle):
     """n > 320 rows: strips hand their last row over through LDS."""
     from caretta_amd import dynamic_time_warping as dtw
