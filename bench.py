@@ -11,6 +11,15 @@ Workloads (BASELINE.json configs; d=10, seeds 20240+k):
   headline : P = round(128*sqrt(N)) structures x 300 residues, all pairs sharded over N GPUs
              (N=1 is BASELINE config 3: 128 x 300 = 8128 pairs; per-GPU work is fixed -> weak scaling)
   c2       : 32 x 150      c4 : 512 x 300      c5 : 64 x 1200
+
+Besides `value` (device-resident rate, SURVEY.md 8(d) and the driver's contract) the line carries
+  value_incl_transfers : the same pair set INCLUDING the upload of the structures and the download of every result
+                         (alignment rows, transforms, metrics) -- the metric as SURVEY.md 8(d) words it;
+  c4_sharded, c5_sharded : BASELINE configs 4 and 5 timed in the same run, pair set sharded over the N ranks + one
+                         all-gather, with the speed-up against ONE GPU running the whole config (measured on rank 0);
+                         at N=1 also `share_of_8`: one GPU's share of the 8-GPU split run on this GPU;
+  nj_gate              : neighbor-joining bipartitions of the GPU matrix = those of the all-core oracle matrix (N=1);
+  roofline, cpu_baseline : as the contract asks (roofline.frac from SURVEY 8(d)'s algorithmic bytes).
 """
 from __future__ import annotations
 
@@ -29,23 +38,28 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # vector FP64, spec; counts an FMA as 2
+CONFIGS = {"c2": (32, 150, 20241), "c3": (128, 300, 20242), "c4": (512, 300, 20243), "c5": (64, 1200, 20244)}
 
 
 def workload(name: str, n_gpus: int):
     if name == "headline":
         return int(round(128 * math.sqrt(n_gpus))), 300, 20242
-    return {"c2": (32, 150, 20241), "c3": (128, 300, 20242), "c4": (512, 300, 20243), "c5": (64, 1200, 20244)}[name]
+    return CONFIGS[name]
 
 
 def stage_bytes(lengths, pairs, d):
-    """Algorithmic HBM bytes per launch of the two fill kernels."""
+    """Algorithmic HBM bytes per launch of the two fill kernels, SURVEY.md 8(d) / DESIGN.md section 5:
+    k_seed reads the two structures' tensors and writes 2 bits per cell; k_align reads the coordinates and writes 4 bits
+    per cell plus the alignment rows.  `*_readback` adds the traceback's re-read of the decision words and the small
+    per-pair records (the round-1 figure)."""
     n = lengths[pairs[:, 0]].astype(np.float64)
     m = lengths[pairs[:, 1]].astype(np.float64)
-    # k_seed: tensors in, 2-bit decisions out and read back by the traceback, aligned coords, transform out
-    seed = 8.0 * d * (n + m) + 2 * (n * m / 4) + 24.0 * (n + m) + 144
-    # k_align: coords + transform in, 4-bit decisions out and back, alignment rows + results out
-    align = 24.0 * (n + m) + 144 + 2 * (n * m / 2) + 8.0 * (n + m) + 160
-    return float(seed.sum()), float(align.sum())
+    seed = 8.0 * d * (n + m) + n * m / 4
+    align = 24.0 * (n + m) + n * m / 2 + 8.0 * (n + m)
+    seed_rb = seed + n * m / 4 + 24.0 * (n + m) + 144
+    align_rb = align + n * m / 2 + 144 + 160
+    return {"k_seed": float(seed.sum()), "k_align": float(align.sum()),
+            "k_seed_readback": float(seed_rb.sum()), "k_align_readback": float(align_rb.sum())}
 
 
 def cpu_model() -> str:
@@ -58,9 +72,12 @@ def cpu_model() -> str:
     return "unknown"
 
 
-def cpu_baseline(coords, tensors, offsets, pairs, gpu_res, gpu_aln, budget_s=12.0):
+def cpu_baseline(coords, tensors, offsets, pairs, gpu_res, gpu_aln, gpu_matrix, budget_s=12.0):
     """Time the C oracle (reference-shaped CPU restatement) on a bounded sample of the same pairs and
-    use its outputs as the correctness gate for the GPU results."""
+    use its outputs as the correctness gate for the GPU results; then the whole pair set on all cores for the
+    neighbor-joining gate (tree topology of the GPU matrix = tree topology of the CPU matrix)."""
+    from caretta_amd import engine
+    from caretta_amd import neighbor_joining as nj
     from oracle.pyoracle import Oracle
     orc = Oracle()
     rng = np.random.default_rng(0)
@@ -74,10 +91,6 @@ def cpu_baseline(coords, tensors, offsets, pairs, gpu_res, gpu_aln, budget_s=12.
     ref, ref_aln = orc.pairwise_batch(coords, tensors, offsets, pairs[sample], want_aln=True, nthreads=1)
     t1 = time.perf_counter() - t0
     cores = max(1, min(orc.max_threads(), os.cpu_count() or 1))
-    big = np.sort(rng.choice(len(pairs), size=min(len(pairs), count * min(cores, 8)), replace=False))
-    t0 = time.perf_counter()
-    orc.pairwise_batch(coords, tensors, offsets, pairs[big], want_aln=False, nthreads=cores)
-    tall = time.perf_counter() - t0
     # correctness gate: integers exact, floats bit-identical (same FP64 operation order on both sides)
     mism = 0
     for k, p in enumerate(sample):
@@ -85,14 +98,32 @@ def cpu_baseline(coords, tensors, offsets, pairs, gpu_res, gpu_aln, budget_s=12.
         ok = int(gpu_res["aln_len"][p]) == ln and np.array_equal(gpu_aln[p, :, :ln], ref_aln[k, :, :ln])
         ok = ok and all(np.array_equal(gpu_res[key][p], ref[key][k]) for key in ("sw", "dtw_score", "rmsd", "tm", "coverage"))
         mism += 0 if ok else 1
-    return {
+    out = {
         "value": count / t1, "unit": "pairs/s", "cores": 1, "kind": "port",
         "sample": f"{count} of {len(pairs)} pairs (random, seed 0), C oracle -O2 -ffp-contract=off, reference-shaped "
                   f"(dense f64 DP matrices + int64 backtrack per pair), 1 thread as the reference's pair loop",
-        "all_cores": {"value": len(big) / tall, "cores": cores, "pairs": int(len(big))},
         "cpu_model": cpu_model(),
         "parity_mismatches": mism, "parity_checked": int(count),
     }
+    # all cores: the WHOLE pair set when it fits ~40 s of CPU time, else a sample (timing only)
+    est_all = per_pair * len(pairs) / cores
+    whole = est_all <= 40.0
+    big = np.arange(len(pairs)) if whole else np.sort(rng.choice(len(pairs), size=min(len(pairs), count * min(cores, 8)), replace=False))
+    t0 = time.perf_counter()
+    full, _ = orc.pairwise_batch(coords, tensors, offsets, pairs[big], want_aln=False, nthreads=cores)
+    tall = time.perf_counter() - t0
+    out["all_cores"] = {"value": len(big) / tall, "cores": cores, "pairs": int(len(big))}
+    gate = None
+    if whole:
+        num = len(offsets) - 1
+        cpu_matrix = engine.assemble_matrix(pairs, full["sw"], num)
+        t_gpu, _ = nj.neighbor_joining(gpu_matrix.max() - gpu_matrix)            # multiple_alignment.py:501
+        t_cpu, _ = orc.neighbor_joining(cpu_matrix.max() - cpu_matrix)
+        gate = {"taxa": int(num), "bipartitions_equal": bool(nj.bipartitions(t_gpu, num) == nj.bipartitions(t_cpu, num)),
+                "trees_identical": bool(np.array_equal(t_gpu, t_cpu)),
+                "matrix_max_abs_diff": float(np.abs(gpu_matrix - cpu_matrix).max()),
+                "cpu_matrix": f"C oracle, all {len(pairs)} pairs on {cores} threads"}
+    return out, gate
 
 
 def main():
@@ -102,6 +133,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="headline", choices=["headline", "c2", "c3", "c4", "c5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip value_incl_transfers and the c4/c5 sharded timings")
     args = ap.parse_args()
 
     import torch
@@ -134,70 +166,159 @@ def main():
     from caretta_amd import distributed as cdist
     from caretta_amd import engine, synthetic
 
-    num, length, seed = workload(args.workload, args.gpus)
     dim = 10
-    fam = synthetic.make_family(num, length, dim=dim, seed=seed)
-    coords, tensors, offsets = synthetic.pack(fam)
-    lengths = np.diff(offsets)
-    pairs = engine.all_pairs(num)
-    mine = cdist.partition_pairs(pairs, lengths, world, rank)
-    shard = cdist.shard_size(len(pairs), world)
-
+    # the kernels run on torch's current stream (the legacy default stream, handle 0, unless the caller changed it):
+    # the all-gather that follows cr_batch_run is ordered behind the kernels by the stream itself
     stream = torch.cuda.current_stream(dev)
     ctx = engine.Context(local_rank, stream=stream.cuda_stream)
-    batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs[mine])
     params = engine.make_params()
-    local = torch.full((shard,), float("nan"), dtype=torch.float64, device=dev)
-    gathered_flat = torch.empty(world * shard, dtype=torch.float64, device=dev)
-    gathered = gathered_flat.view(world, shard)
-
-    def step():
-        batch.run(params, sw_out_device_ptr=local.data_ptr())
-        if use_dist:
-            dist.all_gather_into_tensor(gathered_flat, local)
 
     def fence():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def max_over_ranks(seconds: float) -> float:
+        if not use_dist:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    class Sharded:
+        """One config's pair set sharded over the ranks: batch on this rank's share + the all-gather buffers."""
+
+        def __init__(self, num, length, seed, ranks=world, me=rank, stride=None):
+            self.num, self.length, self.seed = num, length, seed
+            fam = synthetic.make_family(num, length, dim=dim, seed=seed)
+            self.coords, self.tensors, self.offsets = synthetic.pack(fam)
+            self.lengths = np.diff(self.offsets)
+            self.pairs = engine.all_pairs(num)
+            self.mine = cdist.partition_pairs(self.pairs, self.lengths, ranks, me) if stride is None else np.arange(len(self.pairs))[::stride]
+            self.shard = cdist.shard_size(len(self.pairs), ranks)
+            self.gather = use_dist and ranks == world and stride is None
+            self.batch = engine.PairBatch(ctx, self.coords, self.tensors, self.offsets).set_pairs(self.pairs[self.mine])
+            self.local = torch.full((max(self.shard, len(self.mine)),), float("nan"), dtype=torch.float64, device=dev)
+            self.gathered_flat = torch.empty(world * self.local.numel(), dtype=torch.float64, device=dev) if self.gather else None
+
+        def step(self):
+            self.batch.run(params, sw_out_device_ptr=self.local.data_ptr())
+            if self.gather:
+                dist.all_gather_into_tensor(self.gathered_flat, self.local)
+
+        def time(self, steps, warmup, collective=True):
+            """seconds per step: `warmup` untimed steps, then `steps` timed ones between fences, max over ranks."""
+            for _ in range(warmup):
+                self.step()
+            fence() if collective else torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            fence() if collective else torch.cuda.synchronize(dev)
+            el = time.perf_counter() - t0
+            return (max_over_ranks(el) if collective else el) / steps
+
+        def close(self):
+            self.batch.close()
+
+    # ------------------------------------------------------------------ the headline, timed as the contract says
+    num, length, seed = workload(args.workload, args.gpus)
+    head = Sharded(num, length, seed)
     for _ in range(args.warmup):
-        step()
+        head.step()
     fence()
     ctx.set_profiling(min(args.steps, 4096))
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        head.step()
     fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    stage_ms, runs = batch.stage_ms()
-    if not use_dist:
-        gathered.copy_(local.unsqueeze(0))
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    stage_ms, runs = head.batch.stage_ms()
+    ctx.set_profiling(0)
+    gathered = head.gathered_flat.view(world, -1) if head.gather else head.local.unsqueeze(0)
+    res, aln = head.batch.fetch(want_alignments=(rank == 0))
+    matrix = cdist.scatter_to_matrix(gathered.cpu().numpy(), head.pairs, head.lengths, num)
+    pairs, lengths, mine = head.pairs, head.lengths, head.mine
+    coords, tensors, offsets = head.coords, head.tensors, head.offsets
 
-    res, aln = batch.fetch(want_alignments=(rank == 0))
-    matrix = cdist.scatter_to_matrix(gathered.cpu().numpy(), pairs, lengths, num)
+    extras = {}
+    if not args.no_extras:
+        # ---------------------------------------------------------- the same pair set including the PCIe transfers
+        # per step: upload the structures (cr_batch_create), the pair list (cr_batch_set_pairs), run, download EVERY
+        # result -- alignment rows (int32, page-locked arrays kept by the batch), transforms, metrics
+        my_pairs = pairs[mine]
+        pinned = None
+        t_parts = np.zeros(3)
+        reps = max(3, min(args.steps, 10))
+        for it in range(reps + 2):
+            fence()
+            t0 = time.perf_counter()
+            b2 = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(my_pairs)
+            if pinned is not None:
+                b2._pinned_cache = pinned              # result arrays allocated once, as a pipeline would
+            t1 = time.perf_counter()
+            b2.run(params)
+            ctx.synchronize()
+            t2 = time.perf_counter()
+            r2, a2 = b2.fetch(want_alignments=True, pinned=True)
+            t3 = time.perf_counter()
+            pinned = b2._pinned_cache
+            b2.close()
+            if it >= 2:
+                t_parts += (t1 - t0, t2 - t1, t3 - t2)
+        t_parts /= reps
+        t_incl = max_over_ranks(float(t_parts.sum()))
+        if rank == 0:
+            extras["value_incl_transfers"] = len(pairs) / t_incl
+            extras["incl_transfers"] = {
+                "ms_per_step": t_incl * 1e3, "upload_ms": t_parts[0] * 1e3, "run_ms": t_parts[1] * 1e3, "download_ms": t_parts[2] * 1e3,
+                "ratio_to_resident": t_incl / (elapsed / args.steps),
+                "downloaded_bytes_per_rank": int(r2.nbytes + a2.nbytes), "uploaded_bytes_per_rank": int(coords.nbytes + tensors.nbytes + my_pairs.nbytes),
+                "note": "per step: cr_batch_create + cr_batch_set_pairs (H2D of structures and pair list), cr_batch_run, "
+                        "cr_batch_fetch_i32 of all alignment rows + PairResult records into page-locked arrays"}
+        # ---------------------------------------------------------- BASELINE configs 4 and 5, sharded over the ranks
+        for key in ("c4", "c5"):
+            n_c, l_c, s_c = CONFIGS[key]
+            sh = Sharded(n_c, l_c, s_c)
+            t_sh = sh.time(5, 2)
+            sh.close()
+            t_one = None
+            if world > 1:
+                if rank == 0:                           # the whole config on ONE GPU, for the speed-up
+                    one = Sharded(n_c, l_c, s_c, ranks=1, me=0)
+                    t_one = one.time(5, 2, collective=False)
+                    one.close()
+                fence()
+            rec = {"n_gpus": world, "structures": n_c, "residues": l_c, "pairs": n_c * (n_c - 1) // 2,
+                   "ms": t_sh * 1e3, "pairs_per_s": n_c * (n_c - 1) / 2 / t_sh,
+                   "ms_1gpu": (t_one if t_one is not None else t_sh) * 1e3,
+                   "speedup_vs_1gpu": (t_one / t_sh) if t_one is not None else 1.0}
+            if world == 1:
+                # one GPU's share of the 8-GPU split (every 8th pair), run here: what 8 GPUs would each do, before the
+                # (latency-bound, ~1 MB) all-gather
+                part = Sharded(n_c, l_c, s_c, ranks=1, me=0, stride=8)
+                t_part = part.time(10, 3, collective=False)
+                rec["share_of_8"] = {"pairs": int(len(part.mine)), "ms": t_part * 1e3, "projected_speedup_8gpu": t_sh / t_part}
+                part.close()
+            extras[f"{key}_sharded"] = rec
 
     if rank == 0:
         total_pairs = len(pairs)
         ms_per_step = elapsed / args.steps * 1e3
-        seed_b, align_b = stage_bytes(lengths, pairs[mine], dim)
+        sb = stage_bytes(lengths, pairs[mine], dim)
         dom = 1 if stage_ms[1] >= stage_ms[0] else 0
         dom_name = "k_align" if dom == 1 else "k_seed"
-        dom_bytes = align_b if dom == 1 else seed_b
+        dom_bytes = sb[dom_name]
         achieved = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9
+        achieved_rb = sb[dom_name + "_readback"] / (stage_ms[dom] * 1e-3) / 1e9
         cells_rank = float((lengths[pairs[mine][:, 0]] * lengths[pairs[mine][:, 1]]).sum())
         traffic = None
         tfile = ROOT / "profiles" / "pmc_traffic.json"
         if tfile.exists():
             try:
                 rec = json.loads(tfile.read_text())
-                key = f"{args.workload}:{args.gpus}:{dom_name}"
-                traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
+                traffic = rec.get(f"{args.workload}:{args.gpus}:{dom_name}", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -214,8 +335,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": stage_ms[dom],
-                         "note": "fused RBF+DP is FP64-VALU/dependency bound, not HBM bound (DESIGN.md); "
-                                 "cells/s and the VALU estimate are in dtw_mcells_per_s / valu_f64"},
+                         "frac_with_readback": achieved_rb / HBM_PEAK_GBS,
+                         "algorithmic_bytes_with_readback": sb[dom_name + "_readback"],
+                         "note": "SURVEY 8(d) bytes: features in + packed decisions out.  The fused RBF+DP kernels are bound by "
+                                 "FP64-rate VALU issue, not HBM (DESIGN.md section 5; valu_f64 below); the HBM-bound kernel of the "
+                                 "path is the batched explicit-matrix row sweep (profiles/r02/explicit_batch_rate.txt)"},
             "valu_f64": {"est_flop_per_cell": {"seed_fill": 59, "align_fill": 49},
                          "achieved_tflops": (59 + 49) * cells_rank / ((stage_ms[0] + stage_ms[1]) * 1e-3) / 1e12,
                          "peak_tflops": FP64_VALU_PEAK_TFLOPS},
@@ -224,19 +348,26 @@ def main():
         # cycles in which a SIMD issues a VALU instruction = SQ_INSTS_VALU / 1024 SIMDs x 4 cycles / (GRBM_GUI_ACTIVE / 8 XCDs)
         try:
             if args.workload == "headline" and args.gpus == 1:
-                pmc = json.load(open(ROOT / "profiles" / "r01" / "pmc_summary.json"))
-                out["valu_f64"]["issue_frac_pmc"] = {
-                    ("k_seed" if "k_seed" in k else "k_align"): round(v["SQ_INSTS_VALU"] / 1024 * 4 / (v["GRBM_GUI_ACTIVE"] / 8), 4)
-                    for k, v in pmc.items() if "SQ_INSTS_VALU" in v and "GRBM_GUI_ACTIVE" in v}
+                for rnd in ("r02", "r01"):
+                    f = ROOT / "profiles" / rnd / "pmc_summary.json"
+                    if f.exists():
+                        pmc = json.load(open(f))
+                        out["valu_f64"]["issue_frac_pmc"] = {
+                            ("k_seed" if "k_seed" in k else "k_align"): round(v["SQ_INSTS_VALU"] / 1024 * 4 / (v["GRBM_GUI_ACTIVE"] / 8), 4)
+                            for k, v in pmc.items() if "SQ_INSTS_VALU" in v and "GRBM_GUI_ACTIVE" in v}
+                        out["valu_f64"]["issue_frac_pmc"]["source"] = f"profiles/{rnd}/pmc_summary.json"
+                        break
         except (OSError, ValueError, KeyError):
             pass
+        out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(coords, tensors, offsets, pairs, res, aln)
+            out["cpu_baseline"], out["nj_gate"] = cpu_baseline(coords, tensors, offsets, pairs, res, aln, matrix)
             out["speedup_vs_cpu_1thread"] = out["value"] / out["cpu_baseline"]["value"]
         else:
             out["cpu_baseline"] = None
         out["matrix_checksum"] = float(matrix.sum())
         print(json.dumps(out))
+    head.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -53,6 +53,9 @@ SIGNATURES = {
     "cr_batch_set_pairs": [_vp, _vp, _i64],
     "cr_batch_run": [_vp, C.POINTER(Params), _vp],
     "cr_batch_fetch": [_vp, _vp, _vp, _i64],
+    "cr_batch_fetch_i32": [_vp, _vp, _vp, _i64],
+    "cr_host_alloc": [C.c_size_t, _pp],
+    "cr_host_free": [_vp],
     "cr_batch_fetch_scores": [_vp, _vp, _vp],
     "cr_batch_max_aln_len": [_vp, C.POINTER(C.c_int64)],
     "cr_batch_stage_ms": [_vp, C.POINTER(C.c_float * CR_NUM_STAGES), C.POINTER(C.c_int)],

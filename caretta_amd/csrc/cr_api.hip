@@ -255,6 +255,8 @@ struct cr_batch {
     DevBuf<double> seed_score;
     hipStream_t launch_stream = nullptr;  // stream of the next launch_seed / launch_align (null: the context's)
     DevBuf<double> sw_stage;            // cr_batch_fetch_scores: the sw field gathered on the device
+    DevBuf<cr::PairResult> res_packed;  // cr_batch_fetch*: results / alignment rows in the caller's order and layout
+    DevBuf<int64_t> aln_packed;
     DevBuf<cr::PairResult> res;
     int64_t aln_elems = 0;
     double alg_bytes = 0.0, cells = 0.0;
@@ -509,6 +511,44 @@ int padded_width(int64_t d) {
 }
 
 }  // namespace
+
+// Shared body of the two fetch entry points: pack on the device (caller's order and layout), then plain copies
+// straight into the caller's arrays -- DMA speed when those are page-locked (cr_host_alloc), staged by the driver
+// otherwise.
+template <class T>
+int fetch_packed(cr_batch* b, cr_pair_result* results, T* aln, int64_t aln_stride) {
+    CR_REQUIRE(b != nullptr, "null batch");
+    if (!b->ran) return fail(CR_ERR_STATE, "cr_batch_fetch before cr_batch_run");
+    int rc = set_device(b->ctx);
+    if (rc) return rc;
+    hipStream_t st = b->ctx->stream;
+    if (b->npairs == 0) {
+        CR_HIP(hipStreamSynchronize(st));
+        return CR_OK;
+    }
+    if (aln) CR_REQUIRE(aln_stride >= b->max_aln, "aln_stride smaller than the longest possible alignment");
+    if (!results && !aln) {
+        CR_HIP(hipStreamSynchronize(st));
+        return CR_OK;
+    }
+    const size_t np = (size_t)b->npairs;
+    const size_t aln_bytes = aln ? np * 2 * (size_t)aln_stride * sizeof(T) : 0;
+    const bool permute = b->reordered;
+    if (results && permute) CR_HIP(b->res_packed.ensure(np));
+    if (aln) CR_HIP(b->aln_packed.ensure((aln_bytes + 7) / 8));
+    if (aln || (results && permute)) {
+        CR_LAUNCH(cr::k_pack_results<T>, dim3((unsigned)np), dim3(cr::kWave), 0, st, b->pairs.p, b->res.p,
+                  permute ? b->d_order.p : (const int32_t*)nullptr, b->aln.p, aln_stride,
+                  (results && permute) ? b->res_packed.p : (cr::PairResult*)nullptr,
+                  aln ? reinterpret_cast<T*>(b->aln_packed.p) : (T*)nullptr);
+        CR_HIP(hipGetLastError());
+    }
+    if (results)
+        CR_HIP(hipMemcpyAsync(results, permute ? b->res_packed.p : b->res.p, sizeof(cr_pair_result) * np, hipMemcpyDeviceToHost, st));
+    if (aln) CR_HIP(hipMemcpyAsync(aln, b->aln_packed.p, aln_bytes, hipMemcpyDeviceToHost, st));
+    CR_HIP(hipStreamSynchronize(st));
+    return CR_OK;
+}
 
 extern "C" {
 
@@ -948,41 +988,22 @@ int cr_batch_max_aln_len(cr_batch* b, int64_t* out) {
 }
 
 int cr_batch_fetch(cr_batch* b, cr_pair_result* results, int64_t* aln, int64_t aln_stride) {
-    CR_REQUIRE(b != nullptr, "null batch");
-    if (!b->ran) return fail(CR_ERR_STATE, "cr_batch_fetch before cr_batch_run");
-    int rc = set_device(b->ctx);
-    if (rc) return rc;
-    CR_HIP(hipStreamSynchronize(b->ctx->stream));
-    if (b->npairs == 0) return CR_OK;
-    // `res` is in launch order; the caller's arrays are in the order of its pair list
-    std::vector<cr_pair_result> local;
-    cr_pair_result* res = results;
-    if ((!res && aln) || (res && b->reordered)) {
-        local.resize((size_t)b->npairs);
-        res = local.data();
-    }
-    if (res) CR_HIP(hipMemcpy(res, b->res.p, sizeof(cr_pair_result) * (size_t)b->npairs, hipMemcpyDeviceToHost));
-    if (results && b->reordered)
-        for (int64_t k = 0; k < b->npairs; k++) results[b->order[(size_t)k]] = res[k];
-    if (aln) {
-        CR_REQUIRE(aln_stride >= b->max_aln, "aln_stride smaller than the longest possible alignment");
-        std::vector<int32_t> h((size_t)b->aln_elems);
-        CR_HIP(hipMemcpy(h.data(), b->aln.p, sizeof(int32_t) * (size_t)b->aln_elems, hipMemcpyDeviceToHost));
-        for (int64_t p = 0; p < b->npairs; p++) {
-            const cr::PairDesc& pd = b->h_pairs[(size_t)p];
-            const int cap = pd.n + pd.m;
-            const int32_t* a1 = h.data() + pd.aln_off + res[p].aln_start;
-            const int32_t* a2 = a1 + cap;
-            int64_t* o1 = aln + (size_t)b->order[(size_t)p] * 2 * (size_t)aln_stride;
-            int64_t* o2 = o1 + aln_stride;
-            const int len = res[p].aln_len;
-            for (int x = 0; x < len; x++) {
-                o1[x] = a1[x];
-                o2[x] = a2[x];
-            }
-            for (int64_t x = len; x < aln_stride; x++) o1[x] = o2[x] = -2;
-        }
-    }
+    return fetch_packed<int64_t>(b, results, aln, aln_stride);
+}
+
+int cr_batch_fetch_i32(cr_batch* b, cr_pair_result* results, int32_t* aln, int64_t aln_stride) {
+    return fetch_packed<int32_t>(b, results, aln, aln_stride);
+}
+
+int cr_host_alloc(size_t bytes, void** out) {
+    CR_REQUIRE(out != nullptr, "null out");
+    *out = nullptr;
+    CR_HIP(hipHostMalloc(out, std::max<size_t>(bytes, 1), hipHostMallocDefault));
+    return CR_OK;
+}
+
+int cr_host_free(void* p) {
+    if (p) CR_HIP(hipHostFree(p));
     return CR_OK;
 }
 

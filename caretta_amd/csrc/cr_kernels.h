@@ -2090,6 +2090,34 @@ __global__ __launch_bounds__(kTeamWaves* kWave) void k_node_team(const PairDesc*
                         max_entries, bits_base, hand_base, aln_base, Xn_base, Tn_base, Wn_base, outs);
 }
 
+// Results of a batch in the CALLER's pair order and the caller's layout, produced on the device so that the host side
+// of cr_batch_fetch is two plain copies: out_res[order[k]] = res[k]; out_aln[order[k]][0..1][0..stride) = the two
+// alignment rows of launch slot k, left-aligned, padded with -2 (the rows sit back-to-front in `aln`, PairResult has
+// their start and length).  One wave per pair.  T = int32_t or int64_t; order == nullptr: identity.
+template <class T>
+__global__ __launch_bounds__(kWave) void k_pack_results(const PairDesc* __restrict__ pairs,
+                                                       const PairResult* __restrict__ res,
+                                                       const int32_t* __restrict__ order,
+                                                       const int32_t* __restrict__ aln, int64_t stride,
+                                                       PairResult* __restrict__ out_res, T* __restrict__ out_aln) {
+    const int k = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int dst = order ? order[k] : k;
+    const PairDesc pd = pairs[k];
+    const PairResult r = res[k];
+    if (out_res && lane == 0) out_res[dst] = r;
+    if (!out_aln) return;
+    const int cap = pd.n + pd.m;
+    const int32_t* a1 = aln + pd.aln_off + r.aln_start;
+    const int32_t* a2 = a1 + cap;
+    T* o1 = out_aln + (int64_t)dst * 2 * stride;
+    T* o2 = o1 + stride;
+    for (int64_t x = lane; x < stride; x += kWave) {
+        o1[x] = x < r.aln_len ? (T)a1[x] : (T)-2;
+        o2[x] = x < r.aln_len ? (T)a2[x] : (T)-2;
+    }
+}
+
 // out[order[k]] = res[k].sw: the scores of a batch whose launch order differs from the caller's pair order
 template <class Dummy = void>
 __global__ void k_scatter_sw_t(const PairResult* __restrict__ res, const int32_t* __restrict__ order,

@@ -78,6 +78,34 @@ def default_context(device: int = 0) -> Context:
     return _default_ctx[device]
 
 
+class _PinnedBlock:
+    """Owner of one cr_host_alloc block (freed when the last array built on it is gone)."""
+
+    def __init__(self, nbytes: int):
+        self._lib = _capi.load()
+        self.ptr = C.c_void_p()
+        check(self._lib.cr_host_alloc(max(int(nbytes), 1), C.byref(self.ptr)))
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self._lib.cr_host_free(self.ptr)
+                self.ptr = C.c_void_p()
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype) -> np.ndarray:
+    """numpy array in page-locked host memory (device copies into it run at DMA speed)."""
+    dtype = np.dtype(dtype)
+    count = int(np.prod(shape))
+    nbytes = max(count * dtype.itemsize, 1)
+    block = _PinnedBlock(nbytes)
+    buf = (C.c_char * nbytes).from_address(block.ptr.value)
+    buf._owner = block           # the array's base chain holds `buf`, `buf` holds the block
+    return np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
+
+
 def all_pairs(num: int) -> np.ndarray:
     """(i, j), i < j in the row-major order of multiple_alignment.py:162-163."""
     i, j = np.triu_indices(num, k=1)
@@ -111,19 +139,36 @@ class PairBatch:
         check(self._lib.cr_batch_run(self._h, C.byref(params),
                                      C.c_void_p(sw_out_device_ptr) if sw_out_device_ptr else None))
 
-    def fetch(self, want_alignments: bool = True):
-        """-> (structured array of per-pair results, aln int64 [npairs, 2, stride] or None)."""
+    def fetch(self, want_alignments: bool = True, pinned: bool = False):
+        """-> (structured array of per-pair results, aln [npairs, 2, stride] or None).
+
+        Default: fresh numpy arrays, int64 rows as the reference's.  ``pinned=True``: int32 rows in page-locked arrays that
+        this batch keeps and REUSES for the next fetch (DMA-speed copies; copy what has to outlive the next fetch)."""
         n = len(self.pairs)
-        res = np.zeros(n, dtype=_capi.PAIR_RESULT_DTYPE)
-        aln = None
         stride = 0
         if want_alignments:
             mx = C.c_int64(0)
             check(self._lib.cr_batch_max_aln_len(self._h, C.byref(mx)))
             stride = max(int(mx.value), 1)
-            aln = np.empty((n, 2, stride), dtype=np.int64)
+        if pinned:
+            res = self._pinned("res", (n,), _capi.PAIR_RESULT_DTYPE)
+            aln = self._pinned("aln", (n, 2, stride), np.int32) if want_alignments else None
+            check(self._lib.cr_batch_fetch_i32(self._h, ptr(res), ptr(aln) if aln is not None else None, stride))
+            return res, aln
+        res = np.zeros(n, dtype=_capi.PAIR_RESULT_DTYPE)
+        aln = np.empty((n, 2, stride), dtype=np.int64) if want_alignments else None
         check(self._lib.cr_batch_fetch(self._h, ptr(res), ptr(aln) if aln is not None else None, stride))
         return res, aln
+
+    def _pinned(self, key, shape, dtype):
+        """A page-locked numpy array kept by this batch (allocated once per shape)."""
+        cache = self.__dict__.setdefault("_pinned_cache", {})
+        have = cache.get(key)
+        if have is not None and have.shape == tuple(shape) and have.dtype == np.dtype(dtype):
+            return have
+        arr = pinned_empty(shape, dtype)
+        cache[key] = arr
+        return arr
 
     def fetch_scores(self):
         """-> (sw f64[npairs], flags u32[npairs]): the P x P matrix entries only (8 + 4 bytes per pair)."""

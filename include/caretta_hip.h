@@ -111,6 +111,12 @@ int cr_batch_run(cr_batch *b, const cr_params *params, double *d_sw_out);
 /* Synchronise and copy results to host.  Any pointer may be NULL.  results[npairs];
  * aln i64[npairs, 2, aln_stride] (rows padded with -2 after aln_len; aln_stride >= max(n+m)). */
 int cr_batch_fetch(cr_batch *b, cr_pair_result *results, int64_t *aln, int64_t aln_stride);
+/* The same with int32 alignment rows (half the bytes over PCIe).  Both variants lay the rows out on the device and
+ * copy straight into the caller's arrays: at DMA speed when those are page-locked (cr_host_alloc below). */
+int cr_batch_fetch_i32(cr_batch *b, cr_pair_result *results, int32_t *aln, int64_t aln_stride);
+/* page-locked host memory for result arrays */
+int cr_host_alloc(size_t bytes, void **out);
+int cr_host_free(void *p);
 /* Only what make_pairwise_matrix needs (multiple_alignment.py:158-170): sw f64[npairs] = the smith_waterman_score of
  * every pair, flags u32[npairs].  Either pointer may be NULL. */
 int cr_batch_fetch_scores(cr_batch *b, double *sw, uint32_t *flags);
