@@ -1,14 +1,26 @@
+#!/bin/bash
+# Regenerate the measured files of profiles/<round> on the GPU box:  gpurun -- 'bash tools/refresh_profiles.sh r02'
+# (writes under gpurun_out/<round>/; copy what is to be judged into profiles/<round>/).
+R=${1:-r02}
 set -x
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r01b
-python bench.py --steps 20 > gpurun_out/r01b/bench_headline_n1.json 2> gpurun_out/r01b/bench_headline.log
-tail -c 600 gpurun_out/r01b/bench_headline_n1.json
-for w in c2 c4 c5; do python bench.py --workload $w --steps 5 --no-cpu-baseline 2>/dev/null > gpurun_out/r01b/bench_$w.json; done
+O=gpurun_out/$R
+mkdir -p $O
+python bench.py --steps 20 > $O/bench_headline_n1.json 2> $O/bench_headline.log
+tail -c 400 $O/bench_headline_n1.json
+for w in c2 c4 c5; do python bench.py --workload $w --steps 5 --no-cpu-baseline --no-extras 2>/dev/null > $O/bench_$w.json; done
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r01b/ktrace -o kt -- python3 bench.py --no-cpu-baseline --steps 20 > gpurun_out/r01b/ktrace.log 2>&1
-ls gpurun_out/r01b/ktrace
-bash tools/pmc_profile.sh r01b_pmc
-python tools/bench_msa.py 128 300 > gpurun_out/r01b/msa_128.txt 2>&1
-python tools/bench_msa.py 512 300 > gpurun_out/r01b/msa_512.txt 2>&1
-python tools/host_overheads.py 128 300 > gpurun_out/r01b/host_128.txt 2>&1
-tail -n 2 gpurun_out/r01b/msa_128.txt gpurun_out/r01b/msa_512.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace -o kt -- python3 bench.py --no-cpu-baseline --no-extras --steps 20 > $O/ktrace.log 2>&1
+ls $O/ktrace
+bash tools/pmc_profile.sh ${R}_pmc --steps 3 --warmup 1 --no-cpu-baseline --no-extras
+python tools/bench_msa.py 128 300 > $O/msa_128.txt 2>&1
+python tools/bench_msa.py 512 300 > $O/msa_512.txt 2>&1
+python tools/config5_share_time.py > $O/config5_share.txt 2>&1
+python tools/dropin_latency.py > $O/dropin_latency.txt 2>&1
+python tools/explicit_batch_rate.py > $O/explicit_batch_rate.txt 2>&1
+# HBM counters of the batched explicit-matrix row sweep (separate --pmc passes, --kernel-trace only)
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/explicit_$C -- python3 tools/explicit_batch_rate.py 8128 300 > $O/explicit_$C.log 2>&1
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/explicit_ktrace -o kt -- python3 tools/explicit_batch_rate.py 8128 300 > $O/explicit_ktrace.log 2>&1
+tail -n 2 $O/msa_128.txt $O/msa_512.txt $O/config5_share.txt $O/explicit_batch_rate.txt
