@@ -349,6 +349,68 @@ def gen_tree(rng):
     save("f3_tree.npz", out)
 
 
+def gen_tree64():
+    """Pairwise matrix and neighbor-joining tree of a 64-structure family, by the reference's own
+    make_pairwise_matrix (multiple_alignment.py:158-170) and neighbor_joining (neighbor_joining.py:19-157)."""
+    out = {}
+    fam = synthetic.make_family(64, 48, seed=20238, ragged=True, clades=6)
+    store_family(out, "famT64", fam)
+    msa = multiple_alignment.MultipleAlignment(to_proteins(fam))
+    m = msa.make_pairwise_matrix(score_function_params=dict(SF_PARAMS, verbose=False))
+    d = m.max() - m
+    tree, bl = neighbor_joining.neighbor_joining(d.copy())
+    out["famT64_M"], out["famT64_D"] = m, d
+    out["famT64_tree"], out["famT64_branch_lengths"] = tree, bl
+    save("f3_tree64.npz", out)
+
+
+def gen_formats(rng):
+    """The text the reference's writers produce (helper.write_distance_matrix, helper.py:183-202;
+    MultipleAlignment.write_alignment, multiple_alignment.py:299-309; to_sequence_alignment :287-297) and what its
+    reader returns (helper.read_distance_matrix, :205-229), for fixed inputs."""
+    import tempfile
+    out = {}
+    names = ["1kdu", "1pk4/A", "kringle_domain_3", "x"]
+    d = rng.uniform(0.0, 25.0, size=(4, 4))
+    d = (d + d.T) / 2
+    np.fill_diagonal(d, 0.0)
+    d[0, 1] = d[1, 0] = 1234567.891234          # wide numbers, rounding at the 4th decimal
+    d[2, 3] = d[3, 2] = 0.00005
+    d[1, 3] = d[3, 1] = 2.00005
+    with tempfile.TemporaryDirectory() as tmp:
+        path = Path(tmp) / "matrix.mat"
+        helper.write_distance_matrix(names, d, path)
+        out["matrix_text"] = np.frombuffer(path.read_bytes(), dtype=np.uint8)
+        back_names, back = helper.read_distance_matrix(path)
+        out["matrix_names"], out["matrix_D"] = np.array(names), d
+        out["matrix_read_names"], out["matrix_read_D"] = np.array(back_names), back
+        fam = synthetic.make_family(5, 30, seed=20239, ragged=True, clades=2)
+        letters = np.array(list("ACDEFGHIKLMNPQRSTVWY"))
+        fam = [synthetic.Structure(s.name, s.tensors, s.coordinates, "".join(rng.choice(letters, size=len(s.sequence))))
+               for s in fam]
+        store_family(out, "fasta_fam", fam)
+        out["fasta_names"] = np.array([s.name for s in fam])
+        out["fasta_sequences"] = np.array([s.sequence for s in fam])
+        msa = multiple_alignment.MultipleAlignment(to_proteins(fam))
+        # a hand-made alignment (gaps at both ends and inside), independent of any DP
+        width = max(len(s.sequence) for s in fam) + 4
+        aln = {}
+        for k, s in enumerate(fam):
+            row = np.full(width, -1, dtype=np.int64)
+            start = k % 3
+            idx = np.arange(len(s.sequence))
+            cols = start + idx + (idx > len(s.sequence) // 2)      # one internal gap
+            row[cols] = idx
+            aln[s.name] = row
+        out["fasta_alignment"] = np.array([aln[s.name] for s in fam])
+        fasta = Path(tmp) / "aln.fasta"
+        msa.write_alignment(fasta, aln)
+        out["fasta_text"] = np.frombuffer(fasta.read_bytes(), dtype=np.uint8)
+        seq_aln = msa.to_sequence_alignment(aln)
+        out["fasta_rows"] = np.array([seq_aln[s.name] for s in fam])
+    save("f7_formats.npz", out)
+
+
 # --------------------------------------------------------------------------- F4: progressive alignment internals
 def gen_progressive():
     """Every intermediate node of progressive_align (multiple_alignment.py:172-253) for two small families:
@@ -467,6 +529,8 @@ def main():
               ("pipeline", gen_pipeline),
               ("long", gen_pipeline_long),
               ("tree", lambda: gen_tree(np.random.default_rng(20224))),
+              ("tree64", gen_tree64),
+              ("formats", lambda: gen_formats(np.random.default_rng(20222))),
               ("progressive", gen_progressive),
               ("c1", gen_c1_inputs),
               ("postmsa", gen_post_msa),

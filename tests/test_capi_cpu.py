@@ -192,3 +192,34 @@ def test_make_score_matrix_applies_a_plugin_score_function_on_the_host():
     assert got.shape == (3, 4) and np.array_equal(got, want)
     with pytest.raises(TypeError):
         sf.make_score_matrix(a, b, "not callable", 0.5)
+
+
+def test_formats_match_the_reference_writers(tmp_path):
+    """tests/golden/f7_formats.npz holds the text the reference's own writers produced (helper.write_distance_matrix,
+    helper.py:183-202; MultipleAlignment.write_alignment / to_sequence_alignment, multiple_alignment.py:287-309) and what
+    its reader returned (helper.read_distance_matrix, :205-229): the product's writers byte for byte, its reader value
+    for value."""
+    from caretta_amd import helper
+    from caretta_amd import multiple_alignment as ma
+    g = np.load(Path(__file__).resolve().parent / "golden" / "f7_formats.npz", allow_pickle=False)
+    names = [str(x) for x in g["matrix_names"]]
+    path = tmp_path / "matrix.mat"
+    helper.write_distance_matrix(names, g["matrix_D"], path)
+    assert path.read_bytes() == bytes(g["matrix_text"])
+    back_names, back = helper.read_distance_matrix(path)
+    assert back_names == [str(x) for x in g["matrix_read_names"]]
+    assert np.array_equal(back, g["matrix_read_D"])
+    offsets, coords, tensors = g["fasta_fam_offsets"], g["fasta_fam_coords"], g["fasta_fam_tensors"]
+    prots = [ma.Protein(str(name), tensors[offsets[k]:offsets[k + 1]], coords[offsets[k]:offsets[k + 1]], str(seq))
+             for k, (name, seq) in enumerate(zip(g["fasta_names"], g["fasta_sequences"]))]
+    msa = ma.MultipleAlignment(prots)
+    aln = {p.name: g["fasta_alignment"][k] for k, p in enumerate(prots)}
+    fasta = tmp_path / "aln.fasta"
+    msa.write_alignment(fasta, aln)
+    assert fasta.read_bytes() == bytes(g["fasta_text"])
+    rows = msa.to_sequence_alignment(aln)
+    assert [rows[p.name] for p in prots] == [str(x) for x in g["fasta_rows"]]
+    # and back: gapped sequences -> index rows
+    again = ma.alignment_to_numpy(rows)
+    for k, p in enumerate(prots):
+        assert np.array_equal(again[p.name], g["fasta_alignment"][k])

@@ -464,6 +464,70 @@ def test_guide_tree_from_gpu_matrix(ctx, oracle, golden):
         assert np.array_equal(tree, otree) and np.array_equal(bl, obl)
 
 
+def test_guide_tree_64_from_gpu_matrix(oracle, golden):
+    """The 64-structure family of f3_tree64.npz (matrix and tree by the reference's own make_pairwise_matrix and
+    neighbor_joining): GPU matrix to 1e-9, identical bipartitions, tree identical to the oracle's."""
+    from caretta_amd import multiple_alignment as ma, neighbor_joining as nj
+    g = golden("f3_tree64.npz")
+    coords, tensors, offsets = g["famT64_coords"], g["famT64_tensors"], g["famT64_offsets"]
+    p = len(offsets) - 1
+    prots = [ma.Protein(f"s{i}", tensors[offsets[i]:offsets[i + 1]], coords[offsets[i]:offsets[i + 1]], "") for i in range(p)]
+    m = ma.MultipleAlignment(prots).make_pairwise_matrix(dict(flexible=False, gamma_tensor=7.0, gamma_coords=0.03))
+    np.testing.assert_allclose(m, g["famT64_M"], rtol=1e-9)
+    tree, bl = nj.neighbor_joining(m.max() - m)
+    assert nj.bipartitions(tree, p) == nj.bipartitions(g["famT64_tree"], p)
+    otree, obl = oracle.neighbor_joining(m.max() - m)
+    assert np.array_equal(tree, otree) and np.array_equal(bl, obl)
+
+
+def _count_integer_differences(res, aln, ref, ref_aln):
+    """Pairs whose INTEGER outputs differ (alignment rows, lengths, seed length, flags), and the largest relative
+    difference of the float outputs."""
+    bad = 0
+    for p in range(len(res)):
+        ln = int(ref["aln_len"][p])
+        same = (int(res["aln_len"][p]) == ln and int(res["seed_len"][p]) == int(ref["seed_len"][p])
+                and int(res["flags"][p]) == int(ref["flags"][p]) and np.array_equal(aln[p, :, :ln], ref_aln[p, :, :ln]))
+        bad += 0 if same else 1
+    rel = 0.0
+    for key in ("sw", "dtw_score", "rmsd", "tm", "coverage"):
+        denom = np.maximum(np.abs(ref[key]), 1e-300)
+        rel = max(rel, float(np.max(np.abs(res[key] - ref[key]) / denom)))
+    return bad, rel
+
+
+def test_libm_exp_path_at_scale(ctx, oracle_libm):
+    """The reference's numba path calls libm's exp; the kernels their own (<= 1 ulp apart on < 2 % of arguments,
+    test_exp_accuracy).  At BASELINE sizes -- config 2 (all 496 pairs), a sample of config 3 and of config 5 -- the GPU
+    against the libm-exp oracle: ZERO pairs with a differing traceback / seed index, floats within 1e-9 (north star:
+    bit-exact indices, RMSD / TM within 1e-5), and the same neighbor-joining bipartitions at P = 32 and P = 128."""
+    from caretta_amd import engine, neighbor_joining as nj
+    for num, length, seed, stride in ((32, 150, 20241, 1), (128, 300, 20242, 41), (64, 1200, 20244, 168)):
+        fam = synthetic.make_family(num, length, seed=seed)
+        coords, tensors, offsets = synthetic.pack(fam)
+        pairs = engine.all_pairs(num)
+        sample = np.arange(0, len(pairs), stride)
+        batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs[sample])
+        batch.run(engine.make_params())
+        res, aln = batch.fetch(want_alignments=True)
+        batch.close()
+        ref, ref_aln = oracle_libm.pairwise_batch(coords, tensors, offsets, pairs[sample], nthreads=8)
+        bad, rel = _count_integer_differences(res, aln, ref, ref_aln)
+        assert bad == 0, f"{num} x {length}: {bad} of {len(sample)} pairs differ in an alignment / seed index"
+        assert rel < 1e-9, f"{num} x {length}: floats differ by {rel:.3e}"
+        if length <= 300:                                   # tree topology: the whole matrix on both sides
+            full = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
+            full.run(engine.make_params())
+            sw, _ = full.fetch_scores()
+            full.close()
+            cpu, _ = oracle_libm.pairwise_batch(coords, tensors, offsets, pairs, want_aln=False, nthreads=8)
+            m_gpu, m_cpu = engine.assemble_matrix(pairs, sw, num), engine.assemble_matrix(pairs, cpu["sw"], num)
+            np.testing.assert_allclose(m_gpu, m_cpu, rtol=1e-12)
+            t_gpu, _ = nj.neighbor_joining(m_gpu.max() - m_gpu)
+            t_cpu, _ = oracle_libm.neighbor_joining(m_cpu.max() - m_cpu)
+            assert nj.bipartitions(t_gpu, num) == nj.bipartitions(t_cpu, num), f"P = {num}: tree topologies differ"
+
+
 def test_multiple_align_golden(golden):
     """Progressive alignment on the same kernels (a 'next' row): the 8-structure family's MSA."""
     from caretta_amd import multiple_alignment as ma

@@ -251,6 +251,24 @@ def test_pairwise_matrix_and_tree(oracle, golden):
         np.testing.assert_allclose(np.sort(bl.ravel()), np.sort(g[f"fam{fam}_branch_lengths"].ravel()), atol=1e-7)
 
 
+def test_pairwise_matrix_and_tree_64(oracle, oracle_libm, golden):
+    """A 64-structure family through the reference's make_pairwise_matrix + neighbor_joining (f3_tree64.npz): the oracle's
+    matrix to 1e-9, the same bipartitions -- with the shared exp and with libm's exp (what numba calls)."""
+    g = golden("f3_tree64.npz")
+    offsets = g["famT64_offsets"]
+    p = len(offsets) - 1
+    pairs = np.array([(i, j) for i in range(p) for j in range(i + 1, p)], dtype=np.int32)
+    want = tree_bipartitions(g["famT64_tree"], p)
+    for orc in (oracle, oracle_libm):
+        outs, _ = orc.pairwise_batch(g["famT64_coords"], g["famT64_tensors"], offsets, pairs, want_aln=False, nthreads=8)
+        m = np.zeros((p, p))
+        m[pairs[:, 0], pairs[:, 1]] = outs["sw"]
+        m[pairs[:, 1], pairs[:, 0]] = outs["sw"]
+        np.testing.assert_allclose(m, g["famT64_M"], rtol=1e-9)
+        tree, _ = orc.neighbor_joining(m.max() - m)
+        assert tree_bipartitions(tree, p) == want
+
+
 def test_neighbor_joining(oracle, golden):
     g = golden("f3_tree.npz")
     for c in range(int(g["nnj"])):
