@@ -353,8 +353,9 @@ def main():
                     if f.exists():
                         pmc = json.load(open(f))
                         out["valu_f64"]["issue_frac_pmc"] = {
-                            ("k_seed" if "k_seed" in k else "k_align"): round(v["SQ_INSTS_VALU"] / 1024 * 4 / (v["GRBM_GUI_ACTIVE"] / 8), 4)
-                            for k, v in pmc.items() if "SQ_INSTS_VALU" in v and "GRBM_GUI_ACTIVE" in v}
+                            k.split("<")[0]: round(v["SQ_INSTS_VALU"] / 1024 * 4 / (v["GRBM_GUI_ACTIVE"] / 8), 4)
+                            for k, v in pmc.items()
+                            if k.split("<")[0] in ("k_seed", "k_align") and "SQ_INSTS_VALU" in v and "GRBM_GUI_ACTIVE" in v}
                         out["valu_f64"]["issue_frac_pmc"]["source"] = f"profiles/{rnd}/pmc_summary.json"
                         break
         except (OSError, ValueError, KeyError):

@@ -29,9 +29,13 @@ def shard_size(npairs: int, world: int) -> int:
 
 def gather_scores(local_scores, world: int, group=None):
     """All-gather equal-length per-rank score vectors (torch tensors, padded with NaN)."""
+    import os
+
     import torch
     import torch.distributed as dist
-    if world == 1:
+    # CARETTA_FORCE_DIST=1: take the collective also with a single rank (exercises RCCL on a one-GPU box)
+    forced = dist.is_initialized() and os.environ.get("CARETTA_FORCE_DIST") == "1"
+    if world == 1 and not forced:
         return local_scores.unsqueeze(0)
     out = torch.empty(world * local_scores.numel(), dtype=local_scores.dtype, device=local_scores.device)
     dist.all_gather_into_tensor(out, local_scores.contiguous(), group=group)

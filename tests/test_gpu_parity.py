@@ -4,6 +4,8 @@
   * the C oracle on fresh seeded inputs (bit-identical: same FP64 operation order on both sides),
   * size-independent properties at BASELINE.json's full sizes.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -899,3 +901,18 @@ def test_randomised_parity_run():
     out = subprocess.run([sys.executable, str(script), "8", "99"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "all bit-identical to the oracle" in out.stdout
+
+
+def test_rccl_all_gather_single_rank():
+    """The RCCL code path on a one-GPU box: one rank under torch.distributed.run (backend nccl), all-gather forced,
+    matrix identical to the non-distributed one; the gather is ordered behind the kernels without a host sync."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    script = Path(__file__).resolve().parent / "rccl_single_rank_check.py"
+    env = dict(os.environ, CARETTA_FORCE_DIST="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", str(script)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "rccl single-rank matrix ok" in out.stdout
