@@ -326,6 +326,8 @@ int launch_seed_d(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) 
         case 8: return launch_seed<R, 8>(b, ck, prm);
         case 10: return launch_seed<R, 10>(b, ck, prm);
         case 16: return launch_seed<R, 16>(b, ck, prm);
+        case 24: return launch_seed<R, 24>(b, ck, prm);
+        case 32: return launch_seed<R, 32>(b, ck, prm);
         default: return fail(CR_ERR_ARGUMENT, "unsupported tensor width");
     }
 }
@@ -444,7 +446,7 @@ int launch_align_wide(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_pa
 // Can a pair list with these maxima run on the wide kernels with R rows per lane?  (strips <= 16 waves, the columns
 // of the tensor sweep -- the larger of the two -- resident in LDS next to the edge rings)
 bool wide_fits(int R, int n_max, int m_max, int d_pad) {
-    if (R < 1 || R > 3) return false;
+    if (R < 1 || R > 3 || d_pad > 16) return false;          // (the wide seed kernels are built for widths up to 16)
     const int waves = cr::strips_of(n_max, R);
     if (waves > cr::kWideMaxWaves) return false;
     // (sized for sw_gap != 0, where the tensor sweep needs its columns resident too; the parameters come with cr_batch_run)
@@ -506,6 +508,7 @@ int padded_width(int64_t d) {
     if (d <= 8) return 8;
     if (d <= 10) return 10;
     if (d <= 16) return 16;
+    if (d <= 24) return 24;
     if (d <= 32) return 32;
     return 0;
 }
@@ -661,7 +664,7 @@ int cr_batch_create(cr_context* ctx, const double* coords, const double* tensors
     CR_REQUIRE(coords && tensors && offsets, "null input array");
     CR_REQUIRE(num_structures >= 1, "need at least one structure");
     CR_REQUIRE(d >= 1, "tensor width must be >= 1");
-    CR_REQUIRE(padded_width(d) != 0 && padded_width(d) <= 16, "tensor width > 16 is not supported by this build");
+    CR_REQUIRE(padded_width(d) != 0, "tensor width > 32 is not supported by this build");
     CR_REQUIRE(offsets[0] == 0, "offsets[0] must be 0");
     for (int64_t s = 0; s < num_structures; s++) {
         CR_REQUIRE(offsets[s + 1] > offsets[s], "every structure needs at least one residue");

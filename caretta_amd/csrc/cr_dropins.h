@@ -414,6 +414,8 @@ int launch_seed_team_r(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& 
         case 8: return zg ? launch_seed_team_zg<R, 8, true>(b, ck, prm) : launch_seed_team_zg<R, 8, false>(b, ck, prm);
         case 10: return zg ? launch_seed_team_zg<R, 10, true>(b, ck, prm) : launch_seed_team_zg<R, 10, false>(b, ck, prm);
         case 16: return zg ? launch_seed_team_zg<R, 16, true>(b, ck, prm) : launch_seed_team_zg<R, 16, false>(b, ck, prm);
+        case 24: return zg ? launch_seed_team_zg<R, 24, true>(b, ck, prm) : launch_seed_team_zg<R, 24, false>(b, ck, prm);
+        case 32: return zg ? launch_seed_team_zg<R, 32, true>(b, ck, prm) : launch_seed_team_zg<R, 32, false>(b, ck, prm);
         default: return fail(CR_ERR_ARGUMENT, "unsupported tensor width");
     }
 }

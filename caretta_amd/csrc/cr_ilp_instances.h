@@ -8,7 +8,11 @@
     X(2, 4, true) X(2, 4, false) X(2, 8, true) X(2, 8, false) X(2, 10, true) X(2, 10, false) X(2, 16, true) X(2, 16, false) \
     X(3, 4, true) X(3, 4, false) X(3, 8, true) X(3, 8, false) X(3, 10, true) X(3, 10, false) X(3, 16, true) X(3, 16, false) \
     X(4, 4, true) X(4, 4, false) X(4, 8, true) X(4, 8, false) X(4, 10, true) X(4, 10, false) X(4, 16, true) X(4, 16, false) \
-    X(5, 4, true) X(5, 4, false) X(5, 8, true) X(5, 8, false) X(5, 10, true) X(5, 10, false) X(5, 16, true) X(5, 16, false)
+    X(5, 4, true) X(5, 4, false) X(5, 8, true) X(5, 8, false) X(5, 10, true) X(5, 10, false) X(5, 16, true) X(5, 16, false) \
+    X(2, 24, true) X(2, 24, false) X(2, 32, true) X(2, 32, false) \
+    X(3, 24, true) X(3, 24, false) X(3, 32, true) X(3, 32, false) \
+    X(4, 24, true) X(4, 24, false) X(4, 32, true) X(4, 32, false) \
+    X(5, 24, true) X(5, 24, false) X(5, 32, true) X(5, 32, false)
 
 #define CR_ILP_ALIGN_INSTANCES(X) X(2, true) X(2, false) X(3, true) X(3, false) X(4, true) X(4, false)
 
@@ -25,7 +29,12 @@
     X(2, 4, true) X(2, 4, false) X(2, 8, true) X(2, 8, false) X(2, 10, true) X(2, 10, false) X(2, 16, true) X(2, 16, false) \
     X(3, 4, true) X(3, 4, false) X(3, 8, true) X(3, 8, false) X(3, 10, true) X(3, 10, false) X(3, 16, true) X(3, 16, false) \
     X(4, 4, true) X(4, 4, false) X(4, 8, true) X(4, 8, false) X(4, 10, true) X(4, 10, false) X(4, 16, true) X(4, 16, false) \
-    X(5, 4, true) X(5, 4, false) X(5, 8, true) X(5, 8, false) X(5, 10, true) X(5, 10, false) X(5, 16, true) X(5, 16, false)
+    X(5, 4, true) X(5, 4, false) X(5, 8, true) X(5, 8, false) X(5, 10, true) X(5, 10, false) X(5, 16, true) X(5, 16, false) \
+    X(1, 24, true) X(1, 24, false) X(1, 32, true) X(1, 32, false) \
+    X(2, 24, true) X(2, 24, false) X(2, 32, true) X(2, 32, false) \
+    X(3, 24, true) X(3, 24, false) X(3, 32, true) X(3, 32, false) \
+    X(4, 24, true) X(4, 24, false) X(4, 32, true) X(4, 32, false) \
+    X(5, 24, true) X(5, 24, false) X(5, 32, true) X(5, 32, false)
 #define CR_ILP_NODE_TEAM_INSTANCES(X) X(1) X(2) X(3) X(4) X(5)
 
 #define CR_SEED_TEAM_SIGNATURE(R, D, ZG)                                                                                   \

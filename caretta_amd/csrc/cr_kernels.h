@@ -1875,9 +1875,10 @@ CR_D void drain_stores() {
 }
 
 // Stages 1+2: tensor RBF + SW fill (multiple_alignment.py:328-335), then traceback + seed Kabsch.
-// (the column sweep holds R * D row features and little else: three waves per SIMD -- 168 VGPRs -- up to 50 of them)
+// (the column sweep holds R * D row features and little else: three waves per SIMD -- 168 VGPRs -- up to 50 of them,
+// two up to 100, one for the widest tensors)
 template <int R, int D, bool ZG>
-__global__ __launch_bounds__(kWave, (ZG && R * D <= 50) ? 3 : 2) void k_seed(const PairDesc* __restrict__ pairs,
+__global__ __launch_bounds__(kWave, (ZG && R * D <= 50) ? 3 : (R * D <= 100 ? 2 : 1)) void k_seed(const PairDesc* __restrict__ pairs,
                                                const double* __restrict__ tensors, int d,
                                                const double* __restrict__ coords, double gamma, double sw_gap,
                                                int max_entries, uint32_t* __restrict__ dirs,

@@ -466,6 +466,45 @@ def test_guide_tree_from_gpu_matrix(ctx, oracle, golden):
         assert np.array_equal(tree, otree) and np.array_equal(bl, obl)
 
 
+@pytest.mark.parametrize("dim", [17, 20, 24, 29, 32])
+def test_tensor_widths_up_to_32(ctx, oracle, dim):
+    """The tensor width is geometricus' output_dimension (multiple_alignment.py:479-488), a run-time parameter: widths
+    above 16 (padded to 24 / 32 in registers) through the single-wave kernels of every rows-per-lane group, the team
+    kernels (few long pairs), both SW gap settings, and a progressive alignment -- bit-identical to the oracle."""
+    from caretta_amd import engine, multiple_alignment as ma, neighbor_joining as nj
+    fam = synthetic.make_family(10, 330, dim=dim, seed=400 + dim, ragged=True, clades=2)
+    for k, s in enumerate(fam):                         # lengths across the R = 2 .. 5 groups and two strips
+        cut = [330, 60, 128, 200, 256, 300, 330, 90, 150, 40][k]
+        s.coordinates, s.tensors = s.coordinates[:cut].copy(), s.tensors[:cut].copy()
+    coords, tensors, offsets = synthetic.pack(fam)
+    pairs = engine.all_pairs(len(fam))
+    for gap in (0.0, 0.05):
+        prm = engine.make_params(sw_gap=gap)
+        batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
+        batch.run(prm)
+        res, aln = batch.fetch()
+        batch.close()
+        from oracle.pyoracle import default_params
+        ref, ref_aln = oracle.pairwise_batch(coords, tensors, offsets, pairs, params=default_params(sw_gap=gap), nthreads=8)
+        assert_bit_identical(res, aln, ref, ref_aln)
+    long_pairs = np.array([[0, 6], [5, 6]], dtype=np.int32)          # two pairs of ~300 rows: the team kernels
+    batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(long_pairs)
+    batch.run(engine.make_params())
+    res, aln = batch.fetch()
+    batch.close()
+    ref, ref_aln = oracle.pairwise_batch(coords, tensors, offsets, long_pairs, nthreads=2)
+    assert_bit_identical(res, aln, ref, ref_aln)
+    # progressive alignment on the wide tensors: finishes, and its MSA rows index every residue once
+    prots = [ma.Protein(s.name, s.tensors, s.coordinates, s.sequence) for s in fam[:6]]
+    msa = ma.MultipleAlignment(prots)
+    m = msa.make_pairwise_matrix(dict(gamma_tensor=7.0, gamma_coords=0.03))
+    tree, _ = nj.neighbor_joining(m.max() - m)
+    out = msa.progressive_align(tree, 1.0, 0.01, 1.0, 1.0, dict(gamma_tensor=7.0, gamma_coords=0.03), {})
+    for p in prots:
+        row = out[p.name]
+        assert np.array_equal(row[row >= 0], np.arange(len(p)))
+
+
 def test_guide_tree_64_from_gpu_matrix(oracle, golden):
     """The 64-structure family of f3_tree64.npz (matrix and tree by the reference's own make_pairwise_matrix and
     neighbor_joining): GPU matrix to 1e-9, identical bipartitions, tree identical to the oracle's."""
