@@ -729,20 +729,30 @@ struct ColSweep {
         }
         eprev = 0.0;
     }
-    // Column j.  FULL: the stored tensor width equals D (no padded features).  `top`: H of the row above the strip in
-    // this column (wave-uniform; only read when TOP).
-    template <bool FULL, bool TOP>
-    CR_D void step(RbfTensor<R, D>& src, const ExpEntry* tab, int j, double top) {
+    double cnext[D];          // features of the NEXT column (wave-uniform: SGPRs), loaded one step ahead
+
+    // The column's features are wave-uniform: scalar loads, issued one step before they are used so that their
+    // latency hides behind the previous column's arithmetic even with a single wave on the SIMD.  (Always D loads: the
+    // tensor array is allocated with D doubles of slack and the padded features are zeroed by scalar selects --
+    // conditional loads would cost a branch each.)
+    template <bool FULL>
+    CR_D void prefetch(const RbfTensor<R, D>& src, int j) {
         const double* __restrict__ cg = src.cols_g;
         const int d = FULL ? D : src.d;
-        // the column's features are wave-uniform: scalar loads.  (Always D loads: the tensor array is allocated with
-        // D doubles of slack and the padded features are zeroed by scalar selects -- conditional loads would cost a
-        // branch each.)
 #pragma unroll
         for (int k = 0; k < D; k++) {
             const double v = cg[(int64_t)j * d + k];
-            src.col[k] = (FULL || k < d) ? v : 0.0;
+            cnext[k] = (FULL || k < d) ? v : 0.0;
         }
+    }
+    // Column j (prefetch<FULL>(src, j) has been called; `jn` = the column to prefetch now, any valid column).  FULL: the
+    // stored tensor width equals D (no padded features).  `top`: H of the row above the strip in this column
+    // (wave-uniform; only read when TOP).
+    template <bool FULL, bool TOP>
+    CR_D void step(RbfTensor<R, D>& src, const ExpEntry* tab, int j, int jn, double top) {
+#pragma unroll
+        for (int k = 0; k < D; k++) src.col[k] = cnext[k];
+        prefetch<FULL>(src, jn);
         double dg[R], p[R];
 #pragma unroll
         for (int q = 0; q < R; q++) {
@@ -821,10 +831,11 @@ CR_D void sweep_cols(RbfTensor<R, D>& src, const int n, const int m, double* lds
         auto run = [&](auto full_tag, auto top_tag) {
             constexpr bool FULL = decltype(full_tag)::value, TOP = decltype(top_tag)::value;
             double top_vec = 0.0;                // row above the strip, 64 columns per load (lane x: column j0 + x)
+            st.template prefetch<FULL>(src, 0);
 #pragma unroll 1
             for (int j = 0; j < m; j++) {
                 if (TOP && (j & (kWave - 1)) == 0) top_vec = (j + lane < m) ? hand_g[j + lane] : 0.0;
-                st.template step<FULL, TOP>(src, tab, j, TOP ? lane_value(top_vec, j & (kWave - 1)) : 0.0);
+                st.template step<FULL, TOP>(src, tab, j, j + 1 < m ? j + 1 : j, TOP ? lane_value(top_vec, j & (kWave - 1)) : 0.0);
                 if (hand_out && lane == kWave - 1) hand_g[j] = st.hprev[R - 1];
                 if ((j & 15) == 15 || j == m - 1) st.flush(sw_dirs, ((int64_t)(s * TB + (j >> 4)) * R) * kWave + lane);
             }
@@ -894,9 +905,10 @@ CR_D void sweep_cols_team(RbfTensor<R, D>& src, const int n, const int m, double
             // the row above the strip for this chunk: lane x holds column j0 + x
             double top_vec = 0.0;
             if (TOP && lane < kColChunk) top_vec = ring_in[(c & 1) * kColChunk + lane];
+            if (c == 0) st.template prefetch<FULL>(src, 0);
 #pragma unroll 1
             for (int j = j0; j < jend; j++) {
-                st.template step<FULL, TOP>(src, tab, j, TOP ? lane_value(top_vec, j - j0) : 0.0);
+                st.template step<FULL, TOP>(src, tab, j, j + 1 < m ? j + 1 : j, TOP ? lane_value(top_vec, j - j0) : 0.0);
                 if (hand_out && lane == kWave - 1) ring_out[(c & 1) * kColChunk + (j - j0)] = st.hprev[R - 1];
             }
             st.flush(sw_dirs, ((int64_t)(w * TB + c) * R) * kWave + lane);      // one chunk = one decision word per row
