@@ -261,6 +261,7 @@ struct cr_batch {
     int64_t aln_elems = 0;
     double alg_bytes = 0.0, cells = 0.0;
     bool ran = false;
+    bool scores_only = false;           // the last run was cr_batch_run_scores: no alignments, transforms or metrics to fetch
     // The decision scratch (dirs, bits) is sized for one CHUNK of the pair list and reused chunk after
     // chunk in stream order, so an arbitrarily long pair list runs in bounded HBM.
     struct Chunk {
@@ -351,6 +352,36 @@ int launch_align_zg(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm
 template <int R>
 int launch_align(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
     return prm.sw_gap == 0.0 ? launch_align_zg<R, true>(b, ck, prm) : launch_align_zg<R, false>(b, ck, prm);
+}
+
+template <int R>
+int launch_score(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
+    const size_t lds = sizeof(double) * (cr::kExpDoubles + cr::RbfCoords<R>::kRingDoubles);
+    CR_LAUNCH(cr::k_score<R>, dim3((unsigned)ck.count), dim3(cr::kWave), lds, b->launch_stream ? b->launch_stream : b->ctx->stream,
+              b->pairs.p + ck.first, b->coords.p, b->xf.p + ck.first, b->seed_score.p + ck.first, prm.gamma_coords, b->hand.p,
+              b->res.p + ck.first);
+    CR_HIP(hipGetLastError());
+    return CR_OK;
+}
+
+template <int R>
+int launch_score_team(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
+    const int waves = cr::strips_of(ck.n_max, R);
+    const size_t lds = sizeof(double) * cr::sweep_cols_score_team_lds_doubles<cr::RbfCoords<R>>(waves);
+    CR_LAUNCH(cr::k_score_team<R>, dim3((unsigned)ck.count), dim3(waves * cr::kWave), lds, b->launch_stream ? b->launch_stream : b->ctx->stream,
+              b->pairs.p + ck.first, b->coords.p, b->xf.p + ck.first, b->seed_score.p + ck.first, prm.gamma_coords, b->res.p + ck.first);
+    CR_HIP(hipGetLastError());
+    return CR_OK;
+}
+
+int launch_score_team_r(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
+    return R == 1 ? launch_score_team<1>(b, ck, prm) : R == 2 ? launch_score_team<2>(b, ck, prm) : R == 3 ? launch_score_team<3>(b, ck, prm)
+         : R == 4 ? launch_score_team<4>(b, ck, prm) : launch_score_team<5>(b, ck, prm);
+}
+
+int launch_score_r(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
+    return R == 1 ? launch_score<1>(b, ck, prm) : R == 2 ? launch_score<2>(b, ck, prm) : R == 3 ? launch_score<3>(b, ck, prm)
+         : R == 4 ? launch_score<4>(b, ck, prm) : launch_score<5>(b, ck, prm);
 }
 
 // The fused kernels feed rows past the end of a structure features of 1e150 so that their RBF score underflows to
@@ -522,6 +553,7 @@ template <class T>
 int fetch_packed(cr_batch* b, cr_pair_result* results, T* aln, int64_t aln_stride) {
     CR_REQUIRE(b != nullptr, "null batch");
     if (!b->ran) return fail(CR_ERR_STATE, "cr_batch_fetch before cr_batch_run");
+    if (b->scores_only) return fail(CR_ERR_STATE, "the last run was cr_batch_run_scores: only cr_batch_fetch_scores has results");
     int rc = set_device(b->ctx);
     if (rc) return rc;
     hipStream_t st = b->ctx->stream;
@@ -882,7 +914,7 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     return CR_OK;
 }
 
-int cr_batch_run(cr_batch* b, const cr_params* params, double* d_sw_out) {
+static int run_batch(cr_batch* b, const cr_params* params, double* d_sw_out, bool scores_only) {
     CR_REQUIRE(b != nullptr && params != nullptr, "null argument");
     int rc = set_device(b->ctx);
     if (rc) return rc;
@@ -930,7 +962,12 @@ int cr_batch_run(cr_batch* b, const cr_params* params, double* d_sw_out) {
         if (prof) (void)hipEventRecord((*evl)[evi++], st);
         rc = b->wide_sync ? launch_seed_wide(ck.r, b, ck, prm) : b->team ? launch_seed_team(ck.r, b, ck, prm) : launch_seed_r(ck.r, b, ck, prm);
         if (!rc && prof) (void)hipEventRecord((*evl)[evi++], st);
-        if (!rc) rc = b->wide_sync ? launch_align_wide(ck.r, b, ck, prm) : b->team ? launch_align_team(ck.r, b, ck, prm) : launch_align_r(ck.r, b, ck, prm);
+        if (!rc) {
+            // scores only (gap 0): the column sweep without decisions -- one wave per pair, or one wave per strip for the
+            // few-pair batches (team / wide layouts: strips_of(n_max, R) <= 16 waves)
+            if (scores_only && prm.sw_gap == 0.0) rc = b->team ? launch_score_team_r(ck.r, b, ck, prm) : launch_score_r(ck.r, b, ck, prm);
+            else rc = b->wide_sync ? launch_align_wide(ck.r, b, ck, prm) : b->team ? launch_align_team(ck.r, b, ck, prm) : launch_align_r(ck.r, b, ck, prm);
+        }
         if (!rc && prof) (void)hipEventRecord((*evl)[evi++], st);
         b->launch_stream = nullptr;
         if (rc) return rc;
@@ -950,8 +987,13 @@ int cr_batch_run(cr_batch* b, const cr_params* params, double* d_sw_out) {
     }
     if (prof) ctx->runs_recorded++;
     b->ran = true;
+    b->scores_only = scores_only && prm.sw_gap == 0.0;
     return CR_OK;
 }
+
+int cr_batch_run(cr_batch* b, const cr_params* params, double* d_sw_out) { return run_batch(b, params, d_sw_out, false); }
+
+int cr_batch_run_scores(cr_batch* b, const cr_params* params, double* d_sw_out) { return run_batch(b, params, d_sw_out, true); }
 
 int cr_batch_stage_ms(cr_batch* b, float ms[CR_NUM_STAGES], int* runs_averaged) {
     CR_REQUIRE(b != nullptr && ms != nullptr, "null argument");

@@ -953,6 +953,142 @@ __host__ __device__ inline size_t sweep_cols_team_lds_doubles(int waves) {
     return kExpDoubles + (size_t)waves * (2 * kColChunk + 4);
 }
 
+// ---------------------------------------------------------------------------------------------
+// smith_waterman_score (gap 0) of a pair as a column sweep WITHOUT decisions: what MultipleAlignment.make_pairwise_matrix
+// needs of a pair (multiple_alignment.py:164) -- the P x P matrix entry, no alignment.  Same recurrence and scan as
+// sweep_cols; the provider's columns come through its LDS ring (RbfCoords transforms 64 columns per chunk with the seed
+// superposition) and are read back with wave-uniform addresses (LDS broadcast).  np.max of the matrix is H[n][m]
+// (monotone rows and columns).  One wave, strips one after the other; the row above a strip travels through `hand_g`.
+// ---------------------------------------------------------------------------------------------
+template <int R, class Src>
+CR_D double sweep_cols_score(Src& src, const int n, const int m, double* lds, double* __restrict__ hand_g) {
+    const int lane = threadIdx.x;
+    const ExpEntry* tab = reinterpret_cast<const ExpEntry*>(lds);
+    double* ring = lds + kExpDoubles;
+    load_exp_table(lds, lane);
+    src.init_ring(ring, lane);
+    __syncthreads();
+    const int nstrips = strips_of(n, R);
+    double hprev[R], eprev = 0.0;
+    for (int s = 0; s < nstrips; s++) {
+        const int rowbase = (s * kWave + lane) * R;
+        src.load_rows(rowbase, n);
+#pragma unroll
+        for (int q = 0; q < R; q++) hprev[q] = 0.0;
+        eprev = 0.0;
+        const bool hand_out = s + 1 < nstrips;
+        double top_vec = 0.0;
+#pragma unroll 1
+        for (int j = 0; j < m; j++) {
+            if ((j & (kWave - 1)) == 0) {
+                __syncthreads();
+                src.load_chunk(ring, j >> 6, m, lane);
+                if (s > 0) top_vec = (j + lane < m) ? hand_g[j + lane] : 0.0;
+                __syncthreads();
+            }
+            src.fetch_col(ring, j & (kRing - 1));
+            double p[R];
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const double sc = src.score(q, tab);
+                const double dg = (q == 0 ? eprev : hprev[q - 1]) + sc;
+                const double b = vmax(dg, hprev[q]);
+                p[q] = q == 0 ? b : vmax(p[q - 1], b);
+            }
+            double e = wave_shr1(wave_scan_max(p[R - 1]), 0.0);
+            if (s > 0) e = vmax(e, lane_value(top_vec, j & (kWave - 1)));
+#pragma unroll
+            for (int q = 0; q < R; q++) hprev[q] = vmax(p[q], e);
+            eprev = e;
+            if (hand_out && lane == kWave - 1) hand_g[j] = hprev[R - 1];
+        }
+        if (hand_out) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+        }
+    }
+    // H[n][m]: row n - 1 lives in the last strip, lane ((n - 1) / R) % 64, slot (n - 1) % R
+    const int qo = (n - 1) % R;
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < R; q++) v = (q == qo) ? hprev[q] : v;
+    return lane_value(v, ((n - 1) / R) % kWave);
+}
+
+// The same with one wave per strip and all strips in flight (strip s works kColChunk columns behind strip s - 1, one
+// barrier per phase, as sweep_cols_team): for pair lists too short to fill the chip with one wave per pair.  Every wave
+// has its own column ring.  LDS (doubles): exp table | NW column rings | NW edge rings of 2 * kColChunk | NW slots.
+template <int R, class Src>
+CR_D double sweep_cols_score_team(Src& src, const int n, const int m, double* lds) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int NW = (int)(blockDim.x >> 6);
+    const ExpEntry* tab = reinterpret_cast<const ExpEntry*>(lds);
+    double* ring = lds + kExpDoubles + w * Src::kRingDoubles;
+    double* edges = lds + kExpDoubles + NW * Src::kRingDoubles;
+    double* edge_out = edges + w * (2 * kColChunk);
+    const double* edge_in = edges + (w > 0 ? w - 1 : 0) * (2 * kColChunk);
+    double* red = edges + NW * (2 * kColChunk);
+    load_exp_table(lds, threadIdx.x);
+    src.init_ring(ring, lane);
+    const int nstrips = strips_of(n, R);                 // <= NW, guaranteed by the launcher
+    const bool mine = w < nstrips;
+    const int rowbase = (w * kWave + lane) * R;
+    const bool hand_out = w + 1 < nstrips;
+    double hprev[R], eprev = 0.0;
+#pragma unroll
+    for (int q = 0; q < R; q++) hprev[q] = 0.0;
+    if (mine) src.load_rows(rowbase, n);
+    const int chunks = (m + kColChunk - 1) / kColChunk;
+    const int phases = chunks + nstrips - 1;
+#pragma unroll 1
+    for (int g = 0; g < phases; g++) {
+        __syncthreads();                               // the chunk written in phase g - 1 is visible to the strip below
+        const int c = g - w;
+        if (!mine || c < 0 || c >= chunks) continue;
+        const int j0 = c * kColChunk;
+        const int jend = j0 + kColChunk < m ? j0 + kColChunk : m;
+        if ((j0 & (kWave - 1)) == 0) {                 // this wave's own ring: a wave-level fence is enough
+            wave_sync();
+            src.load_chunk(ring, j0 >> 6, m, lane);
+            wave_sync();
+        }
+        double top_vec = 0.0;
+        if (w > 0 && lane < kColChunk) top_vec = edge_in[(c & 1) * kColChunk + lane];
+#pragma unroll 1
+        for (int j = j0; j < jend; j++) {
+            src.fetch_col(ring, j & (kRing - 1));
+            double p[R];
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const double sc = src.score(q, tab);
+                const double dg = (q == 0 ? eprev : hprev[q - 1]) + sc;
+                const double b = vmax(dg, hprev[q]);
+                p[q] = q == 0 ? b : vmax(p[q - 1], b);
+            }
+            double e = wave_shr1(wave_scan_max(p[R - 1]), 0.0);
+            if (w > 0) e = vmax(e, lane_value(top_vec, j - j0));
+#pragma unroll
+            for (int q = 0; q < R; q++) hprev[q] = vmax(p[q], e);
+            eprev = e;
+            if (hand_out && lane == kWave - 1) edge_out[(c & 1) * kColChunk + (j - j0)] = hprev[R - 1];
+        }
+    }
+    const int qo = (n - 1) % R;
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < R; q++) v = (q == qo) ? hprev[q] : v;
+    if (w == (n - 1) / (kWave * R) && lane == ((n - 1) / R) % kWave) red[0] = v;
+    __syncthreads();
+    return red[0];
+}
+
+template <class Src>
+__host__ __device__ inline size_t sweep_cols_score_team_lds_doubles(int waves) {
+    return kExpDoubles + (size_t)waves * (Src::kRingDoubles + 2 * kColChunk) + 8;
+}
+
 // LDS doubles needed by a sweep of the given provider/mode for column count m and row count n
 template <int R, int MODE, class Src>
 __host__ __device__ inline size_t sweep_lds_doubles(int n_max, int m_max) {
@@ -1957,6 +2093,69 @@ __global__ __launch_bounds__(kWave, 4) void k_align(const PairDesc* __restrict__
     r.flags |= xf[blockIdx.x].flags;
     if (threadIdx.x == 0) res[blockIdx.x] = r;
     CR_STAMP(7);
+}
+
+// Stage 3 alone: coordinate RBF on the seed-superposed frames + smith_waterman_score (multiple_alignment.py:347-349,
+// :164) -- the P x P matrix entry of a pair without its pairwise alignment (sw_gap == 0; cr_batch_run_scores).
+template <int R>
+__global__ __launch_bounds__(kWave) void k_score(const PairDesc* __restrict__ pairs, const double* __restrict__ coords,
+                                                const Transform* __restrict__ xf,
+                                                const double* __restrict__ seed_score, double gamma,
+                                                double* __restrict__ hand, PairResult* __restrict__ res) {
+    extern __shared__ double lds[];
+    const PairDesc pd = pairs[blockIdx.x];
+    RbfCoords<R> src;
+    src.rows_g = coords + pd.off_i * 3;
+    src.cols_g = coords + pd.off_j * 3;
+    src.xf = xf + blockIdx.x;
+    src.neg_gamma = -gamma;
+    const double sw = sweep_cols_score<R>(src, pd.n, pd.m, lds, hand + pd.hand_off);
+    if (threadIdx.x == 0) {
+        PairResult r;
+        r.sw = sw;
+        r.dtw_score = 0.0;
+#pragma unroll
+        for (int x = 0; x < 9; x++) r.R[x] = 0.0;
+#pragma unroll
+        for (int x = 0; x < 3; x++) r.t[x] = 0.0;
+        r.rmsd = r.coverage = r.tm = 0.0;
+        r.seed_score = seed_score[blockIdx.x];
+        r.aln_len = r.aln_start = 0;
+        r.seed_len = xf[blockIdx.x].seed_len;
+        r.flags = xf[blockIdx.x].flags;
+        res[blockIdx.x] = r;
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(kWideMaxWaves* kWave) void k_score_team(const PairDesc* __restrict__ pairs,
+                                                                    const double* __restrict__ coords,
+                                                                    const Transform* __restrict__ xf,
+                                                                    const double* __restrict__ seed_score, double gamma,
+                                                                    PairResult* __restrict__ res) {
+    extern __shared__ double lds[];
+    const PairDesc pd = pairs[blockIdx.x];
+    RbfCoords<R> src;
+    src.rows_g = coords + pd.off_i * 3;
+    src.cols_g = coords + pd.off_j * 3;
+    src.xf = xf + blockIdx.x;
+    src.neg_gamma = -gamma;
+    const double sw = sweep_cols_score_team<R>(src, pd.n, pd.m, lds);
+    if (threadIdx.x == 0) {
+        PairResult r;
+        r.sw = sw;
+        r.dtw_score = 0.0;
+#pragma unroll
+        for (int x = 0; x < 9; x++) r.R[x] = 0.0;
+#pragma unroll
+        for (int x = 0; x < 3; x++) r.t[x] = 0.0;
+        r.rmsd = r.coverage = r.tm = 0.0;
+        r.seed_score = seed_score[blockIdx.x];
+        r.aln_len = r.aln_start = 0;
+        r.seed_len = xf[blockIdx.x].seed_len;
+        r.flags = xf[blockIdx.x].flags;
+        res[blockIdx.x] = r;
+    }
 }
 
 // One node of progressive alignment (multiple_alignment.py:193-234), after k_seed has produced the seed

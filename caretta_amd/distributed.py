@@ -85,7 +85,7 @@ def pairwise_matrix_sharded(coords, tensors, offsets, params=None, group=None,
         batch = PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs[mine])
         if params is None:       # Protein.score_function's defaults (multiple_alignment.py:321-322), as make_pairwise_matrix
             params = make_params(gamma_tensor=0.03, gamma_coords=0.03)
-        batch.run(params, sw_out_device_ptr=local.data_ptr())
+        batch.run(params, sw_out_device_ptr=local.data_ptr(), scores_only=True)      # the matrix needs no alignments
         _, flags = batch.fetch_scores()
         batch.close()
         ctx.close()

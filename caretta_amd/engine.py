@@ -134,10 +134,12 @@ class PairBatch:
         check(self._lib.cr_batch_set_pairs(self._h, ptr(self.pairs), len(self.pairs)))
         return self
 
-    def run(self, params: Optional[Params] = None, sw_out_device_ptr: Optional[int] = None):
+    def run(self, params: Optional[Params] = None, sw_out_device_ptr: Optional[int] = None, scores_only: bool = False):
+        """Enqueue the pipeline.  ``scores_only``: just the P x P matrix entries (make_pairwise_matrix): the seed kernel and
+        a smith_waterman_score kernel, no pairwise dtw_align -- afterwards only ``fetch_scores`` has results."""
         params = params or make_params()
-        check(self._lib.cr_batch_run(self._h, C.byref(params),
-                                     C.c_void_p(sw_out_device_ptr) if sw_out_device_ptr else None))
+        fn = self._lib.cr_batch_run_scores if scores_only else self._lib.cr_batch_run
+        check(fn(self._h, C.byref(params), C.c_void_p(sw_out_device_ptr) if sw_out_device_ptr else None))
 
     def fetch(self, want_alignments: bool = True, pinned: bool = False):
         """-> (structured array of per-pair results, aln [npairs, 2, stride] or None).

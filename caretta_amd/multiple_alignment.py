@@ -268,7 +268,7 @@ class MultipleAlignment:
         try:
             pairs = all_pairs(len(self.sequences)) if pairs is None else np.asarray(pairs, np.int32).reshape(-1, 2)
             batch.set_pairs(pairs)
-            batch.run(params)
+            batch.run(params, scores_only=scores_only)
             if scores_only:                       # the matrix entries only: 12 bytes per pair come back
                 sw, flags = batch.fetch_scores()
                 res, aln = np.zeros(len(pairs), dtype=_capi.PAIR_RESULT_DTYPE), None

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity run on one MI355X: the HIP path against the C oracle (TEST infrastructure, oracle/) on many small
-random batches -- ragged lengths from 1 to 700 residues, tensor widths 1..16, all gap / gamma settings, the batched
-pipeline, the device-resident progressive alignment and the explicit-score-matrix drop-ins.  Every output must be bit-identical.
+random batches -- ragged lengths from 1 to 1400 residues, tensor widths 1..32, all gap / gamma settings, the batched
+pipeline on every kernel family (single-wave, team and wide kernels; column and skewed sweeps), the device-resident
+progressive alignment, the explicit-score-matrix drop-ins and their batched forms.  Every output must be bit-identical.
 
     python tests/fuzz_parity.py [seconds] [seed]
 """
@@ -19,7 +20,7 @@ from oracle import pyoracle  # noqa: E402
 
 def random_family(rng):
     kind = rng.integers(0, 4)
-    dim = int(rng.choice([1, 2, 3, 4, 5, 8, 10, 13, 16]))
+    dim = int(rng.choice([1, 2, 3, 4, 5, 8, 10, 13, 16, 10, 10, 17, 24, 29, 32]))
     if kind == 0:      # related structures, ragged
         # up to 18 structures: with both orientations more than 128 pairs, i.e. the grouped single-wave kernels too
         num, length = int(rng.integers(2, 19)), int(rng.choice([12, 40, 90, 150, 200, 260, 330, 450, 700, 1000]))
@@ -36,6 +37,10 @@ def random_family(rng):
         for s in fam:
             s.coordinates[:] = np.round(s.coordinates / 4.0) * 4.0
             s.tensors[:] = np.round(s.tensors * 2.0) / 2.0
+    elif kind == 3 and rng.integers(0, 2):    # a few long structures: the wide kernels (one wave per strip, up to 16 waves)
+        num, length = int(rng.integers(2, 5)), int(rng.choice([400, 520, 770, 1000, 1400]))
+        fam = synthetic.make_family(num, length, dim=min(dim, 16), seed=int(rng.integers(1 << 30)), ragged=True, clades=1)
+        dim = min(dim, 16)
     else:              # far apart: RBF underflows, seeds of <= 3 positions
         num, length = int(rng.integers(2, 6)), int(rng.choice([5, 30, 100]))
         fam = synthetic.make_family(num, length, dim=dim, seed=int(rng.integers(1 << 30)), ragged=True, clades=num)
@@ -138,12 +143,44 @@ def check_dropins(oracle, rng):
     return 1
 
 
+def check_explicit_batch(oracle, rng):
+    """smith_waterman_score_batch / dtw_align_batch on a ragged list of matrices (row sweep, gathers, column strips)."""
+    from caretta_amd import dynamic_time_warping as dtw
+    problems = []
+    for _ in range(int(rng.integers(1, 9))):
+        n = int(rng.choice([1, 2, 9, 63, 64, 65, 150, 300, 513]))
+        m = int(rng.choice([1, 3, 64, 65, 128, 129, 300, 321, 512, 513, 700, 1030]))
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            problems.append((np.arange(n), np.arange(m), rng.uniform(-0.3, 1.0, size=(n, m))))
+        elif kind == 1:                                                             # ties
+            problems.append((np.arange(n), np.arange(m), np.round(rng.uniform(-1.0, 2.0, size=(n, m)))))
+        elif kind == 2:                                                             # alphabet mode
+            sub = rng.normal(size=(int(rng.integers(1, 25)), int(rng.integers(1, 25))))
+            problems.append((rng.integers(0, sub.shape[0], size=n), rng.integers(0, sub.shape[1], size=m), sub))
+        else:                                                                       # a window of a larger matrix
+            big = rng.uniform(size=(n + 5, m + 9)) ** 4
+            problems.append((np.arange(3, n + 3), np.arange(7, m + 7), big))
+    gap = float(rng.choice([0.0, 0.0, 0.0, 0.2]))
+    got = dtw.smith_waterman_score_batch(problems, gap)
+    want = np.array([oracle.smith_waterman_score(a, b, s, gap) for a, b, s in problems])
+    if not np.array_equal(got, want):
+        raise AssertionError(f"smith_waterman_score_batch differs: gap {gap}, shapes {[(len(a), len(b)) for a, b, _ in problems]}")
+    if rng.integers(0, 3) == 0:
+        go, ge = float(rng.choice([0.0, 1.0, 0.5])), float(rng.choice([0.0, 0.01, 0.5]))
+        for (a, b, s), (a1, a2, sc) in zip(problems, dtw.dtw_align_batch(problems, go, ge)):
+            o1, o2, osc = oracle.dtw_align(a, b, s, go, ge)
+            if not (np.array_equal(a1, o1) and np.array_equal(a2, o2) and sc == osc):
+                raise AssertionError(f"dtw_align_batch differs: n {len(a)} m {len(b)} gaps {go} {ge}")
+    return len(problems)
+
+
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
     ctx, oracle = engine.Context(0), pyoracle.Oracle()
-    t0, batches, pairs, nodes, flagged, dropins = time.time(), 0, 0, 0, 0, 0
+    t0, batches, pairs, nodes, flagged, dropins, batched = time.time(), 0, 0, 0, 0, 0, 0
     while time.time() - t0 < seconds:
         fam, _ = random_family(rng)
         n, res = check_batch(ctx, oracle, fam, rng)
@@ -152,9 +189,12 @@ def main():
         if rng.integers(0, 3) == 0:
             nodes += check_progressive(oracle, fam, rng)
         dropins += check_dropins(oracle, rng)
+        if rng.integers(0, 4) == 0:
+            batched += check_explicit_batch(oracle, rng)
         batches += 1
     print(f"fuzz_parity: seed {seed}, {batches} batches, {pairs} pairs ({flagged} with a soft-condition flag), "
-          f"{nodes} progressive nodes, {dropins} explicit-matrix drop-in cases: all bit-identical to the oracle")
+          f"{nodes} progressive nodes, {dropins} explicit-matrix drop-in cases, {batched} matrices in batched explicit calls: "
+          f"all bit-identical to the oracle")
 
 
 if __name__ == "__main__":

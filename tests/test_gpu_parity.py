@@ -505,6 +505,40 @@ def test_tensor_widths_up_to_32(ctx, oracle, dim):
         assert np.array_equal(row[row >= 0], np.arange(len(p)))
 
 
+def test_scores_only_run_matches_the_full_pipeline(ctx):
+    """cr_batch_run_scores (what make_pairwise_matrix needs: multiple_alignment.py:164) gives the same sw / flags as the
+    full pipeline, bit for bit, on every kernel family: one wave per pair (all rows-per-lane groups, several strips),
+    the four-wave teams and the wide layouts (few long pairs)."""
+    from caretta_amd import engine
+    cases = []
+    fam = synthetic.make_family(14, 420, seed=808, ragged=True, clades=3)
+    for k, s in enumerate(fam):
+        cut = [420, 40, 120, 200, 64, 150, 90, 330, 300, 256, 257, 5, 3, 400][k]
+        s.coordinates, s.tensors = s.coordinates[:cut].copy(), s.tensors[:cut].copy()
+    both = np.vstack([engine.all_pairs(14), engine.all_pairs(14)[:, ::-1]])
+    cases.append((fam, both))                                             # 182 pairs: single-wave kernels, grouped
+    cases.append((fam, np.array([[0, 7], [8, 13], [13, 8]], dtype=np.int32)))       # three pairs of 300-420 rows: teams
+    long = synthetic.make_family(3, 900, seed=809, clades=1)
+    cases.append((long, engine.all_pairs(3)))                             # 900 rows: wide kernels, R = 3
+    mid = synthetic.make_family(4, 600, seed=810, ragged=True, clades=1)
+    cases.append((mid, engine.all_pairs(4)))                              # ~600 rows: wide kernels, R = 2
+    for fam, pairs in cases:
+        coords, tensors, offsets = synthetic.pack(fam)
+        batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
+        batch.run(engine.make_params())
+        sw_full, flags_full = batch.fetch_scores()
+        batch.run(engine.make_params(), scores_only=True)
+        sw, flags = batch.fetch_scores()
+        assert np.array_equal(sw, sw_full) and np.array_equal(flags, flags_full)
+        with pytest.raises(Exception):
+            batch.fetch()                                                 # nothing but the scores after a scores-only run
+        batch.run(engine.make_params(sw_gap=0.1), scores_only=True)        # gap != 0: the full pipeline answers
+        sw_gap, _ = batch.fetch_scores()
+        batch.run(engine.make_params(sw_gap=0.1))
+        assert np.array_equal(sw_gap, batch.fetch_scores()[0])
+        batch.close()
+
+
 def test_guide_tree_64_from_gpu_matrix(oracle, golden):
     """The 64-structure family of f3_tree64.npz (matrix and tree by the reference's own make_pairwise_matrix and
     neighbor_joining): GPU matrix to 1e-9, identical bipartitions, tree identical to the oracle's."""

@@ -16,3 +16,11 @@ for _ in range(5): b.run(prm)
 ctx.synchronize()
 sw, _ = b.fetch_scores()
 print(f"{len(pairs)} pairs of 1200 x 1200: {(time.perf_counter()-t0)/5*1e3:.2f} ms per pass, checksum {sw.sum():.6f}")
+for _ in range(2): b.run(prm, scores_only=True)
+ctx.synchronize()
+t0 = time.perf_counter()
+for _ in range(5): b.run(prm, scores_only=True)
+ctx.synchronize()
+sw2, _ = b.fetch_scores()
+print(f"{len(pairs)} pairs of 1200 x 1200, matrix entries only (cr_batch_run_scores): {(time.perf_counter()-t0)/5*1e3:.2f} ms per pass, "
+      f"scores {'identical' if np.array_equal(sw, sw2) else 'DIFFER'}")
