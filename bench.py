@@ -18,6 +18,7 @@ Besides `value` (device-resident rate, SURVEY.md 8(d) and the driver's contract)
   c4_sharded, c5_sharded : BASELINE configs 4 and 5 timed in the same run, pair set sharded over the N ranks + one
                          all-gather, with the speed-up against ONE GPU running the whole config (measured on rank 0);
                          at N=1 also `share_of_8`: one GPU's share of the 8-GPU split run on this GPU;
+  matrix_only          : the P x P matrix entries alone (cr_batch_run_scores), what make_pairwise_matrix -> NJ consumes;
   nj_gate              : neighbor-joining bipartitions of the GPU matrix = those of the all-core oracle matrix (N=1);
   roofline, cpu_baseline : as the contract asks (roofline.frac from SURVEY 8(d)'s algorithmic bytes).
 """
@@ -201,19 +202,20 @@ def main():
             self.local = torch.full((max(self.shard, len(self.mine)),), float("nan"), dtype=torch.float64, device=dev)
             self.gathered_flat = torch.empty(world * self.local.numel(), dtype=torch.float64, device=dev) if self.gather else None
 
-        def step(self):
-            self.batch.run(params, sw_out_device_ptr=self.local.data_ptr())
+        def step(self, scores_only=False):
+            self.batch.run(params, sw_out_device_ptr=self.local.data_ptr(), scores_only=scores_only)
             if self.gather:
                 dist.all_gather_into_tensor(self.gathered_flat, self.local)
 
-        def time(self, steps, warmup, collective=True):
-            """seconds per step: `warmup` untimed steps, then `steps` timed ones between fences, max over ranks."""
+        def time(self, steps, warmup, collective=True, scores_only=False):
+            """seconds per step: `warmup` untimed steps, then `steps` timed ones between fences, max over ranks.
+            scores_only: the matrix entries alone (cr_batch_run_scores: what make_pairwise_matrix -> neighbor_joining needs)."""
             for _ in range(warmup):
-                self.step()
+                self.step(scores_only)
             fence() if collective else torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
             for _ in range(steps):
-                self.step()
+                self.step(scores_only)
             fence() if collective else torch.cuda.synchronize(dev)
             el = time.perf_counter() - t0
             return (max_over_ranks(el) if collective else el) / steps
@@ -244,6 +246,12 @@ def main():
 
     extras = {}
     if not args.no_extras:
+        # ---------------------------------------------------------- the P x P matrix alone (no pairwise alignments)
+        t_mat = head.time(max(3, min(args.steps, 10)), 2, scores_only=True)
+        if rank == 0:
+            extras["matrix_only"] = {"ms_per_step": t_mat * 1e3, "pairs_per_s": len(pairs) / t_mat,
+                                     "note": "cr_batch_run_scores: seed kernel + smith_waterman_score of the coordinate score matrix per pair "
+                                             "(multiple_alignment.py:158-170), no dtw_align / traceback / metrics"}
         # ---------------------------------------------------------- the same pair set including the PCIe transfers
         # per step: upload the structures (cr_batch_create), the pair list (cr_batch_set_pairs), run, download EVERY
         # result -- alignment rows (int32, page-locked arrays kept by the batch), transforms, metrics
@@ -282,24 +290,30 @@ def main():
             n_c, l_c, s_c = CONFIGS[key]
             sh = Sharded(n_c, l_c, s_c)
             t_sh = sh.time(5, 2)
+            t_sh_mat = sh.time(5, 2, scores_only=True)
             sh.close()
-            t_one = None
+            t_one = t_one_mat = None
             if world > 1:
                 if rank == 0:                           # the whole config on ONE GPU, for the speed-up
                     one = Sharded(n_c, l_c, s_c, ranks=1, me=0)
                     t_one = one.time(5, 2, collective=False)
+                    t_one_mat = one.time(5, 2, collective=False, scores_only=True)
                     one.close()
                 fence()
             rec = {"n_gpus": world, "structures": n_c, "residues": l_c, "pairs": n_c * (n_c - 1) // 2,
                    "ms": t_sh * 1e3, "pairs_per_s": n_c * (n_c - 1) / 2 / t_sh,
                    "ms_1gpu": (t_one if t_one is not None else t_sh) * 1e3,
-                   "speedup_vs_1gpu": (t_one / t_sh) if t_one is not None else 1.0}
+                   "speedup_vs_1gpu": (t_one / t_sh) if t_one is not None else 1.0,
+                   "matrix_only": {"ms": t_sh_mat * 1e3, "ms_1gpu": (t_one_mat if t_one_mat is not None else t_sh_mat) * 1e3,
+                                   "speedup_vs_1gpu": (t_one_mat / t_sh_mat) if t_one_mat is not None else 1.0}}
             if world == 1:
                 # one GPU's share of the 8-GPU split (every 8th pair), run here: what 8 GPUs would each do, before the
                 # (latency-bound, ~1 MB) all-gather
                 part = Sharded(n_c, l_c, s_c, ranks=1, me=0, stride=8)
                 t_part = part.time(10, 3, collective=False)
-                rec["share_of_8"] = {"pairs": int(len(part.mine)), "ms": t_part * 1e3, "projected_speedup_8gpu": t_sh / t_part}
+                t_part_mat = part.time(10, 3, collective=False, scores_only=True)
+                rec["share_of_8"] = {"pairs": int(len(part.mine)), "ms": t_part * 1e3, "projected_speedup_8gpu": t_sh / t_part,
+                                     "matrix_only_ms": t_part_mat * 1e3, "matrix_only_projected_speedup_8gpu": t_sh_mat / t_part_mat}
                 part.close()
             extras[f"{key}_sharded"] = rec
 
