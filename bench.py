@@ -375,6 +375,7 @@ def main():
         except (OSError, ValueError, KeyError):
             pass
         out.update(extras)
+        out["build"] = ge.build_provenance()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], out["nj_gate"] = cpu_baseline(coords, tensors, offsets, pairs, res, aln, matrix)
             out["speedup_vs_cpu_1thread"] = out["value"] / out["cpu_baseline"]["value"]

@@ -61,6 +61,11 @@ def check_batch(ctx, oracle, fam, rng):
     batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
     batch.run(engine.make_params(**prm))
     res, aln = batch.fetch()
+    if rng.integers(0, 3) == 0:                                    # the matrix entries alone (cr_batch_run_scores)
+        batch.run(engine.make_params(**prm), scores_only=True)
+        sw_only, flags_only = batch.fetch_scores()
+        if not (np.array_equal(sw_only, res["sw"]) and np.array_equal(flags_only, res["flags"])):
+            raise AssertionError(f"scores-only run differs: params {prm}, lengths {np.diff(offsets)}")
     batch.close()
     ref, ref_aln = oracle.pairwise_batch(coords, tensors, offsets, pairs, pyoracle.default_params(**prm), nthreads=8)
     for key in ("flags", "aln_len", "seed_len", "sw", "dtw_score", "seed_score", "rmsd", "coverage", "tm", "R", "t"):
