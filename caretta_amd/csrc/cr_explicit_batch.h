@@ -11,6 +11,7 @@ struct ExplicitProblem {
     int64_t s_off, seq1_off, seq2_off;   // element offsets of the matrix in S and of the index sequences in seqs
     int64_t hand_off;                    // doubles: hand-off column (row sweep) / hand-off rows (skewed sweep)
     int64_t dirs_off, bits_off, aln_off; // decision words and alignment rows (dtw_align only)
+    int64_t bits_off_s;                  // decision words of the streaming kernels (their own rows per lane)
     int32_t s_rows, s_cols, n, m;
     int32_t col0, ident;                 // ident: seq2[j] == col0 + j for every j (contiguous columns)
 };
@@ -206,13 +207,148 @@ __global__ __launch_bounds__(kWave) void k_explicit_batch(const ExplicitProblem*
     if (threadIdx.x == 0) ends[blockIdx.x] = ae;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Streaming provider for the time-skewed sweep on an explicit matrix with CONTIGUOUS columns: no shared tile.  Every
+// lane consumes its own R rows, one column per step, i.e. one 64-byte block of each row every 8 steps -- but lane o's
+// position t - o and every row's start address put the block boundaries of different (lane, row) streams at different
+// steps.  The provider therefore keeps, per lane and row, a ring of TWO cache-line-ALIGNED 64-byte blocks in LDS
+// ([row slot][ring slot][position][lane]: the per-step read of 64 lanes is conflict-free) and at every step that is a
+// multiple of 8 fetches for every stream the ONE aligned block its next 8 steps will enter: each block of S is
+// requested exactly once (unaligned 64-byte pieces were measured at 1.93 x the bytes: every straddled line came
+// twice).  The loads are full-wave instructions issued 8 steps ahead into registers and COOPERATIVE: in load y the four
+// lanes 4g .. 4g+3 fetch the four 16-byte quarters of the block that lane o = 16y + g will consume -- one aligned
+// 64-byte request per quad.  A wave keeps R * 4 KB in flight and needs R * 8.5 KB of LDS, so several waves share a CU and
+// the sweep is fed from HBM -- against one 132 KB tile per CU of the Explicit provider.  Blocks reach up to 63 doubles
+// before a row (lanes that have not started yet) and 7 after it: into the neighbouring rows, or into the slack the batch
+// keeps on either side of S.
+// ---------------------------------------------------------------------------------------------
+template <int R>
+struct ExplicitStream {
+    static constexpr bool kNonNegative = false;
+    static constexpr bool kMaskRows = true;
+    static constexpr bool kStreams = true;
+    static constexpr int kBlk = 8;                        // doubles per aligned block
+    static constexpr int kLoads = 4;                      // load instructions per row slot and boundary (16 owners each)
+    static constexpr int kRingDoubles = R * 2 * kBlk * kWave + R * kWave;     // block rings | stream offsets of every lane
+    const double* __restrict__ S;                         // the batch's matrices (64-byte aligned)
+    const int32_t* __restrict__ seq1;
+    int64_t s_off, s_cols;
+    int col0;
+    int m_, lane_, t_;
+    double* ring_;
+    int low_[R];                 // this lane's stream offsets modulo 16 (which block / position a column falls in)
+    Pair8 pend[R][kLoads];       // quarter blocks in flight: pend[q][y] belongs to lane 16y + lane / 4
+    double val[R];
+
+    CR_D int64_t* stream_offsets() const { return reinterpret_cast<int64_t*>(ring_ + R * 2 * kBlk * kWave); }
+    // quarter `part` of aligned block `blk + extra` of every owner's streams, where blk = the block the owner's window
+    // that starts at step t0 begins in (extra = 1: the block it ends in)
+    template <bool LAST>
+    CR_D void issue(int t0, Pair8 (&dst)[R][kLoads]) {
+        const int64_t* so = stream_offsets();
+        const int part = lane_ & 3;
+#pragma unroll
+        for (int y = 0; y < kLoads; y++) {
+            const int o = 16 * y + (lane_ >> 2);
+            const int cs = t0 - o;                           // first column of the window
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const int64_t off = so[o * R + q];
+                const int64_t blk = ((off + cs + (LAST ? kBlk - 1 : 0)) >> 3) << 3;     // stream offset of the aligned block
+                const int64_t c0 = blk - off;                                              // its first column
+                Pair8 v{0.0, 0.0};
+                if (off >= 0 && c0 + kBlk > 0 && c0 < m_) v = *reinterpret_cast<const Pair8*>(S + blk + 2 * part);
+                dst[q][y] = v;
+            }
+        }
+    }
+    // park quarter blocks in the ring slot their block number selects
+    template <bool LAST>
+    CR_D void park(int t0, const Pair8 (&src)[R][kLoads]) {
+        const int64_t* so = stream_offsets();
+        const int part = lane_ & 3;
+#pragma unroll
+        for (int y = 0; y < kLoads; y++) {
+            const int o = 16 * y + (lane_ >> 2);
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const int64_t a = so[o * R + q] + (t0 - o) + (LAST ? kBlk - 1 : 0);
+                const int slot = (int)(a >> 3) & 1;
+                ring_[((q * 2 + slot) * kBlk + 2 * part) * kWave + o] = src[q][y].a;
+                ring_[((q * 2 + slot) * kBlk + 2 * part + 1) * kWave + o] = src[q][y].b;
+            }
+        }
+    }
+    CR_D void init_ring(double* ring, int) { ring_ = ring; }
+    CR_D void load_rows(int rowbase, int n) {
+        lane_ = threadIdx.x & (kWave - 1);
+        wave_sync();                                  // the previous strip's readers are done with the offsets
+        int64_t* so = stream_offsets();
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const int64_t off = rowbase + q < n ? s_off + (int64_t)seq1[rowbase + q] * s_cols + col0 : (int64_t)-1;
+            so[lane_ * R + q] = off;
+            low_[q] = (int)(off & 15);
+        }
+        wave_sync();
+        // the window [0, 8): the block it starts in (parked at once) and the block it ends in (parked at step 0)
+        Pair8 first[R][kLoads];
+        issue<false>(0, first);
+        issue<true>(0, pend);
+        park<false>(0, first);
+    }
+    CR_D void load_chunk(double*, int, int, int) {}
+    CR_D void step_begin(double*, int t, int m) {
+        m_ = m;
+        t_ = t;
+        if ((t & (kBlk - 1)) == 0) {
+            park<true>(t, pend);                      // the block the window [t, t + 8) ends in
+            wave_sync();
+            issue<true>(t + kBlk, pend);              // ... and the one the next window will end in
+        }
+    }
+    CR_D void fetch_col(const double* ring, int) {
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const int a = low_[q] + t_ - lane_;          // the column's stream offset modulo 16 (two's complement is fine)
+            val[q] = ring[((q * 2 + ((a >> 3) & 1)) * kBlk + (a & 7)) * kWave + lane_];
+        }
+    }
+    CR_D double score(int q, const ExpEntry*) const { return val[q]; }
+};
+
+template <int R, int MODE>
+__global__ __launch_bounds__(kWave) void k_explicit_stream(const ExplicitProblem* __restrict__ probs,
+                                                          const double* __restrict__ S,
+                                                          const int32_t* __restrict__ seqs, SweepParams prm,
+                                                          uint32_t* __restrict__ bits, double* __restrict__ hand,
+                                                          AlignEnd* __restrict__ ends) {
+    extern __shared__ double lds[];
+    const ExplicitProblem pb = probs[blockIdx.x];
+    ExplicitStream<R> src;
+    src.S = S;
+    src.s_off = pb.s_off;
+    src.seq1 = seqs + pb.seq1_off;
+    src.s_cols = pb.s_cols;
+    src.col0 = pb.col0;
+    src.m_ = pb.m;
+    src.t_ = 0;
+    src.lane_ = threadIdx.x & (kWave - 1);
+    SeedMax sm;
+    AlignEnd ae;
+    ae.sw = ae.dtw_score = 0.0;
+    ae.start_layer = ae.pad = 0;
+    if (pb.m > 0) sweep<R, MODE>(src, pb.n, pb.m, prm, lds, nullptr, bits + pb.bits_off_s, hand + pb.hand_off, sm, ae);
+    if (threadIdx.x == 0) ends[blockIdx.x] = ae;
+}
+
 struct BatchTrace {
     int32_t len, start;
 };
 
 // dtw_align's traceback (dynamic_time_warping.py:90-144) for every problem of the batch: one wave per problem on the
 // register-resident decision blocks of the pairwise kernels (dtw_walk).  LDS: (n + m) packed entries.
-template <int R>
+template <int R, bool STREAM>
 __global__ __launch_bounds__(kWave) void k_dtw_trace_batch(const ExplicitProblem* __restrict__ probs,
                                                           const uint32_t* __restrict__ bits,
                                                           const AlignEnd* __restrict__ ends, int max_entries,
@@ -220,7 +356,8 @@ __global__ __launch_bounds__(kWave) void k_dtw_trace_batch(const ExplicitProblem
     extern __shared__ double lds[];
     const ExplicitProblem pb = probs[blockIdx.x];
     int len, pairs;
-    dtw_walk<R>(pb.n, pb.m, max_entries, bits + pb.bits_off, ends[blockIdx.x].start_layer, lds, aln + pb.aln_off, len, pairs);
+    dtw_walk<R>(pb.n, pb.m, max_entries, bits + (STREAM ? pb.bits_off_s : pb.bits_off), ends[blockIdx.x].start_layer, lds,
+                aln + pb.aln_off, len, pairs);
     if (threadIdx.x == 0) {
         out[blockIdx.x].len = len;
         out[blockIdx.x].start = pb.n + pb.m - len;
@@ -239,6 +376,9 @@ struct cr_explicit_batch {
     // with their column counts cut there (only kept when some sequence holds a -1)
     bool has_minus1 = false;
     int m_max_sw = 0;
+    // every problem has contiguous columns (seq2[j] = col0 + j): the streaming kernels apply
+    bool all_ident = false, all_ident_sw = false;
+    int r_stream = 2;                   // rows per lane of the streaming kernels (rows_per_lane(n_max))
     DevBuf<cr::ExplicitProblem> probs_sw;
     DevBuf<double> S, hand, scores;
     DevBuf<int32_t> seqs, aln;
@@ -252,11 +392,42 @@ struct cr_explicit_batch {
 
 namespace {
 
+constexpr size_t kSlackFront = 128, kSlackBack = 32;     // doubles; the front keeps S 64-byte aligned
+
 template <int CC>
 int launch_sw_rows(cr_explicit_batch* b) {
     const size_t lds = sizeof(double) * 2 * cr::RowSweep<CC>::kBufDoubles;
     CR_LAUNCH(cr::k_sw_score_rows<CC>, dim3((unsigned)b->count), dim3(cr::kWave), lds, b->ctx->stream,
-              b->has_minus1 ? b->probs_sw.p : b->probs.p, b->S.p, b->seqs.p, b->hand.p, b->scores.p);
+              b->has_minus1 ? b->probs_sw.p : b->probs.p, b->S.p + kSlackFront, b->seqs.p, b->hand.p, b->scores.p);
+    CR_HIP(hipGetLastError());
+    return CR_OK;
+}
+
+// the streaming sweep (contiguous columns) with R rows per lane
+template <int R, int MODE>
+int launch_stream(cr_explicit_batch* b, const cr::ExplicitProblem* probs, const cr::SweepParams& prm, uint32_t* bits) {
+    const size_t lds = cr::sweep_lds_doubles<R, MODE, cr::ExplicitStream<R>>(b->n_max, b->m_max) * sizeof(double);
+    int rc = allow_lds(cr::k_explicit_stream<R, MODE>, lds);
+    if (rc) return rc;
+    CR_LAUNCH((cr::k_explicit_stream<R, MODE>), dim3((unsigned)b->count), dim3(cr::kWave), lds, b->ctx->stream, probs,
+              b->S.p + kSlackFront, b->seqs.p, prm, bits, b->hand.p, b->ends.p);
+    CR_HIP(hipGetLastError());
+    return CR_OK;
+}
+
+template <int MODE>
+int launch_stream_r(int R, cr_explicit_batch* b, const cr::ExplicitProblem* probs, const cr::SweepParams& prm, uint32_t* bits) {
+    return R == 2 ? launch_stream<2, MODE>(b, probs, prm, bits) : R == 3 ? launch_stream<3, MODE>(b, probs, prm, bits)
+         : R == 4 ? launch_stream<4, MODE>(b, probs, prm, bits) : launch_stream<5, MODE>(b, probs, prm, bits);
+}
+
+template <int R, bool STREAM>
+int launch_trace(cr_explicit_batch* b, int entries) {
+    const size_t tl = sizeof(double) * cr::trace_lds_doubles(R, entries);
+    int rc = allow_lds(cr::k_dtw_trace_batch<R, STREAM>, tl);
+    if (rc) return rc;
+    CR_LAUNCH((cr::k_dtw_trace_batch<R, STREAM>), dim3((unsigned)b->count), dim3(cr::kWave), tl, b->ctx->stream, b->probs.p, b->bits.p,
+              b->ends.p, entries, b->aln.p, b->trace.p);
     CR_HIP(hipGetLastError());
     return CR_OK;
 }
@@ -281,7 +452,14 @@ int cr_explicit_batch_create(cr_context* ctx, const double* S, int64_t s_elems, 
     std::vector<int32_t> h_seq((size_t)seq_elems);
     std::vector<cr::ExplicitProblem> hp((size_t)count);
     std::vector<cr::ExplicitProblem> hp_sw((size_t)count);
-    bool has_minus1 = false;
+    bool has_minus1 = false, all_ident = true, all_ident_sw = true;
+    int n_all = 0;
+    for (int64_t p = 0; p < count; p++) n_all = std::max<int>(n_all, problems[p].n);
+    // rows per lane of the streaming kernels: 2 (a stream costs 1 KB of LDS per lane-row pair of blocks: with 2 rows six
+    // waves share a CU; measured on 8128 x 300 x 300: R = 2 / 3 / 5 -> 1.92 / 2.07 / 2.37 ms (SW, gap 0.1), 2.52 / 2.68 /
+    // 2.89 ms (DTW)); CARETTA_FORCE_R overrides
+    const int r_stream = std::getenv("CARETTA_FORCE_R") ? rows_per_lane(std::max(n_all, 1)) : 2;
+    int64_t bits_off_s = 0;
     int64_t hand_off = 0, bits_off = 0, aln_off = 0;
     int m_max = 0, n_max = 0, m_max_sw = 0;
     for (int64_t p = 0; p < count; p++) {
@@ -322,6 +500,10 @@ int cr_explicit_batch_create(cr_context* ctx, const double* S, int64_t s_elems, 
         e.col0 = (int32_t)std::max<int64_t>(seqs[q.seq2_off], 0);
         e.hand_off = hand_off;
         e.bits_off = bits_off;
+        e.bits_off_s = bits_off_s;
+        bits_off_s += (int64_t)cr::strips_of(q.n, r_stream) * cr::tblocks(q.m, 8) * r_stream * cr::kWave;
+        all_ident = all_ident && ident;
+        all_ident_sw = all_ident_sw && ident_sw;
         e.dirs_off = 0;
         e.aln_off = aln_off;
         hand_off += 3 * (int64_t)std::max(q.n, q.m);
@@ -349,9 +531,17 @@ int cr_explicit_batch_create(cr_context* ctx, const double* S, int64_t s_elems, 
     b->h_probs = hp;
     b->has_minus1 = has_minus1;
     b->m_max_sw = m_max_sw;
+    b->all_ident = all_ident;
+    b->all_ident_sw = all_ident_sw;
+    b->r_stream = r_stream;
     if (has_minus1 && (rc = upload(b->probs_sw, hp_sw.data(), hp_sw.size(), ctx->stream))) return rc;
     // the gather path reads S[row, seq2[c]] only for c < m; the streaming path reads whole row segments inside the row
-    if ((rc = upload(b->S, S, (size_t)s_elems, ctx->stream))) return rc;
+    // S sits kSlackFront doubles into its buffer and has kSlackBack behind it: the streaming sweep reads whole aligned
+    // 64-byte blocks that may start before the first row (lanes that have not reached column 0) and end after the last
+    CR_HIP(b->S.ensure((size_t)s_elems + kSlackFront + kSlackBack));
+    CR_HIP(hipMemsetAsync(b->S.p, 0, sizeof(double) * kSlackFront, ctx->stream));
+    CR_HIP(hipMemsetAsync(b->S.p + kSlackFront + s_elems, 0, sizeof(double) * kSlackBack, ctx->stream));
+    CR_HIP(hipMemcpyAsync(b->S.p + kSlackFront, S, sizeof(double) * (size_t)s_elems, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = upload(b->seqs, h_seq.data(), h_seq.size(), ctx->stream))) return rc;
     if ((rc = upload(b->probs, hp.data(), hp.size(), ctx->stream))) return rc;
     CR_HIP(b->hand.ensure((size_t)hand_off));
@@ -401,12 +591,17 @@ int cr_smith_waterman_score_batch(cr_explicit_batch* b, double gap, double* scor
         constexpr int R = kExplicitR;
         constexpr int MODE = cr::kSwScore;
         CR_HIP(b->ends.ensure((size_t)b->count));
-        const size_t lds = cr::sweep_lds_doubles<R, MODE, cr::Explicit<R>>(b->n_max, b->m_max) * sizeof(double);
-        if ((rc = allow_lds(cr::k_explicit_batch<R, MODE>, lds))) return rc;
         cr::SweepParams prm{gap, 0.0, 0.0};
-        CR_LAUNCH((cr::k_explicit_batch<R, MODE>), dim3((unsigned)b->count), dim3(cr::kWave), lds, st,
-                  b->has_minus1 ? b->probs_sw.p : b->probs.p, b->S.p, b->seqs.p, prm, (uint32_t*)nullptr, b->hand.p, b->ends.p);
-        CR_HIP(hipGetLastError());
+        const cr::ExplicitProblem* probs = b->has_minus1 ? b->probs_sw.p : b->probs.p;
+        if (b->all_ident_sw) {                           // contiguous columns everywhere: the streaming sweep
+            if ((rc = launch_stream_r<MODE>(b->r_stream, b, probs, prm, nullptr))) return rc;
+        } else {
+            const size_t lds = cr::sweep_lds_doubles<R, MODE, cr::Explicit<R>>(b->n_max, b->m_max) * sizeof(double);
+            if ((rc = allow_lds(cr::k_explicit_batch<R, MODE>, lds))) return rc;
+            CR_LAUNCH((cr::k_explicit_batch<R, MODE>), dim3((unsigned)b->count), dim3(cr::kWave), lds, st, probs, b->S.p + kSlackFront,
+                      b->seqs.p, prm, (uint32_t*)nullptr, b->hand.p, b->ends.p);
+            CR_HIP(hipGetLastError());
+        }
         CR_HIP(hipMemcpy2DAsync(b->scores.p, sizeof(double), b->ends.p, sizeof(cr::AlignEnd), sizeof(double), (size_t)b->count,
                                 hipMemcpyDeviceToDevice, st));
     }
@@ -425,33 +620,37 @@ int cr_dtw_align_batch(cr_explicit_batch* b, double gap_open, double gap_extend,
     CR_REQUIRE(std::isfinite(gap_open) && std::isfinite(gap_extend), "gap penalties must be finite");
     CR_REQUIRE(!aln || (aln_len && aln_stride >= b->cap_max), "aln needs aln_len and a stride of at least the longest n + m");
     CR_REQUIRE(!b->has_minus1, "seq2: index outside the score matrix (-1 only ends a row of smith_waterman_score)");
-    constexpr int R = kExplicitR;
     constexpr int MODE = cr::kDtw;
     hipStream_t st = b->ctx->stream;
+    const bool stream = b->all_ident;                    // contiguous columns everywhere: the streaming sweep
+    const int R = stream ? b->r_stream : kExplicitR;
     int64_t bits_total = 0, aln_total = 0;
     for (const auto& e : b->h_probs) {
-        bits_total = std::max(bits_total, e.bits_off + (int64_t)cr::strips_of(e.n, R) * cr::tblocks(e.m, 8) * R * cr::kWave);
+        bits_total = std::max(bits_total, (stream ? e.bits_off_s : e.bits_off) + (int64_t)cr::strips_of(e.n, R) * cr::tblocks(e.m, 8) * R * cr::kWave);
         aln_total = std::max(aln_total, e.aln_off + 2 * (int64_t)(e.n + e.m));
     }
     CR_HIP(b->bits.ensure((size_t)bits_total));
     CR_HIP(b->ends.ensure((size_t)b->count));
-    const size_t lds = cr::sweep_lds_doubles<R, MODE, cr::Explicit<R>>(b->n_max, b->m_max) * sizeof(double);
-    if ((rc = allow_lds(cr::k_explicit_batch<R, MODE>, lds))) return rc;
     cr::SweepParams prm{0.0, gap_open, gap_extend};
     CR_HIP(hipEventRecord(b->ev0, st));
-    CR_LAUNCH((cr::k_explicit_batch<R, MODE>), dim3((unsigned)b->count), dim3(cr::kWave), lds, st, b->probs.p, b->S.p,
-              b->seqs.p, prm, b->bits.p, b->hand.p, b->ends.p);
-    CR_HIP(hipGetLastError());
+    if (stream) {
+        if ((rc = launch_stream_r<MODE>(R, b, b->probs.p, prm, b->bits.p))) return rc;
+    } else {
+        const size_t lds = cr::sweep_lds_doubles<kExplicitR, MODE, cr::Explicit<kExplicitR>>(b->n_max, b->m_max) * sizeof(double);
+        if ((rc = allow_lds(cr::k_explicit_batch<kExplicitR, MODE>, lds))) return rc;
+        CR_LAUNCH((cr::k_explicit_batch<kExplicitR, MODE>), dim3((unsigned)b->count), dim3(cr::kWave), lds, st, b->probs.p,
+                  b->S.p + kSlackFront, b->seqs.p, prm, b->bits.p, b->hand.p, b->ends.p);
+        CR_HIP(hipGetLastError());
+    }
     std::vector<cr::BatchTrace> tr;
     if (aln) {
         const int entries = b->cap_max;
         CR_HIP(b->aln.ensure((size_t)aln_total));
         CR_HIP(b->trace.ensure((size_t)b->count));
-        const size_t tl = sizeof(double) * cr::trace_lds_doubles(R, entries);
-        if ((rc = allow_lds(cr::k_dtw_trace_batch<R>, tl))) return rc;
-        CR_LAUNCH(cr::k_dtw_trace_batch<R>, dim3((unsigned)b->count), dim3(cr::kWave), tl, st, b->probs.p, b->bits.p, b->ends.p,
-                  entries, b->aln.p, b->trace.p);
-        CR_HIP(hipGetLastError());
+        if (!stream) rc = launch_trace<kExplicitR, false>(b, entries);
+        else rc = R == 2 ? launch_trace<2, true>(b, entries) : R == 3 ? launch_trace<3, true>(b, entries)
+                : R == 4 ? launch_trace<4, true>(b, entries) : launch_trace<5, true>(b, entries);
+        if (rc) return rc;
     }
     CR_HIP(hipEventRecord(b->ev1, st));
     std::vector<cr::AlignEnd> ends((size_t)b->count);

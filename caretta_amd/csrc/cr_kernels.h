@@ -357,6 +357,13 @@ struct Explicit {
     CR_D double score(int q, const ExpEntry*) const { return val[q]; }
 };
 
+// Providers that stream their scores lane by lane (ExplicitStream, cr_explicit_batch.h) get a call at the top of EVERY
+// step from every lane, active or not: `static constexpr bool kStreams = true` + `step_begin(ring, t, m)`.
+template <class S, class = void>
+struct is_streaming : std::false_type {};
+template <class S>
+struct is_streaming<S, std::void_t<decltype(S::kStreams)>> : std::bool_constant<S::kStreams> {};
+
 // Registers a lane carries from column to column of its R rows.
 template <int R>
 struct DpState {
@@ -553,6 +560,7 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
                 }
                 __syncthreads();
             }
+            if constexpr (is_streaming<Src>::value) src.step_begin(ring, t, m);
             const int c = t - lane;
             const bool active = (unsigned)c < (unsigned)m;
 

@@ -111,7 +111,8 @@ int cr_batch_run(cr_batch *b, const cr_params *params, double *d_sw_out);
 /* The same for callers that only want the P x P matrix entries (MultipleAlignment.make_pairwise_matrix,
  * multiple_alignment.py:158-170: smith_waterman_score of Protein.score_function per pair): the seed kernel, then the
  * coordinate score matrix + smith_waterman_score WITHOUT the pairwise dtw_align, its traceback and metrics.
- * Afterwards only cr_batch_fetch_scores (and d_sw_out) have results.  With sw_gap != 0 it runs the full pipeline. */
+ * Afterwards only cr_batch_fetch_scores (and d_sw_out) have results; the flags carry the seed conditions
+ * (CR_FLAG_SEED_SKIPPED, CR_FLAG_SEED_ALL_ZERO) only.  With sw_gap != 0 it runs the full pipeline. */
 int cr_batch_run_scores(cr_batch *b, const cr_params *params, double *d_sw_out);
 /* Synchronise and copy results to host.  Any pointer may be NULL.  results[npairs];
  * aln i64[npairs, 2, aln_stride] (rows padded with -2 after aln_len; aln_stride >= max(n+m)). */

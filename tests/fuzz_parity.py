@@ -64,7 +64,8 @@ def check_batch(ctx, oracle, fam, rng):
     if rng.integers(0, 3) == 0:                                    # the matrix entries alone (cr_batch_run_scores)
         batch.run(engine.make_params(**prm), scores_only=True)
         sw_only, flags_only = batch.fetch_scores()
-        if not (np.array_equal(sw_only, res["sw"]) and np.array_equal(flags_only, res["flags"])):
+        # (the scores-only run reports the seed conditions only: no alignment, hence no "fewer than 3 aligned positions")
+        if not (np.array_equal(sw_only, res["sw"]) and np.array_equal(flags_only & 5, res["flags"] & 5)):
             raise AssertionError(f"scores-only run differs: params {prm}, lengths {np.diff(offsets)}")
     batch.close()
     ref, ref_aln = oracle.pairwise_batch(coords, tensors, offsets, pairs, pyoracle.default_params(**prm), nthreads=8)
