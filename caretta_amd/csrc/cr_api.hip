@@ -304,7 +304,8 @@ template <int R, int D, bool ZG>
 int launch_seed_zg(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
     using Src = cr::RbfTensor<R, D>;
     const int entries = std::min(ck.n_max, ck.m_max);
-    const size_t fill = cr::sweep_lds_doubles<R, cr::kSwTrace, Src>(ck.n_max, ck.m_max);
+    // gap 0: the column sweep needs the exp table only (no column ring, the strip hand-off goes through HBM)
+    const size_t fill = ZG ? (size_t)cr::kExpDoubles : cr::sweep_lds_doubles<R, cr::kSwTrace, Src>(ck.n_max, ck.m_max);
     const size_t lds = sizeof(double) * std::max(fill, (size_t)cr::kExpDoubles + cr::trace_lds_doubles(R, entries));
     int rc = allow_lds(cr::k_seed<R, D, ZG>, lds);
     if (rc) return rc;

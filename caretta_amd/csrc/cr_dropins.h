@@ -395,8 +395,8 @@ template <int R, int D, bool ZG>
 int launch_seed_team_zg(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
     using Src = cr::RbfTensor<R, D>;
     const int entries = std::min(ck.n_max, ck.m_max);
-    const size_t lds = sizeof(double) * std::max(cr::sweep_team_lds_doubles<R, cr::kSwTrace, Src>(cr::kTeamWaves),
-                                                 (size_t)cr::kExpDoubles + cr::trace_lds_doubles(R, entries));
+    const size_t fill = ZG ? cr::sweep_cols_team_lds_doubles(cr::kTeamWaves) : cr::sweep_team_lds_doubles<R, cr::kSwTrace, Src>(cr::kTeamWaves);
+    const size_t lds = sizeof(double) * std::max(fill, (size_t)cr::kExpDoubles + cr::trace_lds_doubles(R, entries));
     int rc = allow_lds(cr::k_seed_team<R, D, ZG>, lds);
     if (rc) return rc;
     CR_LAUNCH((cr::k_seed_team<R, D, ZG>), dim3((unsigned)ck.count), dim3(cr::kTeamWaves * cr::kWave), lds,

@@ -155,7 +155,8 @@ struct RbfTensor {
 #pragma unroll
         for (int k = 0; k < D; k++) col[k] = res[k * stride + c];
     }
-    CR_D double score(int q, const ExpEntry* tab) const {
+    // sum_k (a_ik - b_jk)^2, k ascending
+    CR_D double dist2(int q) const {
         double df = row[q][0] - col[0];
         double acc = df * df;
 #pragma unroll
@@ -163,8 +164,9 @@ struct RbfTensor {
             df = row[q][k] - col[k];
             acc = acc + df * df;
         }
-        return exp_tab<true>(neg_gamma * acc, tab);
+        return acc;
     }
+    CR_D double score(int q, const ExpEntry* tab) const { return exp_tab<true>(neg_gamma * dist2(q), tab); }
 };
 
 // Coordinate RBF on the seed-superposed frames: rows X_i - c1, columns (X_j - c2) @ R
@@ -373,7 +375,7 @@ struct DpState {
     int rowarg[R];                          // ... and its column
     uint32_t swbits[R], dtbits[R];          // decisions of the current word
     double h_diag, m1_diag;                 // row above the lane's block, previous column
-    double h_bot, m0_bot, m1_bot;           // this lane's last row, current column (handed down by DPP)
+    // (this lane's last row, current column -- h_left / m0_left / m1_left [R - 1] -- is handed down by DPP)
     double sw_max;                          // SW score: running maximum
 
     CR_D void reset_column0(double col0_m2) {   // DP border left of column 0
@@ -416,21 +418,37 @@ CR_D void dp_column(const Src& src, DpState<R>& st, const SweepParams& prm, cons
     constexpr bool DTW = (MODE & kDtw) != 0;
     constexpr bool ZG = (MODE & kZeroGap) != 0;        // x - 0.0 == x: the gap subtractions vanish
     constexpr bool NOFLOOR = ZG && Src::kNonNegative;  // all candidates >= +0: max(0, .) is the identity
-    double h_up = h_top, h_dg = st.h_diag;
-    double m0_up = m0_top, m1_up = m1_top, m1_dg = st.m1_diag;
+    // Phase 1: everything that reads the PREVIOUS column's values of the row above (the diagonal terms) and of the row
+    // itself (the horizontal gap layer), for all R rows, before any of them is overwritten: the old values die here, so
+    // the new ones can take their registers (no copies of the loop-carried state).
+    double dg[R], c1[R], m2n[R];
+    bool b2[R];
 #pragma unroll
     for (int q = 0; q < R; q++) {
         const double sc = src.score(q, tab);
+        if constexpr (SW) dg[q] = (q == 0 ? st.h_diag : st.h_left[q - 1]) + sc;
+        if constexpr (DTW) {
+            c1[q] = (q == 0 ? st.m1_diag : st.m1_left[q - 1]) + sc;
+            const double up0 = st.m1_left[q] - prm.gap_open;
+            const double up1 = st.m2_left[q] - prm.gap_extend;
+            b2[q] = up1 > up0;
+            m2n[q] = vmax(up0, up1);
+        }
+    }
+    // Phase 2: the chain down the lane's rows
+    double h_up = h_top;
+    double m0_up = m0_top, m1_up = m1_top;
+#pragma unroll
+    for (int q = 0; q < R; q++) {
         if constexpr (SW) {
             // H = max(0, diag + S, left - gap, up - gap)
-            const double dg = h_dg + sc;
             const double lf = ZG ? st.h_left[q] : st.h_left[q] - prm.sw_gap;
             const double up = ZG ? h_up : h_up - prm.sw_gap;
-            const double h = NOFLOOR ? vmax(vmax(dg, lf), up)
-                                     : vmax(vmax(vmax(0.0, dg), lf), up);
+            const double h = NOFLOOR ? vmax(vmax(dg[q], lf), up)
+                                     : vmax(vmax(vmax(0.0, dg[q]), lf), up);
             if constexpr (TRACE) {
                 // decision replayed by the traceback's equality tests (:255-277)
-                uint32_t code = (h == dg) ? 1u : (h == lf) ? 2u : 3u;
+                uint32_t code = (h == dg[q]) ? 1u : (h == lf) ? 2u : 3u;
                 code = (h > 0.0) ? code : 0u;
                 bool gt = h > st.rowmax[q];
                 if constexpr (Src::kMaskRows) {
@@ -449,7 +467,6 @@ CR_D void dp_column(const Src& src, DpState<R>& st, const SweepParams& prm, cons
                     st.sw_max = vmax(st.sw_max, h);
                 }
             }
-            h_dg = st.h_left[q];
             h_up = h;
             st.h_left[q] = h;
         }
@@ -458,34 +475,22 @@ CR_D void dp_column(const Src& src, DpState<R>& st, const SweepParams& prm, cons
             const double lo1 = m1_up - prm.gap_open;
             const bool b0 = lo1 > lo0;                  // np.argmax keeps the first maximum
             const double m0 = vmax(lo0, lo1);
-            const double up0 = st.m1_left[q] - prm.gap_open;
-            const double up1 = st.m2_left[q] - prm.gap_extend;
-            const bool b2 = up1 > up0;
-            const double m2 = vmax(up0, up1);
-            const double c1 = m1_dg + sc;
-            const bool g1 = c1 > m0;
-            const double m01 = vmax(m0, c1);
-            const bool g2 = m2 > m01;
-            const double m1 = vmax(m01, m2);
-            const uint32_t nib = (b0 ? 1u : 0u) | (g2 ? 4u : (g1 ? 2u : 0u)) | (b2 ? 8u : 0u);
+            const bool g1 = c1[q] > m0;
+            const double m01 = vmax(m0, c1[q]);
+            const bool g2 = m2n[q] > m01;
+            const double m1 = vmax(m01, m2n[q]);
+            const uint32_t nib = (b0 ? 1u : 0u) | (g2 ? 4u : (g1 ? 2u : 0u)) | (b2[q] ? 8u : 0u);
             st.dtbits[q] |= nib << sh4;
-            m1_dg = st.m1_left[q];
             m0_up = m0;
             m1_up = m1;
             st.m0_left[q] = m0;
             st.m1_left[q] = m1;
-            st.m2_left[q] = m2;
+            st.m2_left[q] = m2n[q];
         }
     }
-    if constexpr (SW) {
-        st.h_diag = h_top;
-        st.h_bot = h_up;
-    }
-    if constexpr (DTW) {
-        st.m1_diag = m1_top;
-        st.m0_bot = m0_up;
-        st.m1_bot = m1_up;
-    }
+    // (the values handed down to the next lane are the new h_left / m0_left / m1_left of the lane's last row)
+    if constexpr (SW) st.h_diag = h_top;
+    if constexpr (DTW) st.m1_diag = m1_top;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -542,8 +547,7 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
         st.reset_column0(col0_m2);
 #pragma unroll
         for (int q = 0; q < R; q++) st.swbits[q] = st.dtbits[q] = 0;
-        st.h_bot = st.m0_bot = st.m1_bot = 0.0;
-
+    
         for (int t = 0; t < T; t++) {
             if ((t & (kWave - 1)) == 0) {
                 __syncthreads();
@@ -574,10 +578,10 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
                 }
             }
             double h_top = 0.0, m0_top = 0.0, m1_top = 0.0;
-            if constexpr (SW) h_top = wave_shr1(st.h_bot, h_top0);
+            if constexpr (SW) h_top = wave_shr1(st.h_left[R - 1], h_top0);
             if constexpr (DTW) {
-                m0_top = wave_shr1(st.m0_bot, m0_top0);
-                m1_top = wave_shr1(st.m1_bot, m1_top0);
+                m0_top = wave_shr1(st.m0_left[R - 1], m0_top0);
+                m1_top = wave_shr1(st.m1_left[R - 1], m1_top0);
             }
             const int sh2 = (t & 15) * 2, sh4 = (t & 7) * 4;
 
@@ -586,10 +590,10 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
                 src.fetch_col(ring, c & (kRing - 1));
                 dp_column<R, MODE>(src, st, prm, tab, c, rowbase, n, sh2, sh4, h_top, m0_top, m1_top);
                 if (s + 1 < nstrips && lane == kWave - 1) {
-                    if constexpr (SW) hout[c & (kRing - 1)] = st.h_bot;
+                    if constexpr (SW) hout[c & (kRing - 1)] = st.h_left[R - 1];
                     if constexpr (DTW) {
-                        hout[(NB - 2) * kRing + (c & (kRing - 1))] = st.m0_bot;
-                        hout[(NB - 1) * kRing + (c & (kRing - 1))] = st.m1_bot;
+                        hout[(NB - 2) * kRing + (c & (kRing - 1))] = st.m0_left[R - 1];
+                        hout[(NB - 1) * kRing + (c & (kRing - 1))] = st.m1_left[R - 1];
                     }
                 }
             }
@@ -737,34 +741,34 @@ struct ColSweep {
         }
         eprev = 0.0;
     }
-    double cnext[D];          // features of the NEXT column (wave-uniform: SGPRs), loaded one step ahead
-
-    // The column's features are wave-uniform: scalar loads, issued one step before they are used so that their
-    // latency hides behind the previous column's arithmetic even with a single wave on the SIMD.  (Always D loads: the
-    // tensor array is allocated with D doubles of slack and the padded features are zeroed by scalar selects --
-    // conditional loads would cost a branch each.)
+    // The column's features are wave-uniform: scalar loads into SGPRs (src.col).  A step first forms the R squared
+    // distances -- the only readers of the features -- and then requests the NEXT column into the same registers, so the
+    // load's latency hides behind the exp / DP / scan arithmetic of this step even with a single wave on the SIMD, and one
+    // set of SGPRs suffices.  (Always D loads: the tensor array is allocated with D doubles of slack and the padded
+    // features are zeroed by scalar selects -- conditional loads would cost a branch each.)
     template <bool FULL>
-    CR_D void prefetch(const RbfTensor<R, D>& src, int j) {
+    CR_D void prefetch(RbfTensor<R, D>& src, int j) {
         const double* __restrict__ cg = src.cols_g;
         const int d = FULL ? D : src.d;
 #pragma unroll
         for (int k = 0; k < D; k++) {
             const double v = cg[(int64_t)j * d + k];
-            cnext[k] = (FULL || k < d) ? v : 0.0;
+            src.col[k] = (FULL || k < d) ? v : 0.0;
         }
     }
-    // Column j (prefetch<FULL>(src, j) has been called; `jn` = the column to prefetch now, any valid column).  FULL: the
+    // Column j (prefetch<FULL>(src, j) has been called; `jn` = the column to request now, any valid column).  FULL: the
     // stored tensor width equals D (no padded features).  `top`: H of the row above the strip in this column
     // (wave-uniform; only read when TOP).
     template <bool FULL, bool TOP>
     CR_D void step(RbfTensor<R, D>& src, const ExpEntry* tab, int j, int jn, double top) {
+        double acc[R];
 #pragma unroll
-        for (int k = 0; k < D; k++) src.col[k] = cnext[k];
+        for (int q = 0; q < R; q++) acc[q] = src.dist2(q);
         prefetch<FULL>(src, jn);
         double dg[R], p[R];
 #pragma unroll
         for (int q = 0; q < R; q++) {
-            const double sc = src.score(q, tab);
+            const double sc = exp_tab<true>(src.neg_gamma * acc[q], tab);
             dg[q] = (q == 0 ? eprev : hprev[q - 1]) + sc;
             const double b = vmax(dg[q], hprev[q]);
             p[q] = q == 0 ? b : vmax(p[q - 1], b);
@@ -1160,7 +1164,6 @@ CR_D void sweep_team(Src& src, const int n, const int m, const SweepParams prm, 
     st.reset_column0(col0_m2);
 #pragma unroll
     for (int q = 0; q < R; q++) st.swbits[q] = st.dtbits[q] = 0;
-    st.h_bot = st.m0_bot = st.m1_bot = 0.0;
 
     const int G = kTeamDelay * (nstrips - 1) + m + kWave - 1;
     for (int g = 0; g < G; g++) {
@@ -1185,10 +1188,10 @@ CR_D void sweep_team(Src& src, const int n, const int m, const SweepParams prm, 
             }
         }
         double h_top = 0.0, m0_top = 0.0, m1_top = 0.0;
-        if constexpr (SW) h_top = wave_shr1(st.h_bot, h_top0);
+        if constexpr (SW) h_top = wave_shr1(st.h_left[R - 1], h_top0);
         if constexpr (DTW) {
-            m0_top = wave_shr1(st.m0_bot, m0_top0);
-            m1_top = wave_shr1(st.m1_bot, m1_top0);
+            m0_top = wave_shr1(st.m0_left[R - 1], m0_top0);
+            m1_top = wave_shr1(st.m1_left[R - 1], m1_top0);
         }
         const int sh2 = (t & 15) * 2, sh4 = (t & 7) * 4;
 
@@ -1197,10 +1200,10 @@ CR_D void sweep_team(Src& src, const int n, const int m, const SweepParams prm, 
             src.fetch_col(ring, c & (kRing - 1));
             dp_column<R, MODE>(src, st, prm, tab, c, rowbase, n, sh2, sh4, h_top, m0_top, m1_top);
             if (w + 1 < nstrips && lane == kWave - 1) {
-                if constexpr (SW) edge_out[c & (kEdgeRing - 1)] = st.h_bot;
+                if constexpr (SW) edge_out[c & (kEdgeRing - 1)] = st.h_left[R - 1];
                 if constexpr (DTW) {
-                    edge_out[(NB - 2) * kEdgeRing + (c & (kEdgeRing - 1))] = st.m0_bot;
-                    edge_out[(NB - 1) * kEdgeRing + (c & (kEdgeRing - 1))] = st.m1_bot;
+                    edge_out[(NB - 2) * kEdgeRing + (c & (kEdgeRing - 1))] = st.m0_left[R - 1];
+                    edge_out[(NB - 1) * kEdgeRing + (c & (kEdgeRing - 1))] = st.m1_left[R - 1];
                 }
             }
         }
@@ -1373,7 +1376,6 @@ CR_D void sweep_wide(Src& src, const int n, const int m, const SweepParams prm, 
     st.reset_column0(col0_m2);
 #pragma unroll
     for (int q = 0; q < R; q++) st.swbits[q] = st.dtbits[q] = 0;
-    st.h_bot = st.m0_bot = st.m1_bot = 0.0;
 
     const int G = lag * (nstrips - 1) + m + kWave - 1;
     int until_sync = 0;
@@ -1398,10 +1400,10 @@ CR_D void sweep_wide(Src& src, const int n, const int m, const SweepParams prm, 
             }
         }
         double h_top = 0.0, m0_top = 0.0, m1_top = 0.0;
-        if constexpr (SW) h_top = wave_shr1(st.h_bot, h_top0);
+        if constexpr (SW) h_top = wave_shr1(st.h_left[R - 1], h_top0);
         if constexpr (DTW) {
-            m0_top = wave_shr1(st.m0_bot, m0_top0);
-            m1_top = wave_shr1(st.m1_bot, m1_top0);
+            m0_top = wave_shr1(st.m0_left[R - 1], m0_top0);
+            m1_top = wave_shr1(st.m1_left[R - 1], m1_top0);
         }
         const int sh2 = (t & 15) * 2, sh4 = (t & 7) * 4;
 
@@ -1409,10 +1411,10 @@ CR_D void sweep_wide(Src& src, const int n, const int m, const SweepParams prm, 
             src.fetch_resident(res, stride, c);
             dp_column<R, MODE>(src, st, prm, tab, c, rowbase, n, sh2, sh4, h_top, m0_top, m1_top);
             if (w + 1 < nstrips && lane == kWave - 1) {
-                if constexpr (SW) edge_out[c & (kWideEdge - 1)] = st.h_bot;
+                if constexpr (SW) edge_out[c & (kWideEdge - 1)] = st.h_left[R - 1];
                 if constexpr (DTW) {
-                    edge_out[(NB - 2) * kWideEdge + (c & (kWideEdge - 1))] = st.m0_bot;
-                    edge_out[(NB - 1) * kWideEdge + (c & (kWideEdge - 1))] = st.m1_bot;
+                    edge_out[(NB - 2) * kWideEdge + (c & (kWideEdge - 1))] = st.m0_left[R - 1];
+                    edge_out[(NB - 1) * kWideEdge + (c & (kWideEdge - 1))] = st.m1_left[R - 1];
                 }
             }
         }
