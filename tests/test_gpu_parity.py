@@ -173,6 +173,53 @@ def test_dtw_align_batch_vs_oracle(oracle):
         dtw.dtw_align_batch([(np.arange(3), np.array([0, -1, 2]), np.ones((3, 3)))])
 
 
+def test_explicit_batch_streaming_kernels_vs_oracle(oracle):
+    """Lists in which EVERY problem has contiguous columns take the streaming sweep (per-lane rings of aligned 64-byte
+    blocks): ragged shapes, several strips of every rows-per-lane choice, windows of larger matrices (row starts at every
+    alignment), negative scores -- smith_waterman_score with gap != 0 and dtw_align with alignments, cell-exact."""
+    from caretta_amd import dynamic_time_warping as dtw
+    rng = np.random.default_rng(13)
+    problems = []
+    for n, m in [(1, 1), (2, 9), (63, 64), (64, 63), (129, 300), (300, 300), (257, 77), (500, 513), (7, 1100), (333, 8)]:
+        problems.append((np.arange(n), np.arange(m), rng.uniform(size=(n, m)) ** 3 - 0.15))
+    for shift in range(9):                                # windows: every alignment of the row starts
+        big = rng.normal(size=(70, 101 + shift))
+        problems.append((np.arange(5, 65), np.arange(shift, 90 + shift), big))
+    batch = dtw.ExplicitBatch(problems)
+    for gap in (0.3, 0.0):
+        got = batch.smith_waterman_scores(gap)
+        want = np.array([oracle.smith_waterman_score(a, b, s, gap) for a, b, s in problems])
+        assert np.array_equal(got, want), (gap, np.nonzero(got != want)[0])
+    for go, ge in ((1.0, 0.01), (0.0, 0.0), (0.5, 0.5)):
+        for (a, b, s), (a1, a2, score) in zip(problems, batch.dtw_align(go, ge)):
+            o1, o2, osc = oracle.dtw_align(a, b, s, go, ge)
+            assert np.array_equal(a1, o1) and np.array_equal(a2, o2) and score == osc, (len(a), len(b), go, ge)
+    batch.close()
+
+
+def test_fetch_variants_agree(ctx):
+    """cr_batch_fetch (int64 rows) and cr_batch_fetch_i32 into page-locked arrays: same records, same rows, also when the
+    launch order differs from the caller's pair order (ragged batch, both orientations)."""
+    from caretta_amd import engine
+    fam = synthetic.make_family(9, 260, seed=515, ragged=True, clades=2)
+    for k, s in enumerate(fam):
+        cut = [260, 30, 100, 200, 64, 150, 90, 256, 5][k]
+        s.coordinates, s.tensors = s.coordinates[:cut].copy(), s.tensors[:cut].copy()
+    coords, tensors, offsets = synthetic.pack(fam)
+    pairs = np.vstack([engine.all_pairs(9), engine.all_pairs(9)[:, ::-1]])
+    batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
+    batch.run(engine.make_params())
+    res, aln = batch.fetch()
+    res32, aln32 = batch.fetch(pinned=True)
+    assert aln32.dtype == np.int32 and res.tobytes() == res32.tobytes() and np.array_equal(aln, aln32)
+    res_only, none = batch.fetch(want_alignments=False, pinned=True)
+    assert none is None and res_only.tobytes() == res.tobytes()
+    again, _ = batch.fetch(pinned=True)                   # the page-locked arrays are reused
+    assert again is res32 or np.shares_memory(again, res32)
+    batch.close()
+    assert res32.tobytes() == res.tobytes()               # ... and outlive the batch
+
+
 def test_plugin_pairwise_matrix_runs_batched(oracle):
     """A third-party SequenceBase plugin (multiple_alignment.py:109-127): make_pairwise_matrix = the reference's loop of
     smith_waterman_score over the plugin's own score matrices, computed many matrices per launch."""
