@@ -1,16 +1,21 @@
 // gfx950 kernels of the pairwise alignment path.
 //
-// The DP fills (Smith-Waterman and the 3-layer affine "DTW") run as a STRIP-MINED, TIME-SKEWED
-// WAVEFRONT: one 64-lane wave per structure pair, lane l owns R consecutive rows of the current
-// strip, and at step t it fills column c = t - l of those rows.  The values of the row above a
-// lane's block arrive from lane l-1 by DPP (wave_shr:1), the values to the left stay in registers,
-// a strip's last row is handed to the next strip through LDS.  The residue score S(i,j) is never
-// materialised: the RBF is evaluated in the sweep from row features held in registers and column
-// features streamed through a 128-column LDS ring filled by coalesced HBM reads.  Backtrack
-// decisions are packed (2 bit/cell SW, 4 bit/cell DTW) in the same skewed order and written with
-// 256-byte coalesced stores; the traceback, Kabsch and metric phase follows in the same wave (wave-uniform
-// walk through an LDS window of the decision words, ordered cooperative sums).  Launches with few pairs use
-// the team variants: one workgroup of four waves per pair, one wave per strip (sweep_team).
+// Two kinds of DP fill:
+//  * COLUMN SWEEP (sweep_cols, sweep_cols_team, sweep_cols_score*): Smith-Waterman with gap 0 -- the reference's only
+//    use of smith_waterman / smith_waterman_score in the pipeline -- is monotone along rows and columns, so the `up`
+//    dependency of a column is a prefix maximum: all 64 lanes (R rows each) work on the SAME column every step, a DPP
+//    max-scan (row_shr 1/2/4/8, row_bcast 15/31) resolves the dependency, the column's features are wave-uniform and come
+//    through scalar loads.  No pipeline ramp, every value bit-identical to the cell-by-cell evaluation.
+//  * TIME-SKEWED WAVEFRONT (sweep, sweep_team, sweep_wide): the 3-layer affine "DTW" subtracts rounded gap penalties along
+//    both axes (no exact scan), so lane l owns R consecutive rows of the current strip and at step t fills column
+//    c = t - l of those rows.  The values of the row above a lane's block arrive from lane l-1 by DPP (wave_shr:1), the
+//    values to the left stay in registers, a strip's last row is handed to the next strip through LDS / HBM.
+// The residue score S(i,j) is never materialised: the RBF is evaluated in the sweep from row features held in registers
+// and column features streamed through SGPRs or a 128-column LDS ring.  Backtrack decisions are packed (2 bit/cell SW,
+// 4 bit/cell DTW) in the order the sweep produces them and written with 256-byte coalesced stores; the traceback, Kabsch
+// and metric phase follows in the same wave (Walker: wave-uniform walk on a register-resident block of decision words,
+// whole diagonal runs per ballot; position-ordered cooperative sums).  Launches with few pairs use one WORKGROUP per
+// pair, one wave per strip: four waves (sweep_team) or up to sixteen (sweep_wide, sweep_cols_team).
 //
 // Reference semantics: dynamic_time_warping.py (fills, tie-breaks), score_functions.py (RBF),
 // superposition_functions.py (Kabsch), multiple_alignment.py:321-349, 1028-1054.
