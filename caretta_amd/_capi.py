@@ -94,6 +94,7 @@ SIGNATURES = {
     "cr_mean_axis0": [_vp, _i64, _i64, _vp],
     "cr_get_common_positions": [_vp, _vp, _i64, _vp, _vp, C.POINTER(C.c_int64)],
     "cr_neighbor_joining": [_vp, _i64, _vp, _vp],
+    "cr_neighbor_joining_device": [_vp, _vp, _i64, _vp, _vp],
     "cr_assemble_matrix": [_vp, _vp, _i64, _i64, _vp],
 }
 

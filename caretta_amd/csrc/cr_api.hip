@@ -9,6 +9,7 @@
 #include <thread>
 #include <functional>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -229,6 +230,14 @@ struct cr_context {
     // run side by side they fill each other's partial last rounds (created on first use).
     std::vector<hipStream_t> side;
     std::vector<hipEvent_t> sync_ev;
+    // page-locked landing area for small results of single calls (a first copy into pageable memory costs
+    // milliseconds); grown on demand by host_landing()
+    void* landing = nullptr;
+    size_t landing_bytes = 0;
+    // page-locked ring for transfers between the device and the caller's PAGEABLE memory (staged_copy)
+    void* ring = nullptr;
+    hipEvent_t ring_ev[2] = {nullptr, nullptr};
+    bool ring_busy[2] = {false, false};
 };
 
 struct cr_batch {
@@ -281,6 +290,107 @@ int set_device(cr_context* ctx) {
     CR_REQUIRE(ctx != nullptr, "null context");
     CR_HIP(hipSetDevice(ctx->device));
     g_dirty = true;
+    return CR_OK;
+}
+
+// at least `bytes` of page-locked host memory owned by the context
+int host_landing(cr_context* ctx, size_t bytes, void** out) {
+    if (ctx->landing_bytes < bytes) {
+        if (ctx->landing) (void)hipHostFree(ctx->landing);
+        ctx->landing = nullptr;
+        ctx->landing_bytes = 0;
+        const size_t want = std::max<size_t>(bytes, 64 * 1024);
+        CR_HIP(hipHostMalloc(&ctx->landing, want, hipHostMallocDefault));
+        ctx->landing_bytes = want;
+    }
+    *out = ctx->landing;
+    return CR_OK;
+}
+
+// Copies between the device and memory the CALLER owns.  Handing pageable memory to hipMemcpyAsync makes the runtime
+// pin the pages, copy, and unpin them later: about 1 GB/s, and the deferred unpin stalls the next transfer (measured
+// with rocprofv3 --hip-trace: 18 ms for the 16 MB of a 512-structure batch, 21 ms for the 2 MB matrix of the
+// neighbor joining right behind it).  So pageable memory is staged through a page-locked ring of two slots, filled /
+// drained by memcpy (~10 GB/s) while the other slot is on the wire.  Page-locked caller memory (cr_host_alloc) and
+// small blocks go straight through.  Uploads return with the last slots still in flight (the ring is guarded by
+// events); downloads return when the data is in `dst`.
+constexpr size_t kRingSlot = (size_t)8 << 20;
+constexpr size_t kStageFrom = (size_t)64 << 10;
+
+bool is_page_locked(const void* p) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError();                                   // unknown to the runtime: ordinary pageable memory
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+
+int ring_slot(cr_context* ctx, int slot, char** out) {
+    if (!ctx->ring) {
+        CR_HIP(hipHostMalloc(&ctx->ring, 2 * kRingSlot, hipHostMallocDefault));
+        for (hipEvent_t& e : ctx->ring_ev) CR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    if (ctx->ring_busy[slot]) {
+        CR_HIP(hipEventSynchronize(ctx->ring_ev[slot]));
+        ctx->ring_busy[slot] = false;
+    }
+    *out = static_cast<char*>(ctx->ring) + (size_t)slot * kRingSlot;
+    return CR_OK;
+}
+
+int upload_async(cr_context* ctx, void* dst, const void* src, size_t bytes) {
+    if (bytes < kStageFrom || is_page_locked(src)) {
+        CR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return CR_OK;
+    }
+    int slot = 0;
+    for (size_t off = 0; off < bytes; off += kRingSlot, slot ^= 1) {
+        const size_t len = std::min(kRingSlot, bytes - off);
+        char* stage = nullptr;
+        int rc = ring_slot(ctx, slot, &stage);
+        if (rc) return rc;
+        std::memcpy(stage, static_cast<const char*>(src) + off, len);
+        CR_HIP(hipMemcpyAsync(static_cast<char*>(dst) + off, stage, len, hipMemcpyHostToDevice, ctx->stream));
+        CR_HIP(hipEventRecord(ctx->ring_ev[slot], ctx->stream));
+        ctx->ring_busy[slot] = true;
+    }
+    return CR_OK;
+}
+
+// device -> caller memory; complete on return (wait = false: a direct copy may still be in flight, the caller waits)
+int download(cr_context* ctx, void* dst, const void* src, size_t bytes, bool wait = true) {
+    if (bytes < kStageFrom || is_page_locked(dst)) {
+        CR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        if (wait) CR_HIP(hipStreamSynchronize(ctx->stream));
+        return CR_OK;
+    }
+    // slot k is on the wire while slot k - 1 is drained into dst
+    size_t prev_off = 0, prev_len = 0;
+    int slot = 0;
+    char* prev_stage = nullptr;
+    for (size_t off = 0; off < bytes; off += kRingSlot, slot ^= 1) {
+        const size_t len = std::min(kRingSlot, bytes - off);
+        char* stage = nullptr;
+        int rc = ring_slot(ctx, slot, &stage);
+        if (rc) return rc;
+        CR_HIP(hipMemcpyAsync(stage, static_cast<const char*>(src) + off, len, hipMemcpyDeviceToHost, ctx->stream));
+        CR_HIP(hipEventRecord(ctx->ring_ev[slot], ctx->stream));
+        ctx->ring_busy[slot] = true;
+        if (prev_stage) {
+            CR_HIP(hipEventSynchronize(ctx->ring_ev[slot ^ 1]));
+            ctx->ring_busy[slot ^ 1] = false;
+            std::memcpy(static_cast<char*>(dst) + prev_off, prev_stage, prev_len);
+        }
+        prev_stage = stage;
+        prev_off = off;
+        prev_len = len;
+    }
+    if (prev_stage) {
+        CR_HIP(hipEventSynchronize(ctx->ring_ev[slot ^ 1]));
+        ctx->ring_busy[slot ^ 1] = false;
+        std::memcpy(static_cast<char*>(dst) + prev_off, prev_stage, prev_len);
+    }
     return CR_OK;
 }
 
@@ -547,9 +657,9 @@ int padded_width(int64_t d) {
 
 }  // namespace
 
-// Shared body of the two fetch entry points: pack on the device (caller's order and layout), then plain copies
-// straight into the caller's arrays -- DMA speed when those are page-locked (cr_host_alloc), staged by the driver
-// otherwise.
+// Shared body of the two fetch entry points: pack on the device (caller's order and layout), then copies into the
+// caller's arrays -- straight DMA when those are page-locked (cr_host_alloc), through the context's page-locked ring
+// otherwise (download()).
 template <class T>
 int fetch_packed(cr_batch* b, cr_pair_result* results, T* aln, int64_t aln_stride) {
     CR_REQUIRE(b != nullptr, "null batch");
@@ -579,9 +689,14 @@ int fetch_packed(cr_batch* b, cr_pair_result* results, T* aln, int64_t aln_strid
                   aln ? reinterpret_cast<T*>(b->aln_packed.p) : (T*)nullptr);
         CR_HIP(hipGetLastError());
     }
-    if (results)
-        CR_HIP(hipMemcpyAsync(results, permute ? b->res_packed.p : b->res.p, sizeof(cr_pair_result) * np, hipMemcpyDeviceToHost, st));
-    if (aln) CR_HIP(hipMemcpyAsync(aln, b->aln_packed.p, aln_bytes, hipMemcpyDeviceToHost, st));
+    if (results) {
+        rc = download(b->ctx, results, permute ? (const void*)b->res_packed.p : (const void*)b->res.p, sizeof(cr_pair_result) * np, false);
+        if (rc) return rc;
+    }
+    if (aln) {
+        rc = download(b->ctx, aln, b->aln_packed.p, aln_bytes, false);
+        if (rc) return rc;
+    }
     CR_HIP(hipStreamSynchronize(st));
     return CR_OK;
 }
@@ -654,6 +769,12 @@ int cr_context_destroy(cr_context* ctx) {
     for (auto& e : ctx->sync_ev) (void)hipEventDestroy(e);
     for (auto& st : ctx->side) (void)hipStreamDestroy(st);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->landing) (void)hipHostFree(ctx->landing);
+    if (ctx->ring) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipHostFree(ctx->ring);
+        for (hipEvent_t e : ctx->ring_ev) (void)hipEventDestroy(e);
+    }
     delete ctx;
     return CR_OK;
 }
@@ -716,15 +837,17 @@ int cr_batch_create(cr_context* ctx, const double* coords, const double* tensors
     hipError_t e = b->coords.ensure((size_t)b->total * 3);
     // (+ d_pad doubles of slack: the column sweep always reads a padded row of features, cr_kernels.h sweep_cols)
     if (e == hipSuccess) e = b->tensors.ensure((size_t)b->total * d + (size_t)b->d_pad);
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(b->coords.p, coords, sizeof(double) * b->total * 3, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(b->tensors.p, tensors, sizeof(double) * b->total * d, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         delete b;
         return fail(e == hipErrorOutOfMemory ? CR_ERR_MEMORY : CR_ERR_HIP,
-                    std::string("uploading structures: ") + hipGetErrorString(e));
+                    std::string("allocating structures: ") + hipGetErrorString(e));
+    }
+    int up = upload_async(ctx, b->coords.p, coords, sizeof(double) * b->total * 3);
+    if (!up) up = upload_async(ctx, b->tensors.p, tensors, sizeof(double) * b->total * d);
+    if (!up && hipStreamSynchronize(ctx->stream) != hipSuccess) up = fail(CR_ERR_HIP, "uploading structures");
+    if (up) {
+        delete b;
+        return up;
     }
     *out = b;
     return CR_OK;
@@ -1062,30 +1185,36 @@ int cr_batch_fetch_scores(cr_batch* b, double* sw, uint32_t* flags) {
     // gather the field on the device, then one contiguous copy (8 or 4 bytes per pair instead of 160)
     hipStream_t st = b->ctx->stream;
     const size_t np = (size_t)b->npairs;
+    // both fields land in the context's page-locked area with one wait (a copy straight into the caller's pageable
+    // arrays makes the runtime pin and unpin them, which stalls whatever touches the device next)
+    void* land = nullptr;
+    rc = host_landing(b->ctx, np * (sizeof(double) + sizeof(uint32_t)), &land);
+    if (rc) return rc;
+    double* h_sw = static_cast<double*>(land);
+    uint32_t* h_flags = reinterpret_cast<uint32_t*>(h_sw + np);
+    DevBuf<uint32_t> stage;
     if (sw) {
         CR_HIP(b->sw_stage.ensure(np));
         CR_HIP(hipMemcpy2DAsync(b->sw_stage.p, sizeof(double), reinterpret_cast<const char*>(b->res.p) + offsetof(cr_pair_result, sw),
                                 sizeof(cr::PairResult), sizeof(double), np, hipMemcpyDeviceToDevice, st));
-        CR_HIP(hipMemcpyAsync(sw, b->sw_stage.p, sizeof(double) * np, hipMemcpyDeviceToHost, st));
-        if (b->reordered) {                           // launch order -> the caller's order
-            CR_HIP(hipStreamSynchronize(st));
-            std::vector<double> tmp(sw, sw + np);
-            for (size_t k = 0; k < np; k++) sw[b->order[k]] = tmp[k];
-        }
+        CR_HIP(hipMemcpyAsync(h_sw, b->sw_stage.p, sizeof(double) * np, hipMemcpyDeviceToHost, st));
     }
     if (flags) {
-        DevBuf<uint32_t> stage;
         CR_HIP(stage.ensure(np));
         CR_HIP(hipMemcpy2DAsync(stage.p, sizeof(uint32_t), reinterpret_cast<const char*>(b->res.p) + offsetof(cr_pair_result, flags),
                                 sizeof(cr::PairResult), sizeof(uint32_t), np, hipMemcpyDeviceToDevice, st));
-        CR_HIP(hipMemcpyAsync(flags, stage.p, sizeof(uint32_t) * np, hipMemcpyDeviceToHost, st));
-        CR_HIP(hipStreamSynchronize(st));
-        if (b->reordered) {
-            std::vector<uint32_t> tmp(flags, flags + np);
-            for (size_t k = 0; k < np; k++) flags[b->order[k]] = tmp[k];
-        }
+        CR_HIP(hipMemcpyAsync(h_flags, stage.p, sizeof(uint32_t) * np, hipMemcpyDeviceToHost, st));
     }
     CR_HIP(hipStreamSynchronize(st));
+    // launch order -> the caller's order
+    if (sw) {
+        if (b->reordered) for (size_t k = 0; k < np; k++) sw[b->order[k]] = h_sw[k];
+        else std::memcpy(sw, h_sw, sizeof(double) * np);
+    }
+    if (flags) {
+        if (b->reordered) for (size_t k = 0; k < np; k++) flags[b->order[k]] = h_flags[k];
+        else std::memcpy(flags, h_flags, sizeof(uint32_t) * np);
+    }
     return CR_OK;
 }
 
@@ -1111,3 +1240,4 @@ int cr_batch_destroy(cr_batch* b) {
 #include "cr_dropins.h"
 #include "cr_progressive.h"
 #include "cr_explicit_batch.h"
+#include "cr_nj_device.h"

@@ -458,9 +458,7 @@ int cr_make_score_matrix(cr_context* ctx, const double* a, int64_t n, const doub
     dim3 block(64, 4), grid((unsigned)((m + 63) / 64), (unsigned)((n + 3) / 4));
     CR_LAUNCH(cr::k_score_matrix, grid, block, 0, ctx->stream, da.p, (int)n, db.p, (int)m, (int)k, -gamma, ds.p);
     CR_HIP(hipGetLastError());
-    CR_HIP(hipMemcpyAsync(S, ds.p, sizeof(double) * (size_t)n * m, hipMemcpyDeviceToHost, ctx->stream));
-    CR_HIP(hipStreamSynchronize(ctx->stream));
-    return CR_OK;
+    return download(ctx, S, ds.p, sizeof(double) * (size_t)n * m);
 }
 
 int cr_protein_score_function(cr_context* ctx, const double* coords_i, const double* tensors_i, int64_t n,
@@ -496,11 +494,10 @@ int cr_protein_score_function(cr_context* ctx, const double* coords_i, const dou
             e = hipGetLastError();
         }
         cr::Transform tr;
-        if (e == hipSuccess) e = hipMemcpyAsync(S, ds.p, sizeof(double) * (size_t)n * m, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(&tr, b->xf.p, sizeof(tr), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = fail(CR_ERR_HIP, std::string("score_function: ") + hipGetErrorString(e));
-        else if (flags) *flags = tr.flags;
+        else rc = download(ctx, S, ds.p, sizeof(double) * (size_t)n * m);
+        if (!rc && flags) *flags = tr.flags;
     }
     cr_batch_destroy(b);
     return rc;

@@ -541,7 +541,7 @@ int cr_explicit_batch_create(cr_context* ctx, const double* S, int64_t s_elems, 
     CR_HIP(b->S.ensure((size_t)s_elems + kSlackFront + kSlackBack));
     CR_HIP(hipMemsetAsync(b->S.p, 0, sizeof(double) * kSlackFront, ctx->stream));
     CR_HIP(hipMemsetAsync(b->S.p + kSlackFront + s_elems, 0, sizeof(double) * kSlackBack, ctx->stream));
-    CR_HIP(hipMemcpyAsync(b->S.p + kSlackFront, S, sizeof(double) * (size_t)s_elems, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = upload_async(ctx, b->S.p + kSlackFront, S, sizeof(double) * (size_t)s_elems))) return rc;
     if ((rc = upload(b->seqs, h_seq.data(), h_seq.size(), ctx->stream))) return rc;
     if ((rc = upload(b->probs, hp.data(), hp.size(), ctx->stream))) return rc;
     CR_HIP(b->hand.ensure((size_t)hand_off));

@@ -1,0 +1,485 @@
+// Neighbor joining of a SYMMETRIC distance matrix on the device (neighbor_joining.py:19-157), included by cr_api.hip
+// after cr_dropins.h.  The guide tree is the one sequential step between the P x P matrix and the progressive
+// alignment; at P = 512 the host implementation (cr_neighbor_joining) takes as long as half the matrix.
+//
+// Same values as the reference, bit for bit:
+//  * a row sum is ONE lane's left-to-right sum over the current node order starting from +0.0 (numba's np.sum,
+//    :117-118), formed once per iteration instead of once per (i, j);
+//  * Q(i, j) = ((n - 2) * D[i][j] - sum_i) - sum_j is evaluated for every ORDERED pair, and the first minimum in
+//    row-major order wins (:98-121, strict <): each lane scans its pairs in that order, lanes, waves and workgroups
+//    are combined by (Q, i, j) lexicographically;
+//  * the reference rebuilds the matrix with the new node FIRST and the survivors behind it in their old order
+//    (:60-83).  Here nothing moves: the matrix has a row and a column for every node id (2P - 3 of them), and `order`
+//    lists the node ids in the reference's order.
+//
+// Shape.  One persistent launch of up to kNjMaxGroups workgroups (a fraction of the chip: the work per join is O(n^2)
+// loads and an n-long chain of dependent adds), two grid barriers per join:
+//    A  row sums of the NEW order.  A wave owns a few rows; it loads them 64 columns per instruction (a row sum reads
+//       the ROW, gathered through `order`), parks 256 columns per row in LDS and lets one lane per row add them in
+//       order while the next 256 columns are in flight.  The new node's row does not exist yet: its entries
+//       v_t = 0.5 * ((D[i][t] + D[j][t]) - D[i][j]) are computed where they are needed -- by the wave that owns the
+//       new row (which also writes the new row and column) and, for column 0 of every other row, by that row's wave --
+//       from rows i and j, which nobody writes.  So no barrier separates the join from the sums.
+//    -- grid barrier --
+//    B  every wave scans Q over its rows and publishes its first minimum.
+//    -- grid barrier --
+//    C  every workgroup reduces the published minima (same data, same order: same answer), updates its own copy of
+//       `order`, and goes on with A.
+// The matrix is symmetric and stays so (both triangles receive the same rounded value), which is what lets A read rows
+// i and j where the reference reads columns; cr_neighbor_joining_device checks the symmetry of its input and hands
+// anything else to the host implementation.
+#pragma once
+
+namespace cr {
+
+constexpr int kNjGroupThreads = 256;
+constexpr int kNjGroupWaves = kNjGroupThreads / 64;
+constexpr int kNjMaxGroups = 64;
+constexpr int kNjRowsPerWave = 8;          // rows of one wave (register staging: 4 doubles per row and lane)
+constexpr int kNjChunk = 256;              // columns parked in LDS per step
+constexpr int kNjStride = kNjChunk + 2;    // row pitch of the parking area: rows two bank pairs apart
+constexpr int kNjMaxNodes = kNjMaxGroups * kNjGroupWaves * kNjRowsPerWave;      // 2048
+constexpr unsigned kNjSpinLimit = 1u << 24;
+
+struct NjCandidate {
+    double q, d;           // Q(i, j) and D[i][j]
+    int i, j;
+    int pad[2];
+};
+
+struct NjGridState {
+    unsigned arrived;      // monotone: += 1 per workgroup and barrier
+    unsigned abort;        // a workgroup gave up waiting (a lost workgroup must not hang the device)
+};
+
+inline size_t nj_lds_bytes(int P, int rows_per_wave) {
+    return sizeof(double) * ((size_t)kNjGroupWaves * rows_per_wave * kNjStride + (size_t)P) + sizeof(int) * 2 * (size_t)P;
+}
+
+CR_D bool nj_before(double q, int i, int j, double q2, int i2, int j2) {
+    return q < q2 || (q == q2 && (i < i2 || (i == i2 && j < j2)));
+}
+
+CR_D void nj_wave_first_min(double& q, double& d, int& i, int& j) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        const double q2 = __shfl_xor(q, o), d2 = __shfl_xor(d, o);
+        const int i2 = __shfl_xor(i, o), j2 = __shfl_xor(j, o);
+        if (nj_before(q2, i2, j2, q, i, j)) {
+            q = q2;
+            d = d2;
+            i = i2;
+            j = j2;
+        }
+    }
+}
+
+// All workgroups of the launch meet here; what they wrote before is visible to all after.  false: somebody timed out.
+CR_D bool nj_grid_sync(NjGridState* gs, unsigned& target, int* ok) {
+    target += gridDim.x;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_fetch_add(&gs->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool good = true;
+        unsigned spins = 0;
+        while (__hip_atomic_load(&gs->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kNjSpinLimit || __hip_atomic_load(&gs->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(&gs->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                good = false;
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *ok = good ? 1 : 0;
+    }
+    __syncthreads();
+    return *ok != 0;
+}
+
+// Row sums of the order `order[0 .. n)` into rs_g.  JOIN: position 0 is the new node `order[0]`, not in memory yet,
+// formed from rows pi and pj; the wave that owns position 0 also writes its row and column.
+template <bool JOIN>
+CR_D void nj_row_sums(double* D, int W, const int* order, int n, int rows_per_wave, double* stage, double* rs_g, int pi,
+                      int pj, double dij) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int waves_total = gridDim.x * kNjGroupWaves, gw = blockIdx.x * kNjGroupWaves + wave;
+    if (gw >= n) return;                                    // no row for this wave (rows are dealt round robin)
+    double* park = stage + (size_t)wave * rows_per_wave * kNjStride;
+    const int my_rows = min(rows_per_wave, (n - gw + waves_total - 1) / waves_total);
+    auto entry_of_new = [&](int p) { return 0.5 * ((D[(size_t)pi * W + p] + D[(size_t)pj * W + p]) - dij); };
+    // element t of the row of node pr at position r
+    auto element = [&](int r, int pr, int t) -> double {
+        if (t >= n) return 0.0;
+        const int pt = order[t];
+        if (JOIN) {
+            if (r == 0) return t == 0 ? 0.0 : entry_of_new(pt);
+            if (t == 0) return entry_of_new(pr);
+        }
+        return D[(size_t)pr * W + pt];
+    };
+    int prow[kNjRowsPerWave];
+#pragma unroll
+    for (int u = 0; u < kNjRowsPerWave; u++) prow[u] = u < my_rows ? order[gw + u * waves_total] : 0;
+    double x[kNjRowsPerWave][4];
+    auto load = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < kNjRowsPerWave; u++)
+            if (u < my_rows) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) x[u][e] = element(gw + u * waves_total, prow[u], c0 + lane + 64 * e);
+            }
+    };
+    double s = 0.0;
+    load(0);
+    for (int c0 = 0; c0 < n; c0 += kNjChunk) {
+#pragma unroll
+        for (int u = 0; u < kNjRowsPerWave; u++)
+            if (u < my_rows) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) park[u * kNjStride + lane + 64 * e] = x[u][e];
+            }
+        if (JOIN && gw == 0) {                              // the new node's row and column (its diagonal 0 included)
+            const int fresh = prow[0];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int t = c0 + lane + 64 * e;
+                if (t < n) {
+                    const int pt = order[t];
+                    D[(size_t)fresh * W + pt] = x[0][e];
+                    D[(size_t)pt * W + fresh] = x[0][e];
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (c0 + kNjChunk < n) load(c0 + kNjChunk);
+        if (lane < my_rows) {
+            // columns past n are parked as +0.0, and a sum that starts at +0.0 is never -0.0: adding them changes nothing,
+            // so the chain runs in blocks of 8 with the next block's LDS reads under the current block's adds
+            const double* row = park + lane * kNjStride;
+            const int cnt = (min(kNjChunk, n - c0) + 7) & ~7;
+            double cur[8], nxt[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) cur[k] = row[k];
+            for (int t = 0; t < cnt; t += 8) {
+                if (t + 8 < cnt) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) nxt[k] = row[t + 8 + k];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) s += cur[k];
+#pragma unroll
+                for (int k = 0; k < 8; k++) cur[k] = nxt[k];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (lane < my_rows) rs_g[gw + lane * waves_total] = s;
+}
+
+__global__ __launch_bounds__(kNjGroupThreads) void k_neighbor_joining(const double* __restrict__ dense, double* D, int W, int P, int rows_per_wave,
+                                                                      double* rs_g, NjCandidate* cand, NjGridState* gs,
+                                                                      unsigned long long* __restrict__ tree,
+                                                                      double* __restrict__ bl, long long* prof) {
+    extern __shared__ double nj_lds[];
+    // prof (diagnostic, else null): shader-clock cycles workgroup 0 spent in A, barrier, B, barrier, C
+    long long clk = 0;
+    auto lap = [&](int k) {
+        if (prof && blockIdx.x == 0 && threadIdx.x == 0) {
+            const long long now = __builtin_readcyclecounter();
+            if (k >= 0) prof[k] += now - clk;
+            clk = now;
+        }
+    };
+    double* stage = nj_lds;                                                 // [waves][rows_per_wave][kNjStride]
+    double* rs = stage + (size_t)kNjGroupWaves * rows_per_wave * kNjStride; // row sum by position
+    int* order = reinterpret_cast<int*>(rs + P);                            // node id (= matrix row) by position, two copies
+    __shared__ double red_q[kNjGroupWaves], red_d[kNjGroupWaves];
+    __shared__ int red_i[kNjGroupWaves], red_j[kNjGroupWaves], sync_ok;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int waves_total = gridDim.x * kNjGroupWaves, gw = blockIdx.x * kNjGroupWaves + wave;
+    const double inf = __builtin_inf();
+    for (int t = tid; t < P; t += kNjGroupThreads) order[t] = t;
+    int* order_new = order + P;
+    int n = P, index = 0, node = P;
+    unsigned target = 0;
+    // the caller's P x P matrix into the (2P - 3)-wide layout (a strided upload from pageable memory goes row by row)
+    for (int r = blockIdx.x; r < P; r += gridDim.x)
+        for (int c = tid; c < P; c += kNjGroupThreads) D[(size_t)r * W + c] = dense[(size_t)r * P + c];
+    if (!nj_grid_sync(gs, target, &sync_ok)) return;
+    lap(-1);
+    nj_row_sums<false>(D, W, order, n, rows_per_wave, stage, rs_g, 0, 0, 0.0);
+    lap(0);
+    if (!nj_grid_sync(gs, target, &sync_ok)) return;
+    lap(1);
+    while (n > 3) {
+        // B: first minimum of Q over this wave's rows (the rows it summed).  The matrix entries are requested before
+        // the row sums are copied, 256 columns ahead of the scan.
+        const double nm2 = (double)(n - 2);
+        double bq = inf, bd = 0.0;
+        int bi = 0x7fffffff, bj = 0x7fffffff;
+        {
+            const int my_rows = gw < n ? min(rows_per_wave, (n - gw + waves_total - 1) / waves_total) : 0;
+            const double* rowp[kNjRowsPerWave];
+#pragma unroll
+            for (int u = 0; u < kNjRowsPerWave; u++) rowp[u] = D + (size_t)(u < my_rows ? order[gw + u * waves_total] : 0) * W;
+            double x[kNjRowsPerWave][4];
+            auto load = [&](int c0) {
+#pragma unroll
+                for (int u = 0; u < kNjRowsPerWave; u++)
+                    if (u < my_rows) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const int j = c0 + lane + 64 * e;
+                            x[u][e] = j < n ? rowp[u][order[j]] : 0.0;
+                        }
+                    }
+            };
+            load(0);
+            for (int t = tid; t < n; t += kNjGroupThreads) rs[t] = rs_g[t];
+            __syncthreads();
+            // rows in increasing order within a chunk only: a lane sees (i, j) out of row-major order across chunks,
+            // so ties are broken by (i, j) explicitly
+            for (int c0 = 0; c0 < n; c0 += kNjChunk) {
+                double y[kNjRowsPerWave][4];
+#pragma unroll
+                for (int u = 0; u < kNjRowsPerWave; u++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) y[u][e] = x[u][e];
+                if (c0 + kNjChunk < n) load(c0 + kNjChunk);
+#pragma unroll
+                for (int u = 0; u < kNjRowsPerWave; u++)
+                    if (u < my_rows) {
+                        const int i = gw + u * waves_total;
+                        const double ri = rs[i];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const int j = c0 + lane + 64 * e;
+                            if (j < n && j != i) {
+                                const double q = (nm2 * y[u][e] - ri) - rs[j];
+                                if (nj_before(q, i, j, bq, bi, bj)) {
+                                    bq = q;
+                                    bd = y[u][e];
+                                    bi = i;
+                                    bj = j;
+                                }
+                            }
+                        }
+                    }
+            }
+        }
+        nj_wave_first_min(bq, bd, bi, bj);
+        if (lane == 0) cand[gw] = NjCandidate{bq, bd, bi, bj, {0, 0}};
+        lap(2);
+        if (!nj_grid_sync(gs, target, &sync_ok)) return;
+        lap(3);
+        // C: the same reduction in every workgroup
+        bq = inf;
+        bd = 0.0;
+        bi = bj = 0x7fffffff;
+        for (int w = tid; w < waves_total; w += kNjGroupThreads) {
+            const NjCandidate c = cand[w];
+            if (nj_before(c.q, c.i, c.j, bq, bi, bj)) {
+                bq = c.q;
+                bd = c.d;
+                bi = c.i;
+                bj = c.j;
+            }
+        }
+        nj_wave_first_min(bq, bd, bi, bj);
+        if (lane == 0) {
+            red_q[wave] = bq;
+            red_d[wave] = bd;
+            red_i[wave] = bi;
+            red_j[wave] = bj;
+        }
+        __syncthreads();
+        bq = red_q[0];
+        bd = red_d[0];
+        bi = red_i[0];
+        bj = red_j[0];
+        for (int w = 1; w < kNjGroupWaves; w++)
+            if (nj_before(red_q[w], red_i[w], red_j[w], bq, bi, bj)) {
+                bq = red_q[w];
+                bd = red_d[w];
+                bi = red_i[w];
+                bj = red_j[w];
+            }
+        int pi, pj;
+        double dij;
+        if (bi >= n) {                                      // nothing compared below +inf (NaN or inf input)
+            bi = 0;
+            bj = 1;
+            pi = order[0];
+            pj = order[1];
+            dij = D[(size_t)pi * W + pj];
+        } else {
+            pi = order[bi];
+            pj = order[bj];
+            dij = bd;
+        }
+        if (blockIdx.x == 0 && tid == 0) {                  // _find_branch_length (:124-136)
+            const double di = 0.5 * dij + (0.5 / nm2) * (rs[bi] - rs[bj]);
+            tree[2 * index] = (unsigned long long)pi;
+            tree[2 * index + 1] = (unsigned long long)node;
+            bl[index] = di;
+            tree[2 * index + 2] = (unsigned long long)pj;
+            tree[2 * index + 3] = (unsigned long long)node;
+            bl[index + 1] = dij - di;
+        }
+        // the new order: the new node, then the survivors (:60-83)
+        for (int k = tid; k < n; k += kNjGroupThreads) {
+            if (k == bi || k == bj) continue;
+            order_new[1 + k - (k > bi ? 1 : 0) - (k > bj ? 1 : 0)] = order[k];
+        }
+        if (tid == 0) order_new[0] = node;
+        __syncthreads();
+        n--;
+        lap(4);
+        nj_row_sums<true>(D, W, order_new, n, rows_per_wave, stage, rs_g, pi, pj, dij);
+        lap(0);
+        int* swap = order;
+        order = order_new;
+        order_new = swap;
+        index += 2;
+        node++;
+        if (!nj_grid_sync(gs, target, &sync_ok)) return;
+        lap(1);
+    }
+    // the last three nodes in order (:85-94)
+    if (blockIdx.x == 0 && tid == 0) {
+        auto at = [&](int a, int b) { return D[(size_t)order[a] * W + order[b]]; };
+        const double s1 = ((0.0 + at(1, 0)) + at(1, 1)) + at(1, 2), s2 = ((0.0 + at(2, 0)) + at(2, 1)) + at(2, 2);
+        const double d12 = at(1, 2);
+        const double di = 0.5 * d12 + (0.5 / (double)(n - 2)) * (s1 - s2);
+        tree[2 * index] = (unsigned long long)order[1];
+        tree[2 * index + 1] = (unsigned long long)node;
+        bl[index++] = di;
+        tree[2 * index] = (unsigned long long)order[2];
+        tree[2 * index + 1] = (unsigned long long)node;
+        bl[index++] = d12 - di;
+        tree[2 * index] = (unsigned long long)order[0];
+        tree[2 * index + 1] = (unsigned long long)node;
+        bl[index++] = 0.5 * ((at(1, 0) + at(2, 0)) - d12);
+    }
+}
+
+}  // namespace cr
+
+namespace {
+
+// workgroups of the launch: enough waves for 2 rows each, at most kNjMaxGroups (CARETTA_NJ_GROUPS overrides, for
+// calibration)
+int nj_groups(int64_t P) {
+    int g = (int)std::min<int64_t>(cr::kNjMaxGroups, std::max<int64_t>(1, (P + 2 * cr::kNjGroupWaves - 1) / (2 * cr::kNjGroupWaves)));
+    if (const char* env = std::getenv("CARETTA_NJ_GROUPS")) {
+        const int e = std::atoi(env);
+        if (e >= 1 && e <= cr::kNjMaxGroups) g = e;
+    }
+    while ((int64_t)g * cr::kNjGroupWaves * cr::kNjRowsPerWave < P) g++;
+    return g;
+}
+
+}  // namespace
+
+extern "C" {
+
+// neighbor_joining.neighbor_joining on the device (see the top of this file): the result equals cr_neighbor_joining's
+// bit for bit.  A matrix that is not exactly symmetric, or has more than kNjMaxNodes rows, runs on the host
+// implementation, whose row sums read rows.
+int cr_neighbor_joining_device(cr_context* ctx, const double* D0, int64_t P, uint64_t* tree, double* bl) {
+    CR_REQUIRE(D0 && tree && bl, "null argument");
+    CR_REQUIRE(P >= 3, "neighbor joining needs at least 3 taxa");
+    bool symmetric = P <= cr::kNjMaxNodes;
+    for (int64_t i = 0; i < P && symmetric; i++)
+        for (int64_t j = 0; j < i; j++)
+            if (std::memcmp(&D0[i * P + j], &D0[j * P + i], sizeof(double)) != 0) {
+                symmetric = false;
+                break;
+            }
+    if (!symmetric) return cr_neighbor_joining(D0, P, tree, bl);
+    const auto t_start = std::chrono::steady_clock::now();
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+    };
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    const int groups = nj_groups(P);
+    const int waves_total = groups * cr::kNjGroupWaves;
+    const int rows_per_wave = (int)((P + waves_total - 1) / waves_total);
+    const int64_t W = (2 * P - 3 + 15) / 16 * 16;            // a row and a column per node id
+    const size_t rows = (size_t)(2 * P - 3);
+    DevBuf<double> d, dense, drs;
+    DevBuf<unsigned long long> dout;                       // [tree 2 * rows | branch lengths rows | barrier state]
+    DevBuf<cr::NjCandidate> dcand;
+    DevBuf<long long> dprof;
+    const bool profile = std::getenv("CARETTA_NJ_PROFILE") != nullptr;     // diagnostic: cycles per phase to stderr
+    if (profile) {
+        CR_HIP(dprof.ensure(8));
+        CR_HIP(hipMemsetAsync(dprof.p, 0, 8 * sizeof(long long), ctx->stream));
+    }
+    CR_HIP(d.ensure((size_t)(W * W)));
+    CR_HIP(dense.ensure((size_t)(P * P)));
+    CR_HIP(drs.ensure((size_t)P));
+    CR_HIP(dout.ensure(3 * rows + 1));
+    CR_HIP(dcand.ensure((size_t)waves_total));
+    unsigned long long* dtree = dout.p;
+    double* dbl = reinterpret_cast<double*>(dout.p + 2 * rows);
+    cr::NjGridState* dstate = reinterpret_cast<cr::NjGridState*>(dout.p + 3 * rows);
+    const double ms_alloc = ms_since(t_start);
+    if (profile) {
+        CR_HIP(hipStreamSynchronize(ctx->stream));
+        std::fprintf(stderr, "[nj] stream idle after %.3f ms\n", ms_since(t_start));
+    }
+    CR_HIP(hipMemsetAsync(dstate, 0, sizeof(cr::NjGridState), ctx->stream));
+    if (profile) {
+        CR_HIP(hipStreamSynchronize(ctx->stream));
+        std::fprintf(stderr, "[nj] memset done after %.3f ms\n", ms_since(t_start));
+    }
+    rc = upload_async(ctx, dense.p, D0, sizeof(double) * (size_t)(P * P));
+    if (rc) return rc;
+    double ms_copied = 0.0;
+    if (profile) {
+        CR_HIP(hipStreamSynchronize(ctx->stream));
+        ms_copied = ms_since(t_start);
+    }
+    const size_t lds = cr::nj_lds_bytes((int)P, rows_per_wave);
+    rc = allow_lds(cr::k_neighbor_joining, lds);
+    if (rc) return rc;
+    CR_LAUNCH(cr::k_neighbor_joining, dim3(groups), dim3(cr::kNjGroupThreads), lds, ctx->stream, dense.p, d.p, (int)W, (int)P,
+              rows_per_wave, drs.p, dcand.p, dstate, dtree, dbl, profile ? dprof.p : nullptr);
+    CR_HIP(hipGetLastError());
+    double ms_kernel = 0.0;
+    if (profile) {
+        CR_HIP(hipStreamSynchronize(ctx->stream));
+        ms_kernel = ms_since(t_start);
+    }
+    const double ms_enqueued = ms_since(t_start);
+    // one copy of [tree | branch lengths | barrier state] into page-locked memory
+    const size_t tree_bytes = sizeof(uint64_t) * 2 * rows, bl_bytes = sizeof(double) * rows;
+    void* land = nullptr;
+    rc = host_landing(ctx, tree_bytes + bl_bytes + sizeof(cr::NjGridState), &land);
+    if (rc) return rc;
+    CR_HIP(hipMemcpyAsync(land, dout.p, tree_bytes + bl_bytes + sizeof(cr::NjGridState), hipMemcpyDeviceToHost, ctx->stream));
+    CR_HIP(hipStreamSynchronize(ctx->stream));
+    cr::NjGridState state;
+    std::memcpy(tree, land, tree_bytes);
+    std::memcpy(bl, static_cast<char*>(land) + tree_bytes, bl_bytes);
+    std::memcpy(&state, static_cast<char*>(land) + tree_bytes + bl_bytes, sizeof(state));
+    if (profile) {
+        long long c[8];
+        CR_HIP(hipMemcpy(c, dprof.p, sizeof(c), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[nj P=%lld groups=%d] cycles: row sums %lld  barrier %lld  Q scan %lld  barrier %lld  reduce+order %lld;"
+                     " host ms: buffers %.3f  copied %.3f  kernel done %.3f  enqueued %.3f  done %.3f\n",
+                     (long long)P, groups, c[0], c[1], c[2], c[3], c[4], ms_alloc, ms_copied, ms_kernel, ms_enqueued, ms_since(t_start));
+    }
+    if (state.abort) return fail(CR_ERR_HIP, "neighbor joining: a workgroup of the persistent launch did not arrive");
+    return CR_OK;
+}
+
+}  // extern "C"

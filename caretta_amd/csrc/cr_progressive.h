@@ -232,7 +232,7 @@ int run_tree_planned(cr_progressive* h, const std::vector<std::vector<int64_t>>&
     CR_HIP(hipMemcpyAsync(descs.data(), h->d_nodes.p, sizeof(cr::NodeDesc) * (size_t)num_nodes, hipMemcpyDeviceToHost, stream));
     CR_HIP(hipMemcpyAsync(len.data(), d_len.p, sizeof(int64_t) * len.size(), hipMemcpyDeviceToHost, stream));
     CR_HIP(hipMemcpyAsync(off.data(), d_off.p, sizeof(int64_t) * off.size(), hipMemcpyDeviceToHost, stream));
-    CR_HIP(hipMemcpyAsync(rows_host.data(), b.aln.p, sizeof(int32_t) * (size_t)aln_total, hipMemcpyDeviceToHost, stream));
+    if ((rc = download(h->ctx, rows_host.data(), b.aln.p, sizeof(int32_t) * (size_t)aln_total, false))) return rc;
     CR_HIP(hipMemcpyAsync(&overflow, d_overflow.p, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     CR_HIP(hipMemcpyAsync(&used, d_used.p, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
     CR_HIP(hipStreamSynchronize(stream));
@@ -347,8 +347,10 @@ int cr_progressive_align(cr_context* ctx, const double* coords, const double* te
     {
         std::vector<double> w((size_t)total, consensus_weight);
         hipStream_t st = ctx->stream;
-        CR_HIP(hipMemcpyAsync(h->scratch.coords.p, coords, sizeof(double) * (size_t)total * 3, hipMemcpyHostToDevice, st));
-        CR_HIP(hipMemcpyAsync(h->scratch.tensors.p, tensors, sizeof(double) * (size_t)(total * d), hipMemcpyHostToDevice, st));
+        rc = upload_async(ctx, h->scratch.coords.p, coords, sizeof(double) * (size_t)total * 3);
+        if (rc) return rc;
+        rc = upload_async(ctx, h->scratch.tensors.p, tensors, sizeof(double) * (size_t)(total * d));
+        if (rc) return rc;
         CR_HIP(hipMemcpyAsync(h->weights.p, w.data(), sizeof(double) * (size_t)total, hipMemcpyHostToDevice, st));
         CR_HIP(hipStreamSynchronize(st));
     }
@@ -434,7 +436,8 @@ int cr_progressive_fetch_nodes(cr_progressive* h, int64_t* aln, double* coords, 
     std::vector<double> host;
     auto slice = [&](const double* dev, int64_t width, double* dst) -> int {
         host.resize((size_t)(h->used * width));
-        CR_HIP(hipMemcpy(host.data(), dev, sizeof(double) * (size_t)(h->used * width), hipMemcpyDeviceToHost));
+        int drc = download(h->ctx, host.data(), dev, sizeof(double) * (size_t)(h->used * width));
+        if (drc) return drc;
         int64_t o = 0;
         for (int64_t id = h->P; id < 2 * h->P - 1; id++) {
             const int64_t cnt = h->len[(size_t)id] * width;

@@ -1,22 +1,42 @@
-"""Drop-in for the reference's ``caretta/neighbor_joining.py`` (:19-157): host-side C++ in
-libcaretta_hip, row sums hoisted out of the pair loop without changing any rounded value."""
+"""Drop-in for the reference's ``caretta/neighbor_joining.py`` (:19-157).  Two implementations in libcaretta_hip
+with bit-identical results: host C++ (``cr_neighbor_joining``) and one workgroup on the GPU
+(``cr_neighbor_joining_device``); both form each row sum once per iteration in the reference's order, so no rounded
+value and no tie changes."""
 from __future__ import annotations
+
+import os
 
 import numpy as np
 
 from . import _capi
 from ._capi import check, f64, ptr
 
+# from this many nodes on the device kernel is the faster one (tools/nj_time.py on an MI355X box)
+DEVICE_MIN_NODES = int(os.environ.get("CARETTA_NJ_DEVICE_MIN_NODES", "384"))
 
-def neighbor_joining(distance_matrix):
-    """-> (tree uint64 (2P-3, 2) rows (child, parent), branch_lengths float64 (2P-3, 1))."""
+
+def neighbor_joining(distance_matrix, device=None, ctx=None):
+    """-> (tree uint64 (2P-3, 2) rows (child, parent), branch_lengths float64 (2P-3, 1)).
+
+    ``device``: True = GPU kernel (error without a GPU), False = host C++, None = the GPU kernel when there is a GPU
+    and the matrix has at least ``DEVICE_MIN_NODES`` rows.  The result does not depend on the choice."""
     d = f64(distance_matrix)
     if d.ndim != 2 or d.shape[0] != d.shape[1]:
         raise ValueError("distance_matrix must be square")
     p = d.shape[0]
     tree = np.zeros((2 * p - 3, 2), dtype=np.uint64)
     bl = np.zeros((2 * p - 3, 1), dtype=np.float64)
-    check(_capi.load().cr_neighbor_joining(ptr(d), p, ptr(tree), ptr(bl)))
+    lib = _capi.load()
+    if device is None:
+        from . import engine
+        device = ctx is not None or (p >= DEVICE_MIN_NODES and engine.device_count() > 0)
+    if device:
+        if ctx is None:
+            from . import engine
+            ctx = engine.default_context()
+        check(lib.cr_neighbor_joining_device(ctx._h, ptr(d), p, ptr(tree), ptr(bl)))
+    else:
+        check(lib.cr_neighbor_joining(ptr(d), p, ptr(tree), ptr(bl)))
     return tree, bl
 
 

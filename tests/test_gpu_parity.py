@@ -793,6 +793,41 @@ def test_progressive_unrelated_structures_outgrow_the_bound(oracle):
         sizes.append(tot)
 
 
+def test_neighbor_joining_device_matches_oracle(ctx, oracle, golden):
+    """cr_neighbor_joining_device (one workgroup) against the oracle and the host implementation: trees and branch lengths
+    bit for bit on the reference's golden matrices, random symmetric matrices, tie-heavy integer matrices, the 3-node
+    case, and an asymmetric matrix (handed to the host implementation)."""
+    from caretta_amd import neighbor_joining as nj
+    g = golden("f3_tree.npz")
+    cases = [(f"golden{c}", g[f"nj{c}_D"]) for c in range(int(g["nnj"]))] + [(f"fam{t}", g[f"fam{t}_D"]) for t in ("T8", "T16")]
+    for tag, d in cases[:]:
+        tree, _ = nj.neighbor_joining(d, device=True, ctx=ctx)
+        key = tag.replace("golden", "nj") + "_tree"
+        assert nj.bipartitions(tree, d.shape[0]) == nj.bipartitions(g[key], d.shape[0]), tag
+    rng = np.random.default_rng(11)
+    for p in (3, 4, 5, 17, 64, 65, 130, 300, 1025, 1100):
+        a = rng.uniform(0.5, 40.0, size=(p, p))
+        d = a + a.T
+        d[np.diag_indices(p)] = rng.uniform(0.0, 80.0)           # constant non-zero diagonal, as max(M) - M has
+        cases.append((f"uniform{p}", d))
+    for p in (8, 33, 96):                                          # many equal Q values: the first in row-major order wins
+        a = rng.integers(1, 4, size=(p, p)).astype(np.float64)
+        d = np.triu(a, 1) + np.triu(a, 1).T
+        cases.append((f"ties{p}", d))
+    cases.append(("zeros12", np.zeros((12, 12))))
+    asym = rng.uniform(1.0, 9.0, size=(40, 40))
+    cases.append(("asymmetric40", asym))
+    for tag, d in cases:
+        p = d.shape[0]
+        tree, bl = nj.neighbor_joining(d, device=True, ctx=ctx)
+        htree, hbl = nj.neighbor_joining(d, device=False)
+        assert np.array_equal(tree, htree) and np.array_equal(bl, hbl), tag
+        if p <= 300:
+            otree, obl = oracle.neighbor_joining(d, hoist=(p > 40))
+            assert np.array_equal(tree.astype(np.int64), np.asarray(otree).astype(np.int64)), tag
+            assert np.array_equal(bl.ravel(), np.asarray(obl).ravel()), tag
+
+
 def test_progressive_tree_validation(ctx):
     from caretta_amd import multiple_alignment as ma, synthetic
     fam = synthetic.make_family(4, 40, seed=5, clades=2)
