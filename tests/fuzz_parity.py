@@ -181,12 +181,41 @@ def check_explicit_batch(oracle, rng):
     return len(problems)
 
 
+def check_neighbor_joining(ctx, oracle, rng):
+    """The persistent device kernel against the host implementation (any size) and the oracle (small sizes): uniform,
+    tie-heavy, clustered and near-degenerate symmetric matrices."""
+    p = int(rng.choice([3, 4, 5, 8, 31, 64, 65, 100, 257, 300, 420, 600]))
+    kind = int(rng.integers(0, 4))
+    if kind == 0:
+        a = rng.uniform(0.1, 50.0, size=(p, p))
+        d = a + a.T
+    elif kind == 1:                                                                 # few distinct values: ties everywhere
+        a = rng.integers(0, 4, size=(p, p)).astype(np.float64)
+        d = np.triu(a, 1) + np.triu(a, 1).T
+    elif kind == 2:                                                                 # points in space, some coincident
+        x = np.round(rng.normal(size=(p, 3)) * float(rng.choice([1.0, 3.0])), int(rng.integers(0, 3)))
+        d = np.sqrt(((x[:, None] - x[None]) ** 2).sum(-1))
+    else:                                                                           # shaped like max(M) - M
+        a = rng.uniform(0.0, 300.0, size=(p, p))
+        m = np.triu(a, 1) + np.triu(a, 1).T
+        d = m.max() - m
+    tree, bl = nj.neighbor_joining(d, device=True, ctx=ctx)
+    htree, hbl = nj.neighbor_joining(d, device=False)
+    if not (np.array_equal(tree, htree) and np.array_equal(bl, hbl)):
+        raise AssertionError(f"device neighbor joining differs from the host implementation: P {p} kind {kind}")
+    if p <= 100:
+        otree, obl = oracle.neighbor_joining(d, hoist=(p > 40))
+        if not (np.array_equal(tree, otree) and np.array_equal(bl, obl)):
+            raise AssertionError(f"neighbor joining differs from the oracle: P {p} kind {kind}")
+    return 1
+
+
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
     ctx, oracle = engine.Context(0), pyoracle.Oracle()
-    t0, batches, pairs, nodes, flagged, dropins, batched = time.time(), 0, 0, 0, 0, 0, 0
+    t0, batches, pairs, nodes, flagged, dropins, batched, trees = time.time(), 0, 0, 0, 0, 0, 0, 0
     while time.time() - t0 < seconds:
         fam, _ = random_family(rng)
         n, res = check_batch(ctx, oracle, fam, rng)
@@ -197,10 +226,12 @@ def main():
         dropins += check_dropins(oracle, rng)
         if rng.integers(0, 4) == 0:
             batched += check_explicit_batch(oracle, rng)
+        if rng.integers(0, 4) == 0:
+            trees += check_neighbor_joining(ctx, oracle, rng)
         batches += 1
     print(f"fuzz_parity: seed {seed}, {batches} batches, {pairs} pairs ({flagged} with a soft-condition flag), "
-          f"{nodes} progressive nodes, {dropins} explicit-matrix drop-in cases, {batched} matrices in batched explicit calls: "
-          f"all bit-identical to the oracle")
+          f"{nodes} progressive nodes, {dropins} explicit-matrix drop-in cases, {batched} matrices in batched explicit calls, "
+          f"{trees} device neighbor joinings: all bit-identical to the oracle")
 
 
 if __name__ == "__main__":
