@@ -13,18 +13,25 @@
 //    lists the node ids in the reference's order.
 //
 // Shape.  One persistent launch of up to kNjMaxGroups workgroups (a fraction of the chip: the work per join is O(n^2)
-// loads and an n-long chain of dependent adds), two grid barriers per join:
+// loads and an n-long chain of dependent adds).  Per join:
 //    A  row sums of the NEW order.  A wave owns a few rows; it loads them 64 columns per instruction (a row sum reads
 //       the ROW, gathered through `order`), parks 256 columns per row in LDS and lets one lane per row add them in
 //       order while the next 256 columns are in flight.  The new node's row does not exist yet: its entries
 //       v_t = 0.5 * ((D[i][t] + D[j][t]) - D[i][j]) are computed where they are needed -- by the wave that owns the
 //       new row (which also writes the new row and column) and, for column 0 of every other row, by that row's wave --
-//       from rows i and j, which nobody writes.  So no barrier separates the join from the sums.
-//    -- grid barrier --
-//    B  every wave scans Q over its rows and publishes its first minimum.
-//    -- grid barrier --
-//    C  every workgroup reduces the published minima (same data, same order: same answer), updates its own copy of
-//       `order`, and goes on with A.
+//       from rows i and j, which nobody writes.  Each sum is published as one 8-byte word.
+//    B  every workgroup collects all row sums, every wave scans Q over its rows (matrix entries requested before the
+//       sums arrive; the entry in the new column is the one the wave formed itself in A) and publishes its first
+//       minimum as three 8-byte words.
+//    C  every workgroup collects all minima and reduces them (same data, same order: same answer), updates its own
+//       copy of `order`, and goes on with A.
+// There is no barrier in the loop: a consumer polls the published words themselves.  Each word lives in three
+// generations (join k uses generation k % 3); a producer writes its word of this generation and resets its word of
+// the next one to a reserved NaN pattern, and a consumer spins on a word until it is not that pattern.  Device-scope
+// release before publishing / acquire after collecting the row sums make the new row and column (plain stores by one
+// wave) visible to the waves that later read them as rows i or j.  A join is then 3 - 4 dependent round trips to
+// memory (each ~1.5 us when the line comes from another XCD) instead of 7 with two counter barriers.  A spin that
+// does not end (lost workgroup, NaN input) gives up after a bounded number of polls and the call returns an error.
 // The matrix is symmetric and stays so (both triangles receive the same rounded value), which is what lets A read rows
 // i and j where the reference reads columns; cr_neighbor_joining_device checks the symmetry of its input and hands
 // anything else to the host implementation.
@@ -41,16 +48,16 @@ constexpr int kNjStride = kNjChunk + 2;    // row pitch of the parking area: row
 constexpr int kNjMaxNodes = kNjMaxGroups * kNjGroupWaves * kNjRowsPerWave;      // 2048
 constexpr unsigned kNjSpinLimit = 1u << 24;
 
-struct NjCandidate {
-    double q, d;           // Q(i, j) and D[i][j]
-    int i, j;
-    int pad[2];
-};
-
 struct NjGridState {
-    unsigned arrived;      // monotone: += 1 per workgroup and barrier
+    unsigned arrived;      // monotone: += 1 per workgroup and barrier (the one barrier before the loop)
     unsigned abort;        // a workgroup gave up waiting (a lost workgroup must not hang the device)
 };
+
+// a published word that has not been written in this generation: a NaN no sum, Q value or matrix entry can be
+// (sums and entries are finite -- checked on the host --, and a Q value that is NaN never wins a comparison, so it
+// is never published)
+constexpr unsigned long long kNjEmpty = 0x7ff8dead0badf00dull;
+constexpr int kNjCandWords = 4;            // Q, D[i][j], (i << 32 | j), unused
 
 inline size_t nj_lds_bytes(int P, int rows_per_wave) {
     return sizeof(double) * ((size_t)kNjGroupWaves * rows_per_wave * kNjStride + (size_t)P) + sizeof(int) * 2 * (size_t)P;
@@ -72,6 +79,37 @@ CR_D void nj_wave_first_min(double& q, double& d, int& i, int& j) {
             j = j2;
         }
     }
+}
+
+CR_D unsigned long long nj_peek(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+CR_D void nj_post(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// a matrix entry as the device sees it now (entries are appended to rows by other workgroups: a cached line may
+// predate its newest entry)
+CR_D double nj_entry(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT));
+}
+// every store this wave has issued has been acknowledged (the words are device-scope stores, written through: once
+// acknowledged they are where a device-scope load finds them)
+CR_D void nj_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+CR_D unsigned long long nj_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
+CR_D double nj_value(unsigned long long b) { return __longlong_as_double((long long)b); }
+
+// spin until the word has been published; false: gave up (and told everybody)
+CR_D bool nj_await(const unsigned long long* p, NjGridState* gs, unsigned long long& v) {
+    unsigned spins = 0;
+    while ((v = nj_peek(p)) == kNjEmpty) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kNjSpinLimit || ((spins & 255u) == 0 && __hip_atomic_load(&gs->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            __hip_atomic_store(&gs->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+    return true;
 }
 
 // All workgroups of the launch meet here; what they wrote before is visible to all after.  false: somebody timed out.
@@ -98,38 +136,46 @@ CR_D bool nj_grid_sync(NjGridState* gs, unsigned& target, int* ok) {
     return *ok != 0;
 }
 
-// Row sums of the order `order[0 .. n)` into rs_g.  JOIN: position 0 is the new node `order[0]`, not in memory yet,
-// formed from rows pi and pj; the wave that owns position 0 also writes its row and column.
+// Row sums of the order `order[0 .. n)`, published in rs_pub (and the words of the next generation reset).  JOIN:
+// position 0 is the new node `order[0]`, not in memory yet, formed from rows pi and pj; the wave that owns position
+// 0 also writes its row and column.  newcol[u] (lane 0): the entry of row u in the new node's column.
 template <bool JOIN>
-CR_D void nj_row_sums(double* D, int W, const int* order, int n, int rows_per_wave, double* stage, double* rs_g, int pi,
-                      int pj, double dij) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+CR_D void nj_row_sums(double* D, int W, const int* order, int n, int rows_per_wave, double* stage, unsigned long long* rs_pub,
+                      unsigned long long* rs_reset, int pi, int pj, double dij, double (&newcol)[kNjRowsPerWave]) {
+    // (the wave index through readfirstlane: the compiler then knows that everything derived from it is wave-uniform and
+    // branches on it with scalar jumps, which do not serialise the loads on either side)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int waves_total = gridDim.x * kNjGroupWaves, gw = blockIdx.x * kNjGroupWaves + wave;
     if (gw >= n) return;                                    // no row for this wave (rows are dealt round robin)
     double* park = stage + (size_t)wave * rows_per_wave * kNjStride;
     const int my_rows = min(rows_per_wave, (n - gw + waves_total - 1) / waves_total);
-    auto entry_of_new = [&](int p) { return 0.5 * ((D[(size_t)pi * W + p] + D[(size_t)pj * W + p]) - dij); };
-    // element t of the row of node pr at position r
-    auto element = [&](int r, int pr, int t) -> double {
-        if (t >= n) return 0.0;
-        const int pt = order[t];
-        if (JOIN) {
-            if (r == 0) return t == 0 ? 0.0 : entry_of_new(pt);
-            if (t == 0) return entry_of_new(pr);
-        }
-        return D[(size_t)pr * W + pt];
-    };
+    auto entry_of_new = [&](int p) { return 0.5 * ((nj_entry(D + (size_t)pi * W + p) + nj_entry(D + (size_t)pj * W + p)) - dij); };
     int prow[kNjRowsPerWave];
 #pragma unroll
-    for (int u = 0; u < kNjRowsPerWave; u++) prow[u] = u < my_rows ? order[gw + u * waves_total] : 0;
+    for (int u = 0; u < kNjRowsPerWave; u++) prow[u] = u < my_rows ? __builtin_amdgcn_readfirstlane(order[gw + u * waves_total]) : 0;
+    // the entry of every row in the new node's column (formed here; the copy in memory is being written by wave 0)
+#pragma unroll
+    for (int u = 0; u < kNjRowsPerWave; u++) newcol[u] = (JOIN && u < my_rows && !(gw == 0 && u == 0)) ? entry_of_new(prow[u]) : 0.0;
     double x[kNjRowsPerWave][4];
+    // element t of the row at position gw + u * waves_total, for t = c0 + lane + 64 e.  No lane-dependent branch: every
+    // lane loads (from a clamped column) and selects afterwards, so all the loads of a chunk are in flight together
     auto load = [&](int c0) {
 #pragma unroll
         for (int u = 0; u < kNjRowsPerWave; u++)
             if (u < my_rows) {
+                const bool new_row = JOIN && gw == 0 && u == 0;
 #pragma unroll
-                for (int e = 0; e < 4; e++) x[u][e] = element(gw + u * waves_total, prow[u], c0 + lane + 64 * e);
+                for (int e = 0; e < 4; e++) {
+                    const int t = c0 + lane + 64 * e;
+                    const int pt = order[min(t, n - 1)];
+                    const double v = new_row ? entry_of_new(pt) : nj_entry(D + (size_t)prow[u] * W + pt);
+                    x[u][e] = t < n ? v : 0.0;
+                }
             }
+        if (JOIN && c0 == 0 && lane == 0) {
+#pragma unroll
+            for (int u = 0; u < kNjRowsPerWave; u++) x[u][0] = newcol[u];
+        }
     };
     double s = 0.0;
     load(0);
@@ -147,8 +193,8 @@ CR_D void nj_row_sums(double* D, int W, const int* order, int n, int rows_per_wa
                 const int t = c0 + lane + 64 * e;
                 if (t < n) {
                     const int pt = order[t];
-                    D[(size_t)fresh * W + pt] = x[0][e];
-                    D[(size_t)pt * W + fresh] = x[0][e];
+                    nj_post(reinterpret_cast<unsigned long long*>(D + (size_t)fresh * W + pt), nj_bits(x[0][e]));
+                    nj_post(reinterpret_cast<unsigned long long*>(D + (size_t)pt * W + fresh), nj_bits(x[0][e]));
                 }
             }
         }
@@ -158,36 +204,48 @@ CR_D void nj_row_sums(double* D, int W, const int* order, int n, int rows_per_wa
         if (c0 + kNjChunk < n) load(c0 + kNjChunk);
         if (lane < my_rows) {
             // columns past n are parked as +0.0, and a sum that starts at +0.0 is never -0.0: adding them changes nothing,
-            // so the chain runs in blocks of 8 with the next block's LDS reads under the current block's adds
+            // so the chain runs in blocks of 16.  Two register blocks in turn, each read one block ahead of its adds (the
+            // last read-ahead runs past the chunk into the next row or the array behind: read, never added); the same
+            // number of reads is outstanding on every path into the loop, so the waits the compiler places are exact
             const double* row = park + lane * kNjStride;
-            const int cnt = (min(kNjChunk, n - c0) + 7) & ~7;
-            double cur[8], nxt[8];
+            const int cnt = (min(kNjChunk, n - c0) + 15) & ~15;
+            double a[8], b[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) cur[k] = row[k];
-            for (int t = 0; t < cnt; t += 8) {
-                if (t + 8 < cnt) {
+            for (int k = 0; k < 8; k++) a[k] = row[k];
+            for (int t = 0; t < cnt; t += 16) {
 #pragma unroll
-                    for (int k = 0; k < 8; k++) nxt[k] = row[t + 8 + k];
-                }
+                for (int k = 0; k < 8; k++) b[k] = row[t + 8 + k];
+                __builtin_amdgcn_sched_barrier(0);          // (the scheduler would sink the reads below the adds)
 #pragma unroll
-                for (int k = 0; k < 8; k++) s += cur[k];
+                for (int k = 0; k < 8; k++) s += a[k];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int k = 0; k < 8; k++) cur[k] = nxt[k];
+                for (int k = 0; k < 8; k++) a[k] = row[t + 16 + k];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 8; k++) s += b[k];
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    if (lane < my_rows) rs_g[gw + lane * waves_total] = s;
+    // (the new row and column are device-scope stores still in flight here: nobody reads them before the next A, and
+    // no workgroup gets there before it has this wave's minimum, which is sent after the stores are acknowledged)
+    if (lane < my_rows) {
+        nj_post(&rs_pub[gw + lane * waves_total], nj_bits(s));
+        nj_post(&rs_reset[gw + lane * waves_total], kNjEmpty);
+    }
 }
 
 __global__ __launch_bounds__(kNjGroupThreads) void k_neighbor_joining(const double* __restrict__ dense, double* D, int W, int P, int rows_per_wave,
-                                                                      double* rs_g, NjCandidate* cand, NjGridState* gs,
-                                                                      unsigned long long* __restrict__ tree,
+                                                                      unsigned long long* rs_words, unsigned long long* cand_words,
+                                                                      NjGridState* gs, unsigned long long* __restrict__ tree,
                                                                       double* __restrict__ bl, long long* prof) {
     extern __shared__ double nj_lds[];
-    // prof (diagnostic, else null): shader-clock cycles workgroup 0 spent in A, barrier, B, barrier, C
+    // prof (diagnostic, else null): shader-clock cycles workgroup 0 spent in A (row sums), collecting the sums, B (Q scan),
+    // collecting the minima, C (reduction + new order)
     long long clk = 0;
     auto lap = [&](int k) {
         if (prof && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -201,25 +259,31 @@ __global__ __launch_bounds__(kNjGroupThreads) void k_neighbor_joining(const doub
     int* order = reinterpret_cast<int*>(rs + P);                            // node id (= matrix row) by position, two copies
     __shared__ double red_q[kNjGroupWaves], red_d[kNjGroupWaves];
     __shared__ int red_i[kNjGroupWaves], red_j[kNjGroupWaves], sync_ok;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int waves_total = gridDim.x * kNjGroupWaves, gw = blockIdx.x * kNjGroupWaves + wave;
     const double inf = __builtin_inf();
     for (int t = tid; t < P; t += kNjGroupThreads) order[t] = t;
     int* order_new = order + P;
     int n = P, index = 0, node = P;
     unsigned target = 0;
-    // the caller's P x P matrix into the (2P - 3)-wide layout (a strided upload from pageable memory goes row by row)
+    // the caller's P x P matrix into the (2P - 3)-wide layout (a strided upload from pageable memory goes row by row),
+    // every published word empty
     for (int r = blockIdx.x; r < P; r += gridDim.x)
         for (int c = tid; c < P; c += kNjGroupThreads) D[(size_t)r * W + c] = dense[(size_t)r * P + c];
+    for (int t = blockIdx.x * kNjGroupThreads + tid; t < 3 * P; t += gridDim.x * kNjGroupThreads) nj_post(&rs_words[t], kNjEmpty);
+    for (int t = blockIdx.x * kNjGroupThreads + tid; t < 3 * waves_total * kNjCandWords; t += gridDim.x * kNjGroupThreads)
+        nj_post(&cand_words[t], kNjEmpty);
     if (!nj_grid_sync(gs, target, &sync_ok)) return;
     lap(-1);
-    nj_row_sums<false>(D, W, order, n, rows_per_wave, stage, rs_g, 0, 0, 0.0);
+    double newcol[kNjRowsPerWave];
+    int gen = 0;                                                            // generation of the published words: join % 3
+    nj_row_sums<false>(D, W, order, n, rows_per_wave, stage, rs_words, rs_words + P, 0, 0, 0.0, newcol);
+    bool joined = false;
     lap(0);
-    if (!nj_grid_sync(gs, target, &sync_ok)) return;
-    lap(1);
     while (n > 3) {
+        const int gen_next = gen == 2 ? 0 : gen + 1;
         // B: first minimum of Q over this wave's rows (the rows it summed).  The matrix entries are requested before
-        // the row sums are copied, 256 columns ahead of the scan.
+        // the row sums are collected, 256 columns ahead of the scan.
         const double nm2 = (double)(n - 2);
         double bq = inf, bd = 0.0;
         int bi = 0x7fffffff, bj = 0x7fffffff;
@@ -227,24 +291,34 @@ __global__ __launch_bounds__(kNjGroupThreads) void k_neighbor_joining(const doub
             const int my_rows = gw < n ? min(rows_per_wave, (n - gw + waves_total - 1) / waves_total) : 0;
             const double* rowp[kNjRowsPerWave];
 #pragma unroll
-            for (int u = 0; u < kNjRowsPerWave; u++) rowp[u] = D + (size_t)(u < my_rows ? order[gw + u * waves_total] : 0) * W;
+            for (int u = 0; u < kNjRowsPerWave; u++)
+                rowp[u] = D + (size_t)(u < my_rows ? __builtin_amdgcn_readfirstlane(order[gw + u * waves_total]) : 0) * W;
             double x[kNjRowsPerWave][4];
             auto load = [&](int c0) {
 #pragma unroll
                 for (int u = 0; u < kNjRowsPerWave; u++)
                     if (u < my_rows) {
 #pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            const int j = c0 + lane + 64 * e;
-                            x[u][e] = j < n ? rowp[u][order[j]] : 0.0;
-                        }
+                        for (int e = 0; e < 4; e++) x[u][e] = nj_entry(rowp[u] + order[min(c0 + lane + 64 * e, n - 1)]);
                     }
+                // column 0 of a joined order is the node made in A: other waves' stores, not acquired yet -- the wave
+                // formed the same value itself
+                if (joined && c0 == 0 && lane == 0) {
+#pragma unroll
+                    for (int u = 0; u < kNjRowsPerWave; u++) x[u][0] = newcol[u];
+                }
             };
             load(0);
-            for (int t = tid; t < n; t += kNjGroupThreads) rs[t] = rs_g[t];
-            __syncthreads();
-            // rows in increasing order within a chunk only: a lane sees (i, j) out of row-major order across chunks,
-            // so ties are broken by (i, j) explicitly
+            bool lost = false;
+            const unsigned long long* words = rs_words + (size_t)gen * P;
+            for (int t = tid; t < n; t += kNjGroupThreads) {
+                unsigned long long v;
+                lost |= !nj_await(&words[t], gs, v);
+                rs[t] = nj_value(v);
+            }
+            if (__syncthreads_or(lost)) return;
+            lap(1);
+            // a lane sees (i, j) out of row-major order across rows and chunks, so ties are broken by (i, j) explicitly
             for (int c0 = 0; c0 < n; c0 += kNjChunk) {
                 double y[kNjRowsPerWave][4];
 #pragma unroll
@@ -274,21 +348,37 @@ __global__ __launch_bounds__(kNjGroupThreads) void k_neighbor_joining(const doub
             }
         }
         nj_wave_first_min(bq, bd, bi, bj);
-        if (lane == 0) cand[gw] = NjCandidate{bq, bd, bi, bj, {0, 0}};
+        if (lane == 0) {
+            unsigned long long* mine = cand_words + ((size_t)gen * waves_total + gw) * kNjCandWords;
+            unsigned long long* next = cand_words + ((size_t)gen_next * waves_total + gw) * kNjCandWords;
+            // this wave's stores so far -- the new row and column if it made them, its resets of the next generation -- have
+            // landed before the words that let the others go on
+            nj_stores_done();
+            nj_post(&next[0], kNjEmpty);
+            nj_post(&next[1], kNjEmpty);
+            nj_post(&next[2], kNjEmpty);
+            nj_post(&mine[0], nj_bits(bq));
+            nj_post(&mine[1], nj_bits(bd));
+            nj_post(&mine[2], ((unsigned long long)(unsigned)bi << 32) | (unsigned)bj);
+        }
         lap(2);
-        if (!nj_grid_sync(gs, target, &sync_ok)) return;
-        lap(3);
         // C: the same reduction in every workgroup
         bq = inf;
         bd = 0.0;
         bi = bj = 0x7fffffff;
+        bool lost = false;
         for (int w = tid; w < waves_total; w += kNjGroupThreads) {
-            const NjCandidate c = cand[w];
-            if (nj_before(c.q, c.i, c.j, bq, bi, bj)) {
-                bq = c.q;
-                bd = c.d;
-                bi = c.i;
-                bj = c.j;
+            const unsigned long long* c = cand_words + ((size_t)gen * waves_total + w) * kNjCandWords;
+            unsigned long long vq, vd, vij;
+            lost |= !nj_await(&c[0], gs, vq);
+            lost |= !nj_await(&c[1], gs, vd);
+            lost |= !nj_await(&c[2], gs, vij);
+            const int ci = (int)(unsigned)(vij >> 32), cj = (int)(unsigned)(vij & 0xffffffffu);
+            if (nj_before(nj_value(vq), ci, cj, bq, bi, bj)) {
+                bq = nj_value(vq);
+                bd = nj_value(vd);
+                bi = ci;
+                bj = cj;
             }
         }
         nj_wave_first_min(bq, bd, bi, bj);
@@ -298,7 +388,8 @@ __global__ __launch_bounds__(kNjGroupThreads) void k_neighbor_joining(const doub
             red_i[wave] = bi;
             red_j[wave] = bj;
         }
-        __syncthreads();
+        if (__syncthreads_or(lost)) return;
+        lap(3);
         bq = red_q[0];
         bd = red_d[0];
         bi = red_i[0];
@@ -312,12 +403,12 @@ __global__ __launch_bounds__(kNjGroupThreads) void k_neighbor_joining(const doub
             }
         int pi, pj;
         double dij;
-        if (bi >= n) {                                      // nothing compared below +inf (NaN or inf input)
+        if (bi >= n) {                                      // nothing compared below +inf (inf input)
             bi = 0;
             bj = 1;
             pi = order[0];
             pj = order[1];
-            dij = D[(size_t)pi * W + pj];
+            dij = nj_entry(D + (size_t)pi * W + pj);
         } else {
             pi = order[bi];
             pj = order[bj];
@@ -341,19 +432,21 @@ __global__ __launch_bounds__(kNjGroupThreads) void k_neighbor_joining(const doub
         __syncthreads();
         n--;
         lap(4);
-        nj_row_sums<true>(D, W, order_new, n, rows_per_wave, stage, rs_g, pi, pj, dij);
-        lap(0);
+        gen = gen_next;
+        nj_row_sums<true>(D, W, order_new, n, rows_per_wave, stage, rs_words + (size_t)gen * P,
+                          rs_words + (size_t)(gen == 2 ? 0 : gen + 1) * P, pi, pj, dij, newcol);
+        joined = true;
         int* swap = order;
         order = order_new;
         order_new = swap;
         index += 2;
         node++;
-        if (!nj_grid_sync(gs, target, &sync_ok)) return;
-        lap(1);
+        lap(0);
     }
-    // the last three nodes in order (:85-94)
+    // the last three nodes in order (:85-94); the last new row and column were written by wave 0 of this workgroup
+    __syncthreads();
     if (blockIdx.x == 0 && tid == 0) {
-        auto at = [&](int a, int b) { return D[(size_t)order[a] * W + order[b]]; };
+        auto at = [&](int a, int b) { return nj_entry(D + (size_t)order[a] * W + order[b]); };
         const double s1 = ((0.0 + at(1, 0)) + at(1, 1)) + at(1, 2), s2 = ((0.0 + at(2, 0)) + at(2, 1)) + at(2, 2);
         const double d12 = at(1, 2);
         const double di = 0.5 * d12 + (0.5 / (double)(n - 2)) * (s1 - s2);
@@ -395,10 +488,12 @@ extern "C" {
 int cr_neighbor_joining_device(cr_context* ctx, const double* D0, int64_t P, uint64_t* tree, double* bl) {
     CR_REQUIRE(D0 && tree && bl, "null argument");
     CR_REQUIRE(P >= 3, "neighbor joining needs at least 3 taxa");
+    // the device kernel wants a symmetric matrix of finite entries (its row sums read rows, and a NaN is its mark for
+    // "not published yet"); anything else is the host implementation's
     bool symmetric = P <= cr::kNjMaxNodes;
     for (int64_t i = 0; i < P && symmetric; i++)
-        for (int64_t j = 0; j < i; j++)
-            if (std::memcmp(&D0[i * P + j], &D0[j * P + i], sizeof(double)) != 0) {
+        for (int64_t j = 0; j <= i; j++)
+            if (std::memcmp(&D0[i * P + j], &D0[j * P + i], sizeof(double)) != 0 || !std::isfinite(D0[i * P + j])) {
                 symmetric = false;
                 break;
             }
@@ -414,9 +509,9 @@ int cr_neighbor_joining_device(cr_context* ctx, const double* D0, int64_t P, uin
     const int rows_per_wave = (int)((P + waves_total - 1) / waves_total);
     const int64_t W = (2 * P - 3 + 15) / 16 * 16;            // a row and a column per node id
     const size_t rows = (size_t)(2 * P - 3);
-    DevBuf<double> d, dense, drs;
+    DevBuf<double> d, dense;
+    DevBuf<unsigned long long> dwords;                     // published words: [3][P] row sums, [3][waves][kNjCandWords] minima
     DevBuf<unsigned long long> dout;                       // [tree 2 * rows | branch lengths rows | barrier state]
-    DevBuf<cr::NjCandidate> dcand;
     DevBuf<long long> dprof;
     const bool profile = std::getenv("CARETTA_NJ_PROFILE") != nullptr;     // diagnostic: cycles per phase to stderr
     if (profile) {
@@ -425,9 +520,8 @@ int cr_neighbor_joining_device(cr_context* ctx, const double* D0, int64_t P, uin
     }
     CR_HIP(d.ensure((size_t)(W * W)));
     CR_HIP(dense.ensure((size_t)(P * P)));
-    CR_HIP(drs.ensure((size_t)P));
+    CR_HIP(dwords.ensure(3 * (size_t)P + 3 * (size_t)waves_total * cr::kNjCandWords));
     CR_HIP(dout.ensure(3 * rows + 1));
-    CR_HIP(dcand.ensure((size_t)waves_total));
     unsigned long long* dtree = dout.p;
     double* dbl = reinterpret_cast<double*>(dout.p + 2 * rows);
     cr::NjGridState* dstate = reinterpret_cast<cr::NjGridState*>(dout.p + 3 * rows);
@@ -452,7 +546,7 @@ int cr_neighbor_joining_device(cr_context* ctx, const double* D0, int64_t P, uin
     rc = allow_lds(cr::k_neighbor_joining, lds);
     if (rc) return rc;
     CR_LAUNCH(cr::k_neighbor_joining, dim3(groups), dim3(cr::kNjGroupThreads), lds, ctx->stream, dense.p, d.p, (int)W, (int)P,
-              rows_per_wave, drs.p, dcand.p, dstate, dtree, dbl, profile ? dprof.p : nullptr);
+              rows_per_wave, dwords.p, dwords.p + 3 * (size_t)P, dstate, dtree, dbl, profile ? dprof.p : nullptr);
     CR_HIP(hipGetLastError());
     double ms_kernel = 0.0;
     if (profile) {
@@ -474,7 +568,7 @@ int cr_neighbor_joining_device(cr_context* ctx, const double* D0, int64_t P, uin
     if (profile) {
         long long c[8];
         CR_HIP(hipMemcpy(c, dprof.p, sizeof(c), hipMemcpyDeviceToHost));
-        std::fprintf(stderr, "[nj P=%lld groups=%d] cycles: row sums %lld  barrier %lld  Q scan %lld  barrier %lld  reduce+order %lld;"
+        std::fprintf(stderr, "[nj P=%lld groups=%d] cycles: row sums %lld  collecting them %lld  Q scan %lld  collecting minima %lld  reduce+order %lld;"
                      " host ms: buffers %.3f  copied %.3f  kernel done %.3f  enqueued %.3f  done %.3f\n",
                      (long long)P, groups, c[0], c[1], c[2], c[3], c[4], ms_alloc, ms_copied, ms_kernel, ms_enqueued, ms_since(t_start));
     }

@@ -12,7 +12,7 @@ from . import _capi
 from ._capi import check, f64, ptr
 
 # from this many nodes on the device kernel is the faster one (tools/nj_time.py on an MI355X box)
-DEVICE_MIN_NODES = int(os.environ.get("CARETTA_NJ_DEVICE_MIN_NODES", "384"))
+DEVICE_MIN_NODES = int(os.environ.get("CARETTA_NJ_DEVICE_MIN_NODES", "256"))
 
 
 def neighbor_joining(distance_matrix, device=None, ctx=None):

@@ -817,12 +817,16 @@ def test_neighbor_joining_device_matches_oracle(ctx, oracle, golden):
     cases.append(("zeros12", np.zeros((12, 12))))
     asym = rng.uniform(1.0, 9.0, size=(40, 40))
     cases.append(("asymmetric40", asym))
+    huge = rng.uniform(1.0, 9.0, size=(20, 20))
+    huge = huge + huge.T
+    huge[3, 7] = huge[7, 3] = np.inf                               # not finite: the host implementation's, no hang
+    cases.append(("inf20", huge))
     for tag, d in cases:
         p = d.shape[0]
         tree, bl = nj.neighbor_joining(d, device=True, ctx=ctx)
         htree, hbl = nj.neighbor_joining(d, device=False)
         assert np.array_equal(tree, htree) and np.array_equal(bl, hbl), tag
-        if p <= 300:
+        if p <= 300 and np.all(np.isfinite(d)):
             otree, obl = oracle.neighbor_joining(d, hoist=(p > 40))
             assert np.array_equal(tree.astype(np.int64), np.asarray(otree).astype(np.int64)), tag
             assert np.array_equal(bl.ravel(), np.asarray(obl).ravel()), tag

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """End-to-end timing of the path and its immediate consumers on one MI355X:
-make_pairwise_matrix (batched GPU) -> max - M -> neighbor_joining (host C++ below 384 structures, the one-launch device kernel from there) -> progressive_align (GPU, whole tree resident, one launch pair per tree level).
+make_pairwise_matrix (batched GPU) -> max - M -> neighbor_joining (host C++ below 256 structures, the one-launch device kernel from there) -> progressive_align (GPU, whole tree resident, one launch pair per tree level).
 
     python tools/bench_msa.py [P] [L]
 """
