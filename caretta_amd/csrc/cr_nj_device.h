@@ -27,11 +27,14 @@
 //       copy of `order`, and goes on with A.
 // There is no barrier in the loop: a consumer polls the published words themselves.  Each word lives in three
 // generations (join k uses generation k % 3); a producer writes its word of this generation and resets its word of
-// the next one to a reserved NaN pattern, and a consumer spins on a word until it is not that pattern.  Device-scope
-// release before publishing / acquire after collecting the row sums make the new row and column (plain stores by one
-// wave) visible to the waves that later read them as rows i or j.  A join is then 3 - 4 dependent round trips to
-// memory (each ~1.5 us when the line comes from another XCD) instead of 7 with two counter barriers.  A spin that
-// does not end (lost workgroup, NaN input) gives up after a bounded number of polls and the call returns an error.
+// the next one to a reserved NaN pattern, and a consumer spins on a word until it is not that pattern.  Everything
+// that crosses workgroups -- the words, and every matrix entry, since rows keep getting entries appended by whoever
+// makes the next node -- moves with device-scope loads and stores (written through to memory, read past the per-XCD
+// L2), so the loop holds no cache write-back and no invalidate; a wave publishes its minimum only after its own
+// stores have been acknowledged (s_waitcnt vmcnt(0)), and nobody starts the next A before it has every minimum:
+// that is what orders the new row and column, and the resets, before their readers.  A join is then 3 - 4 dependent
+// round trips to memory instead of 7 with two counter barriers.  A spin that does not end (lost workgroup) gives up
+// after a bounded number of polls and the call returns an error.
 // The matrix is symmetric and stays so (both triangles receive the same rounded value), which is what lets A read rows
 // i and j where the reference reads columns; cr_neighbor_joining_device checks the symmetry of its input and hands
 // anything else to the host implementation.
