@@ -116,6 +116,7 @@ struct RbfTensor {
     double neg_gamma;
     double row[R][D];
     double col[D];
+    double col2[D];                       // second set of column features (column sweep with few rows per lane)
     static constexpr int kRingDoubles = D * kRing;
     static constexpr bool kMaskRows = false;
 
@@ -161,12 +162,13 @@ struct RbfTensor {
         for (int k = 0; k < D; k++) col[k] = res[k * stride + c];
     }
     // sum_k (a_ik - b_jk)^2, k ascending
-    CR_D double dist2(int q) const {
-        double df = row[q][0] - col[0];
+    CR_D double dist2(int q) const { return dist2_of(q, col); }
+    CR_D double dist2_of(int q, const double (&c)[D]) const {
+        double df = row[q][0] - c[0];
         double acc = df * df;
 #pragma unroll
         for (int k = 1; k < D; k++) {
-            df = row[q][k] - col[k];
+            df = row[q][k] - c[k];
             acc = acc + df * df;
         }
         return acc;
@@ -729,6 +731,12 @@ CR_D double wave_scan_max(double v) {
     return v;
 }
 
+// rows per lane up to which the column sweep keeps two sets of column features (ColSweep::step; 32 structures x 150:
+// k_seed 0.114 -> 0.110 ms -- with one wave per SIMD and three rows per lane the step is bound by the latency of its
+// dependent FP64 chains, about 6 cycles per instruction, more than by the scalar loads)
+template <int R>
+constexpr bool kTwoColumnSets = R <= 3;
+
 // Per-lane state of the column sweep and one column step.
 template <int R, int D>
 struct ColSweep {
@@ -753,23 +761,32 @@ struct ColSweep {
     // features are zeroed by scalar selects -- conditional loads would cost a branch each.)
     template <bool FULL>
     CR_D void prefetch(RbfTensor<R, D>& src, int j) {
+        prefetch_into<FULL>(src, j, src.col);
+    }
+    template <bool FULL>
+    CR_D void prefetch_into(RbfTensor<R, D>& src, int j, double (&set)[D]) {
         const double* __restrict__ cg = src.cols_g;
         const int d = FULL ? D : src.d;
 #pragma unroll
         for (int k = 0; k < D; k++) {
             const double v = cg[(int64_t)j * d + k];
-            src.col[k] = (FULL || k < d) ? v : 0.0;
+            set[k] = (FULL || k < d) ? v : 0.0;
         }
     }
     // Column j (prefetch<FULL>(src, j) has been called; `jn` = the column to request now, any valid column).  FULL: the
     // stored tensor width equals D (no padded features).  `top`: H of the row above the strip in this column
     // (wave-uniform; only read when TOP).
-    template <bool FULL, bool TOP>
+    // SET 0: one set of feature registers, as described above.  SET 1 / 2 (few rows per lane: the arithmetic behind the
+    // squared distances is too short to cover a scalar load that misses): two sets in turn -- column j is in set SET,
+    // column jn is requested into the other one BEFORE anything else, so the load has the whole step to arrive.
+    template <bool FULL, bool TOP, int SET = 0>
     CR_D void step(RbfTensor<R, D>& src, const ExpEntry* tab, int j, int jn, double top) {
         double acc[R];
+        if constexpr (SET == 1) prefetch_into<FULL>(src, jn, src.col2);
+        if constexpr (SET == 2) prefetch_into<FULL>(src, jn, src.col);
 #pragma unroll
-        for (int q = 0; q < R; q++) acc[q] = src.dist2(q);
-        prefetch<FULL>(src, jn);
+        for (int q = 0; q < R; q++) acc[q] = SET == 2 ? src.dist2_of(q, src.col2) : src.dist2_of(q, src.col);
+        if constexpr (SET == 0) prefetch<FULL>(src, jn);
         double dg[R], p[R];
 #pragma unroll
         for (int q = 0; q < R; q++) {
@@ -849,12 +866,22 @@ CR_D void sweep_cols(RbfTensor<R, D>& src, const int n, const int m, double* lds
             constexpr bool FULL = decltype(full_tag)::value, TOP = decltype(top_tag)::value;
             double top_vec = 0.0;                // row above the strip, 64 columns per load (lane x: column j0 + x)
             st.template prefetch<FULL>(src, 0);
-#pragma unroll 1
-            for (int j = 0; j < m; j++) {
+            auto column = [&](auto set_tag, int j) {
+                constexpr int SET = decltype(set_tag)::value;
                 if (TOP && (j & (kWave - 1)) == 0) top_vec = (j + lane < m) ? hand_g[j + lane] : 0.0;
-                st.template step<FULL, TOP>(src, tab, j, j + 1 < m ? j + 1 : j, TOP ? lane_value(top_vec, j & (kWave - 1)) : 0.0);
+                st.template step<FULL, TOP, SET>(src, tab, j, j + 1 < m ? j + 1 : j, TOP ? lane_value(top_vec, j & (kWave - 1)) : 0.0);
                 if (hand_out && lane == kWave - 1) hand_g[j] = st.hprev[R - 1];
                 if ((j & 15) == 15 || j == m - 1) st.flush(sw_dirs, ((int64_t)(s * TB + (j >> 4)) * R) * kWave + lane);
+            };
+            if constexpr (kTwoColumnSets<R>) {
+#pragma unroll 1
+                for (int j = 0; j < m; j += 2) {
+                    column(std::integral_constant<int, 1>{}, j);
+                    if (j + 1 < m) column(std::integral_constant<int, 2>{}, j + 1);
+                }
+            } else {
+#pragma unroll 1
+                for (int j = 0; j < m; j++) column(std::integral_constant<int, 0>{}, j);
             }
         };
         if (s == 0) {

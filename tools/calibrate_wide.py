@@ -21,6 +21,8 @@ WORKLOADS = {
     "c5share": (64, 1200, 20244, 8),      # 252 pairs: one GPU's share of BASELINE config 5 on 8 GPUs
     "c5": (64, 1200, 20244, 1),
     "c2": (32, 150, 20241, 1),
+    "c2half": (32, 150, 20241, 2),        # 248 pairs: at most one wave per CU
+    "c2x4": (64, 150, 20241, 1),          # 2016 pairs: two per SIMD
     "one300": (2, 300, 7, 1),
     "p64x300": (12, 300, 11, 1),          # 66 pairs
     "p120x600": (16, 600, 12, 1),         # 120 pairs
