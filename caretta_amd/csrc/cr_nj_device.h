@@ -511,6 +511,17 @@ int cr_neighbor_joining_device(cr_context* ctx, const double* D0, int64_t P, uin
     const int waves_total = groups * cr::kNjGroupWaves;
     const int rows_per_wave = (int)((P + waves_total - 1) / waves_total);
     const int64_t W = (2 * P - 3 + 15) / 16 * 16;            // a row and a column per node id
+    const size_t lds = cr::nj_lds_bytes((int)P, rows_per_wave);
+    rc = allow_lds(cr::k_neighbor_joining, lds);
+    if (rc) return rc;
+    // the workgroups wait for each other: all of them must fit on the device at once (a partition with few CUs may not
+    // take them), else the host implementation
+    {
+        int per_cu = 0, cus = 0;
+        CR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cr::k_neighbor_joining, cr::kNjGroupThreads, lds));
+        CR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+        if ((int64_t)per_cu * cus < groups) return cr_neighbor_joining(D0, P, tree, bl);
+    }
     const size_t rows = (size_t)(2 * P - 3);
     DevBuf<double> d, dense;
     DevBuf<unsigned long long> dwords;                     // published words: [3][P] row sums, [3][waves][kNjCandWords] minima
@@ -529,15 +540,7 @@ int cr_neighbor_joining_device(cr_context* ctx, const double* D0, int64_t P, uin
     double* dbl = reinterpret_cast<double*>(dout.p + 2 * rows);
     cr::NjGridState* dstate = reinterpret_cast<cr::NjGridState*>(dout.p + 3 * rows);
     const double ms_alloc = ms_since(t_start);
-    if (profile) {
-        CR_HIP(hipStreamSynchronize(ctx->stream));
-        std::fprintf(stderr, "[nj] stream idle after %.3f ms\n", ms_since(t_start));
-    }
     CR_HIP(hipMemsetAsync(dstate, 0, sizeof(cr::NjGridState), ctx->stream));
-    if (profile) {
-        CR_HIP(hipStreamSynchronize(ctx->stream));
-        std::fprintf(stderr, "[nj] memset done after %.3f ms\n", ms_since(t_start));
-    }
     rc = upload_async(ctx, dense.p, D0, sizeof(double) * (size_t)(P * P));
     if (rc) return rc;
     double ms_copied = 0.0;
@@ -545,9 +548,6 @@ int cr_neighbor_joining_device(cr_context* ctx, const double* D0, int64_t P, uin
         CR_HIP(hipStreamSynchronize(ctx->stream));
         ms_copied = ms_since(t_start);
     }
-    const size_t lds = cr::nj_lds_bytes((int)P, rows_per_wave);
-    rc = allow_lds(cr::k_neighbor_joining, lds);
-    if (rc) return rc;
     CR_LAUNCH(cr::k_neighbor_joining, dim3(groups), dim3(cr::kNjGroupThreads), lds, ctx->stream, dense.p, d.p, (int)W, (int)P,
               rows_per_wave, dwords.p, dwords.p + 3 * (size_t)P, dstate, dtree, dbl, profile ? dprof.p : nullptr);
     CR_HIP(hipGetLastError());

@@ -17,6 +17,7 @@ python tools/bench_msa.py 128 300 > $O/msa_128.txt 2>&1
 python tools/bench_msa.py 512 300 > $O/msa_512.txt 2>&1
 python tools/config5_share_time.py > $O/config5_share.txt 2>&1
 python tools/dropin_latency.py > $O/dropin_latency.txt 2>&1
+python tools/nj_device_time.py > $O/nj_device_time.txt 2>&1
 python tools/explicit_batch_rate.py > $O/explicit_batch_rate.txt 2>&1
 # HBM counters of the batched explicit-matrix row sweep (separate --pmc passes, --kernel-trace only)
 for C in FETCH_SIZE WRITE_SIZE; do
