@@ -220,6 +220,38 @@ def test_fetch_variants_agree(ctx):
     assert res32.tobytes() == res.tobytes()               # ... and outlive the batch
 
 
+def test_transfers_through_the_ring_match_direct_ones(ctx):
+    """Pageable caller memory goes through the context's page-locked ring in 8 MiB slots (upload_async / download), page-
+    locked memory goes straight: same bytes either way, for sizes below one slot, across a slot boundary and not a
+    multiple of the slot."""
+    from caretta_amd import engine, score_functions as sf
+    rng = np.random.default_rng(77)
+    # download: a 1100 x 1100 score matrix (9.7 MB: two slots, the second partial) into pageable and into page-locked memory
+    a, b = rng.normal(size=(1100, 3)), rng.normal(size=(1100, 3))
+    want = np.exp(-0.03 * ((a[:, None, :] - b[None, :, :]) ** 2).sum(-1))
+    got = sf.make_score_matrix(a, b, sf.get_gaussian_score, 0.03)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+    # upload: 64 structures x 2000 residues x (3 + 10) doubles = 3 + 10 MB of pageable arrays (the tensors cross a slot
+    # boundary) against the same data in page-locked arrays; fetch into pageable and into page-locked arrays
+    fam = synthetic.make_family(64, 2000, seed=99, clades=3)
+    coords, tensors, offsets = synthetic.pack(fam)
+    pairs = engine.all_pairs(64)[::90]
+    pinned_coords, pinned_tensors = engine.pinned_empty(coords.shape, np.float64), engine.pinned_empty(tensors.shape, np.float64)
+    pinned_coords[...] = coords
+    pinned_tensors[...] = tensors
+    out = []
+    for c, t in ((coords, tensors), (pinned_coords, pinned_tensors)):
+        batch = engine.PairBatch(ctx, c, t, offsets).set_pairs(pairs)
+        batch.run(engine.make_params())
+        out.append((batch.fetch(), batch.fetch(pinned=True)))
+        batch.close()
+    (res_a, aln_a), (res_a32, aln_a32) = out[0]
+    (res_b, aln_b), (res_b32, aln_b32) = out[1]
+    assert res_a.tobytes() == res_b.tobytes() == res_a32.tobytes() == res_b32.tobytes()
+    assert np.array_equal(aln_a, aln_b) and np.array_equal(aln_a, aln_a32) and np.array_equal(aln_a32, aln_b32)
+    assert tensors.nbytes > 8 << 20 and got.nbytes > 8 << 20
+
+
 def test_plugin_pairwise_matrix_runs_batched(oracle):
     """A third-party SequenceBase plugin (multiple_alignment.py:109-127): make_pairwise_matrix = the reference's loop of
     smith_waterman_score over the plugin's own score matrices, computed many matrices per launch."""
