@@ -230,11 +230,10 @@ struct cr_context {
     // run side by side they fill each other's partial last rounds (created on first use).
     std::vector<hipStream_t> side;
     std::vector<hipEvent_t> sync_ev;
-    // page-locked landing area for small results of single calls (a first copy into pageable memory costs
-    // milliseconds); grown on demand by host_landing()
+    // page-locked landing area for small results of single calls; grown on demand by host_landing()
     void* landing = nullptr;
     size_t landing_bytes = 0;
-    // page-locked ring for transfers between the device and the caller's PAGEABLE memory (staged_copy)
+    // page-locked ring for transfers between the device and the caller's PAGEABLE memory (upload_async / download)
     void* ring = nullptr;
     hipEvent_t ring_ev[2] = {nullptr, nullptr};
     bool ring_busy[2] = {false, false};
@@ -307,13 +306,12 @@ int host_landing(cr_context* ctx, size_t bytes, void** out) {
     return CR_OK;
 }
 
-// Copies between the device and memory the CALLER owns.  Handing pageable memory to hipMemcpyAsync makes the runtime
-// pin the pages, copy, and unpin them later: about 1 GB/s, and the deferred unpin stalls the next transfer (measured
-// with rocprofv3 --hip-trace: 18 ms for the 16 MB of a 512-structure batch, 21 ms for the 2 MB matrix of the
-// neighbor joining right behind it).  So pageable memory is staged through a page-locked ring of two slots, filled /
-// drained by memcpy (~10 GB/s) while the other slot is on the wire.  Page-locked caller memory (cr_host_alloc) and
-// small blocks go straight through.  Uploads return with the last slots still in flight (the ring is guarded by
-// events); downloads return when the data is in `dst`.
+// Copies between the device and memory the CALLER owns.  Pageable memory handed to hipMemcpyAsync is pinned, copied and
+// unpinned (or bounced through the runtime's own staging) inside the call; here it is staged through a page-locked ring
+// of two slots owned by the context, filled / drained by memcpy (~10 GB/s) while the other slot is on the wire, so the
+// device side of every transfer is a plain DMA from or to page-locked memory.  Page-locked caller memory
+// (cr_host_alloc) and small blocks go straight through.  Uploads return with the last slots still in flight (the ring
+// is guarded by events; the caller's buffer is free again on return); downloads return when the data is in `dst`.
 constexpr size_t kRingSlot = (size_t)8 << 20;
 constexpr size_t kStageFrom = (size_t)64 << 10;
 
@@ -1185,8 +1183,7 @@ int cr_batch_fetch_scores(cr_batch* b, double* sw, uint32_t* flags) {
     // gather the field on the device, then one contiguous copy (8 or 4 bytes per pair instead of 160)
     hipStream_t st = b->ctx->stream;
     const size_t np = (size_t)b->npairs;
-    // both fields land in the context's page-locked area with one wait (a copy straight into the caller's pageable
-    // arrays makes the runtime pin and unpin them, which stalls whatever touches the device next)
+    // both fields land in the context's page-locked area with one wait, then go to the caller's arrays in its order
     void* land = nullptr;
     rc = host_landing(b->ctx, np * (sizeof(double) + sizeof(uint32_t)), &land);
     if (rc) return rc;
