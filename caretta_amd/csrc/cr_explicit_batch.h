@@ -237,8 +237,7 @@ struct ExplicitStream {
     int m_, lane_, t_;
     double* ring_;
     int low_[R];                 // this lane's stream offsets modulo 16 (which block / position a column falls in)
-    Pair8 pend[R][kLoads];       // quarter blocks in flight: pend[q][y] belongs to lane 16y + lane / 4 (parked at the next boundary)
-    Pair8 pend2[R][kLoads];      // ... and the blocks behind them (parked one boundary later): 16 steps of flight time
+    Pair8 pend[R][kLoads];       // quarter blocks in flight: pend[q][y] belongs to lane 16y + lane / 4
     double val[R];
 
     CR_D int64_t* stream_offsets() const { return reinterpret_cast<int64_t*>(ring_ + R * 2 * kBlk * kWave); }
@@ -292,12 +291,10 @@ struct ExplicitStream {
             low_[q] = (int)(off & 15);
         }
         wave_sync();
-        // the window [0, 8): the block it starts in (parked at once) and the block it ends in (parked at step 0); the
-        // block the window [8, 16) ends in (parked at step 8)
+        // the window [0, 8): the block it starts in (parked at once) and the block it ends in (parked at step 0)
         Pair8 first[R][kLoads];
         issue<false>(0, first);
         issue<true>(0, pend);
-        issue<true>(kBlk, pend2);
         park<false>(0, first);
     }
     CR_D void load_chunk(double*, int, int, int) {}
@@ -307,11 +304,7 @@ struct ExplicitStream {
         if ((t & (kBlk - 1)) == 0) {
             park<true>(t, pend);                      // the block the window [t, t + 8) ends in
             wave_sync();
-#pragma unroll
-            for (int q = 0; q < R; q++)
-#pragma unroll
-                for (int y = 0; y < kLoads; y++) pend[q][y] = pend2[q][y];
-            issue<true>(t + 2 * kBlk, pend2);         // ... and the one the window after next will end in
+            issue<true>(t + kBlk, pend);              // ... and the one the next window will end in
         }
     }
     CR_D void fetch_col(const double* ring, int) {
