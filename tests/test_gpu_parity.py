@@ -837,7 +837,7 @@ def test_neighbor_joining_device_matches_oracle(ctx, oracle, golden):
         key = tag.replace("golden", "nj") + "_tree"
         assert nj.bipartitions(tree, d.shape[0]) == nj.bipartitions(g[key], d.shape[0]), tag
     rng = np.random.default_rng(11)
-    for p in (3, 4, 5, 17, 64, 65, 130, 300, 1025, 1100):
+    for p in (3, 4, 5, 17, 64, 65, 130, 256, 300, 1025, 1100, 2048, 2049):      # 2048: the kernel's largest; 2049: host
         a = rng.uniform(0.5, 40.0, size=(p, p))
         d = a + a.T
         d[np.diag_indices(p)] = rng.uniform(0.0, 80.0)           # constant non-zero diagonal, as max(M) - M has
