@@ -306,8 +306,11 @@ int host_landing(cr_context* ctx, size_t bytes, void** out) {
     return CR_OK;
 }
 
-// Copies between the device and memory the CALLER owns.  Pageable memory handed to hipMemcpyAsync is pinned, copied and
-// unpinned (or bounced through the runtime's own staging) inside the call; here it is staged through a page-locked ring
+// Copies between the device and memory the library does not own (the caller's arrays, host vectors).  Pageable memory
+// handed to hipMemcpyAsync for a large copy is pinned by the runtime as a user pointer; when the host allocator later
+// unmaps or recycles such pages the process's queues are held back while the mapping is revalidated -- measured as the
+// first kernel of the NEXT call starting ~20 ms late (tools/stall_probe.py).  So nothing of 64 KB
+// or more is ever handed over directly: it is staged through a page-locked ring
 // of two slots owned by the context, filled / drained by memcpy (~10 GB/s) while the other slot is on the wire, so the
 // device side of every transfer is a plain DMA from or to page-locked memory.  Page-locked caller memory
 // (cr_host_alloc) and small blocks go straight through.  Uploads return with the last slots still in flight (the ring
@@ -1024,15 +1027,12 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     if (e == hipSuccess) e = b->seed_score.ensure((size_t)npairs);
     if (e == hipSuccess) e = b->res.ensure((size_t)npairs);
     if (e == hipSuccess && b->reordered) e = b->d_order.ensure((size_t)npairs);
-    if (e == hipSuccess && b->reordered)
-        e = hipMemcpyAsync(b->d_order.p, b->order.data(), sizeof(int32_t) * (size_t)npairs, hipMemcpyHostToDevice, b->ctx->stream);
-    if (e == hipSuccess && npairs)
-        e = hipMemcpyAsync(b->pairs.p, b->h_pairs.data(), sizeof(cr::PairDesc) * (size_t)npairs, hipMemcpyHostToDevice,
-                           b->ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(b->ctx->stream);
     if (e != hipSuccess)
         return fail(e == hipErrorOutOfMemory ? CR_ERR_MEMORY : CR_ERR_HIP,
                     std::string("allocating pair scratch: ") + hipGetErrorString(e));
+    if (b->reordered && (rc = upload_async(b->ctx, b->d_order.p, b->order.data(), sizeof(int32_t) * (size_t)npairs))) return rc;
+    if (npairs && (rc = upload_async(b->ctx, b->pairs.p, b->h_pairs.data(), sizeof(cr::PairDesc) * (size_t)npairs))) return rc;
+    CR_HIP(hipStreamSynchronize(b->ctx->stream));
     return CR_OK;
 }
 

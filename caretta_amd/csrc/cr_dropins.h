@@ -273,12 +273,11 @@ __global__ __launch_bounds__(kWave) void k_reference_superpose(const double* __r
 namespace {
 
 template <class T>
-int upload(DevBuf<T>& buf, const T* host, size_t count, hipStream_t stream) {
+int upload(DevBuf<T>& buf, const T* host, size_t count, cr_context* ctx) {
     hipError_t e = buf.ensure(count);
-    if (e == hipSuccess && count) e = hipMemcpyAsync(buf.p, host, sizeof(T) * count, hipMemcpyHostToDevice, stream);
     if (e != hipSuccess)
         return fail(e == hipErrorOutOfMemory ? CR_ERR_MEMORY : CR_ERR_HIP, std::string("upload: ") + hipGetErrorString(e));
-    return CR_OK;
+    return count ? upload_async(ctx, buf.p, host, sizeof(T) * count) : CR_OK;
 }
 
 int to_i32(const int64_t* seq, int64_t len, int64_t bound, std::vector<int32_t>& out, const char* what) {
@@ -314,9 +313,9 @@ int run_explicit(cr_context* ctx, const int64_t* seq1, int64_t n, const int64_t*
     std::vector<int32_t> h1, h2;
     if ((rc = to_i32(seq1, n, s_rows, h1, "seq1"))) return rc;
     if ((rc = to_i32(seq2, m, s_cols, h2, "seq2"))) return rc;
-    if ((rc = upload(r.S, S, (size_t)s_rows * s_cols, ctx->stream))) return rc;
-    if ((rc = upload(r.s1, h1.data(), (size_t)n, ctx->stream))) return rc;
-    if ((rc = upload(r.s2, h2.data(), (size_t)m, ctx->stream))) return rc;
+    if ((rc = upload(r.S, S, (size_t)s_rows * s_cols, ctx))) return rc;
+    if ((rc = upload(r.s1, h1.data(), (size_t)n, ctx))) return rc;
+    if ((rc = upload(r.s2, h2.data(), (size_t)m, ctx))) return rc;
     constexpr int R = kExplicitR;
     const size_t nd = (size_t)cr::strips_of((int)n, R) * cr::tblocks((int)m, 16) * R * cr::kWave;
     const size_t nb = (size_t)cr::strips_of((int)n, R) * cr::tblocks((int)m, 8) * R * cr::kWave;
@@ -452,8 +451,8 @@ int cr_make_score_matrix(cr_context* ctx, const double* a, int64_t n, const doub
     CR_REQUIRE(all_finite(a, (size_t)n * k) && all_finite(b, (size_t)m * k) && std::isfinite(gamma),
                "inputs contain NaN or infinity");
     DevBuf<double> da, db, ds;
-    if ((rc = upload(da, a, (size_t)n * k, ctx->stream))) return rc;
-    if ((rc = upload(db, b, (size_t)m * k, ctx->stream))) return rc;
+    if ((rc = upload(da, a, (size_t)n * k, ctx))) return rc;
+    if ((rc = upload(db, b, (size_t)m * k, ctx))) return rc;
     CR_HIP(ds.ensure((size_t)n * m));
     dim3 block(64, 4), grid((unsigned)((m + 63) / 64), (unsigned)((n + 3) / 4));
     CR_LAUNCH(cr::k_score_matrix, grid, block, 0, ctx->stream, da.p, (int)n, db.p, (int)m, (int)k, -gamma, ds.p);
@@ -545,7 +544,7 @@ int cr_progressive_node(cr_context* ctx, const double* coords_1, const double* t
     const int64_t cap = n + m;
     DevBuf<double> dw, dxn, dtn, dwn;
     DevBuf<cr::NodeOut> dout;
-    if ((rc = upload(dw, weights.data(), (size_t)cap, ctx->stream))) return rc;
+    if ((rc = upload(dw, weights.data(), (size_t)cap, ctx))) return rc;
     CR_HIP(dxn.ensure((size_t)cap * 3));
     CR_HIP(dtn.ensure((size_t)cap * d));
     CR_HIP(dwn.ensure((size_t)cap));
@@ -554,7 +553,7 @@ int cr_progressive_node(cr_context* ctx, const double* coords_1, const double* t
     const int entries = (int)cap;
     const cr::NodeDesc hnd{mult1, mult2, 0};
     DevBuf<cr::NodeDesc> dnd;
-    if ((rc = upload(dnd, &hnd, 1, ctx->stream))) return rc;
+    if ((rc = upload(dnd, &hnd, 1, ctx))) return rc;
     rc = b->team ? launch_node_team(R, ctx->stream, 1, (int)n, (int)m, entries, b->pairs.p, b->coords.p, b->tensors.p, (int)d,
                                     dw.p, dnd.p, b->xf.p, prm, gamma_weight, b->bits.p, b->hand.p, b->aln.p, dxn.p, dtn.p, dwn.p,
                                     dout.p)
@@ -656,8 +655,8 @@ int cr_paired_svd_superpose(cr_context* ctx, const double* x1, const double* x2,
         return CR_OK;
     }
     DevBuf<double> d1, d2, out;
-    if ((rc = upload(d1, x1, (size_t)k * 3, ctx->stream))) return rc;
-    if ((rc = upload(d2, x2, (size_t)k * 3, ctx->stream))) return rc;
+    if ((rc = upload(d1, x1, (size_t)k * 3, ctx))) return rc;
+    if ((rc = upload(d2, x2, (size_t)k * 3, ctx))) return rc;
     CR_HIP(out.ensure(18));
     CR_LAUNCH(cr::k_kabsch, dim3(1), dim3(1), 0, ctx->stream, d1.p, d2.p, (int)k, out.p);
     CR_HIP(hipGetLastError());
@@ -676,10 +675,10 @@ int cr_paired_svd_superpose_with_subset(cr_context* ctx, const double* c1, int64
     if (rc) return rc;
     CR_REQUIRE(c1 && c2 && s1 && s2 && o1 && o2 && k >= 1 && n >= 1 && m >= 1, "bad argument");
     DevBuf<double> dc1, dc2, ds1, ds2, kab, r1, r2, r3;
-    if ((rc = upload(dc1, c1, (size_t)n * 3, ctx->stream))) return rc;
-    if ((rc = upload(dc2, c2, (size_t)m * 3, ctx->stream))) return rc;
-    if ((rc = upload(ds1, s1, (size_t)k * 3, ctx->stream))) return rc;
-    if ((rc = upload(ds2, s2, (size_t)k * 3, ctx->stream))) return rc;
+    if ((rc = upload(dc1, c1, (size_t)n * 3, ctx))) return rc;
+    if ((rc = upload(dc2, c2, (size_t)m * 3, ctx))) return rc;
+    if ((rc = upload(ds1, s1, (size_t)k * 3, ctx))) return rc;
+    if ((rc = upload(ds2, s2, (size_t)k * 3, ctx))) return rc;
     CR_HIP(kab.ensure(18));
     CR_HIP(r1.ensure((size_t)n * 3));
     CR_HIP(r2.ensure((size_t)m * 3));
@@ -709,8 +708,8 @@ int cr_apply_rotran(cr_context* ctx, const double* x, int64_t k, const double* R
     double rt[12];
     std::memcpy(rt, R, sizeof(double) * 9);
     std::memcpy(rt + 9, t, sizeof(double) * 3);
-    if ((rc = upload(dx, x, (size_t)k * 3, ctx->stream))) return rc;
-    if ((rc = upload(dr, rt, 12, ctx->stream))) return rc;
+    if ((rc = upload(dx, x, (size_t)k * 3, ctx))) return rc;
+    if ((rc = upload(dr, rt, 12, ctx))) return rc;
     CR_HIP(dout.ensure((size_t)k * 3));
     const int th = 256;
     CR_LAUNCH(cr::k_transform, dim3((unsigned)((k + th - 1) / th)), dim3(th), 0, ctx->stream, dx.p, (int)k, dr.p,
@@ -730,8 +729,8 @@ static int rmsd_tm(cr_context* ctx, const double* x1, const double* x2, int64_t 
         return CR_OK;
     }
     DevBuf<double> d1, d2, out;
-    if ((rc = upload(d1, x1, (size_t)k * 3, ctx->stream))) return rc;
-    if ((rc = upload(d2, x2, (size_t)k * 3, ctx->stream))) return rc;
+    if ((rc = upload(d1, x1, (size_t)k * 3, ctx))) return rc;
+    if ((rc = upload(d2, x2, (size_t)k * 3, ctx))) return rc;
     CR_HIP(out.ensure(2));
     CR_LAUNCH(cr::k_rmsd_tm, dim3(1), dim3(1), 0, ctx->stream, d1.p, d2.p, (int)k, l1, l2, out.p);
     CR_HIP(hipGetLastError());
@@ -787,10 +786,10 @@ int cr_msa_metrics(cr_context* ctx, const double* coords, const int64_t* offsets
     DevBuf<double> dc, dout;
     DevBuf<int64_t> doff;
     DevBuf<int32_t> dmsa, dpairs;
-    if ((rc = upload(dc, coords, (size_t)total * 3, ctx->stream))) return rc;
-    if ((rc = upload(doff, offsets, (size_t)P + 1, ctx->stream))) return rc;
-    if ((rc = upload(dmsa, msa, (size_t)P * W, ctx->stream))) return rc;
-    if ((rc = upload(dpairs, pairs.data(), pairs.size(), ctx->stream))) return rc;
+    if ((rc = upload(dc, coords, (size_t)total * 3, ctx))) return rc;
+    if ((rc = upload(doff, offsets, (size_t)P + 1, ctx))) return rc;
+    if ((rc = upload(dmsa, msa, (size_t)P * W, ctx))) return rc;
+    if ((rc = upload(dpairs, pairs.data(), pairs.size(), ctx))) return rc;
     CR_HIP(dout.ensure((size_t)npairs * 4));
     const size_t lds = sizeof(double) * (((size_t)W + 3) / 4 * 2 + (size_t)cr::kWave * cr::kMaxAcc);
     if ((rc = allow_lds(cr::k_msa_metrics, lds))) return rc;
@@ -843,10 +842,10 @@ int cr_superpose_core(cr_context* ctx, const double* coords, const int64_t* offs
     DevBuf<double> dc, dout, dx1, dcen;
     DevBuf<int64_t> doff;
     DevBuf<int32_t> dmsa, dcore;
-    if ((rc = upload(dc, coords, (size_t)total * 3, ctx->stream))) return rc;
-    if ((rc = upload(doff, offsets, (size_t)P + 1, ctx->stream))) return rc;
-    if ((rc = upload(dmsa, msa, (size_t)P * W, ctx->stream))) return rc;
-    if ((rc = upload(dcore, core, (size_t)ncore, ctx->stream))) return rc;
+    if ((rc = upload(dc, coords, (size_t)total * 3, ctx))) return rc;
+    if ((rc = upload(doff, offsets, (size_t)P + 1, ctx))) return rc;
+    if ((rc = upload(dmsa, msa, (size_t)P * W, ctx))) return rc;
+    if ((rc = upload(dcore, core, (size_t)ncore, ctx))) return rc;
     CR_HIP(dout.ensure((size_t)total * 3));
     CR_HIP(dx1.ensure((size_t)ncore * 3));
     CR_HIP(dcen.ensure(3));
@@ -881,10 +880,10 @@ int cr_superpose_reference(cr_context* ctx, const double* coords, const int64_t*
     // list order of the reference's loop: structures before the reference, the reference itself, the rest
     std::vector<int32_t> which((size_t)P);
     for (int64_t s = 0; s < P; s++) which[(size_t)s] = (int32_t)s;
-    if ((rc = upload(dc, coords, (size_t)total * 3, ctx->stream))) return rc;
-    if ((rc = upload(doff, offsets, (size_t)P + 1, ctx->stream))) return rc;
-    if ((rc = upload(dmsa, msa, (size_t)P * W, ctx->stream))) return rc;
-    if ((rc = upload(dwhich, which.data(), (size_t)P, ctx->stream))) return rc;
+    if ((rc = upload(dc, coords, (size_t)total * 3, ctx))) return rc;
+    if ((rc = upload(doff, offsets, (size_t)P + 1, ctx))) return rc;
+    if ((rc = upload(dmsa, msa, (size_t)P * W, ctx))) return rc;
+    if ((rc = upload(dwhich, which.data(), (size_t)P, ctx))) return rc;
     CR_HIP(dout.ensure((size_t)total * 3));
     CR_HIP(dcounts.ensure((size_t)P));
     const size_t lds = sizeof(double) * (((size_t)W + 3) / 4 * 2 + (size_t)cr::kWave * cr::kMaxAcc);
@@ -923,10 +922,10 @@ int cr_superpose_members(cr_context* ctx, double* coords, const int64_t* offsets
     DevBuf<double> dc, dout;
     DevBuf<int64_t> doff;
     DevBuf<int32_t> dmsa, dwhich, dcounts;
-    if ((rc = upload(dc, coords, (size_t)total * 3, ctx->stream))) return rc;
-    if ((rc = upload(doff, offsets, (size_t)P + 1, ctx->stream))) return rc;
-    if ((rc = upload(dmsa, msa, (size_t)P * W, ctx->stream))) return rc;
-    if ((rc = upload(dwhich, which, (size_t)nwhich, ctx->stream))) return rc;
+    if ((rc = upload(dc, coords, (size_t)total * 3, ctx))) return rc;
+    if ((rc = upload(doff, offsets, (size_t)P + 1, ctx))) return rc;
+    if ((rc = upload(dmsa, msa, (size_t)P * W, ctx))) return rc;
+    if ((rc = upload(dwhich, which, (size_t)nwhich, ctx))) return rc;
     CR_HIP(dout.ensure((size_t)total * 3));
     CR_HIP(dcounts.ensure((size_t)nwhich));
     CR_HIP(hipMemcpyAsync(dout.p, dc.p, sizeof(double) * (size_t)total * 3, hipMemcpyDeviceToDevice, ctx->stream));

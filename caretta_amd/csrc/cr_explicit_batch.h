@@ -534,7 +534,7 @@ int cr_explicit_batch_create(cr_context* ctx, const double* S, int64_t s_elems, 
     b->all_ident = all_ident;
     b->all_ident_sw = all_ident_sw;
     b->r_stream = r_stream;
-    if (has_minus1 && (rc = upload(b->probs_sw, hp_sw.data(), hp_sw.size(), ctx->stream))) return rc;
+    if (has_minus1 && (rc = upload(b->probs_sw, hp_sw.data(), hp_sw.size(), ctx))) return rc;
     // the gather path reads S[row, seq2[c]] only for c < m; the streaming path reads whole row segments inside the row
     // S sits kSlackFront doubles into its buffer and has kSlackBack behind it: the streaming sweep reads whole aligned
     // 64-byte blocks that may start before the first row (lanes that have not reached column 0) and end after the last
@@ -542,8 +542,8 @@ int cr_explicit_batch_create(cr_context* ctx, const double* S, int64_t s_elems, 
     CR_HIP(hipMemsetAsync(b->S.p, 0, sizeof(double) * kSlackFront, ctx->stream));
     CR_HIP(hipMemsetAsync(b->S.p + kSlackFront + s_elems, 0, sizeof(double) * kSlackBack, ctx->stream));
     if ((rc = upload_async(ctx, b->S.p + kSlackFront, S, sizeof(double) * (size_t)s_elems))) return rc;
-    if ((rc = upload(b->seqs, h_seq.data(), h_seq.size(), ctx->stream))) return rc;
-    if ((rc = upload(b->probs, hp.data(), hp.size(), ctx->stream))) return rc;
+    if ((rc = upload(b->seqs, h_seq.data(), h_seq.size(), ctx))) return rc;
+    if ((rc = upload(b->probs, hp.data(), hp.size(), ctx))) return rc;
     CR_HIP(b->hand.ensure((size_t)hand_off));
     CR_HIP(b->scores.ensure((size_t)count));
     CR_HIP(hipEventCreate(&b->ev0));

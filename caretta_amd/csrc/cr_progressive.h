@@ -351,7 +351,8 @@ int cr_progressive_align(cr_context* ctx, const double* coords, const double* te
         if (rc) return rc;
         rc = upload_async(ctx, h->scratch.tensors.p, tensors, sizeof(double) * (size_t)(total * d));
         if (rc) return rc;
-        CR_HIP(hipMemcpyAsync(h->weights.p, w.data(), sizeof(double) * (size_t)total, hipMemcpyHostToDevice, st));
+        rc = upload_async(ctx, h->weights.p, w.data(), sizeof(double) * (size_t)total);
+        if (rc) return rc;
         CR_HIP(hipStreamSynchronize(st));
     }
     std::vector<std::vector<int64_t>> by_level((size_t)h->levels + 1);

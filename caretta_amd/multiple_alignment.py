@@ -271,7 +271,10 @@ class MultipleAlignment:
             batch.run(params, scores_only=scores_only)
             if scores_only:                       # the matrix entries only: 12 bytes per pair come back
                 sw, flags = batch.fetch_scores()
-                res, aln = np.zeros(len(pairs), dtype=_capi.PAIR_RESULT_DTYPE), None
+                # (two columns, not a zeroed PAIR_RESULT record per pair: 21 MB of host memory at 512 structures that nobody
+                # reads, 5 ms to fault in, and allocator churn of that size is what used to delay the next kernel --
+                # DESIGN.md section 8)
+                res, aln = np.zeros(len(pairs), dtype=[("sw", np.float64), ("flags", np.uint32)]), None
                 res["sw"], res["flags"] = sw, flags
             else:
                 res, aln = batch.fetch(want_alignments)

@@ -4,10 +4,10 @@
     python tools/stall_probe.py kernel | d2h | h2d_pageable | h2d_pinned | sleep<ms>
 
 Runs make_pairwise_matrix for 512 x 300 (38 ms of kernels), then one small operation (two kernels of a resident
-four-structure batch, or a transfer), then the same operation again.  Measured on MI355X (rocprofv3 kernel + HIP trace
-of the same script): a KERNEL launched within ~15 ms of the end of the burst starts on the device only ~20 - 25 ms after
-the burst ended, with nothing executing in between; transfers are not delayed; after >= 15 ms of idling (sleep15) the
-first kernel starts at once.
+four-structure batch, or a transfer), then the same operation again.  Before every large transfer went through the
+context's page-locked ring (and while the scores-only path built a 21 MB record array), the first KERNEL after the call
+started on the device ~20 ms after its launch with nothing executing in between (rocprofv3 kernel + HIP trace of this
+script); now it starts within 0.1 ms.  DESIGN.md section 8 has the story.
 """
 import sys, time, numpy as np
 sys.path.insert(0,'/root/repo')
