@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Benchmark of the all-vs-all pairwise structural alignment path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W        (N>1: starts its own N rank processes, one per GPU; under
+                                                          torch.distributed.run it is one of the ranks already)
 
 A "step" is one pass of the pairwise pipeline (seed fill -> seed traceback+Kabsch -> alignment fill
 -> alignment traceback+metrics, plus the all-gather of the score vectors when N>1) over the whole
@@ -127,6 +128,45 @@ def cpu_baseline(coords, tensors, offsets, pairs, gpu_res, gpu_aln, gpu_matrix, 
     return out, gate
 
 
+def spawn_ranks(n_gpus: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start one rank process per GPU (children of this process, which
+    itself makes no GPU call and imports neither torch nor the HIP library), hand rank 0's JSON line on, and return
+    non-zero if any rank fails.  Rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n_gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), LOCAL_WORLD_SIZE=str(n_gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = None                                   # set when a rank has failed: the others may be stuck in a collective
+    while any(p.poll() is None for p in procs):
+        if deadline is None and any(p.poll() not in (None, 0) for p in procs):
+            deadline = time.monotonic() + 15.0
+        if deadline is not None and time.monotonic() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                          # exactly the processes started above
+        time.sleep(0.05)
+    reader.join(timeout=5)
+    codes = [p.returncode for p in procs]
+    sys.stdout.write(b"".join(chunks).decode("utf-8", "replace"))
+    sys.stdout.flush()
+    if any(codes):
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,6 +177,10 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip value_incl_transfers and the c4/c5 sharded timings")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process starts the N ranks itself (it never touches a GPU)
+        raise SystemExit(spawn_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
 
@@ -144,8 +188,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: caretta_amd has no CPU path")

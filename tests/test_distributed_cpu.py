@@ -86,3 +86,17 @@ def test_default_compute_fails_loudly_without_gpu():
     fam = synthetic.make_family(3, 20, seed=1)
     with pytest.raises(Exception):
         cdist.pairwise_matrix_sharded(*synthetic.pack(fam))
+
+
+def test_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must start two rank processes itself.  Without a GPU each
+    RANK (not the launcher) stops with the "needs an MI355X" message, and the parent reports their exit codes."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["HIP_VISIBLE_DEVICES"] = env["ROCR_VISIBLE_DEVICES"] = ""          # also on a GPU box: no device for the ranks
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode != 0
+    assert "must be launched with" not in p.stderr
+    assert p.stderr.count("needs an MI355X") == 2, p.stderr
+    assert "rank exit codes [1, 1]" in p.stderr
