@@ -84,15 +84,21 @@ struct BlockCache {
     std::mutex mu;
     std::map<size_t, std::vector<void*>> bins;
     size_t held = 0;
-    // bytes kept per device at most (CARETTA_CACHE_MB overrides the 24 GiB default; the decision scratch of a
-    // 512-structure batch is 8 GiB, and re-allocating blocks of that size from the driver costs 300-400 ms)
-    static size_t limit() {
-        static const size_t v = [] {
-            const char* env = std::getenv("CARETTA_CACHE_MB");
-            const long long mb = env ? std::atoll(env) : 0;
-            return mb > 0 ? (size_t)mb << 20 : (size_t)24 << 30;
-        }();
-        return v;
+    // Bytes kept per device at most: a tenth of the device's memory, 24 GiB at the most (28.8 GB on a 288 GB MI355X ->
+    // 24 GiB; a small partition keeps proportionally less), so that what other allocators of the process (PyTorch's)
+    // cannot see stays a bounded fraction; CARETTA_CACHE_MB overrides it.  (The decision scratch of a 512-structure
+    // batch is 8 GiB, and re-allocating blocks of that size from the driver costs 300-400 ms.)
+    size_t cap = 0;                                       // 0: not determined yet (first give() on the device)
+    size_t limit() {                                      // called with `mu` held and the device current
+        if (cap) return cap;
+        const char* env = std::getenv("CARETTA_CACHE_MB");
+        const long long mb = env ? std::atoll(env) : 0;
+        if (mb > 0) return cap = (size_t)mb << 20;
+        size_t free_b = 0, total_b = 0;
+        cap = (size_t)24 << 30;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) cap = std::min(cap, total_b / 10);
+        else (void)hipGetLastError();
+        return cap;
     }
     static size_t size_class(size_t bytes) {          // 8 steps per power of two: at most 12.5 % over
         size_t c = 256;
@@ -230,6 +236,10 @@ struct cr_context {
     // run side by side they fill each other's partial last rounds (created on first use).
     std::vector<hipStream_t> side;
     std::vector<hipEvent_t> sync_ev;
+    // copy stream of the pipelined run + fetch (cr_batch_run_fetch_i32): results of one part of the pair list travel to
+    // the host while the kernels of the next part run (created on first use)
+    hipStream_t copy_stream = nullptr;
+    std::vector<hipEvent_t> copy_ev;
     // page-locked landing area for small results of single calls; grown on demand by host_landing()
     void* landing = nullptr;
     size_t landing_bytes = 0;
@@ -394,6 +404,23 @@ int download(cr_context* ctx, void* dst, const void* src, size_t bytes, bool wai
     }
     return CR_OK;
 }
+
+// the copy helpers as statements (return the error code of the enclosing entry point)
+#define CR_UPLOAD(ctx_, dst, src, bytes)                               \
+    do {                                                               \
+        const int _rc = upload_async((ctx_), (dst), (src), (bytes));   \
+        if (_rc) return _rc;                                           \
+    } while (0)
+#define CR_DOWNLOAD(ctx_, dst, src, bytes)                             \
+    do {                                                               \
+        const int _rc = download((ctx_), (dst), (src), (bytes), false);\
+        if (_rc) return _rc;                                           \
+    } while (0)
+#define CR_DOWNLOAD_WAIT(ctx_, dst, src, bytes)                        \
+    do {                                                               \
+        const int _rc = download((ctx_), (dst), (src), (bytes), true); \
+        if (_rc) return _rc;                                           \
+    } while (0)
 
 // every kernel launch of the library goes through this (see g_dirty)
 #define CR_LAUNCH(...)                   \
@@ -765,17 +792,22 @@ int cr_context_create_on_stream(int device, void* stream, cr_context** out) { re
 int cr_context_destroy(cr_context* ctx) {
     if (!ctx) return CR_OK;
     (void)hipSetDevice(ctx->device);
+    // drain first: the staging ring and the landing area may still be the source or target of copies queued on the
+    // context's streams, and nothing below may touch a stream after it has been destroyed
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& st : ctx->side) (void)hipStreamSynchronize(st);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    if (ctx->ring) (void)hipHostFree(ctx->ring);
+    for (hipEvent_t e : ctx->ring_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->landing) (void)hipHostFree(ctx->landing);
     for (auto& l : ctx->ev)
         for (auto& e : l) (void)hipEventDestroy(e);
     for (auto& e : ctx->sync_ev) (void)hipEventDestroy(e);
+    for (auto& e : ctx->copy_ev) (void)hipEventDestroy(e);
     for (auto& st : ctx->side) (void)hipStreamDestroy(st);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
-    if (ctx->landing) (void)hipHostFree(ctx->landing);
-    if (ctx->ring) {
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipHostFree(ctx->ring);
-        for (hipEvent_t e : ctx->ring_ev) (void)hipEventDestroy(e);
-    }
     delete ctx;
     return CR_OK;
 }

@@ -337,11 +337,11 @@ int run_explicit(cr_context* ctx, const int64_t* seq1, int64_t n, const int64_t*
 int fetch_alignment(cr_context* ctx, ExplicitRun& r, int64_t n, int64_t m, int64_t* aln1, int64_t* aln2,
                     int64_t* aln_len) {
     cr::TraceOut to;
-    CR_HIP(hipMemcpyAsync(&to, r.tout.p, sizeof(to), hipMemcpyDeviceToHost, ctx->stream));
+    CR_DOWNLOAD(ctx, &to, r.tout.p, sizeof(to));
     CR_HIP(hipStreamSynchronize(ctx->stream));
     const int64_t cap = n + m;
     std::vector<int32_t> h((size_t)(2 * cap));
-    CR_HIP(hipMemcpy(h.data(), r.aln.p, sizeof(int32_t) * (size_t)(2 * cap), hipMemcpyDeviceToHost));
+    CR_DOWNLOAD_WAIT(ctx, h.data(), r.aln.p, sizeof(int32_t) * (size_t)(2 * cap));
     for (int x = 0; x < to.len; x++) {
         aln1[x] = h[(size_t)(to.start + x)];
         aln2[x] = h[(size_t)(cap + to.start + x)];
@@ -562,17 +562,17 @@ int cr_progressive_node(cr_context* ctx, const double* coords_1, const double* t
     if (rc) return rc;
     CR_HIP(hipGetLastError());
     cr::NodeOut no;
-    CR_HIP(hipMemcpyAsync(&no, dout.p, sizeof(no), hipMemcpyDeviceToHost, ctx->stream));
+    CR_DOWNLOAD(ctx, &no, dout.p, sizeof(no));
     CR_HIP(hipStreamSynchronize(ctx->stream));
     std::vector<int32_t> ha((size_t)(2 * cap));
-    CR_HIP(hipMemcpy(ha.data(), b->aln.p, sizeof(int32_t) * (size_t)(2 * cap), hipMemcpyDeviceToHost));
+    CR_DOWNLOAD_WAIT(ctx, ha.data(), b->aln.p, sizeof(int32_t) * (size_t)(2 * cap));
     for (int x = 0; x < no.len; x++) {
         aln1[x] = ha[(size_t)(no.first + x)];
         aln2[x] = ha[(size_t)(cap + no.first + x)];
     }
-    CR_HIP(hipMemcpy(coords_out, dxn.p + (size_t)no.first * 3, sizeof(double) * (size_t)no.len * 3, hipMemcpyDeviceToHost));
-    CR_HIP(hipMemcpy(tensors_out, dtn.p + (size_t)no.first * d, sizeof(double) * (size_t)no.len * d, hipMemcpyDeviceToHost));
-    CR_HIP(hipMemcpy(weights_out, dwn.p + no.first, sizeof(double) * (size_t)no.len, hipMemcpyDeviceToHost));
+    CR_DOWNLOAD_WAIT(ctx, coords_out, dxn.p + (size_t)no.first * 3, sizeof(double) * (size_t)no.len * 3);
+    CR_DOWNLOAD_WAIT(ctx, tensors_out, dtn.p + (size_t)no.first * d, sizeof(double) * (size_t)no.len * d);
+    CR_DOWNLOAD_WAIT(ctx, weights_out, dwn.p + no.first, sizeof(double) * (size_t)no.len);
     *aln_len = no.len;
     if (flags) *flags = no.flags;
     return CR_OK;
@@ -591,7 +591,7 @@ int cr_dtw_align(cr_context* ctx, const int64_t* seq1, int64_t n, const int64_t*
                            r.end.p, r.aln.p, r.tout.p);
         CR_HIP(hipGetLastError());
     }
-    CR_HIP(hipMemcpyAsync(&e, r.end.p, sizeof(e), hipMemcpyDeviceToHost, ctx->stream));
+    CR_DOWNLOAD(ctx, &e, r.end.p, sizeof(e));
     CR_HIP(hipStreamSynchronize(ctx->stream));
     if (score) *score = e.dtw_score;
     if (aln1 && aln2) return fetch_alignment(ctx, r, n, m, aln1, aln2, aln_len);
@@ -611,7 +611,7 @@ int cr_smith_waterman_score(cr_context* ctx, const int64_t* seq1, int64_t n, con
     int rc = run_explicit<cr::kSwScore>(ctx, seq1, n, seq2, m_eff, S, s_rows, s_cols, prm, r);
     if (rc) return rc;
     cr::AlignEnd e;
-    CR_HIP(hipMemcpyAsync(&e, r.end.p, sizeof(e), hipMemcpyDeviceToHost, ctx->stream));
+    CR_DOWNLOAD(ctx, &e, r.end.p, sizeof(e));
     CR_HIP(hipStreamSynchronize(ctx->stream));
     *score = e.sw;
     return CR_OK;
@@ -629,7 +629,7 @@ int cr_smith_waterman(cr_context* ctx, const int64_t* seq1, int64_t n, const int
                        r.seed.p, r.aln.p, r.tout.p);
     CR_HIP(hipGetLastError());
     cr::SeedMax sm;
-    CR_HIP(hipMemcpyAsync(&sm, r.seed.p, sizeof(sm), hipMemcpyDeviceToHost, ctx->stream));
+    CR_DOWNLOAD(ctx, &sm, r.seed.p, sizeof(sm));
     CR_HIP(hipStreamSynchronize(ctx->stream));
     *score = sm.score;
     if (all_zero) *all_zero = (sm.i == 0) ? 1 : 0;
@@ -661,7 +661,7 @@ int cr_paired_svd_superpose(cr_context* ctx, const double* x1, const double* x2,
     CR_LAUNCH(cr::k_kabsch, dim3(1), dim3(1), 0, ctx->stream, d1.p, d2.p, (int)k, out.p);
     CR_HIP(hipGetLastError());
     double h[18];
-    CR_HIP(hipMemcpyAsync(h, out.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    CR_DOWNLOAD(ctx, h, out.p, sizeof(h));
     CR_HIP(hipStreamSynchronize(ctx->stream));
     std::memcpy(R, h, sizeof(double) * 9);
     std::memcpy(t, h + 9, sizeof(double) * 3);
@@ -692,9 +692,9 @@ int cr_paired_svd_superpose_with_subset(cr_context* ctx, const double* c1, int64
     CR_LAUNCH(cr::k_transform, dim3((unsigned)((k + th - 1) / th)), dim3(th), 0, ctx->stream, ds2.p, (int)k,
                        kab.p, kab.p + 9, (const double*)nullptr, r3.p);
     CR_HIP(hipGetLastError());
-    CR_HIP(hipMemcpyAsync(o1, r1.p, sizeof(double) * (size_t)n * 3, hipMemcpyDeviceToHost, ctx->stream));
-    CR_HIP(hipMemcpyAsync(o2, r2.p, sizeof(double) * (size_t)m * 3, hipMemcpyDeviceToHost, ctx->stream));
-    if (o3) CR_HIP(hipMemcpyAsync(o3, r3.p, sizeof(double) * (size_t)k * 3, hipMemcpyDeviceToHost, ctx->stream));
+    CR_DOWNLOAD(ctx, o1, r1.p, sizeof(double) * (size_t)n * 3);
+    CR_DOWNLOAD(ctx, o2, r2.p, sizeof(double) * (size_t)m * 3);
+    if (o3) CR_DOWNLOAD(ctx, o3, r3.p, sizeof(double) * (size_t)k * 3);
     CR_HIP(hipStreamSynchronize(ctx->stream));
     return CR_OK;
 }
@@ -715,7 +715,7 @@ int cr_apply_rotran(cr_context* ctx, const double* x, int64_t k, const double* R
     CR_LAUNCH(cr::k_transform, dim3((unsigned)((k + th - 1) / th)), dim3(th), 0, ctx->stream, dx.p, (int)k, dr.p,
                        dr.p + 9, (const double*)nullptr, dout.p);
     CR_HIP(hipGetLastError());
-    CR_HIP(hipMemcpyAsync(out, dout.p, sizeof(double) * (size_t)k * 3, hipMemcpyDeviceToHost, ctx->stream));
+    CR_DOWNLOAD(ctx, out, dout.p, sizeof(double) * (size_t)k * 3);
     CR_HIP(hipStreamSynchronize(ctx->stream));
     return CR_OK;
 }
@@ -734,7 +734,7 @@ static int rmsd_tm(cr_context* ctx, const double* x1, const double* x2, int64_t 
     CR_HIP(out.ensure(2));
     CR_LAUNCH(cr::k_rmsd_tm, dim3(1), dim3(1), 0, ctx->stream, d1.p, d2.p, (int)k, l1, l2, out.p);
     CR_HIP(hipGetLastError());
-    CR_HIP(hipMemcpyAsync(h, out.p, sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->stream));
+    CR_DOWNLOAD(ctx, h, out.p, sizeof(double) * 2);
     CR_HIP(hipStreamSynchronize(ctx->stream));
     return CR_OK;
 }
@@ -797,7 +797,7 @@ int cr_msa_metrics(cr_context* ctx, const double* coords, const int64_t* offsets
                        (int)P, (int)W, superpose, dpairs.p, dout.p);
     CR_HIP(hipGetLastError());
     std::vector<double> h((size_t)npairs * 4);
-    CR_HIP(hipMemcpyAsync(h.data(), dout.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
+    CR_DOWNLOAD(ctx, h.data(), dout.p, sizeof(double) * h.size());
     CR_HIP(hipStreamSynchronize(ctx->stream));
     for (int64_t p = 0; p < npairs; p++) {
         const int64_t i = pairs[(size_t)2 * p], j = pairs[(size_t)2 * p + 1];
@@ -858,7 +858,7 @@ int cr_superpose_core(cr_context* ctx, const double* coords, const int64_t* offs
     CR_LAUNCH(cr::k_core_superpose, dim3((unsigned)P), dim3(cr::kWave), lds2, ctx->stream, dc.p, doff.p, dmsa.p, (int)W,
                        dcore.p, (int)ncore, (int)ref, dx1.p, dcen.p, dout.p);
     CR_HIP(hipGetLastError());
-    CR_HIP(hipMemcpyAsync(coords_out, dout.p, sizeof(double) * (size_t)total * 3, hipMemcpyDeviceToHost, ctx->stream));
+    CR_DOWNLOAD(ctx, coords_out, dout.p, sizeof(double) * (size_t)total * 3);
     CR_HIP(hipStreamSynchronize(ctx->stream));
     return CR_OK;
 }
@@ -898,8 +898,8 @@ int cr_superpose_reference(cr_context* ctx, const double* coords, const int64_t*
     launch(ref + 1, P - ref - 1, dout.p + offsets[ref] * 3);       // after it: the refitted reference
     CR_HIP(hipGetLastError());
     std::vector<int32_t> counts((size_t)P);
-    CR_HIP(hipMemcpyAsync(counts.data(), dcounts.p, sizeof(int32_t) * (size_t)P, hipMemcpyDeviceToHost, ctx->stream));
-    CR_HIP(hipMemcpyAsync(coords_out, dout.p, sizeof(double) * (size_t)total * 3, hipMemcpyDeviceToHost, ctx->stream));
+    CR_DOWNLOAD(ctx, counts.data(), dcounts.p, sizeof(int32_t) * (size_t)P);
+    CR_DOWNLOAD(ctx, coords_out, dout.p, sizeof(double) * (size_t)total * 3);
     CR_HIP(hipStreamSynchronize(ctx->stream));
     for (int64_t s = 0; s < P; s++)
         CR_REQUIRE(counts[(size_t)s] > 3, "a structure shares 3 or fewer alignment columns with the reference (reference: assert len(pos_1) > 3)");
@@ -936,8 +936,8 @@ int cr_superpose_members(cr_context* ctx, double* coords, const int64_t* offsets
     CR_HIP(hipGetLastError());
     std::vector<int32_t> counts((size_t)nwhich);
     std::vector<double> moved((size_t)total * 3);
-    CR_HIP(hipMemcpyAsync(counts.data(), dcounts.p, sizeof(int32_t) * (size_t)nwhich, hipMemcpyDeviceToHost, ctx->stream));
-    CR_HIP(hipMemcpyAsync(moved.data(), dout.p, sizeof(double) * (size_t)total * 3, hipMemcpyDeviceToHost, ctx->stream));
+    CR_DOWNLOAD(ctx, counts.data(), dcounts.p, sizeof(int32_t) * (size_t)nwhich);
+    CR_DOWNLOAD(ctx, moved.data(), dout.p, sizeof(double) * (size_t)total * 3);
     CR_HIP(hipStreamSynchronize(ctx->stream));
     for (int64_t b = 0; b < nwhich; b++)
         CR_REQUIRE(counts[(size_t)b] > 3, "a structure shares 3 or fewer alignment columns with the reference (reference: assert len(pos_1) > 3)");

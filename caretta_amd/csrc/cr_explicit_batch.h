@@ -606,7 +606,7 @@ int cr_smith_waterman_score_batch(cr_explicit_batch* b, double gap, double* scor
                                 hipMemcpyDeviceToDevice, st));
     }
     CR_HIP(hipEventRecord(b->ev1, st));
-    CR_HIP(hipMemcpyAsync(scores, b->scores.p, sizeof(double) * (size_t)b->count, hipMemcpyDeviceToHost, st));
+    CR_DOWNLOAD(b->ctx, scores, b->scores.p, sizeof(double) * (size_t)b->count);
     CR_HIP(hipStreamSynchronize(st));
     CR_HIP(hipEventElapsedTime(&b->last_ms, b->ev0, b->ev1));
     return CR_OK;
@@ -654,13 +654,13 @@ int cr_dtw_align_batch(cr_explicit_batch* b, double gap_open, double gap_extend,
     }
     CR_HIP(hipEventRecord(b->ev1, st));
     std::vector<cr::AlignEnd> ends((size_t)b->count);
-    CR_HIP(hipMemcpyAsync(ends.data(), b->ends.p, sizeof(cr::AlignEnd) * ends.size(), hipMemcpyDeviceToHost, st));
+    CR_DOWNLOAD(b->ctx, ends.data(), b->ends.p, sizeof(cr::AlignEnd) * ends.size());
     std::vector<int32_t> h_aln;
     if (aln) {
         tr.resize((size_t)b->count);
         h_aln.resize((size_t)aln_total);
-        CR_HIP(hipMemcpyAsync(tr.data(), b->trace.p, sizeof(cr::BatchTrace) * tr.size(), hipMemcpyDeviceToHost, st));
-        CR_HIP(hipMemcpyAsync(h_aln.data(), b->aln.p, sizeof(int32_t) * h_aln.size(), hipMemcpyDeviceToHost, st));
+        CR_DOWNLOAD(b->ctx, tr.data(), b->trace.p, sizeof(cr::BatchTrace) * tr.size());
+        CR_DOWNLOAD(b->ctx, h_aln.data(), b->aln.p, sizeof(int32_t) * h_aln.size());
     }
     CR_HIP(hipStreamSynchronize(st));
     CR_HIP(hipEventElapsedTime(&b->last_ms, b->ev0, b->ev1));

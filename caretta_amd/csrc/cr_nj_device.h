@@ -354,12 +354,14 @@ __global__ __launch_bounds__(kNjGroupThreads) void k_neighbor_joining(const doub
         if (lane == 0) {
             unsigned long long* mine = cand_words + ((size_t)gen * waves_total + gw) * kNjCandWords;
             unsigned long long* next = cand_words + ((size_t)gen_next * waves_total + gw) * kNjCandWords;
-            // this wave's stores so far -- the new row and column if it made them, its resets of the next generation -- have
-            // landed before the words that let the others go on
-            nj_stores_done();
+            // The resets of the next generation are posted FIRST and waited for together with this wave's other stores (the
+            // new row and column if it made them, the row-sum resets of A): everything has been acknowledged before the
+            // words that let the others go on are sent, so no consumer that has seen this minimum can still find the value
+            // of join k - 2 in a word of generation k + 1.
             nj_post(&next[0], kNjEmpty);
             nj_post(&next[1], kNjEmpty);
             nj_post(&next[2], kNjEmpty);
+            nj_stores_done();
             nj_post(&mine[0], nj_bits(bq));
             nj_post(&mine[1], nj_bits(bd));
             nj_post(&mine[2], ((unsigned long long)(unsigned)bi << 32) | (unsigned)bj);
@@ -575,7 +577,13 @@ int cr_neighbor_joining_device(cr_context* ctx, const double* D0, int64_t P, uin
                      " host ms: buffers %.3f  copied %.3f  kernel done %.3f  enqueued %.3f  done %.3f\n",
                      (long long)P, groups, c[0], c[1], c[2], c[3], c[4], ms_alloc, ms_copied, ms_kernel, ms_enqueued, ms_since(t_start));
     }
-    if (state.abort) return fail(CR_ERR_HIP, "neighbor joining: a workgroup of the persistent launch did not arrive");
+    if (state.abort) {
+        // A workgroup did not arrive (the device is shared or busy and the workgroups were not co-resident): a scheduling
+        // accident, not an error of the input.  The host implementation gives the same tree bit for bit;
+        // CARETTA_NJ_DEVICE_STRICT=1 keeps the error (tests of the device kernel itself).
+        if (std::getenv("CARETTA_NJ_DEVICE_STRICT")) return fail(CR_ERR_HIP, "neighbor joining: a workgroup of the persistent launch did not arrive");
+        return cr_neighbor_joining(D0, P, tree, bl);
+    }
     return CR_OK;
 }
 

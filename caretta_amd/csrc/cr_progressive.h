@@ -110,8 +110,8 @@ int run_level(cr_progressive* h, const std::vector<int64_t>& ids, const cr_param
     CR_HIP(b.seed_score.ensure(count));
     CR_HIP(h->d_nodes.ensure(count));
     CR_HIP(h->d_outs.ensure(count));
-    CR_HIP(hipMemcpyAsync(b.pairs.p, pairs, sizeof(cr::PairDesc) * count, hipMemcpyHostToDevice, stream));
-    CR_HIP(hipMemcpyAsync(h->d_nodes.p, nodes, sizeof(cr::NodeDesc) * count, hipMemcpyHostToDevice, stream));
+    CR_UPLOAD(h->ctx, b.pairs.p, pairs, sizeof(cr::PairDesc) * count);
+    CR_UPLOAD(h->ctx, h->d_nodes.p, nodes, sizeof(cr::NodeDesc) * count);
     b.r_seed = b.r_align = R;
     const cr_batch::Chunk ck{0, (int64_t)count, n_max, m_max, cap_max};
     rc = team ? launch_seed_team(R, &b, ck, prm) : launch_seed_r(R, &b, ck, prm);
@@ -126,8 +126,8 @@ int run_level(cr_progressive* h, const std::vector<int64_t>& ids, const cr_param
     CR_HIP(h->p_rows.ensure((size_t)aln_off));
     cr::NodeOut* outs = h->p_outs.p;
     int32_t* rows_host = h->p_rows.p;
-    CR_HIP(hipMemcpyAsync(outs, h->d_outs.p, sizeof(cr::NodeOut) * count, hipMemcpyDeviceToHost, stream));
-    CR_HIP(hipMemcpyAsync(rows_host, b.aln.p, sizeof(int32_t) * (size_t)aln_off, hipMemcpyDeviceToHost, stream));
+    CR_DOWNLOAD(h->ctx, outs, h->d_outs.p, sizeof(cr::NodeOut) * count);
+    CR_DOWNLOAD(h->ctx, rows_host, b.aln.p, sizeof(int32_t) * (size_t)aln_off);
     CR_HIP(hipStreamSynchronize(stream));
     for (size_t x = 0; x < count; x++) {
         const int64_t id = ids[x], k = id - h->P;
@@ -200,10 +200,10 @@ int run_tree_planned(cr_progressive* h, const std::vector<std::vector<int64_t>>&
     CR_HIP(b.dirs.ensure((size_t)dirs_words));
     CR_HIP(b.bits.ensure((size_t)bits_words));
     CR_HIP(b.aln.ensure((size_t)aln_total));
-    CR_HIP(hipMemcpyAsync(d_plan.p, plan.data(), sizeof(cr::PlanNode) * plan.size(), hipMemcpyHostToDevice, stream));
-    CR_HIP(hipMemcpyAsync(d_len.p, h->len.data(), sizeof(int64_t) * (size_t)(2 * P - 1), hipMemcpyHostToDevice, stream));
-    CR_HIP(hipMemcpyAsync(d_off.p, h->off.data(), sizeof(int64_t) * (size_t)(2 * P - 1), hipMemcpyHostToDevice, stream));
-    CR_HIP(hipMemcpyAsync(d_used.p, &total, sizeof(int64_t), hipMemcpyHostToDevice, stream));
+    CR_UPLOAD(h->ctx, d_plan.p, plan.data(), sizeof(cr::PlanNode) * plan.size());
+    CR_UPLOAD(h->ctx, d_len.p, h->len.data(), sizeof(int64_t) * (size_t)(2 * P - 1));
+    CR_UPLOAD(h->ctx, d_off.p, h->off.data(), sizeof(int64_t) * (size_t)(2 * P - 1));
+    CR_UPLOAD(h->ctx, d_used.p, &total, sizeof(int64_t));
     CR_HIP(hipMemsetAsync(d_overflow.p, 0, sizeof(int32_t), stream));
     b.r_seed = b.r_align = R;
     for (int64_t lv = 1; lv <= h->levels + 1; lv++) {
@@ -228,13 +228,13 @@ int run_tree_planned(cr_progressive* h, const std::vector<std::vector<int64_t>>&
     std::vector<int32_t> rows_host((size_t)aln_total);
     int32_t overflow = 0;
     int64_t used = 0;
-    CR_HIP(hipMemcpyAsync(outs.data(), h->d_outs.p, sizeof(cr::NodeOut) * (size_t)num_nodes, hipMemcpyDeviceToHost, stream));
-    CR_HIP(hipMemcpyAsync(descs.data(), h->d_nodes.p, sizeof(cr::NodeDesc) * (size_t)num_nodes, hipMemcpyDeviceToHost, stream));
-    CR_HIP(hipMemcpyAsync(len.data(), d_len.p, sizeof(int64_t) * len.size(), hipMemcpyDeviceToHost, stream));
-    CR_HIP(hipMemcpyAsync(off.data(), d_off.p, sizeof(int64_t) * off.size(), hipMemcpyDeviceToHost, stream));
+    CR_DOWNLOAD(h->ctx, outs.data(), h->d_outs.p, sizeof(cr::NodeOut) * (size_t)num_nodes);
+    CR_DOWNLOAD(h->ctx, descs.data(), h->d_nodes.p, sizeof(cr::NodeDesc) * (size_t)num_nodes);
+    CR_DOWNLOAD(h->ctx, len.data(), d_len.p, sizeof(int64_t) * len.size());
+    CR_DOWNLOAD(h->ctx, off.data(), d_off.p, sizeof(int64_t) * off.size());
     if ((rc = download(h->ctx, rows_host.data(), b.aln.p, sizeof(int32_t) * (size_t)aln_total, false))) return rc;
-    CR_HIP(hipMemcpyAsync(&overflow, d_overflow.p, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-    CR_HIP(hipMemcpyAsync(&used, d_used.p, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    CR_DOWNLOAD(h->ctx, &overflow, d_overflow.p, sizeof(int32_t));
+    CR_DOWNLOAD(h->ctx, &used, d_used.p, sizeof(int64_t));
     CR_HIP(hipStreamSynchronize(stream));
     if (overflow) return 1;
     h->len = len;

@@ -71,6 +71,7 @@ def pairwise_matrix_sharded(coords, tensors, offsets, params=None, group=None,
     pairs = all_pairs(num)
     mine = partition_pairs(pairs, lengths, world, rank)
     size = shard_size(len(pairs), world)
+    bad_local = 0
     if compute_fn is not None:
         local = torch.full((size,), float("nan"), dtype=torch.float64)
         local[:len(mine)] = torch.from_numpy(np.asarray(compute_fn(coords, tensors, offsets, pairs[mine]), dtype=np.float64))
@@ -90,14 +91,15 @@ def pairwise_matrix_sharded(coords, tensors, offsets, params=None, group=None,
         batch.close()
         ctx.close()
         # The reference raises at a pair whose tensor score matrix has no positive local alignment (smith_waterman:
-        # max_pos is None).  The owner marks such a pair NaN BEFORE the collective, so every rank takes part in the
-        # all-gather and every rank raises afterwards.
-        bad = np.nonzero(flags & _capi.FLAG_SEED_ALL_ZERO)[0]
-        if len(bad):
-            local[torch.from_numpy(bad).to(dev)] = float("nan")
+        # max_pos is None).  That condition travels as its own count (below), not as a NaN among the scores: a NaN in
+        # the gathered vector then only ever means a collective or partition fault and is reported as such.
+        bad_local = int(np.count_nonzero(flags & _capi.FLAG_SEED_ALL_ZERO))
+    # every rank takes part in both collectives and every rank raises the same exception afterwards
+    bad = torch.tensor([float(bad_local)], dtype=torch.float64, device=local.device)
+    if dist.is_initialized() and world > 1:
+        dist.all_reduce(bad, op=dist.ReduceOp.SUM, group=group)
     gathered = gather_scores(local, world, group)
-    try:
-        return scatter_to_matrix(gathered.cpu().numpy(), pairs, lengths, num)
-    except RuntimeError as exc:
+    if float(bad.item()) > 0:
         raise TypeError("a pair of the family has no positive local alignment of its tensor score matrix "
-                        "(reference: max_pos is None)") from exc
+                        "(reference: max_pos is None)")
+    return scatter_to_matrix(gathered.cpu().numpy(), pairs, lengths, num)

@@ -1,7 +1,8 @@
 """Drop-in for the reference's ``caretta/neighbor_joining.py`` (:19-157).  Two implementations in libcaretta_hip
-with bit-identical results: host C++ (``cr_neighbor_joining``) and one workgroup on the GPU
-(``cr_neighbor_joining_device``); both form each row sum once per iteration in the reference's order, so no rounded
-value and no tie changes."""
+with bit-identical results: host C++ (``cr_neighbor_joining``) and one persistent launch of up to 64 workgroups on
+the GPU (``cr_neighbor_joining_device``, symmetric matrices of 256 - 2048 nodes; a launch whose workgroups cannot all
+be resident falls back to the host implementation); both form each row sum once per iteration in the reference's
+order, so no rounded value and no tie changes."""
 from __future__ import annotations
 
 import os

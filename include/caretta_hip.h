@@ -261,9 +261,11 @@ int cr_get_common_positions(const int64_t *a1, const int64_t *a2, int64_t len, i
 /* neighbor_joining.neighbor_joining; tree u64[2P-3, 2], branch_lengths f64[2P-3]
  *                                                                      neighbor_joining.py:19-157 */
 int cr_neighbor_joining(const double *D, int64_t P, uint64_t *tree, double *branch_lengths);
-/* the same on the device: one workgroup, every sum and tie in the reference's order (results equal
- * cr_neighbor_joining's bit for bit).  Symmetric matrices of up to 4096 nodes; anything else is handed to
- * cr_neighbor_joining.                                                 neighbor_joining.py:19-157 */
+/* the same on the device: ONE persistent launch of up to 64 workgroups (4 waves each, a wave owns up to 8 rows), no
+ * barrier in the join loop; every sum and tie in the reference's order (results equal cr_neighbor_joining's bit for
+ * bit).  Symmetric finite matrices of up to 2048 nodes; anything else -- and a launch whose workgroups could not all
+ * be resident (busy or partitioned device) -- is handed to cr_neighbor_joining.
+ *                                                                      neighbor_joining.py:19-157 */
 int cr_neighbor_joining_device(cr_context *ctx, const double *D, int64_t P, uint64_t *tree, double *branch_lengths);
 /* scatter per-pair scores into the symmetric P x P matrix (multiple_alignment.py:161-169) */
 int cr_assemble_matrix(const int32_t *pairs, const double *scores, int64_t npairs, int64_t P, double *M);
