@@ -62,6 +62,12 @@ SIGNATURES = {
     "cr_batch_stage_ms": [_vp, C.POINTER(C.c_float * CR_NUM_STAGES), C.POINTER(C.c_int)],
     "cr_batch_work": [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "cr_batch_destroy": [_vp],
+    "cr_multi_create": [_vp, _i32, _pp],
+    "cr_multi_device_count": [_vp, C.POINTER(C.c_int)],
+    "cr_multi_pairwise_scores": [_vp, _vp, _vp, _vp, _i64, _i64, C.POINTER(Params), _vp, _vp],
+    "cr_multi_last_ms": [_vp, C.POINTER(C.c_float * 3)],
+    "cr_multi_destroy": [_vp],
+    "cr_partition_pairs": [_vp, _i64, _i32, _i32, _vp, C.POINTER(C.c_int64)],
     "cr_make_score_matrix": [_vp, _vp, _i64, _vp, _i64, _i64, _f64, _vp],
     "cr_protein_score_function": [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _f64, _f64, _vp, C.POINTER(C.c_uint32)],
     "cr_progressive_node": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _f64, _f64, C.POINTER(Params), _f64,
@@ -124,6 +130,28 @@ def _share_torch_hip_runtime():
                 C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
             except OSError:
                 return
+
+
+def share_torch_rccl():
+    """One RCCL per process, for the single-process multi-GPU path (cr_multi_*, which binds librccl at run time and
+    prefers a copy that is already loaded): when a torch installation is present its librccl.so is loaded now, so that a
+    later ``import torch.distributed`` in the same process finds the same object.  Without torch (or with
+    CARETTA_SYSTEM_HIP=1) the library falls back to the loader's search path and /opt/rocm/lib."""
+    if os.environ.get("CARETTA_SYSTEM_HIP") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = Path(spec.origin).parent / "lib" / "librccl.so"
+    if cand.exists():
+        try:
+            C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def load() -> C.CDLL:

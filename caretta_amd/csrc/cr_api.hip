@@ -1270,3 +1270,4 @@ int cr_batch_destroy(cr_batch* b) {
 #include "cr_progressive.h"
 #include "cr_explicit_batch.h"
 #include "cr_nj_device.h"
+#include "cr_multi.h"

@@ -2380,6 +2380,14 @@ __global__ void k_scatter_sw_t(const PairResult* __restrict__ res, const int32_t
     if (k < n) out[order[k]] = res[k].sw;
 }
 constexpr auto k_scatter_sw = k_scatter_sw_t<>;
+// the same for the flags
+template <class Dummy = void>
+__global__ void k_scatter_flags_t(const PairResult* __restrict__ res, const int32_t* __restrict__ order,
+                                  uint32_t* __restrict__ out, int n) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[order[k]] = res[k].flags;
+}
+constexpr auto k_scatter_flags = k_scatter_flags_t<>;
 
 // ---------------------------------------------------------------------------------------------
 // Device-side planning of one level of the guide tree (cr_progressive.h, the launch sequence without host

@@ -20,7 +20,7 @@ def partition_pairs(pairs: np.ndarray, lengths: np.ndarray, world: int, rank: in
     lengths = np.asarray(lengths, dtype=np.int64)
     cost = lengths[pairs[:, 0]] * lengths[pairs[:, 1]]
     order = np.argsort(-cost, kind="stable")
-    return np.sort(order[rank::world])
+    return np.sort(order[rank::world])      # (cr_partition_pairs is the same deal for the all-pairs list: test_capi_cpu)
 
 
 def shard_size(npairs: int, world: int) -> int:

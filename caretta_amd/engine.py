@@ -204,6 +204,80 @@ class PairBatch:
             pass
 
 
+class MultiDevice:
+    """Several GPUs of one node driven from THIS process (cr_multi_*): one context per device, the pair set dealt over
+    them, one grouped RCCL all-gather of the score vectors.  ``devices``: indices, or None for every visible device."""
+
+    def __init__(self, devices: Optional[Sequence[int]] = None):
+        self._lib = _capi.load()
+        _capi.share_torch_rccl()
+        self._h = C.c_void_p()
+        if devices is None:
+            check(self._lib.cr_multi_create(None, 0, C.byref(self._h)))
+        else:
+            arr = np.ascontiguousarray(devices, dtype=np.int32)
+            check(self._lib.cr_multi_create(ptr(arr), len(arr), C.byref(self._h)))
+        n = C.c_int(0)
+        check(self._lib.cr_multi_device_count(self._h, C.byref(n)))
+        self.num_devices = n.value
+
+    def pairwise_scores(self, coords, tensors, offsets, params: Optional[Params] = None):
+        """-> (sw f64[npairs], flags u32[npairs]) for all pairs i < j in row-major order (``all_pairs``)."""
+        coords, tensors, offsets = f64(coords), f64(tensors), i64(offsets)
+        num = len(offsets) - 1
+        npairs = num * (num - 1) // 2
+        params = params or make_params()
+        sw, flags = np.empty(npairs), np.zeros(npairs, np.uint32)
+        check(self._lib.cr_multi_pairwise_scores(self._h, ptr(coords), ptr(tensors), ptr(offsets), num, tensors.shape[1],
+                                                 C.byref(params), ptr(sw), ptr(flags)))
+        return sw, flags
+
+    def last_ms(self):
+        """wall ms of the last call: (upload + kernels, all-gather, download + scatter)"""
+        buf = (C.c_float * 3)()
+        check(self._lib.cr_multi_last_ms(self._h, C.byref(buf)))
+        return tuple(buf)
+
+    def close(self):
+        if self._h:
+            self._lib.cr_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_multi = None
+MULTI_DEVICE_MIN_PAIRS = 16384        # below this one GPU is not even full (256 CUs x 16 wave slots = 4096 pairs per round)
+
+
+def multi_device() -> Optional[MultiDevice]:
+    """The process-wide MultiDevice over all visible GPUs, or None when there is only one (or CARETTA_SINGLE_DEVICE=1)."""
+    global _multi
+    import os
+    if os.environ.get("CARETTA_SINGLE_DEVICE") == "1":
+        return None
+    if _multi is None:
+        if device_count() < 2:
+            return None
+        _multi = MultiDevice()
+    return _multi
+
+
+def partition_pairs(lengths, world: int, rank: int) -> np.ndarray:
+    """cr_partition_pairs: indices into ``all_pairs(len(lengths))`` owned by ``rank`` of ``world`` (host only)."""
+    lengths = i64(lengths)
+    num = len(lengths)
+    cap = (num * (num - 1) // 2 + world - 1) // world
+    idx = np.zeros(max(cap, 1), np.int64)
+    cnt = C.c_int64(0)
+    check(_capi.load().cr_partition_pairs(ptr(lengths), num, int(world), int(rank), ptr(idx), C.byref(cnt)))
+    return idx[:cnt.value].copy()
+
+
 def assemble_matrix(pairs, scores, num: int) -> np.ndarray:
     """Symmetric P x P score matrix with a zero diagonal (multiple_alignment.py:161-169)."""
     pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)

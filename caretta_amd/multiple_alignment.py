@@ -286,6 +286,25 @@ class MultipleAlignment:
                             "(reference: max_pos is None)")
         return PairwiseResults(pairs, res, aln)
 
+    def _pairwise_matrix_multi(self, multi, score_function_params=None):
+        """make_pairwise_matrix (multiple_alignment.py:158-170) for Proteins on every device of `multi`
+        (engine.MultiDevice): same matrix as the one-device path, bit for bit."""
+        prm = dict(score_function_params or {})
+        prm.pop("verbose", None)
+        prm.pop("flexible", None)
+        params = make_params(gamma_tensor=prm.pop("gamma_tensor", 0.03), gamma_coords=prm.pop("gamma_coords", 0.03))
+        if prm:
+            raise TypeError(f"unknown score_function parameters {sorted(prm)}")
+        num = len(self.sequences)
+        coords, tensors, offsets = pack_proteins(self.sequences)
+        sw, flags = multi.pairwise_scores(coords, tensors, offsets, params)
+        pairs = all_pairs(num)
+        if np.any(flags & _capi.FLAG_SEED_ALL_ZERO):
+            bad = pairs[np.nonzero(flags & _capi.FLAG_SEED_ALL_ZERO)[0][0]]
+            raise TypeError(f"tensor score matrix of pair {tuple(bad)} has no positive local alignment "
+                            "(reference: max_pos is None)")
+        return assemble_matrix(pairs, sw, num)
+
     def make_pairwise_matrix(self, score_function_params=None):
         """multiple_alignment.py:158-170"""
         if score_function_params is None:
@@ -294,6 +313,12 @@ class MultipleAlignment:
         if num < 2:
             return np.zeros((num, num))
         if self._all_proteins() and not score_function_params.get("flexible", False):
+            from . import engine
+            npairs = num * (num - 1) // 2
+            multi = engine.multi_device() if npairs >= engine.MULTI_DEVICE_MIN_PAIRS else None
+            if multi is not None:
+                # several GPUs visible to this process: the pair set dealt over all of them, one RCCL all-gather
+                return self._pairwise_matrix_multi(multi, score_function_params)
             out = self.pairwise(score_function_params, want_alignments=False, scores_only=True)
             return assemble_matrix(out.pairs, out.results["sw"], num)
         # third-party SequenceBase plugins: the score matrices come from the plugin's own score_function (its Python),

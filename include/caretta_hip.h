@@ -133,6 +133,32 @@ int cr_batch_stage_ms(cr_batch *b, float ms[CR_NUM_STAGES], int *runs_averaged);
 int cr_batch_work(cr_batch *b, double *alg_bytes, double *cells);
 int cr_batch_destroy(cr_batch *b);
 
+/* ---- the same matrix over several GPUs of one node, from ONE process ---------------------- */
+/* The reference calls make_pairwise_matrix from a single process (multiple_alignment.py:497-501 inside
+ * align_from_structure_files); its pair loop (:158-170) has no cross-pair dependency.  A cr_multi owns one context
+ * (device + stream) per listed GPU.  cr_multi_pairwise_scores replicates the structures on every GPU, deals the pair
+ * set with cr_partition_pairs, runs every GPU's share from its own host thread (cr_batch_run_scores: no data-path
+ * collective), and assembles the score vector with ONE grouped RCCL all-gather over xGMI (ncclCommInitAll +
+ * ncclGroupStart / ncclAllGather per device / ncclGroupEnd; librccl is bound at run time).  The result does not
+ * depend on the number of devices, bit for bit.
+ * devices == NULL or ndev <= 0: every visible device. */
+typedef struct cr_multi cr_multi;
+int cr_multi_create(const int *devices, int ndev, cr_multi **out);
+int cr_multi_device_count(cr_multi *m, int *ndev);
+/* scores f64[P(P-1)/2] = smith_waterman_score of Protein.score_function per pair, flags u32[P(P-1)/2] (may be NULL),
+ * both in the row-major i < j order of multiple_alignment.py:162-163 (what cr_assemble_matrix takes). */
+int cr_multi_pairwise_scores(cr_multi *m, const double *coords, const double *tensors, const int64_t *offsets,
+                             int64_t num_structures, int64_t d, const cr_params *params, double *scores, uint32_t *flags);
+/* wall ms of the last call: [0] upload + kernels on all devices, [1] the all-gather, [2] download + scatter
+ * ([0] and [1] are only separated when CARETTA_MULTI_TIMING is set: that costs a device wait in between) */
+int cr_multi_last_ms(cr_multi *m, float ms[3]);
+int cr_multi_destroy(cr_multi *m);
+/* The deal of the pair set over `world` devices or ranks (host only): indices into the row-major i < j pair list owned
+ * by `rank`, ascending -- pairs sorted by DP cell count (descending, stable on the index) and dealt round robin; equal
+ * lengths: index % world == rank.  idx_out (may be NULL to query the count) needs ceil(npairs / world) entries. */
+int cr_partition_pairs(const int64_t *lengths, int64_t num_structures, int world, int rank, int64_t *idx_out,
+                       int64_t *count_out);
+
 /* ---- single-call drop-ins (host buffers in, host buffers out) --------------------------- */
 /* score_functions.make_score_matrix(a, b, get_gaussian_score, gamma)   score_functions.py:23-51 */
 int cr_make_score_matrix(cr_context *ctx, const double *a, int64_t n, const double *b, int64_t m, int64_t k,

@@ -223,3 +223,29 @@ def test_formats_match_the_reference_writers(tmp_path):
     again = ma.alignment_to_numpy(rows)
     for k, p in enumerate(prots):
         assert np.array_equal(again[p.name], g["fasta_alignment"][k])
+
+
+def test_partition_pairs_is_the_deal_of_distributed_py(lib):
+    """cr_partition_pairs (the deal the single-process multi-GPU path makes, cr_multi_pairwise_scores) = the deal of
+    caretta_amd.distributed.partition_pairs (one process per GPU), ragged and equal lengths, every world size."""
+    from caretta_amd import distributed as cdist
+    from caretta_amd import engine
+    rng = np.random.default_rng(3)
+    for lengths in (rng.integers(20, 400, size=23), np.full(17, 300), rng.integers(5, 9, size=40), np.array([7, 9])):
+        pairs = engine.all_pairs(len(lengths))
+        for world in (1, 2, 3, 4, 8):
+            got = [engine.partition_pairs(lengths, world, r) for r in range(world)]
+            for r in range(world):
+                assert np.array_equal(got[r], cdist.partition_pairs(pairs, lengths, world, r))
+            assert np.array_equal(np.sort(np.concatenate(got)), np.arange(len(pairs)))
+            assert max(len(g) for g in got) <= cdist.shard_size(len(pairs), world)
+
+
+def test_multi_device_needs_a_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from caretta_amd import _capi, engine
+    assert engine.multi_device() is None
+    with pytest.raises(_capi.CarettaHipError):
+        engine.MultiDevice([0])

@@ -1107,3 +1107,34 @@ def test_rccl_all_gather_single_rank():
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "rccl single-rank matrix ok" in out.stdout
+
+
+def test_single_process_multi_device_path_equals_the_batch(ctx):
+    """cr_multi_pairwise_scores (one process, a context per listed GPU, cr_partition_pairs, one grouped RCCL all-gather)
+    with the device list [0]: scores and flags equal cr_batch_run_scores bit for bit, ragged (scatter kernel) and equal
+    lengths; MultipleAlignment._pairwise_matrix_multi gives make_pairwise_matrix's matrix.  (More devices than one are
+    not available on the test box: the deal itself is pinned on the CPU, tests/test_capi_cpu.py.)"""
+    from caretta_amd import engine
+    from caretta_amd import multiple_alignment as ma
+    multi = engine.MultiDevice([0])
+    assert multi.num_devices == 1
+    for fam in (synthetic.make_family(11, 70, seed=4041, ragged=True, clades=2), synthetic.make_family(24, 150, seed=4042)):
+        coords, tensors, offsets = synthetic.pack(fam)
+        pairs = engine.all_pairs(len(fam))
+        batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
+        batch.run(engine.make_params(), scores_only=True)
+        sw_ref, flags_ref = batch.fetch_scores()
+        batch.close()
+        for _ in range(2):                                 # the second call reuses the communicator and the buffers
+            sw, flags = multi.pairwise_scores(coords, tensors, offsets, engine.make_params())
+            assert np.array_equal(sw, sw_ref) and np.array_equal(flags, flags_ref)
+        msa = ma.MultipleAlignment([ma.Protein(s.name, s.tensors, s.coordinates, s.sequence) for s in fam])
+        prm = dict(gamma_tensor=7.0, gamma_coords=0.03)
+        assert np.array_equal(msa._pairwise_matrix_multi(multi, prm), msa.make_pairwise_matrix(prm))
+    # a structure without any positive local alignment of the tensor scores: the reference's TypeError, not a NaN fault
+    far = synthetic.make_family(3, 30, seed=4043, clades=1)
+    far[1].tensors = far[1].tensors + 1e3
+    msa = ma.MultipleAlignment([ma.Protein(s.name, s.tensors, s.coordinates, s.sequence) for s in far])
+    with pytest.raises(TypeError):
+        msa._pairwise_matrix_multi(multi, dict(gamma_tensor=7.0, gamma_coords=0.03))
+    multi.close()
