@@ -94,12 +94,7 @@ def cpu_baseline(coords, tensors, offsets, pairs, gpu_res, gpu_aln, gpu_matrix, 
     t1 = time.perf_counter() - t0
     cores = max(1, min(orc.max_threads(), os.cpu_count() or 1))
     # correctness gate: integers exact, floats bit-identical (same FP64 operation order on both sides)
-    mism = 0
-    for k, p in enumerate(sample):
-        ln = int(ref["aln_len"][k])
-        ok = int(gpu_res["aln_len"][p]) == ln and np.array_equal(gpu_aln[p, :, :ln], ref_aln[k, :, :ln])
-        ok = ok and all(np.array_equal(gpu_res[key][p], ref[key][k]) for key in ("sw", "dtw_score", "rmsd", "tm", "coverage"))
-        mism += 0 if ok else 1
+    mism = pair_mismatches(gpu_res, gpu_aln, ref, ref_aln, sample)
     out = {
         "value": count / t1, "unit": "pairs/s", "cores": 1, "kind": "port",
         "sample": f"{count} of {len(pairs)} pairs (random, seed 0), C oracle -O2 -ffp-contract=off, reference-shaped "
@@ -126,6 +121,50 @@ def cpu_baseline(coords, tensors, offsets, pairs, gpu_res, gpu_aln, gpu_matrix, 
                 "matrix_max_abs_diff": float(np.abs(gpu_matrix - cpu_matrix).max()),
                 "cpu_matrix": f"C oracle, all {len(pairs)} pairs on {cores} threads"}
     return out, gate
+
+
+def pair_mismatches(gpu_res, gpu_aln, ref, ref_aln, where):
+    """Pairs whose GPU results differ from the oracle's: integers exact, floats bit-identical.  `where[k]` = index of the
+    oracle's k-th pair in the GPU arrays."""
+    mism = 0
+    for k, p in enumerate(where):
+        ln = int(ref["aln_len"][k])
+        ok = int(gpu_res["aln_len"][p]) == ln and np.array_equal(gpu_aln[p, :, :ln], ref_aln[k, :, :ln])
+        ok = ok and all(np.array_equal(gpu_res[key][p], ref[key][k]) for key in ("sw", "dtw_score", "rmsd", "tm", "coverage"))
+        mism += 0 if ok else 1
+    return mism
+
+
+def config_gate(orc, coords, tensors, offsets, pairs, gpu_scores, gpu_res, gpu_aln, gpu_idx, min_frac=0.01):
+    """SURVEY.md 8(d) correctness gate of one BASELINE configuration (all oracle work on all cores):
+      * `nj_gate`: the GPU's P x P matrix (gpu_scores, one per pair of `pairs`) against the oracle's matrix of ALL pairs --
+        largest difference, neighbor-joining trees identical, bipartition sets identical (neighbor_joining.py:118-129 is
+        1-ulp sensitive);
+      * `pair_gate`: every output of pipeline H on a sample of at least min_frac of all pairs (all of them when they are
+        few) drawn from the pairs the GPU batch behind gpu_res / gpu_aln ran (gpu_idx: their indices into `pairs`)."""
+    from caretta_amd import engine
+    from caretta_amd import neighbor_joining as nj
+    num = len(offsets) - 1
+    cores = max(1, min(orc.max_threads(), os.cpu_count() or 1))
+    t0 = time.perf_counter()
+    full, _ = orc.pairwise_batch(coords, tensors, offsets, pairs, want_aln=False, nthreads=cores)
+    t_all = time.perf_counter() - t0
+    cpu_matrix = engine.assemble_matrix(pairs, full["sw"], num)
+    gpu_matrix = engine.assemble_matrix(pairs, gpu_scores, num)
+    t_gpu, _ = nj.neighbor_joining(gpu_matrix.max() - gpu_matrix)                # multiple_alignment.py:501
+    t_cpu, _ = orc.neighbor_joining(cpu_matrix.max() - cpu_matrix)
+    gate = {"nj_gate": {"taxa": int(num), "bipartitions_equal": bool(nj.bipartitions(t_gpu, num) == nj.bipartitions(t_cpu, num)),
+                        "trees_identical": bool(np.array_equal(t_gpu, t_cpu)),
+                        "matrix_max_abs_diff": float(np.abs(gpu_matrix - cpu_matrix).max()),
+                        "cpu_matrix": f"C oracle, all {len(pairs)} pairs on {cores} threads in {t_all:.1f} s"}}
+    want = max(int(math.ceil(min_frac * len(pairs))), min(len(gpu_idx), 512))
+    rng = np.random.default_rng(1)
+    pick = np.sort(rng.choice(len(gpu_idx), size=min(want, len(gpu_idx)), replace=False))
+    ref, ref_aln = orc.pairwise_batch(coords, tensors, offsets, pairs[gpu_idx[pick]], want_aln=True, nthreads=cores)
+    gate["pair_gate"] = {"checked": int(len(pick)), "of_pairs": int(len(pairs)), "fraction": len(pick) / len(pairs),
+                         "mismatches": int(pair_mismatches(gpu_res, gpu_aln, ref, ref_aln, pick)),
+                         "what": "alignment rows and lengths exact; sw, dtw_score, rmsd, tm, coverage bit-identical"}
+    return gate
 
 
 def spawn_ranks(n_gpus: int) -> int:
@@ -295,44 +334,106 @@ def main():
                                      "note": "cr_batch_run_scores: seed kernel + smith_waterman_score of the coordinate score matrix per pair "
                                              "(multiple_alignment.py:158-170), no dtw_align / traceback / metrics"}
         # ---------------------------------------------------------- the same pair set including the PCIe transfers
-        # per step: upload the structures (cr_batch_create), the pair list (cr_batch_set_pairs), run, download EVERY
-        # result -- alignment rows (int32, page-locked arrays kept by the batch), transforms, metrics
+        # (SURVEY.md 8(d) words the metric this way).  Per step: upload the structures (cr_batch_create) and the pair list
+        # (cr_batch_set_pairs) from page-locked arrays, run with the download folded in (cr_batch_run_stream_i32: the
+        # alignment kernel writes every pair's int32 rows and record into page-locked host arrays as it finishes the
+        # pair), wait.  Nothing is copied after the last kernel.
         my_pairs = pairs[mine]
+        pin_c, pin_t = engine.pinned_empty(coords.shape, np.float64), engine.pinned_empty(tensors.shape, np.float64)
+        pin_c[...], pin_t[...] = coords, tensors           # (what a loader that feeds the GPU would produce)
         pinned = None
-        t_parts = np.zeros(3)
+        t_parts = np.zeros(2)
         reps = max(3, min(args.steps, 10))
+        streamed_ok = None
         for it in range(reps + 2):
             fence()
             t0 = time.perf_counter()
-            b2 = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(my_pairs)
+            b2 = engine.PairBatch(ctx, pin_c, pin_t, offsets).set_pairs(my_pairs)
             if pinned is not None:
                 b2._pinned_cache = pinned              # result arrays allocated once, as a pipeline would
             t1 = time.perf_counter()
-            b2.run(params)
+            r2, a2 = b2.run_streamed(params)
             ctx.synchronize()
             t2 = time.perf_counter()
-            r2, a2 = b2.fetch(want_alignments=True, pinned=True)
-            t3 = time.perf_counter()
             pinned = b2._pinned_cache
+            if it == 0 and rank == 0:                  # what the kernels wrote = what cr_batch_fetch copies
+                streamed_ok = bool(r2.tobytes() == res.tobytes() and np.array_equal(a2[:, :, :aln.shape[2]], aln[:, :, :a2.shape[2]]))
             b2.close()
             if it >= 2:
-                t_parts += (t1 - t0, t2 - t1, t3 - t2)
+                t_parts += (t1 - t0, t2 - t1)
         t_parts /= reps
         t_incl = max_over_ranks(float(t_parts.sum()))
+        # steady state of a stream of such batches: two contexts (streams) fed by two host threads, so that the upload of
+        # one batch and the tail of another overlap with kernels (ctypes releases the GIL inside the library)
+        import threading
+        ctxs = [engine.Context(local_rank) for _ in range(2)]
+        per_thread = max(4, min(args.steps, 12))
+
+        def feeder(c, store):
+            keep = None
+            for _ in range(per_thread):
+                bb = engine.PairBatch(c, pin_c, pin_t, offsets).set_pairs(my_pairs)
+                if keep is not None:
+                    bb._pinned_cache = keep
+                bb.run_streamed(params)
+                c.synchronize()
+                keep = bb._pinned_cache
+                bb.close()
+            store.append(keep)
+
+        for timed in (False, True):                    # first round: allocations and page-locked arrays
+            fence()
+            t0 = time.perf_counter()
+            th = [threading.Thread(target=feeder, args=(c, [])) for c in ctxs]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            torch.cuda.synchronize(dev)
+            t_stream = (time.perf_counter() - t0) / (2 * per_thread)
+        t_stream = max_over_ranks(t_stream)
+        for c in ctxs:
+            c.close()
         if rank == 0:
             extras["value_incl_transfers"] = len(pairs) / t_incl
             extras["incl_transfers"] = {
-                "ms_per_step": t_incl * 1e3, "upload_ms": t_parts[0] * 1e3, "run_ms": t_parts[1] * 1e3, "download_ms": t_parts[2] * 1e3,
+                "ms_per_step": t_incl * 1e3, "upload_ms": t_parts[0] * 1e3, "run_and_download_ms": t_parts[1] * 1e3,
                 "ratio_to_resident": t_incl / (elapsed / args.steps),
+                "pipelined_ms_per_batch": t_stream * 1e3, "pipelined_pairs_per_s": len(pairs) / t_stream,
+                "pipelined_ratio_to_resident": t_stream / (elapsed / args.steps),
+                "streamed_results_equal_fetched": streamed_ok,
                 "downloaded_bytes_per_rank": int(r2.nbytes + a2.nbytes), "uploaded_bytes_per_rank": int(coords.nbytes + tensors.nbytes + my_pairs.nbytes),
-                "note": "per step: cr_batch_create + cr_batch_set_pairs (H2D of structures and pair list), cr_batch_run, "
-                        "cr_batch_fetch_i32 of all alignment rows + PairResult records into page-locked arrays"}
+                "note": "per step, one batch alone: cr_batch_create + cr_batch_set_pairs (H2D of structures and pair list from page-locked "
+                        "arrays), cr_batch_run_stream_i32 (the alignment kernel stores all int32 alignment rows + PairResult records "
+                        "into page-locked host arrays while the other waves compute), wait; `pipelined`: a stream of such batches "
+                        "through two contexts fed by two host threads"}
         # ---------------------------------------------------------- BASELINE configs 4 and 5, sharded over the ranks
+        gated = world == 1 and not args.no_cpu_baseline
+        orc = None
+        if gated:
+            from oracle.pyoracle import Oracle
+            orc = Oracle()
+        if args.workload != "c2":
+            # ------------------------------------------------------ BASELINE config 2: every one of the 496 pairs gated
+            n_c, l_c, s_c = CONFIGS["c2"]
+            small = Sharded(n_c, l_c, s_c)
+            t_small_mat = small.time(20, 3, scores_only=True)
+            t_small = small.time(20, 3)
+            if rank == 0:
+                rec = {"n_gpus": world, "structures": n_c, "residues": l_c, "pairs": len(small.pairs), "ms": t_small * 1e3,
+                       "pairs_per_s": len(small.pairs) / t_small, "matrix_only_ms": t_small_mat * 1e3}
+                if gated:
+                    r_s, a_s = small.batch.fetch(want_alignments=True)
+                    rec.update(config_gate(orc, small.coords, small.tensors, small.offsets, small.pairs, r_s["sw"], r_s, a_s,
+                                           np.arange(len(small.pairs)), min_frac=1.0))
+                extras["c2"] = rec
+            small.close()
         for key in ("c4", "c5"):
             n_c, l_c, s_c = CONFIGS[key]
             sh = Sharded(n_c, l_c, s_c)
-            t_sh = sh.time(5, 2)
             t_sh_mat = sh.time(5, 2, scores_only=True)
+            t_sh = sh.time(5, 2)
+            full_scores = sh.local[:len(sh.pairs)].cpu().numpy() if world == 1 else None
             sh.close()
             t_one = t_one_mat = None
             if world > 1:
@@ -352,10 +453,15 @@ def main():
                 # one GPU's share of the 8-GPU split (every 8th pair), run here: what 8 GPUs would each do, before the
                 # (latency-bound, ~1 MB) all-gather
                 part = Sharded(n_c, l_c, s_c, ranks=1, me=0, stride=8)
-                t_part = part.time(10, 3, collective=False)
                 t_part_mat = part.time(10, 3, collective=False, scores_only=True)
+                t_part = part.time(10, 3, collective=False)
                 rec["share_of_8"] = {"pairs": int(len(part.mine)), "ms": t_part * 1e3, "projected_speedup_8gpu": t_sh / t_part,
                                      "matrix_only_ms": t_part_mat * 1e3, "matrix_only_projected_speedup_8gpu": t_sh_mat / t_part_mat}
+                if gated:
+                    # the whole config's matrix (the one-GPU run above) against the oracle's, and every output of the
+                    # share's pairs (>= 1 % of the config's pairs) against the oracle's
+                    r_p, a_p = part.batch.fetch(want_alignments=True, pinned=True)
+                    rec.update(config_gate(orc, part.coords, part.tensors, part.offsets, part.pairs, full_scores, r_p, a_p, part.mine))
                 part.close()
             extras[f"{key}_sharded"] = rec
 

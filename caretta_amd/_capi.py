@@ -53,6 +53,7 @@ SIGNATURES = {
     "cr_batch_set_pairs": [_vp, _vp, _i64],
     "cr_batch_run": [_vp, C.POINTER(Params), _vp],
     "cr_batch_run_scores": [_vp, C.POINTER(Params), _vp],
+    "cr_batch_run_stream_i32": [_vp, C.POINTER(Params), _vp, _vp, _i64, _vp],
     "cr_batch_fetch": [_vp, _vp, _vp, _i64],
     "cr_batch_fetch_i32": [_vp, _vp, _vp, _i64],
     "cr_host_alloc": [C.c_size_t, _pp],

@@ -21,7 +21,7 @@
                                          uint32_t*, double*, cr::Transform*, double*);
 #define CR_ALIGN_SIGNATURE(R, ZG)                                                                                      \
     __global__ void cr::k_align<R, ZG>(const cr::PairDesc*, const double*, const cr::Transform*, const double*, double, \
-                                       double, double, double, int, uint32_t*, double*, int32_t*, cr::PairResult*);
+                                       double, double, double, int, uint32_t*, double*, int32_t*, cr::PairResult*, const cr::HostOut);
 
 // the team kernels of the progressive alignment levels (+4 % under the same scheduler)
 #define CR_ILP_SEED_TEAM_INSTANCES(X)                                                                                  \
@@ -56,4 +56,4 @@
                                               int, uint32_t*, cr::Transform*, double*);
 #define CR_ALIGN_WIDE_SIGNATURE(R, ZG)                                                                                      \
     __global__ void cr::k_align_wide<R, ZG>(const cr::PairDesc*, const double*, const cr::Transform*, const double*, double, \
-                                            double, double, double, int, int, uint32_t*, int32_t*, cr::PairResult*);
+                                            double, double, double, int, int, uint32_t*, int32_t*, cr::PairResult*, const cr::HostOut);

@@ -1640,6 +1640,19 @@ struct PairResult {          // per-pair scalar outputs, device and host layout
     uint32_t flags;
 };
 
+// Results that leave the device from the kernel that produces them (cr_batch_run_stream_i32): page-locked host arrays
+// in the caller's layout, written over PCIe by the wave that finished the pair -- 256-byte coalesced stores, posted, under
+// the fills of the other waves -- so that the download costs no time after the last kernel.  All null: nothing streamed.
+struct HostOut {
+    int32_t* aln;            // [npairs][2][stride], rows left-aligned and padded with -2 (cr_batch_fetch_i32's layout)
+    int64_t stride;
+    PairResult* res;         // [npairs]
+    const int32_t* order;    // launch slot -> index in the caller's pair list (null: identity)
+    int32_t first;           // launch slot of block 0 of this launch
+    int32_t pad;
+    CR_D int dst(int block) const { return order ? order[first + block] : first + block; }
+};
+
 // ---------------------------------------------------------------------------------------------
 // Traceback + superposition stages.  ONE WAVE PER PAIR.
 //
@@ -2019,7 +2032,7 @@ CR_D void dtw_walk(int n0, int m0, int max_entries, const uint32_t* __restrict__
 template <int R>
 CR_D void align_trace(const PairDesc& pd, int max_entries, const double* __restrict__ coords,
                       const uint32_t* __restrict__ bits, const AlignEnd e, double* lds,
-                      int32_t* __restrict__ aln, PairResult& r) {
+                      int32_t* __restrict__ aln, PairResult& r, const HostOut hout = HostOut{}) {
     const int lane = threadIdx.x;
     uint32_t* arow = reinterpret_cast<uint32_t*>(lds);
     double* scratch = lds + ((size_t)max_entries + 3) / 4 * 2;
@@ -2028,6 +2041,20 @@ CR_D void align_trace(const PairDesc& pd, int max_entries, const double* __restr
     dtw_walk<R>(pd.n, pd.m, max_entries, bits + pd.bt_off, e.start_layer, lds, aln + pd.aln_off, idx, k);
     CR_STAMP(6);
     const int first = cap - idx;
+    if (hout.aln) {                                   // the rows straight into the caller's page-locked array
+        int32_t* o1 = hout.aln + (int64_t)hout.dst(blockIdx.x) * 2 * hout.stride;
+        int32_t* o2 = o1 + hout.stride;
+        for (int x = lane; x < (int)hout.stride; x += kWave) {
+            int i = -2, j = -2;
+            if (x < idx) {
+                const uint32_t u = arow[first + x];
+                i = (u & 0xffffu) == kGap16 ? -1 : (int)(u & 0xffffu);
+                j = (u >> 16) == kGap16 ? -1 : (int)(u >> 16);
+            }
+            __builtin_nontemporal_store(i, o1 + x);
+            __builtin_nontemporal_store(j, o2 + x);
+        }
+    }
     r.sw = e.sw;
     r.dtw_score = e.dtw_score;
 #pragma unroll
@@ -2110,7 +2137,7 @@ __global__ __launch_bounds__(kWave, 4) void k_align(const PairDesc* __restrict__
                                                 double sw_gap, double gap_open, double gap_extend,
                                                 int max_entries, uint32_t* __restrict__ bits,
                                                 double* __restrict__ hand, int32_t* __restrict__ aln,
-                                                PairResult* __restrict__ res) {
+                                                PairResult* __restrict__ res, const HostOut hout) {
     extern __shared__ double lds[];
     CR_STAMP(4);
     const PairDesc pd = pairs[blockIdx.x];
@@ -2129,11 +2156,14 @@ __global__ __launch_bounds__(kWave, 4) void k_align(const PairDesc* __restrict__
     drain_stores();
     CR_STAMP(5);
     PairResult r;
-    align_trace<R>(pd, max_entries, coords, bits, e, lds + kExpDoubles, aln, r);
+    align_trace<R>(pd, max_entries, coords, bits, e, lds + kExpDoubles, aln, r, hout);
     r.seed_score = seed_score[blockIdx.x];
     r.seed_len = xf[blockIdx.x].seed_len;
     r.flags |= xf[blockIdx.x].flags;
-    if (threadIdx.x == 0) res[blockIdx.x] = r;
+    if (threadIdx.x == 0) {
+        res[blockIdx.x] = r;
+        if (hout.res) hout.res[hout.dst(blockIdx.x)] = r;
+    }
     CR_STAMP(7);
 }
 
@@ -2499,7 +2529,7 @@ __global__ __launch_bounds__(kTeamWaves* kWave) void k_align_team(const PairDesc
                                                                  const double* __restrict__ seed_score, double gamma,
                                                                  double sw_gap, double gap_open, double gap_extend,
                                                                  int max_entries, uint32_t* __restrict__ bits,
-                                                                 int32_t* __restrict__ aln, PairResult* __restrict__ res) {
+                                                                 int32_t* __restrict__ aln, PairResult* __restrict__ res, const HostOut hout) {
     extern __shared__ double lds[];
     CR_STAMP(4);
     const PairDesc pd = pairs[blockIdx.x];
@@ -2517,11 +2547,14 @@ __global__ __launch_bounds__(kTeamWaves* kWave) void k_align_team(const PairDesc
     if (threadIdx.x >= kWave) return;                  // wave 0 goes on alone (wave_sync, no s_barrier from here on)
     CR_STAMP(5);
     PairResult r;
-    align_trace<R>(pd, max_entries, coords, bits, e, lds + kExpDoubles, aln, r);
+    align_trace<R>(pd, max_entries, coords, bits, e, lds + kExpDoubles, aln, r, hout);
     r.seed_score = seed_score[blockIdx.x];
     r.seed_len = xf[blockIdx.x].seed_len;
     r.flags |= xf[blockIdx.x].flags;
-    if (threadIdx.x == 0) res[blockIdx.x] = r;
+    if (threadIdx.x == 0) {
+        res[blockIdx.x] = r;
+        if (hout.res) hout.res[hout.dst(blockIdx.x)] = r;
+    }
     CR_STAMP(7);
 }
 
@@ -2569,7 +2602,7 @@ __global__ __launch_bounds__(kWideMaxWaves* kWave) void k_align_wide(const PairD
                                                                     double sw_gap, double gap_open, double gap_extend,
                                                                     int max_entries, int sync_every,
                                                                     uint32_t* __restrict__ bits,
-                                                                    int32_t* __restrict__ aln, PairResult* __restrict__ res) {
+                                                                    int32_t* __restrict__ aln, PairResult* __restrict__ res, const HostOut hout) {
     extern __shared__ double lds[];
     CR_STAMP(4);
     const PairDesc pd = pairs[blockIdx.x];
@@ -2587,11 +2620,14 @@ __global__ __launch_bounds__(kWideMaxWaves* kWave) void k_align_wide(const PairD
     if (threadIdx.x >= kWave) return;                  // wave 0 goes on alone (wave_sync, no s_barrier from here on)
     CR_STAMP(5);
     PairResult r;
-    align_trace<R>(pd, max_entries, coords, bits, e, lds + kExpDoubles, aln, r);
+    align_trace<R>(pd, max_entries, coords, bits, e, lds + kExpDoubles, aln, r, hout);
     r.seed_score = seed_score[blockIdx.x];
     r.seed_len = xf[blockIdx.x].seed_len;
     r.flags |= xf[blockIdx.x].flags;
-    if (threadIdx.x == 0) res[blockIdx.x] = r;
+    if (threadIdx.x == 0) {
+        res[blockIdx.x] = r;
+        if (hout.res) hout.res[hout.dst(blockIdx.x)] = r;
+    }
     CR_STAMP(7);
 }
 

@@ -141,6 +141,23 @@ class PairBatch:
         fn = self._lib.cr_batch_run_scores if scores_only else self._lib.cr_batch_run
         check(fn(self._h, C.byref(params), C.c_void_p(sw_out_device_ptr) if sw_out_device_ptr else None))
 
+    def run_streamed(self, params: Optional[Params] = None, want_alignments: bool = True, sw_out_device_ptr: Optional[int] = None):
+        """``run`` with the download folded in (cr_batch_run_stream_i32): the alignment kernel writes every pair's rows
+        (int32) and record straight into page-locked arrays kept by this batch.  Asynchronous; -> (results, aln) that are
+        complete after ``ctx.synchronize()`` and are REUSED by the next call."""
+        params = params or make_params()
+        n = len(self.pairs)
+        stride = 0
+        if want_alignments:
+            mx = C.c_int64(0)
+            check(self._lib.cr_batch_max_aln_len(self._h, C.byref(mx)))
+            stride = max(int(mx.value), 1)
+        res = self._pinned("res", (n,), _capi.PAIR_RESULT_DTYPE)
+        aln = self._pinned("aln", (n, 2, stride), np.int32) if want_alignments else None
+        check(self._lib.cr_batch_run_stream_i32(self._h, C.byref(params), ptr(res), ptr(aln) if aln is not None else None, stride,
+                                                C.c_void_p(sw_out_device_ptr) if sw_out_device_ptr else None))
+        return res, aln
+
     def fetch(self, want_alignments: bool = True, pinned: bool = False):
         """-> (structured array of per-pair results, aln [npairs, 2, stride] or None).
 

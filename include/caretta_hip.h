@@ -108,6 +108,15 @@ int cr_batch_set_pairs(cr_batch *b, const int32_t *pairs, int64_t npairs);
  * DEVICE pointer to f64[npairs] that also receives the `sw` scores (e.g. a torch tensor that is
  * then all-gathered over RCCL). */
 int cr_batch_run(cr_batch *b, const cr_params *params, double *d_sw_out);
+/* cr_batch_run with the download folded in: `results` (npairs records) and / or `aln` (int32 [npairs][2][aln_stride],
+ * cr_batch_fetch_i32's layout) are PAGE-LOCKED host arrays (cr_host_alloc) that the alignment kernel itself writes
+ * into -- every wave stores its pair's rows and record over PCIe when it has finished the pair, under the fills of the
+ * other waves -- so nothing is left to copy after the last kernel.  Asynchronous like cr_batch_run: the arrays are
+ * complete after cr_context_synchronize.  (The device-side copies stay valid: cr_batch_fetch* still work.)
+ * This is how the reference's per-pair results (multiple_alignment.py:263-275: every alignment goes back to the
+ * caller) leave the device without a serial download phase. */
+int cr_batch_run_stream_i32(cr_batch *b, const cr_params *params, cr_pair_result *results, int32_t *aln,
+                            int64_t aln_stride, double *d_sw_out);
 /* The same for callers that only want the P x P matrix entries (MultipleAlignment.make_pairwise_matrix,
  * multiple_alignment.py:158-170: smith_waterman_score of Protein.score_function per pair): the seed kernel, then the
  * coordinate score matrix + smith_waterman_score WITHOUT the pairwise dtw_align, its traceback and metrics.

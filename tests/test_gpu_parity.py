@@ -652,11 +652,13 @@ def _count_integer_differences(res, aln, ref, ref_aln):
 
 def test_libm_exp_path_at_scale(ctx, oracle_libm):
     """The reference's numba path calls libm's exp; the kernels their own (<= 1 ulp apart on < 2 % of arguments,
-    test_exp_accuracy).  At BASELINE sizes -- config 2 (all 496 pairs), a sample of config 3 and of config 5 -- the GPU
-    against the libm-exp oracle: ZERO pairs with a differing traceback / seed index, floats within 1e-9 (north star:
-    bit-exact indices, RMSD / TM within 1e-5), and the same neighbor-joining bipartitions at P = 32 and P = 128."""
+    test_exp_accuracy).  At BASELINE sizes -- config 2 (all 496 pairs), samples of configs 3, 5 and 4 (999 of its 130 816
+    pairs) -- the GPU against the libm-exp oracle: ZERO pairs with a differing traceback / seed index, floats within 1e-9
+    (north star: bit-exact indices, RMSD / TM within 1e-5), and the same neighbor-joining bipartitions at P = 32, 128
+    and 512 (whole matrices on both sides)."""
     from caretta_amd import engine, neighbor_joining as nj
-    for num, length, seed, stride in ((32, 150, 20241, 1), (128, 300, 20242, 41), (64, 1200, 20244, 168)):
+    threads = max(8, int(oracle_libm.max_threads()))
+    for num, length, seed, stride in ((32, 150, 20241, 1), (128, 300, 20242, 41), (64, 1200, 20244, 168), (512, 300, 20243, 131)):
         fam = synthetic.make_family(num, length, seed=seed)
         coords, tensors, offsets = synthetic.pack(fam)
         pairs = engine.all_pairs(num)
@@ -665,7 +667,7 @@ def test_libm_exp_path_at_scale(ctx, oracle_libm):
         batch.run(engine.make_params())
         res, aln = batch.fetch(want_alignments=True)
         batch.close()
-        ref, ref_aln = oracle_libm.pairwise_batch(coords, tensors, offsets, pairs[sample], nthreads=8)
+        ref, ref_aln = oracle_libm.pairwise_batch(coords, tensors, offsets, pairs[sample], nthreads=threads)
         bad, rel = _count_integer_differences(res, aln, ref, ref_aln)
         assert bad == 0, f"{num} x {length}: {bad} of {len(sample)} pairs differ in an alignment / seed index"
         assert rel < 1e-9, f"{num} x {length}: floats differ by {rel:.3e}"
@@ -674,7 +676,7 @@ def test_libm_exp_path_at_scale(ctx, oracle_libm):
             full.run(engine.make_params())
             sw, _ = full.fetch_scores()
             full.close()
-            cpu, _ = oracle_libm.pairwise_batch(coords, tensors, offsets, pairs, want_aln=False, nthreads=8)
+            cpu, _ = oracle_libm.pairwise_batch(coords, tensors, offsets, pairs, want_aln=False, nthreads=threads)
             m_gpu, m_cpu = engine.assemble_matrix(pairs, sw, num), engine.assemble_matrix(pairs, cpu["sw"], num)
             np.testing.assert_allclose(m_gpu, m_cpu, rtol=1e-12)
             t_gpu, _ = nj.neighbor_joining(m_gpu.max() - m_gpu)
@@ -1138,3 +1140,33 @@ def test_single_process_multi_device_path_equals_the_batch(ctx):
     with pytest.raises(TypeError):
         msa._pairwise_matrix_multi(multi, dict(gamma_tensor=7.0, gamma_coords=0.03))
     multi.close()
+
+
+def test_streamed_run_writes_what_fetch_copies(ctx):
+    """cr_batch_run_stream_i32: the alignment kernels store rows and records straight into page-locked host arrays.  Same
+    bytes as cr_batch_fetch_i32 afterwards, for every kernel family: one wave per pair (ragged: launch order differs from
+    the caller's), the four-wave teams, the wide layout; pageable arrays are refused."""
+    from caretta_amd import _capi, engine
+    cases = [(synthetic.make_family(12, 90, seed=5051, ragged=True, clades=2), None),
+             (synthetic.make_family(20, 150, seed=5052), None),
+             (synthetic.make_family(4, 300, seed=5053, clades=1), None),               # 6 pairs of 300 rows: teams
+             (synthetic.make_family(3, 700, seed=5054, clades=1), None)]               # 700 rows: wide kernels
+    for fam, _ in cases:
+        coords, tensors, offsets = synthetic.pack(fam)
+        pairs = engine.all_pairs(len(fam))
+        batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
+        res_s, aln_s = batch.run_streamed(engine.make_params())
+        ctx.synchronize()
+        res_s, aln_s = res_s.copy(), aln_s.copy()
+        res_f, aln_f = batch.fetch(want_alignments=True, pinned=False)
+        assert res_s.tobytes() == res_f.tobytes()
+        assert np.array_equal(aln_s, aln_f)
+        # records only
+        r_only, none = batch.run_streamed(engine.make_params(), want_alignments=False)
+        ctx.synchronize()
+        assert none is None and r_only.tobytes() == res_f.tobytes()
+        with pytest.raises(ValueError):
+            import ctypes as C
+            bad = np.zeros(len(pairs), dtype=_capi.PAIR_RESULT_DTYPE)
+            _capi.check(batch._lib.cr_batch_run_stream_i32(batch._h, C.byref(engine.make_params()), _capi.ptr(bad), None, 0, None))
+        batch.close()
