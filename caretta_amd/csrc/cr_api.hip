@@ -1077,9 +1077,9 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     if (e != hipSuccess)
         return fail(e == hipErrorOutOfMemory ? CR_ERR_MEMORY : CR_ERR_HIP,
                     std::string("allocating pair scratch: ") + hipGetErrorString(e));
+    // (no wait: both sources are members of the batch or already staged, and every consumer is queued on the same stream)
     if (b->reordered && (rc = upload_async(b->ctx, b->d_order.p, b->order.data(), sizeof(int32_t) * (size_t)npairs))) return rc;
     if (npairs && (rc = upload_async(b->ctx, b->pairs.p, b->h_pairs.data(), sizeof(cr::PairDesc) * (size_t)npairs))) return rc;
-    CR_HIP(hipStreamSynchronize(b->ctx->stream));
     return CR_OK;
 }
 

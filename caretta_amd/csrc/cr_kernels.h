@@ -1644,7 +1644,7 @@ struct PairResult {          // per-pair scalar outputs, device and host layout
 // in the caller's layout, written over PCIe by the wave that finished the pair -- 256-byte coalesced stores, posted, under
 // the fills of the other waves -- so that the download costs no time after the last kernel.  All null: nothing streamed.
 struct HostOut {
-    int32_t* aln;            // [npairs][2][stride], rows left-aligned and padded with -2 (cr_batch_fetch_i32's layout)
+    int32_t* aln;            // [npairs][2][stride], rows left-aligned (cr_batch_fetch_i32's layout without the -2 padding)
     int64_t stride;
     PairResult* res;         // [npairs]
     const int32_t* order;    // launch slot -> index in the caller's pair list (null: identity)
@@ -2044,13 +2044,11 @@ CR_D void align_trace(const PairDesc& pd, int max_entries, const double* __restr
     if (hout.aln) {                                   // the rows straight into the caller's page-locked array
         int32_t* o1 = hout.aln + (int64_t)hout.dst(blockIdx.x) * 2 * hout.stride;
         int32_t* o2 = o1 + hout.stride;
-        for (int x = lane; x < (int)hout.stride; x += kWave) {
-            int i = -2, j = -2;
-            if (x < idx) {
-                const uint32_t u = arow[first + x];
-                i = (u & 0xffffu) == kGap16 ? -1 : (int)(u & 0xffffu);
-                j = (u >> 16) == kGap16 ? -1 : (int)(u >> 16);
-            }
+        // (only the aln_len entries of each row cross the link: what lies behind them in the caller's array is not touched)
+        for (int x = lane; x < idx; x += kWave) {
+            const uint32_t u = arow[first + x];
+            const int i = (u & 0xffffu) == kGap16 ? -1 : (int)(u & 0xffffu);
+            const int j = (u >> 16) == kGap16 ? -1 : (int)(u >> 16);
             __builtin_nontemporal_store(i, o1 + x);
             __builtin_nontemporal_store(j, o2 + x);
         }

@@ -108,8 +108,9 @@ int cr_batch_set_pairs(cr_batch *b, const int32_t *pairs, int64_t npairs);
  * DEVICE pointer to f64[npairs] that also receives the `sw` scores (e.g. a torch tensor that is
  * then all-gathered over RCCL). */
 int cr_batch_run(cr_batch *b, const cr_params *params, double *d_sw_out);
-/* cr_batch_run with the download folded in: `results` (npairs records) and / or `aln` (int32 [npairs][2][aln_stride],
- * cr_batch_fetch_i32's layout) are PAGE-LOCKED host arrays (cr_host_alloc) that the alignment kernel itself writes
+/* cr_batch_run with the download folded in: `results` (npairs records) and / or `aln` (int32 [npairs][2][aln_stride]:
+ * cr_batch_fetch_i32's layout, except that only the first results[p].aln_len entries of a row are written -- what lies
+ * behind them in the caller's array is left as it was) are PAGE-LOCKED host arrays (cr_host_alloc) that the alignment kernel itself writes
  * into -- every wave stores its pair's rows and record over PCIe when it has finished the pair, under the fills of the
  * other waves -- so nothing is left to copy after the last kernel.  Asynchronous like cr_batch_run: the arrays are
  * complete after cr_context_synchronize.  (The device-side copies stay valid: cr_batch_fetch* still work.)
