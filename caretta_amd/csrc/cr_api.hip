@@ -40,10 +40,10 @@ CR_ILP_SEED_TEAM_INSTANCES(CR_X)
 #define CR_X(R) extern template CR_NODE_TEAM_SIGNATURE(R)
 CR_ILP_NODE_TEAM_INSTANCES(CR_X)
 #undef CR_X
-#define CR_X(R, D, ZG) extern template CR_SEED_WIDE_SIGNATURE(R, D, ZG)
+#define CR_X(RA, RB, D, ZG) extern template CR_SEED_WIDE_SIGNATURE(RA, RB, D, ZG)
 CR_ILP_SEED_WIDE_INSTANCES(CR_X)
 #undef CR_X
-#define CR_X(R, ZG) extern template CR_ALIGN_WIDE_SIGNATURE(R, ZG)
+#define CR_X(RA, RB, ZG) extern template CR_ALIGN_WIDE_SIGNATURE(RA, RB, ZG)
 CR_ILP_ALIGN_WIDE_INSTANCES(CR_X)
 #undef CR_X
 #endif
@@ -259,6 +259,7 @@ struct cr_batch {
     int r_seed = 5, r_align = 5, d_pad = 0;
     bool team = false;                  // few pairs: one workgroup of kTeamWaves waves per pair (k_seed_team / k_align_team)
     int wide_sync = 0;                  // > 0: the wide kernels (one wave per strip, up to 16 waves per pair) with a barrier every wide_sync steps
+    int r_b = 5, wide_na = 0;           // wide kernels: strips [0, wide_na) have r_seed rows per lane, the others r_b (r_b == r_seed: all alike)
     int n_max = 0, m_max = 0;
     int64_t max_aln = 0;
     std::vector<cr::PairDesc> h_pairs;  // in LAUNCH order: most cells first (order[k] = index in the caller's list)
@@ -473,6 +474,20 @@ int launch_seed_d(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) 
     }
 }
 
+// cr::WidePlan with run-time rows per lane (the host's view: strips and row slots of a pair with n rows)
+struct StripPlan {
+    int ra, rb, na;
+    int strips(int n) const {
+        if (ra == rb || n <= na * cr::kWave * ra) return (n + cr::kWave * ra - 1) / (cr::kWave * ra);
+        return na + (n - na * cr::kWave * ra + cr::kWave * rb - 1) / (cr::kWave * rb);
+    }
+    int slots(int n) const {
+        const int st = strips(n);
+        return (ra == rb || st <= na) ? st * ra : na * ra + (st - na) * rb;
+    }
+};
+StripPlan plan_of(const cr_batch* b) { return StripPlan{b->r_seed, b->wide_sync ? b->r_b : b->r_seed, b->wide_sync ? b->wide_na : 0}; }
+
 // the host arrays of a streamed run as this chunk's launch sees them
 cr::HostOut host_out_for(const cr_batch* b, const cr_batch::Chunk& ck) {
     cr::HostOut h = b->host_out;
@@ -511,19 +526,20 @@ int launch_score(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
     return CR_OK;
 }
 
-template <int R>
+template <int RA, int RB>
 int launch_score_team(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
-    const int waves = cr::strips_of(ck.n_max, R);
-    const size_t lds = sizeof(double) * cr::sweep_cols_score_team_lds_doubles<cr::RbfCoords<R>>(waves);
-    CR_LAUNCH(cr::k_score_team<R>, dim3((unsigned)ck.count), dim3(waves * cr::kWave), lds, b->launch_stream ? b->launch_stream : b->ctx->stream,
-              b->pairs.p + ck.first, b->coords.p, b->xf.p + ck.first, b->seed_score.p + ck.first, prm.gamma_coords, b->res.p + ck.first);
+    const int waves = plan_of(b).strips(ck.n_max);
+    const size_t lds = sizeof(double) * cr::sweep_cols_score_team_lds_doubles<cr::RbfCoords<RA>>(waves);
+    CR_LAUNCH((cr::k_score_team<RA, RB>), dim3((unsigned)ck.count), dim3(waves * cr::kWave), lds, b->launch_stream ? b->launch_stream : b->ctx->stream,
+              b->pairs.p + ck.first, b->coords.p, b->xf.p + ck.first, b->seed_score.p + ck.first, prm.gamma_coords, b->wide_na, b->res.p + ck.first);
     CR_HIP(hipGetLastError());
     return CR_OK;
 }
 
 int launch_score_team_r(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
-    return R == 1 ? launch_score_team<1>(b, ck, prm) : R == 2 ? launch_score_team<2>(b, ck, prm) : R == 3 ? launch_score_team<3>(b, ck, prm)
-         : R == 4 ? launch_score_team<4>(b, ck, prm) : launch_score_team<5>(b, ck, prm);
+    if (b->wide_sync && b->r_b != b->r_seed) return launch_score_team<3, 2>(b, ck, prm);
+    return R == 1 ? launch_score_team<1, 1>(b, ck, prm) : R == 2 ? launch_score_team<2, 2>(b, ck, prm) : R == 3 ? launch_score_team<3, 3>(b, ck, prm)
+         : R == 4 ? launch_score_team<4, 4>(b, ck, prm) : launch_score_team<5, 5>(b, ck, prm);
 }
 
 int launch_score_r(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
@@ -561,77 +577,114 @@ int launch_align_team(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_pa
 }
 
 // ---- wide kernels: one wave per strip, up to kWideMaxWaves waves per pair, columns resident in LDS ----------
-template <int R, int D, bool ZG>
+template <int RA, int RB, int D, bool ZG>
 int launch_seed_wide_zg(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
-    using Src = cr::RbfTensor<R, D>;
+    using Src = cr::RbfTensor<RA, D>;
     const int entries = std::min(ck.n_max, ck.m_max);
-    const int waves = cr::strips_of(ck.n_max, R);
+    const int waves = plan_of(b).strips(ck.n_max);
     // gap 0: the column sweep (scalar column loads, no resident columns)
     const size_t fill = ZG ? cr::sweep_cols_team_lds_doubles(waves) : cr::sweep_wide_lds_doubles<cr::kSwTrace, Src>(waves, ck.m_max);
-    const size_t lds = sizeof(double) * std::max(fill, (size_t)cr::kExpDoubles + cr::trace_lds_doubles(R, entries));
-    int rc = allow_lds(cr::k_seed_wide<R, D, ZG>, lds);
+    const size_t lds = sizeof(double) * std::max(fill, (size_t)cr::kExpDoubles + cr::trace_lds_doubles(RA, entries));
+    int rc = allow_lds(cr::k_seed_wide<RA, RB, D, ZG>, lds);
     if (rc) return rc;
-    CR_LAUNCH((cr::k_seed_wide<R, D, ZG>), dim3((unsigned)ck.count), dim3(waves * cr::kWave), lds,
+    CR_LAUNCH((cr::k_seed_wide<RA, RB, D, ZG>), dim3((unsigned)ck.count), dim3(waves * cr::kWave), lds,
                        b->launch_stream ? b->launch_stream : b->ctx->stream, b->pairs.p + ck.first, b->tensors.p, (int)b->d,
-                       b->coords.p, prm.gamma_tensor, prm.sw_gap, entries, b->wide_sync, b->dirs.p, b->xf.p + ck.first,
+                       b->coords.p, prm.gamma_tensor, prm.sw_gap, entries, b->wide_sync, b->wide_na, b->dirs.p, b->xf.p + ck.first,
                        b->seed_score.p + ck.first);
     CR_HIP(hipGetLastError());
     return CR_OK;
 }
 
-template <int R>
+template <int RA, int RB>
 int launch_seed_wide_r(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
     const bool zg = prm.sw_gap == 0.0;
     switch (b->d_pad) {
-        case 4: return zg ? launch_seed_wide_zg<R, 4, true>(b, ck, prm) : launch_seed_wide_zg<R, 4, false>(b, ck, prm);
-        case 8: return zg ? launch_seed_wide_zg<R, 8, true>(b, ck, prm) : launch_seed_wide_zg<R, 8, false>(b, ck, prm);
-        case 10: return zg ? launch_seed_wide_zg<R, 10, true>(b, ck, prm) : launch_seed_wide_zg<R, 10, false>(b, ck, prm);
-        case 16: return zg ? launch_seed_wide_zg<R, 16, true>(b, ck, prm) : launch_seed_wide_zg<R, 16, false>(b, ck, prm);
+        case 4: return zg ? launch_seed_wide_zg<RA, RB, 4, true>(b, ck, prm) : launch_seed_wide_zg<RA, RB, 4, false>(b, ck, prm);
+        case 8: return zg ? launch_seed_wide_zg<RA, RB, 8, true>(b, ck, prm) : launch_seed_wide_zg<RA, RB, 8, false>(b, ck, prm);
+        case 10: return zg ? launch_seed_wide_zg<RA, RB, 10, true>(b, ck, prm) : launch_seed_wide_zg<RA, RB, 10, false>(b, ck, prm);
+        case 16: return zg ? launch_seed_wide_zg<RA, RB, 16, true>(b, ck, prm) : launch_seed_wide_zg<RA, RB, 16, false>(b, ck, prm);
         default: return fail(CR_ERR_ARGUMENT, "unsupported tensor width");
     }
 }
 
 int launch_seed_wide(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
-    return R == 1 ? launch_seed_wide_r<1>(b, ck, prm) : R == 2 ? launch_seed_wide_r<2>(b, ck, prm) : launch_seed_wide_r<3>(b, ck, prm);
+    if (b->r_b != b->r_seed) return launch_seed_wide_r<3, 2>(b, ck, prm);
+    return R == 1 ? launch_seed_wide_r<1, 1>(b, ck, prm) : R == 2 ? launch_seed_wide_r<2, 2>(b, ck, prm) : launch_seed_wide_r<3, 3>(b, ck, prm);
 }
 
-template <int R, bool ZG>
+template <int RA, int RB, bool ZG>
 int launch_align_wide_zg(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
-    using Src = cr::RbfCoords<R>;
+    using Src = cr::RbfCoords<RA>;
     const int entries = ck.max_aln;
-    const int waves = cr::strips_of(ck.n_max, R);
+    const int waves = plan_of(b).strips(ck.n_max);
     const size_t lds = sizeof(double) * std::max(cr::sweep_wide_lds_doubles<cr::kSwScore | cr::kDtw, Src>(waves, ck.m_max),
-                                                 (size_t)cr::kExpDoubles + cr::trace_lds_doubles(R, entries));
-    int rc = allow_lds(cr::k_align_wide<R, ZG>, lds);
+                                                 (size_t)cr::kExpDoubles + cr::trace_lds_doubles(RA, entries));
+    int rc = allow_lds(cr::k_align_wide<RA, RB, ZG>, lds);
     if (rc) return rc;
-    CR_LAUNCH((cr::k_align_wide<R, ZG>), dim3((unsigned)ck.count), dim3(waves * cr::kWave), lds,
+    CR_LAUNCH((cr::k_align_wide<RA, RB, ZG>), dim3((unsigned)ck.count), dim3(waves * cr::kWave), lds,
                        b->launch_stream ? b->launch_stream : b->ctx->stream, b->pairs.p + ck.first, b->coords.p, b->xf.p + ck.first,
                        b->seed_score.p + ck.first, prm.gamma_coords, prm.sw_gap, prm.gap_open, prm.gap_extend, entries,
-                       b->wide_sync, b->bits.p, b->aln.p, b->res.p + ck.first, host_out_for(b, ck));
+                       b->wide_sync, b->wide_na, b->bits.p, b->aln.p, b->res.p + ck.first, host_out_for(b, ck));
     CR_HIP(hipGetLastError());
     return CR_OK;
 }
 
 int launch_align_wide(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
     const bool zg = prm.sw_gap == 0.0;
+    if (b->r_b != b->r_seed) return zg ? launch_align_wide_zg<3, 2, true>(b, ck, prm) : launch_align_wide_zg<3, 2, false>(b, ck, prm);
     switch (R) {
-        case 1: return zg ? launch_align_wide_zg<1, true>(b, ck, prm) : launch_align_wide_zg<1, false>(b, ck, prm);
-        case 2: return zg ? launch_align_wide_zg<2, true>(b, ck, prm) : launch_align_wide_zg<2, false>(b, ck, prm);
-        default: return zg ? launch_align_wide_zg<3, true>(b, ck, prm) : launch_align_wide_zg<3, false>(b, ck, prm);
+        case 1: return zg ? launch_align_wide_zg<1, 1, true>(b, ck, prm) : launch_align_wide_zg<1, 1, false>(b, ck, prm);
+        case 2: return zg ? launch_align_wide_zg<2, 2, true>(b, ck, prm) : launch_align_wide_zg<2, 2, false>(b, ck, prm);
+        default: return zg ? launch_align_wide_zg<3, 3, true>(b, ck, prm) : launch_align_wide_zg<3, 3, false>(b, ck, prm);
     }
 }
 
-// Can a pair list with these maxima run on the wide kernels with R rows per lane?  (strips <= 16 waves, the columns
+// Can a pair list with these maxima run on the wide kernels with this strip plan?  (strips <= 16 waves, the columns
 // of the tensor sweep -- the larger of the two -- resident in LDS next to the edge rings)
-bool wide_fits(int R, int n_max, int m_max, int d_pad) {
-    if (R < 1 || R > 3 || d_pad > 16) return false;          // (the wide seed kernels are built for widths up to 16)
-    const int waves = cr::strips_of(n_max, R);
+bool wide_fits(const StripPlan& p, int n_max, int m_max, int d_pad) {
+    if (p.ra < 1 || p.ra > 3 || p.rb < 1 || p.rb > p.ra || d_pad > 16) return false;   // (the wide seed kernels are built for widths up to 16)
+    if (p.ra != p.rb && !(p.ra == 3 && p.rb == 2)) return false;                        // (the one mixed instance)
+    const int waves = p.strips(n_max);
     if (waves > cr::kWideMaxWaves) return false;
     // (sized for sw_gap != 0, where the tensor sweep needs its columns resident too; the parameters come with cr_batch_run)
     const size_t seed = cr::kExpDoubles + (size_t)d_pad * m_max + (size_t)waves * (cr::kWideEdge + 8);
     const size_t align = cr::kExpDoubles + (size_t)3 * m_max + (size_t)waves * (3 * cr::kWideEdge + 8);
-    const size_t trace = cr::kExpDoubles + cr::trace_lds_doubles(R, n_max + m_max);
+    const size_t trace = cr::kExpDoubles + cr::trace_lds_doubles(p.ra, n_max + m_max);
     return sizeof(double) * std::max(std::max(seed, align), trace) <= 160 * 1024;
+}
+
+// The strip plan of a wide launch.  A workgroup's waves are dealt round robin to the CU's four SIMDs; a SIMD issues one
+// FP64-rate instruction per 4 cycles when two or more waves share it and a lone wave gets one per ~6.5,
+// and all strips advance together (barriers), so a sweep step costs what the fullest SIMD needs for its row slots.  The
+// skewed DTW fill takes lag * (S - 1) + m + 63 steps, the column sweeps of the seed and the score m + 16 * (S - 1).
+// Candidates: 2 or 3 rows per lane everywhere, or 3 in the first nA strips and 2 in the others.
+// 1200 rows: (3,3,3,2,2,2,2,2) -- 5,5,5,4 row slots per SIMD where seven strips of 3 have 6,6,6,3.
+StripPlan choose_wide_plan(int n_max, int m_max, int d_pad, int sync_every) {
+    StripPlan best{0, 0, 0};
+    double best_cost = 1e300;
+    auto consider = [&](const StripPlan& p) {
+        if (!wide_fits(p, n_max, m_max, d_pad)) return;
+        const int S = p.strips(n_max);
+        int load[4] = {0, 0, 0, 0}, waves[4] = {0, 0, 0, 0};
+        for (int w = 0; w < S; w++) {
+            load[w & 3] += (p.ra == p.rb || w < p.na) ? p.ra : p.rb;
+            waves[w & 3]++;
+        }
+        double step = 0.0;
+        for (int k = 0; k < 4; k++) step = std::max(step, load[k] * (waves[k] >= 2 ? 4.0 : 6.5));
+        const double lag = cr::kWave - 1 + sync_every;
+        const double steps = (lag * (S - 1) + m_max + cr::kWave - 1) + 2.0 * (m_max + 16.0 * (S - 1));
+        const double cost = step * steps;
+        if (cost < best_cost - 1e-9) {
+            best_cost = cost;
+            best = p;
+        }
+    };
+    consider(StripPlan{2, 2, 0});
+    consider(StripPlan{3, 3, 0});
+    for (int na = 1; na < cr::kWideMaxWaves; na++)
+        if (na * cr::kWave * 3 < n_max) consider(StripPlan{3, 2, na});
+    return best;
 }
 
 constexpr int64_t kTeamPairLimit = 256;
@@ -933,22 +986,28 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     // about 60 % of it.  Measured (tools/calibrate_wide.py): 120 pairs of 600: 1.14 -> 1.05 ms (R = 2), 252 pairs of
     // 1200 (one GPU's share of BASELINE config 5 on 8 GPUs): 2.95 -> 2.72 ms (R = 3); 66 pairs of 300: no gain.
     b->wide_sync = 0;
+    b->wide_na = 0;
     if (b->team && b->n_max > 6 * cr::kWave && !g_no_wide && !std::getenv("CARETTA_NO_WIDE")) {
-        const int r = b->n_max <= 12 * cr::kWave ? 2 : 3;
-        if (wide_fits(r, b->n_max, b->m_max, b->d_pad)) {
+        const StripPlan p = choose_wide_plan(b->n_max, b->m_max, b->d_pad, 8);
+        if (p.ra) {
             b->wide_sync = 8;
-            b->r_seed = b->r_align = r;
+            b->r_seed = b->r_align = p.ra;
+            b->r_b = p.rb;
+            b->wide_na = p.na;
         }
     }
-    if (const char* env = std::getenv("CARETTA_WIDE")) {           // calibration: "R,B" forces the wide kernels
-        int r = 0, sync = 0;
-        if (std::sscanf(env, "%d,%d", &r, &sync) == 2 && npairs > 0 && sync >= 1 && sync <= cr::kWideMaxSync && !g_no_wide &&
-            wide_fits(r, b->n_max, b->m_max, b->d_pad)) {
-            b->team = true;                                         // same layout rules as the team kernels: one group, one R
+    if (const char* env = std::getenv("CARETTA_WIDE")) {           // calibration: "RA,RB,nA,B" forces the wide kernels with this plan
+        int ra = 0, rb = 0, na = 0, sync = 0;
+        if (std::sscanf(env, "%d,%d,%d,%d", &ra, &rb, &na, &sync) == 4 && npairs > 0 && sync >= 1 && sync <= cr::kWideMaxSync && !g_no_wide &&
+            na >= 0 && na < cr::kWideMaxWaves && wide_fits(StripPlan{ra, rb, ra == rb ? 0 : na}, b->n_max, b->m_max, b->d_pad)) {
+            b->team = true;                                         // same layout rules as the team kernels: one group, one plan
             b->wide_sync = sync;
-            b->r_seed = b->r_align = r;
+            b->r_seed = b->r_align = ra;
+            b->r_b = rb;
+            b->wide_na = ra == rb ? 0 : na;
         }
     }
+    if (!b->wide_sync) b->r_b = b->r_seed;
     // scratch budget per chunk (decision words); CARETTA_SCRATCH_MB overrides the 8 GiB default
     int64_t budget_words = (int64_t)8192 * 1024 * 1024 / 4;
     if (const char* env = std::getenv("CARETTA_SCRATCH_MB")) {
@@ -1021,8 +1080,10 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
         pd.off_i = b->offsets[i];
         pd.off_j = b->offsets[j];
         const int R = grouped ? group((int32_t)orig) : b->r_seed;
-        const int64_t dw = (int64_t)cr::strips_of(pd.n, R) * cr::tblocks(pd.m, 16) * R * cr::kWave;
-        const int64_t bw = (int64_t)cr::strips_of(pd.n, R) * cr::tblocks(pd.m, 8) * R * cr::kWave;
+        // row slots of the pair's strips (wide launches: the batch's strip plan) x time blocks x 64 lanes
+        const int64_t slots = b->wide_sync ? plan_of(b).slots(pd.n) : cr::strips_of(pd.n, R) * R;
+        const int64_t dw = slots * cr::tblocks(pd.m, 16) * cr::kWave;
+        const int64_t bw = slots * cr::tblocks(pd.m, 8) * cr::kWave;
         if (ck.count > 0 && R != ck.r) {                       // next group: its own region and stream
             b->chunks.push_back(ck);
             ck = cr_batch::Chunk{p, 0, 0, 0, 0};
@@ -1061,6 +1122,7 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     }
     if (ck.count > 0) b->chunks.push_back(ck);
     if (!b->chunks.empty()) b->r_seed = b->r_align = b->chunks[0].r;     // single-chunk callers (drop-ins) read these
+    if (!b->wide_sync) b->r_b = b->r_seed;
     b->max_aln = max_aln;
     b->aln_elems = aln_off;
     b->alg_bytes = bytes;

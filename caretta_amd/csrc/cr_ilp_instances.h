@@ -45,15 +45,17 @@
                                        const cr::NodeDesc*, const cr::Transform*, double, double, double, double, int,       \
                                        uint32_t*, double*, int32_t*, double*, double*, double*, cr::NodeOut*);
 
-// wide kernels (one wave per strip, up to 16 waves per pair)
-#define CR_ILP_SEED_WIDE_INSTANCES(X)                                                                                  \
-    X(1, 4, true) X(1, 4, false) X(1, 8, true) X(1, 8, false) X(1, 10, true) X(1, 10, false) X(1, 16, true) X(1, 16, false) \
-    X(2, 4, true) X(2, 4, false) X(2, 8, true) X(2, 8, false) X(2, 10, true) X(2, 10, false) X(2, 16, true) X(2, 16, false) \
-    X(3, 4, true) X(3, 4, false) X(3, 8, true) X(3, 8, false) X(3, 10, true) X(3, 10, false) X(3, 16, true) X(3, 16, false)
-#define CR_ILP_ALIGN_WIDE_INSTANCES(X) X(1, true) X(1, false) X(2, true) X(2, false) X(3, true) X(3, false)
-#define CR_SEED_WIDE_SIGNATURE(R, D, ZG)                                                                                   \
-    __global__ void cr::k_seed_wide<R, D, ZG>(const cr::PairDesc*, const double*, int, const double*, double, double, int, \
-                                              int, uint32_t*, cr::Transform*, double*);
-#define CR_ALIGN_WIDE_SIGNATURE(R, ZG)                                                                                      \
-    __global__ void cr::k_align_wide<R, ZG>(const cr::PairDesc*, const double*, const cr::Transform*, const double*, double, \
-                                            double, double, double, int, int, uint32_t*, int32_t*, cr::PairResult*, const cr::HostOut);
+// wide kernels (one wave per strip, up to 16 waves per pair; RA rows per lane in the first strips, RB in the others)
+#define CR_ILP_SEED_WIDE_D(X, RA, RB) \
+    X(RA, RB, 4, true) X(RA, RB, 4, false) X(RA, RB, 8, true) X(RA, RB, 8, false) X(RA, RB, 10, true) X(RA, RB, 10, false) \
+    X(RA, RB, 16, true) X(RA, RB, 16, false)
+#define CR_ILP_SEED_WIDE_INSTANCES(X) CR_ILP_SEED_WIDE_D(X, 1, 1) CR_ILP_SEED_WIDE_D(X, 2, 2) CR_ILP_SEED_WIDE_D(X, 3, 3) CR_ILP_SEED_WIDE_D(X, 3, 2)
+#define CR_ILP_ALIGN_WIDE_INSTANCES(X) \
+    X(1, 1, true) X(1, 1, false) X(2, 2, true) X(2, 2, false) X(3, 3, true) X(3, 3, false) X(3, 2, true) X(3, 2, false)
+#define CR_SEED_WIDE_SIGNATURE(RA, RB, D, ZG)                                                                                   \
+    __global__ void cr::k_seed_wide<RA, RB, D, ZG>(const cr::PairDesc*, const double*, int, const double*, double, double, int, \
+                                                   int, int, uint32_t*, cr::Transform*, double*);
+#define CR_ALIGN_WIDE_SIGNATURE(RA, RB, ZG)                                                                                      \
+    __global__ void cr::k_align_wide<RA, RB, ZG>(const cr::PairDesc*, const double*, const cr::Transform*, const double*, double, \
+                                                 double, double, double, int, int, int, uint32_t*, int32_t*, cr::PairResult*,    \
+                                                 const cr::HostOut);

@@ -99,6 +99,58 @@ CR_D double lane_value(double v, int src_lane) {
 CR_HD int strips_of(int n, int R) { return (n + kWave * R - 1) / (kWave * R); }
 CR_HD int tblocks(int m, int per_word) { return (m + kWave - 1 + per_word - 1) / per_word; }
 
+// Where the strips of a one-wave-per-strip sweep lie.  The strips of one pair need not have the same number of rows per
+// lane: a workgroup's waves are dealt round robin to the CU's four SIMDs, and e.g. 1200 rows as 7 strips of 3 rows per
+// lane put 6 row slots on three SIMDs and 3 on the fourth, while (3,3,3,2,2,2,2,2) puts 5,5,5,4 -- the sweep advances
+// at the pace of the fullest SIMD.  Strips [0, nA) have RA rows per lane, the others RB (RA == RB: all alike).
+// "Row slot": one of a strip's R lane-rows; decision word of (strip, time block tb, row slot q, lane l) =
+// ((slot0 * TB + tb * R + q) * 64 + l, slot0 = the row slots of all strips before it -- which for equal strips is the
+// ((strip * TB + tb) * R + q) * 64 + l of the single-wave sweeps.
+struct StripGeom {
+    int nstrips;             // strips that hold rows of this pair
+    int rowbase0;            // first row of this wave's strip
+    int slot0;               // row slots of the strips before it
+    int owner_wave, owner_lane, owner_q;   // where row n - 1 lives
+};
+
+template <int RA, int RB = RA>
+struct WidePlan {
+    int nA;                  // strips with RA rows per lane (ignored when RA == RB)
+    CR_HD int rows_a() const { return nA * kWave * RA; }
+    CR_HD bool in_a(int row) const { return RA == RB || row < rows_a(); }
+    CR_HD bool wave_in_a(int w) const { return RA == RB || w < nA; }
+    CR_HD int strips(int n) const {
+        if (RA == RB || n <= rows_a()) return (n + kWave * RA - 1) / (kWave * RA);
+        return nA + (n - rows_a() + kWave * RB - 1) / (kWave * RB);
+    }
+    CR_HD int slots(int n) const {                      // row slots of strips(n) strips
+        const int st = strips(n);
+        return (RA == RB || st <= nA) ? st * RA : nA * RA + (st - nA) * RB;
+    }
+    CR_HD StripGeom geom(int w, int n) const {
+        StripGeom g;
+        g.nstrips = strips(n);
+        const bool a = wave_in_a(w);
+        g.rowbase0 = a ? w * kWave * RA : rows_a() + (w - nA) * kWave * RB;
+        g.slot0 = a ? w * RA : nA * RA + (w - nA) * RB;
+        const int last = n - 1;
+        if (in_a(last)) {
+            g.owner_wave = last / (kWave * RA);
+            const int rem = last - g.owner_wave * kWave * RA;
+            g.owner_lane = rem / RA;
+            g.owner_q = rem - g.owner_lane * RA;
+        } else {
+            const int x = last - rows_a();
+            const int sb = x / (kWave * RB);
+            g.owner_wave = nA + sb;
+            const int rem = x - sb * kWave * RB;
+            g.owner_lane = rem / RB;
+            g.owner_q = rem - g.owner_lane * RB;
+        }
+        return g;
+    }
+};
+
 // ---------------------------------------------------------------------------------------------
 // Score providers.  load_rows(): once per strip, lane-private row data into registers.
 // load_chunk(): once per 64 steps, the next 64 columns into the LDS ring.  fetch_col(): once per
@@ -914,7 +966,7 @@ constexpr int kColChunk = 16;
 
 template <int R, int D>
 CR_D void sweep_cols_team(RbfTensor<R, D>& src, const int n, const int m, double* lds,
-                          uint32_t* __restrict__ sw_dirs, SeedMax& seed_out) {
+                          uint32_t* __restrict__ sw_dirs, SeedMax& seed_out, const StripGeom geom) {
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int NW = (int)(blockDim.x >> 6);
@@ -925,11 +977,11 @@ CR_D void sweep_cols_team(RbfTensor<R, D>& src, const int n, const int m, double
     double* red = rings + NW * (2 * kColChunk);
     load_exp_table(lds, threadIdx.x);
 
-    const int nstrips = strips_of(n, R);                 // <= NW, guaranteed by the launcher
+    const int nstrips = geom.nstrips;                    // <= NW, guaranteed by the launcher
     const int TB = (m + 15) >> 4;
     const bool mine = w < nstrips;
     const bool full = src.d == D;
-    const int rowbase = (w * kWave + lane) * R;
+    const int rowbase = geom.rowbase0 + lane * R;
     const bool hand_out = w + 1 < nstrips;
     ColSweep<R, D> st;
     st.reset();
@@ -955,7 +1007,7 @@ CR_D void sweep_cols_team(RbfTensor<R, D>& src, const int n, const int m, double
                 st.template step<FULL, TOP>(src, tab, j, j + 1 < m ? j + 1 : j, TOP ? lane_value(top_vec, j - j0) : 0.0);
                 if (hand_out && lane == kWave - 1) ring_out[(c & 1) * kColChunk + (j - j0)] = st.hprev[R - 1];
             }
-            st.flush(sw_dirs, ((int64_t)(w * TB + c) * R) * kWave + lane);      // one chunk = one decision word per row
+            st.flush(sw_dirs, ((int64_t)geom.slot0 * TB + (int64_t)c * R) * kWave + lane);      // one chunk = one decision word per row
         }
     };
     if (w == 0) {
@@ -1064,7 +1116,7 @@ CR_D double sweep_cols_score(Src& src, const int n, const int m, double* lds, do
 // barrier per phase, as sweep_cols_team): for pair lists too short to fill the chip with one wave per pair.  Every wave
 // has its own column ring.  LDS (doubles): exp table | NW column rings | NW edge rings of 2 * kColChunk | NW slots.
 template <int R, class Src>
-CR_D double sweep_cols_score_team(Src& src, const int n, const int m, double* lds) {
+CR_D double sweep_cols_score_team(Src& src, const int n, const int m, double* lds, const StripGeom geom) {
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int NW = (int)(blockDim.x >> 6);
@@ -1076,9 +1128,9 @@ CR_D double sweep_cols_score_team(Src& src, const int n, const int m, double* ld
     double* red = edges + NW * (2 * kColChunk);
     load_exp_table(lds, threadIdx.x);
     src.init_ring(ring, lane);
-    const int nstrips = strips_of(n, R);                 // <= NW, guaranteed by the launcher
+    const int nstrips = geom.nstrips;                    // <= NW, guaranteed by the launcher
     const bool mine = w < nstrips;
-    const int rowbase = (w * kWave + lane) * R;
+    const int rowbase = geom.rowbase0 + lane * R;
     const bool hand_out = w + 1 < nstrips;
     double hprev[R], eprev = 0.0;
 #pragma unroll
@@ -1119,11 +1171,11 @@ CR_D double sweep_cols_score_team(Src& src, const int n, const int m, double* ld
             if (hand_out && lane == kWave - 1) edge_out[(c & 1) * kColChunk + (j - j0)] = hprev[R - 1];
         }
     }
-    const int qo = (n - 1) % R;
+    const int qo = geom.owner_q;
     double v = 0.0;
 #pragma unroll
     for (int q = 0; q < R; q++) v = (q == qo) ? hprev[q] : v;
-    if (w == (n - 1) / (kWave * R) && lane == ((n - 1) / R) % kWave) red[0] = v;
+    if (w == geom.owner_wave && lane == geom.owner_lane) red[0] = v;
     __syncthreads();
     return red[0];
 }
@@ -1373,7 +1425,7 @@ constexpr int kWideMaxSync = 32;
 template <int R, int MODE, class Src>
 CR_D void sweep_wide(Src& src, const int n, const int m, const SweepParams prm, double* lds, const int sync_every,
                      uint32_t* __restrict__ sw_dirs, uint32_t* __restrict__ dtw_bits, SeedMax& seed_out,
-                     AlignEnd& end_out) {
+                     AlignEnd& end_out, const StripGeom geom) {
     constexpr bool SW = (MODE & (kSwTrace | kSwScore)) != 0;
     constexpr bool TRACE = (MODE & kSwTrace) != 0;
     constexpr bool DTW = (MODE & kDtw) != 0;
@@ -1392,12 +1444,12 @@ CR_D void sweep_wide(Src& src, const int n, const int m, const SweepParams prm, 
     load_exp_table(lds, threadIdx.x);
     src.load_resident(res, stride, m, (int)threadIdx.x, (int)blockDim.x);
 
-    const int nstrips = strips_of(n, R);                 // <= NW, guaranteed by the launcher
+    const int nstrips = geom.nstrips;                    // <= NW, guaranteed by the launcher
     const int TB_SW = tblocks(m, 16), TB_DTW = tblocks(m, 8);
     const double col0_m2 = kMinF64 - prm.gap_open;
     const bool mine = w < nstrips;
-    const int rowbase = (w * kWave + lane) * R;
-    const int rows_here = n - w * kWave * R;
+    const int rowbase = geom.rowbase0 + lane * R;
+    const int rows_here = n - geom.rowbase0;
     const int lanes_here = rows_here >= kWave * R ? kWave : (rows_here + R - 1) / R;
     const int T = mine ? m + lanes_here - 1 : 0;
     const int lag = kWave - 1 + sync_every;
@@ -1452,7 +1504,7 @@ CR_D void sweep_wide(Src& src, const int n, const int m, const SweepParams prm, 
         }
         if constexpr (TRACE) {
             if ((t & 15) == 15 || t == T - 1) {
-                const int64_t base = ((int64_t)(w * TB_SW + (t >> 4)) * R) * kWave + lane;
+                const int64_t base = ((int64_t)geom.slot0 * TB_SW + (int64_t)(t >> 4) * R) * kWave + lane;
 #pragma unroll
                 for (int q = 0; q < R; q++) {
                     sw_dirs[base + q * kWave] = st.swbits[q];
@@ -1462,7 +1514,7 @@ CR_D void sweep_wide(Src& src, const int n, const int m, const SweepParams prm, 
         }
         if constexpr (DTW) {
             if ((t & 7) == 7 || t == T - 1) {
-                const int64_t base = ((int64_t)(w * TB_DTW + (t >> 3)) * R) * kWave + lane;
+                const int64_t base = ((int64_t)geom.slot0 * TB_DTW + (int64_t)(t >> 3) * R) * kWave + lane;
 #pragma unroll
                 for (int q = 0; q < R; q++) {
                     dtw_bits[base + q * kWave] = st.dtbits[q];
@@ -1498,7 +1550,7 @@ CR_D void sweep_wide(Src& src, const int n, const int m, const SweepParams prm, 
     if constexpr ((MODE & kSwScore) != 0) {
         for (int off = 32; off > 0; off >>= 1) sw_max = __builtin_fmax(sw_max, __shfl_xor(sw_max, off));
     }
-    const int owner_wave = (n - 1) / (kWave * R);
+    const int owner_wave = geom.owner_wave;
     if (lane == 0) {
         red[w * 8 + 0] = best_v;
         red[w * 8 + 1] = (double)best_i;
@@ -1507,8 +1559,8 @@ CR_D void sweep_wide(Src& src, const int n, const int m, const SweepParams prm, 
     }
     if constexpr (DTW) {
         if (w == owner_wave) {
-            const int owner = ((n - 1) / R) % kWave;
-            const int qo = (n - 1) % R;
+            const int owner = geom.owner_lane;
+            const int qo = geom.owner_q;
             double fin0 = 0.0, fin1 = 0.0, fin2 = 0.0;
 #pragma unroll
             for (int q = 0; q < R; q++) {
@@ -1686,73 +1738,131 @@ CR_D uint32_t pack_entry(int i, int j) { return ((uint32_t)i & 0xffffu) | ((uint
 // SKEW = 1: words written by the time-skewed sweeps (time step of a cell = column + fill lane); SKEW = 0: words of
 // the column sweep (time step = column).
 // ---------------------------------------------------------------------------------------------
-template <int R, int BITS, int SKEW = 1>
+template <int R, int BITS, int SKEW = 1, int RB = R>
 struct Walker {
     static constexpr int kLog = BITS == 2 ? 4 : 3;                 // log2(steps per word)
     static constexpr int kStepMask = (1 << kLog) - 1;
     static constexpr uint32_t kFieldMask = (1u << BITS) - 1u;
     static constexpr int kBlockRows = 16, kBlockWords = 4;
+    static constexpr bool kMixed = RB != R;    // strips [0, nA) have R rows per lane, the others RB (WidePlan)
     const uint32_t* __restrict__ words;
-    int TB;
+    int TB, nA;
     int ax, wx;               // per lane: row offset and word slot held by this lane
     uint32_t blk;             // per lane: the word
     int lax;                  // per lane: fill lane of this lane's row
     int r0, c0, bs, amax;     // block key (wave-uniform): anchor cell, strip (-1: empty), deepest row offset held
     int s, l, q;              // position of the current row (wave-uniform): strip, fill lane, row slot
+    int rs, base, slot0;      // of strip s (wave-uniform): rows per lane, first row, row slots before it
+    // A second block, requested when a block is loaded and consumed when the walk leaves that block: the 16 rows above
+    // it, anchored one block further along the diagonal (the direction a structural alignment mostly takes).  Its load
+    // is in flight while the walk crosses the current block, so a correct guess costs no memory round trip.
+    uint32_t nblk;
+    int nlax;
+    int nr0, nc0, ns, namax;  // its key; ns = -1: none
 
-    CR_D void init(const uint32_t* __restrict__ w, int tb, int lane) {
+    CR_D void init(const uint32_t* __restrict__ w, int tb, int lane, int na = 0) {
         words = w;
         TB = tb;
+        nA = na;
         ax = lane >> 2;
         wx = lane & 3;
-        blk = 0;
-        lax = 0;
-        r0 = c0 = 0;
-        bs = -1;                  // no strip: the first lookup fills the block
-        amax = -1;
+        blk = nblk = 0;
+        lax = nlax = 0;
+        r0 = c0 = nr0 = nc0 = 0;
+        bs = ns = -1;             // no strip: the first lookup fills the block
+        amax = namax = -1;
         s = l = q = 0;
+        rs = R;
+        base = slot0 = 0;
     }
     CR_D void set_row(int row) {
-        s = row / (kWave * R);
-        const int rem = row - s * (kWave * R);
-        l = rem / R;
-        q = rem - l * R;
+        if (!kMixed || row < nA * (kWave * R)) {
+            s = row / (kWave * R);
+            const int rem = row - s * (kWave * R);
+            l = rem / R;
+            q = rem - l * R;
+            rs = R;
+            base = s * (kWave * R);
+            slot0 = s * R;
+        } else {
+            const int x = row - nA * (kWave * R);
+            const int sb = x / (kWave * RB);
+            const int rem = x - sb * (kWave * RB);
+            l = rem / RB;
+            q = rem - l * RB;
+            s = nA + sb;
+            rs = RB;
+            base = nA * (kWave * R) + sb * (kWave * RB);
+            slot0 = nA * R + sb * RB;
+        }
     }
     CR_D void row_up() {
         if (q > 0) {
             q--;
-        } else {
-            q = R - 1;
-            if (l > 0) {
-                l--;
-            } else {
-                l = kWave - 1;
-                s--;
-            }
+        } else if (l > 0) {
+            l--;
+            q = rs - 1;
+        } else {                                      // last row of the strip above
+            s--;
+            l = kWave - 1;
+            if (kMixed) rs = s < nA ? R : RB;
+            base -= kWave * rs;
+            slot0 -= rs;
+            q = rs - 1;
         }
     }
-    CR_D void refill(int r, int c) {
-        r0 = r;
-        c0 = c;
-        bs = s;
-        const int base = s * (kWave * R);
-        amax = r - base < kBlockRows - 1 ? r - base : kBlockRows - 1;
+    // the word of lane (ax, wx) in the block of the current strip anchored at (r, c); `la_out`: the fill lane of its row
+    CR_D uint32_t load_block(int r, int c, int& la_out) const {
         const int rel = r - ax - base;                    // this lane's row, relative to the strip
         const bool rv = rel >= 0;
         const int relc = rv ? rel : 0;
-        const int la = relc / R, qa = relc - la * R;
-        lax = la;
+        const int la = (!kMixed || rs == R) ? relc / R : relc / RB;
+        const int qa = relc - la * rs;
+        la_out = la;
         const int tb = ((c + la * SKEW) >> kLog) - wx;
-        blk = (rv && tb >= 0) ? words[((int64_t)(s * TB + tb) * R + qa) * kWave + la] : 0u;
+        return (rv && tb >= 0) ? words[((int64_t)slot0 * TB + (int64_t)tb * rs + qa) * kWave + la] : 0u;
+    }
+    CR_D void refill(int r, int c) {
+        // the block requested ahead: taken when it is the current strip's, starts at this row, and its words reach the
+        // column (words only extend to the left of an anchor)
+        bool hit = false;
+        if (ns == s && nr0 == r && c <= nc0) {
+            const int w = ((nc0 + l * SKEW) >> kLog) - ((c + l * SKEW) >> kLog);
+            hit = w < kBlockWords;
+        }
+        if (hit) {
+            blk = nblk;
+            lax = nlax;
+            r0 = nr0;
+            c0 = nc0;
+            amax = namax;
+        } else {
+            r0 = r;
+            c0 = c;
+            amax = r - base < kBlockRows - 1 ? r - base : kBlockRows - 1;
+            blk = load_block(r, c, lax);
+        }
+        bs = s;
+        // request the block above this one, one block along the diagonal from the anchor in use
+        const int pr = r0 - kBlockRows, pc = c0 - kBlockRows;
+        if (pr >= base && pc >= 0) {
+            ns = s;
+            nr0 = pr;
+            nc0 = pc;
+            namax = pr - base < kBlockRows - 1 ? pr - base : kBlockRows - 1;
+            nblk = load_block(pr, pc, nlax);
+        } else {
+            ns = -1;
+        }
     }
     // decision field of cell (r, c); (s, l, q) must be the position of row r
     CR_D uint32_t get(int r, int c) {
         int a = r0 - r;
         int w = ((c0 + l * SKEW) >> kLog) - ((c + l * SKEW) >> kLog);
-        if (!(s == bs && a <= amax && w < kBlockWords)) {
+        if (!(s == bs && a <= amax && w < kBlockWords && w >= 0)) {
             refill(r, c);
-            a = 0;
-            w = 0;
+            a = r0 - r;
+            w = ((c0 + l * SKEW) >> kLog) - ((c + l * SKEW) >> kLog);
         }
         const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)blk, a * 4 + w);
         return (word >> (((c + l * SKEW) & kStepMask) * BITS)) & kFieldMask;
@@ -1852,9 +1962,9 @@ __host__ __device__ inline size_t trace_lds_doubles(int /*R*/, int max_entries) 
 // Stage 2: SW traceback on the stored decisions, common positions, seed Kabsch
 // (dynamic_time_warping.py:249-278, helper.py:13-42, superposition_functions.py:39-60).
 // Wave-uniform; `lds` is this stage's LDS.  Returns the transform in every lane.
-template <int R, int SKEW = 1>
+template <int R, int SKEW = 1, int RB = R>
 CR_D void seed_trace(const PairDesc& pd, int max_entries, const double* __restrict__ coords,
-                     const uint32_t* __restrict__ dirs, const SeedMax sm, double* lds, Transform& tr) {
+                     const uint32_t* __restrict__ dirs, const SeedMax sm, double* lds, Transform& tr, const int nA = 0) {
     const int lane = threadIdx.x;
     uint32_t* plist = reinterpret_cast<uint32_t*>(lds);          // aligned pairs, filled back-to-front
     double* scratch = lds + ((size_t)max_entries + 3) / 4 * 2;   // 16-byte aligned, after the list
@@ -1864,8 +1974,8 @@ CR_D void seed_trace(const PairDesc& pd, int max_entries, const double* __restri
     if (sm.i == 0) {
         flags |= kFlagSeedAllZero;
     } else {
-        Walker<R, 2, SKEW> wk;
-        wk.init(dirs + pd.dirs_off, SKEW ? tblocks(pd.m, 16) : (pd.m + 15) >> 4, lane);
+        Walker<R, 2, SKEW, RB> wk;
+        wk.init(dirs + pd.dirs_off, SKEW ? tblocks(pd.m, 16) : (pd.m + 15) >> 4, lane, nA);
         // the walk is wave-uniform: pin its state to SGPRs so that it compiles to scalar code
         int i = __builtin_amdgcn_readfirstlane(sm.i), j = __builtin_amdgcn_readfirstlane(sm.j);
         wk.set_row(i - 1);
@@ -1966,14 +2076,14 @@ CR_D void rmsd_tm_ordered(const double* __restrict__ Xi, const double* __restric
 // DTW traceback (dynamic_time_warping.py:90-144) on the packed decisions: leaves the alignment columns
 // as packed entries in lds[first .. cap) (cap = n + m), writes the rows to HBM (back-to-front in
 // [aln, aln + 2*cap)), returns the number of columns and of aligned pairs.  Wave-uniform.
-template <int R>
+template <int R, int RB = R>
 CR_D void dtw_walk(int n0, int m0, int max_entries, const uint32_t* __restrict__ w, int start_layer,
-                   double* lds, int32_t* __restrict__ aln, int& len_out, int& pairs_out) {
+                   double* lds, int32_t* __restrict__ aln, int& len_out, int& pairs_out, const int nA = 0) {
     const int lane = threadIdx.x;
     uint32_t* arow = reinterpret_cast<uint32_t*>(lds);           // packed alignment columns, back-to-front
     const int cap = n0 + m0;
-    Walker<R, 4> wk;
-    wk.init(w, tblocks(m0, 8), lane);
+    Walker<R, 4, 1, RB> wk;
+    wk.init(w, tblocks(m0, 8), lane, nA);
     // the walk is wave-uniform: pin its state to SGPRs so that it compiles to scalar code
     int n = __builtin_amdgcn_readfirstlane(n0), m = __builtin_amdgcn_readfirstlane(m0);
     int dir = __builtin_amdgcn_readfirstlane(start_layer), idx = 0, k = 0;
@@ -2029,16 +2139,16 @@ CR_D void dtw_walk(int n0, int m0, int max_entries, const uint32_t* __restrict__
 
 // Stage 4: DTW traceback, common positions, Kabsch on the original coordinates, RMSD / coverage / TM
 // (multiple_alignment.py:1033-1054, :59-70).  Wave-uniform.
-template <int R>
+template <int R, int RB = R>
 CR_D void align_trace(const PairDesc& pd, int max_entries, const double* __restrict__ coords,
                       const uint32_t* __restrict__ bits, const AlignEnd e, double* lds,
-                      int32_t* __restrict__ aln, PairResult& r, const HostOut hout = HostOut{}) {
+                      int32_t* __restrict__ aln, PairResult& r, const HostOut hout = HostOut{}, const int nA = 0) {
     const int lane = threadIdx.x;
     uint32_t* arow = reinterpret_cast<uint32_t*>(lds);
     double* scratch = lds + ((size_t)max_entries + 3) / 4 * 2;
     const int cap = pd.n + pd.m;
     int idx, k;
-    dtw_walk<R>(pd.n, pd.m, max_entries, bits + pd.bt_off, e.start_layer, lds, aln + pd.aln_off, idx, k);
+    dtw_walk<R, RB>(pd.n, pd.m, max_entries, bits + pd.bt_off, e.start_layer, lds, aln + pd.aln_off, idx, k, nA);
     CR_STAMP(6);
     const int first = cap - idx;
     if (hout.aln) {                                   // the rows straight into the caller's page-locked array
@@ -2197,20 +2307,29 @@ __global__ __launch_bounds__(kWave) void k_score(const PairDesc* __restrict__ pa
     }
 }
 
-template <int R>
+template <int RA, int RB>
 __global__ __launch_bounds__(kWideMaxWaves* kWave) void k_score_team(const PairDesc* __restrict__ pairs,
                                                                     const double* __restrict__ coords,
                                                                     const Transform* __restrict__ xf,
                                                                     const double* __restrict__ seed_score, double gamma,
-                                                                    PairResult* __restrict__ res) {
+                                                                    int nA, PairResult* __restrict__ res) {
     extern __shared__ double lds[];
     const PairDesc pd = pairs[blockIdx.x];
-    RbfCoords<R> src;
-    src.rows_g = coords + pd.off_i * 3;
-    src.cols_g = coords + pd.off_j * 3;
-    src.xf = xf + blockIdx.x;
-    src.neg_gamma = -gamma;
-    const double sw = sweep_cols_score_team<R>(src, pd.n, pd.m, lds);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const WidePlan<RA, RB> plan{nA};
+    const StripGeom geom = plan.geom(w, pd.n);
+    double sw = 0.0;
+    auto fill = [&](auto rtag) {
+        constexpr int R = decltype(rtag)::value;
+        RbfCoords<R> src;
+        src.rows_g = coords + pd.off_i * 3;
+        src.cols_g = coords + pd.off_j * 3;
+        src.xf = xf + blockIdx.x;
+        src.neg_gamma = -gamma;
+        sw = sweep_cols_score_team<R>(src, pd.n, pd.m, lds, geom);
+    };
+    if (plan.wave_in_a(w)) fill(std::integral_constant<int, RA>{});
+    else if constexpr (RA != RB) fill(std::integral_constant<int, RB>{});
     if (threadIdx.x == 0) {
         PairResult r;
         r.sw = sw;
@@ -2506,7 +2625,8 @@ __global__ __launch_bounds__(kTeamWaves* kWave) void k_seed_team(const PairDesc*
         src.d = d;
         src.neg_gamma = -gamma;
         SweepParams prm{sw_gap, 0.0, 0.0};
-        if constexpr (ZG) sweep_cols_team<R, D>(src, pd.n, pd.m, lds, dirs + pd.dirs_off, sm);
+        if constexpr (ZG) sweep_cols_team<R, D>(src, pd.n, pd.m, lds, dirs + pd.dirs_off, sm,
+                                                WidePlan<R>{0}.geom(__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), pd.n));
         else sweep_team<R, kSwTrace>(src, pd.n, pd.m, prm, lds, dirs + pd.dirs_off, nullptr, sm, unused);
     }
     if (threadIdx.x >= kWave) return;                  // wave 0 goes on alone (wave_sync, no s_barrier from here on)
@@ -2558,33 +2678,40 @@ __global__ __launch_bounds__(kTeamWaves* kWave) void k_align_team(const PairDesc
 
 // Wide versions (sweep_wide): up to kWideMaxWaves waves per pair, columns resident in LDS, a barrier every
 // `sync_every` steps.  Requires strips_of(n, R) <= blockDim.x / 64 and the resident columns to fit the LDS.
-template <int R, int D, bool ZG>
+template <int RA, int RB, int D, bool ZG>
 __global__ __launch_bounds__(kWideMaxWaves* kWave) void k_seed_wide(const PairDesc* __restrict__ pairs,
                                                                    const double* __restrict__ tensors, int d,
                                                                    const double* __restrict__ coords, double gamma,
-                                                                   double sw_gap, int max_entries, int sync_every,
+                                                                   double sw_gap, int max_entries, int sync_every, int nA,
                                                                    uint32_t* __restrict__ dirs,
                                                                    Transform* __restrict__ xf,
                                                                    double* __restrict__ seed_score) {
     extern __shared__ double lds[];
     CR_STAMP(0);
     const PairDesc pd = pairs[blockIdx.x];
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const WidePlan<RA, RB> plan{nA};
+    const StripGeom geom = plan.geom(w, pd.n);
     SeedMax sm;
     AlignEnd unused;
-    {
+    // every wave runs the sweep instantiated for ITS strip's rows per lane; both have the same barriers
+    auto fill = [&](auto rtag) {
+        constexpr int R = decltype(rtag)::value;
         RbfTensor<R, D> src;
         src.rows_g = tensors + pd.off_i * d;
         src.cols_g = tensors + pd.off_j * d;
         src.d = d;
         src.neg_gamma = -gamma;
         SweepParams prm{sw_gap, 0.0, 0.0};
-        if constexpr (ZG) sweep_cols_team<R, D>(src, pd.n, pd.m, lds, dirs + pd.dirs_off, sm);
-        else sweep_wide<R, kSwTrace>(src, pd.n, pd.m, prm, lds, sync_every, dirs + pd.dirs_off, nullptr, sm, unused);
-    }
+        if constexpr (ZG) sweep_cols_team<R, D>(src, pd.n, pd.m, lds, dirs + pd.dirs_off, sm, geom);
+        else sweep_wide<R, kSwTrace>(src, pd.n, pd.m, prm, lds, sync_every, dirs + pd.dirs_off, nullptr, sm, unused, geom);
+    };
+    if (plan.wave_in_a(w)) fill(std::integral_constant<int, RA>{});
+    else if constexpr (RA != RB) fill(std::integral_constant<int, RB>{});
     if (threadIdx.x >= kWave) return;                  // wave 0 goes on alone (wave_sync, no s_barrier from here on)
     CR_STAMP(1);
     Transform tr;
-    seed_trace<R, ZG ? 0 : 1>(pd, max_entries, coords, dirs, sm, lds + kExpDoubles, tr);
+    seed_trace<RA, ZG ? 0 : 1, RB>(pd, max_entries, coords, dirs, sm, lds + kExpDoubles, tr, nA);
     if (threadIdx.x == 0) {
         xf[blockIdx.x] = tr;
         seed_score[blockIdx.x] = sm.score;
@@ -2592,33 +2719,39 @@ __global__ __launch_bounds__(kWideMaxWaves* kWave) void k_seed_wide(const PairDe
     CR_STAMP(3);
 }
 
-template <int R, bool ZG>
+template <int RA, int RB, bool ZG>
 __global__ __launch_bounds__(kWideMaxWaves* kWave) void k_align_wide(const PairDesc* __restrict__ pairs,
                                                                     const double* __restrict__ coords,
                                                                     const Transform* __restrict__ xf,
                                                                     const double* __restrict__ seed_score, double gamma,
                                                                     double sw_gap, double gap_open, double gap_extend,
-                                                                    int max_entries, int sync_every,
+                                                                    int max_entries, int sync_every, int nA,
                                                                     uint32_t* __restrict__ bits,
                                                                     int32_t* __restrict__ aln, PairResult* __restrict__ res, const HostOut hout) {
     extern __shared__ double lds[];
     CR_STAMP(4);
     const PairDesc pd = pairs[blockIdx.x];
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const WidePlan<RA, RB> plan{nA};
+    const StripGeom geom = plan.geom(w, pd.n);
     SeedMax unused;
     AlignEnd e;
-    {
+    auto fill = [&](auto rtag) {
+        constexpr int R = decltype(rtag)::value;
         RbfCoords<R> src;
         src.rows_g = coords + pd.off_i * 3;
         src.cols_g = coords + pd.off_j * 3;
         src.xf = xf + blockIdx.x;
         src.neg_gamma = -gamma;
         SweepParams prm{sw_gap, gap_open, gap_extend};
-        sweep_wide<R, kSwScore | kDtw | (ZG ? kZeroGap : 0)>(src, pd.n, pd.m, prm, lds, sync_every, nullptr, bits + pd.bt_off, unused, e);
-    }
+        sweep_wide<R, kSwScore | kDtw | (ZG ? kZeroGap : 0)>(src, pd.n, pd.m, prm, lds, sync_every, nullptr, bits + pd.bt_off, unused, e, geom);
+    };
+    if (plan.wave_in_a(w)) fill(std::integral_constant<int, RA>{});
+    else if constexpr (RA != RB) fill(std::integral_constant<int, RB>{});
     if (threadIdx.x >= kWave) return;                  // wave 0 goes on alone (wave_sync, no s_barrier from here on)
     CR_STAMP(5);
     PairResult r;
-    align_trace<R>(pd, max_entries, coords, bits, e, lds + kExpDoubles, aln, r, hout);
+    align_trace<RA, RB>(pd, max_entries, coords, bits, e, lds + kExpDoubles, aln, r, hout, nA);
     r.seed_score = seed_score[blockIdx.x];
     r.seed_len = xf[blockIdx.x].seed_len;
     r.flags |= xf[blockIdx.x].flags;

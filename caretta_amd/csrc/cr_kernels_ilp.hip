@@ -20,9 +20,9 @@ CR_ILP_SEED_TEAM_INSTANCES(CR_X)
 #define CR_X(R) template CR_NODE_TEAM_SIGNATURE(R)
 CR_ILP_NODE_TEAM_INSTANCES(CR_X)
 #undef CR_X
-#define CR_X(R, D, ZG) template CR_SEED_WIDE_SIGNATURE(R, D, ZG)
+#define CR_X(RA, RB, D, ZG) template CR_SEED_WIDE_SIGNATURE(RA, RB, D, ZG)
 CR_ILP_SEED_WIDE_INSTANCES(CR_X)
 #undef CR_X
-#define CR_X(R, ZG) template CR_ALIGN_WIDE_SIGNATURE(R, ZG)
+#define CR_X(RA, RB, ZG) template CR_ALIGN_WIDE_SIGNATURE(RA, RB, ZG)
 CR_ILP_ALIGN_WIDE_INSTANCES(CR_X)
 #undef CR_X

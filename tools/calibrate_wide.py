@@ -3,9 +3,11 @@
 
     python tools/calibrate_wide.py [workload ...]      workloads: c5share c2 c5 one300 p64x300 p120x600
 
-For every workload: time the default path, then every feasible (rows per lane R, barrier cadence B) of the wide
-kernels (CARETTA_WIDE=R,B is read by cr_batch_set_pairs), and demand bit-identical results (all PairResult fields and
-the alignment rows) against the default path, which tests/test_gpu_parity.py pins to the oracle.
+For every workload: time the default path (the library's own choice) and the path WITHOUT the wide kernels
+(CARETTA_NO_WIDE: four-wave teams or one wave per pair), then strip plans of the wide kernels -- RA rows per lane in the
+first nA strips, RB in the others, a barrier every B steps (CARETTA_WIDE=RA,RB,nA,B is read by cr_batch_set_pairs) -- and
+demand bit-identical results (all PairResult fields and the alignment rows) against the path without wide kernels, which
+tests/test_gpu_parity.py pins to the oracle.
 """
 import os
 import sys
@@ -27,8 +29,29 @@ WORKLOADS = {
     "p64x300": (12, 300, 11, 1),          # 66 pairs
     "p120x600": (16, 600, 12, 1),         # 120 pairs
     "c4share": (512, 300, 20243, 8),      # 16352 pairs: one GPU's share of config 4
+    "p120x900": (16, 900, 13, 1),
+    "p105x1500": (15, 1500, 14, 1),
+    "p120x450": (16, 450, 15, 1),
 }
-GRID = [(r, b) for r in (1, 2, 3) for b in (2, 4, 8)]
+
+
+def grid(length):
+    plans = [(1, 1, 0, 8), (2, 2, 0, 8), (3, 3, 0, 8), (2, 2, 0, 4), (3, 3, 0, 4)]
+    for na in range(1, 8):
+        if na * 192 < length:
+            plans.append((3, 2, na, 8))
+    return plans
+
+
+def timed_scores(batch, ctx, prm, reps):
+    for _ in range(2):
+        batch.run(prm, scores_only=True)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        batch.run(prm, scores_only=True)
+    ctx.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
 
 
 def timed(batch, ctx, prm, reps):
@@ -67,16 +90,19 @@ def main():
         reps = 5 if length >= 600 else 20
         os.environ.pop("CARETTA_WIDE", None)
         b = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
+        print(f"{name}: {len(pairs)} pairs of {length}: default {timed(b, ctx, prm, reps):.3f} ms, scores only {timed_scores(b, ctx, prm, reps):.3f} ms", flush=True)
+        dflt = b.fetch() if False else None
+        b.run(prm)
+        dflt = b.fetch()
+        os.environ["CARETTA_NO_WIDE"] = "1"
+        b.set_pairs(pairs)
         base_ms = timed(b, ctx, prm, reps)
-        ctx.set_profiling(reps)
-        for _ in range(reps):
-            b.run(prm)
-        st, _ = b.stage_ms()
-        ctx.set_profiling(0)
         base = b.fetch()
-        print(f"{name}: {len(pairs)} pairs of {length}: default {base_ms:.3f} ms (k_seed {st[0]:.3f} k_align {st[1]:.3f})", flush=True)
-        for r, sync in GRID:
-            os.environ["CARETTA_WIDE"] = f"{r},{sync}"
+        os.environ.pop("CARETTA_NO_WIDE", None)
+        verdict = same(base, dflt)
+        print(f"  without wide kernels: {base_ms:.3f} ms; default path {'bit-identical' if verdict is None else 'MISMATCH: ' + verdict}", flush=True)
+        for ra, rb, na, sync in grid(length):
+            os.environ["CARETTA_WIDE"] = f"{ra},{rb},{na},{sync}"
             b.set_pairs(pairs)
             ms = timed(b, ctx, prm, reps)
             ctx.set_profiling(reps)
@@ -85,8 +111,11 @@ def main():
             st, _ = b.stage_ms()
             ctx.set_profiling(0)
             verdict = same(base, b.fetch())
-            waves = -(-length // (64 * r))
-            print(f"  R={r} B={sync:2d} ({waves:2d} waves): {ms:.3f} ms (k_seed {st[0]:.3f} k_align {st[1]:.3f})  "
+            ms_sc = timed_scores(b, ctx, prm, reps)
+            sw_sc, _ = b.fetch_scores()
+            if verdict is None and not np.array_equal(sw_sc, base[0]["sw"]):
+                verdict = "scores-only run differs"
+            print(f"  RA={ra} RB={rb} nA={na} B={sync:2d}: {ms:.3f} ms (k_seed {st[0]:.3f} k_align {st[1]:.3f}), scores only {ms_sc:.3f} ms  "
                   f"{'bit-identical' if verdict is None else 'MISMATCH: ' + verdict}", flush=True)
         os.environ.pop("CARETTA_WIDE", None)
         b.close()
