@@ -1911,21 +1911,72 @@ CR_D double ordered_sums(int count, int lane, double* scratch, TermFn term) {
     return acc;
 }
 
+// The coordinates of one alignment column (a packed entry): both residues, or pair = false for a gap column (then the
+// values are those of residue 0 and must not be used).
+struct ColumnXYZ {
+    double a[3], b[3];       // residue of X_i, residue of X_j
+    bool pair;
+};
+
+// Issue the loads of column e (clamped: every lane loads, lanes past `count` get pair = false) -- no arithmetic on the
+// loaded values here, so the wait for them sits at their first use.
+CR_D ColumnXYZ load_column(const double* __restrict__ Xi, const double* __restrict__ Xj, const uint32_t* entries, int e, int count) {
+    ColumnXYZ c;
+    const bool in = e < count;
+    const uint32_t u = entries[in ? e : 0];
+    const uint32_t i = u & 0xffffu, j = u >> 16;
+    c.pair = in && i != kGap16 && j != kGap16;
+    const double* v1 = Xi + (int64_t)(c.pair ? i : 0) * 3;
+    const double* v2 = Xj + (int64_t)(c.pair ? j : 0) * 3;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        c.a[k] = v1[k];
+        c.b[k] = v2[k];
+    }
+    return c;
+}
+
+// Sum per-column term vectors over `count` packed entries in position order.  term(column, out[NACC]) is evaluated by the
+// lane that owns the column; lane a < NACC returns sum_e term(e)[a] accumulated e = 0, 1, 2, ... (exactly the rounding
+// sequence of a sequential loop).  `scratch` = 64 * NACC doubles of LDS.  The coordinates of the NEXT 64 columns are
+// requested before the 64 dependent additions of the current ones, so that the gather's trip to L2 / HBM (about as long
+// as the chain) is hidden behind it -- a lone wave per SIMD (one pair per CU) has nobody else to hide it.
+template <int NACC, class TermFn>
+CR_D double ordered_sums(const double* __restrict__ Xi, const double* __restrict__ Xj, const uint32_t* entries, int count,
+                         int lane, double* scratch, TermFn term) {
+    double acc = 0.0;
+    ColumnXYZ cur = load_column(Xi, Xj, entries, lane, count);
+    for (int base = 0; base < count; base += kWave) {
+        const int e = base + lane;
+        if (e < count) {
+            double tv[NACC];
+            term(cur, tv);
+#pragma unroll
+            for (int a = 0; a < NACC; a++) scratch[lane * NACC + a] = tv[a];
+        }
+        wave_sync();
+        const ColumnXYZ nxt = load_column(Xi, Xj, entries, e + kWave, count);
+        const int cnt = count - base < kWave ? count - base : kWave;
+        if (lane < NACC) {
+#pragma unroll 8
+            for (int x = 0; x < cnt; x++) acc += scratch[x * NACC + lane];
+        }
+        wave_sync();
+        cur = nxt;
+    }
+    return acc;
+}
+
 // Kabsch over `count` packed alignment entries of which `k` are aligned pairs
 // (superposition_functions.py:7-35), every sum in position order.  Results in all lanes.
 CR_D void kabsch_ordered(const double* __restrict__ Xi, const double* __restrict__ Xj, const uint32_t* entries,
                          int count, int k, int lane, double* scratch, double* c1, double* c2, double* R, double* t) {
     // column means (helper.py:46-53): lanes 0-2 sum X_i columns, lanes 3-5 X_j columns
-    const double msum = ordered_sums<6>(count, lane, scratch, [&](int e, double* out) {
-        const uint32_t u = entries[e];
-        const uint32_t i = u & 0xffffu, j = u >> 16;
-        const bool pair = i != kGap16 && j != kGap16;
-        const double* v1 = Xi + (int64_t)(pair ? i : 0) * 3;
-        const double* v2 = Xj + (int64_t)(pair ? j : 0) * 3;
+    const double msum = ordered_sums<6>(Xi, Xj, entries, count, lane, scratch, [&](const ColumnXYZ& c, double* out) {
 #pragma unroll
         for (int a = 0; a < 3; a++) {
-            out[a] = pair ? v1[a] : 0.0;
-            out[3 + a] = pair ? v2[a] : 0.0;
+            out[a] = c.pair ? c.a[a] : 0.0;
+            out[3 + a] = c.pair ? c.b[a] : 0.0;
         }
     });
     const double mean = msum / (double)k;
@@ -1935,18 +1986,13 @@ CR_D void kabsch_ordered(const double* __restrict__ Xi, const double* __restrict
         c2[a] = lane_value(mean, 3 + a);
     }
     // correlation matrix C = (X_j - c2)^T (X_i - c1)  (superposition_functions.py:26-27)
-    const double csum = ordered_sums<9>(count, lane, scratch, [&](int e, double* out) {
-        const uint32_t u = entries[e];
-        const uint32_t i = u & 0xffffu, j = u >> 16;
-        const bool pair = i != kGap16 && j != kGap16;
-        const double* v1 = Xi + (int64_t)(pair ? i : 0) * 3;
-        const double* v2 = Xj + (int64_t)(pair ? j : 0) * 3;
-        const double a[3] = {v2[0] - c2[0], v2[1] - c2[1], v2[2] - c2[2]};
-        const double b[3] = {v1[0] - c1[0], v1[1] - c1[1], v1[2] - c1[2]};
+    const double csum = ordered_sums<9>(Xi, Xj, entries, count, lane, scratch, [&](const ColumnXYZ& col, double* out) {
+        const double a[3] = {col.b[0] - c2[0], col.b[1] - c2[1], col.b[2] - c2[2]};
+        const double b[3] = {col.a[0] - c1[0], col.a[1] - c1[1], col.a[2] - c1[2]};
 #pragma unroll
         for (int r = 0; r < 3; r++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) out[3 * r + c] = pair ? a[r] * b[c] : 0.0;
+            for (int c = 0; c < 3; c++) out[3 * r + c] = col.pair ? a[r] * b[c] : 0.0;
     });
     double C[9];
 #pragma unroll
@@ -2028,22 +2074,19 @@ CR_D void rmsd_tm_ordered(const double* __restrict__ Xi, const double* __restric
     const double d1 = 1.24 * (double)(len1 - 15) / 3.0 - 1.8;
     const double d2 = 1.24 * (double)(len2 - 15) / 3.0 - 1.8;
     double acc = 0.0;
+    ColumnXYZ cur = load_column(Xi, Xj, ent, lane, count);
     for (int base = 0; base < count; base += kWave) {
         const int x = base + lane;
         if (x < count) {
-            const uint32_t u = ent[x];
-            const uint32_t i = u & 0xffffu, j = u >> 16;
-            const bool pair = i != kGap16 && j != kGap16;
-            const double* v1 = Xi + (int64_t)(pair ? i : 0) * 3;
-            const double* v2 = Xj + (int64_t)(pair ? j : 0) * 3;
-            double mv[3] = {v2[0], v2[1], v2[2]};
+            const bool pair = cur.pair;
+            double mv[3] = {cur.b[0], cur.b[1], cur.b[2]};
             if constexpr (MOVE) {
-                rot3(v2, R, mv);
+                rot3(cur.b, R, mv);
                 mv[0] = mv[0] + t[0];
                 mv[1] = mv[1] + t[1];
                 mv[2] = mv[2] + t[2];
             }
-            const double e0 = v1[0] - mv[0], e1 = v1[1] - mv[1], e2 = v1[2] - mv[2];
+            const double e0 = cur.a[0] - mv[0], e1 = cur.a[1] - mv[1], e2 = cur.a[2] - mv[2];
             const double sg = (e0 + e1) + e2;
             const double q1 = sg / d1, q2 = sg / d2;
             scratch[lane * 5 + 0] = pair ? e0 * e0 : 0.0;
@@ -2053,6 +2096,7 @@ CR_D void rmsd_tm_ordered(const double* __restrict__ Xi, const double* __restric
             scratch[lane * 5 + 4] = pair ? 1.0 / (1.0 + q2 * q2) : 0.0;
         }
         wave_sync();
+        const ColumnXYZ nxt = load_column(Xi, Xj, ent, x + kWave, count);     // in flight during the chain below
         const int cnt = count - base < kWave ? count - base : kWave;
         if (lane == 0) {
             for (int y = 0; y < cnt; y++) {
@@ -2065,6 +2109,7 @@ CR_D void rmsd_tm_ordered(const double* __restrict__ Xi, const double* __restric
             for (int y = 0; y < cnt; y++) acc += scratch[y * 5 + 2 + lane];
         }
         wave_sync();
+        cur = nxt;
     }
     const double ss = lane_value(acc, 0), sum1 = lane_value(acc, 1), sum2 = lane_value(acc, 2);
     rmsd = sqrt(ss / (double)k);
