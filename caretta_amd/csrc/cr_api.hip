@@ -43,8 +43,8 @@ CR_ILP_NODE_TEAM_INSTANCES(CR_X)
 #define CR_X(RA, RB, D, ZG) extern template CR_SEED_WIDE_SIGNATURE(RA, RB, D, ZG)
 CR_ILP_SEED_WIDE_INSTANCES(CR_X)
 #undef CR_X
-#define CR_X(RA, RB, ZG) extern template CR_ALIGN_WIDE_SIGNATURE(RA, RB, ZG)
-CR_ILP_ALIGN_WIDE_INSTANCES(CR_X)
+#define CR_X(RA, RB, D, ZG, SC) extern template CR_PAIR_WIDE_SIGNATURE(RA, RB, D, ZG, SC)
+CR_ILP_PAIR_WIDE_INSTANCES(CR_X)
 #undef CR_X
 #endif
 
@@ -537,7 +537,6 @@ int launch_score_team(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& p
 }
 
 int launch_score_team_r(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
-    if (b->wide_sync && b->r_b != b->r_seed) return launch_score_team<3, 2>(b, ck, prm);
     return R == 1 ? launch_score_team<1, 1>(b, ck, prm) : R == 2 ? launch_score_team<2, 2>(b, ck, prm) : R == 3 ? launch_score_team<3, 3>(b, ck, prm)
          : R == 4 ? launch_score_team<4, 4>(b, ck, prm) : launch_score_team<5, 5>(b, ck, prm);
 }
@@ -609,40 +608,56 @@ int launch_seed_wide_r(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& 
 
 int launch_seed_wide(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
     if (b->r_b != b->r_seed) return launch_seed_wide_r<3, 2>(b, ck, prm);
-    return R == 1 ? launch_seed_wide_r<1, 1>(b, ck, prm) : R == 2 ? launch_seed_wide_r<2, 2>(b, ck, prm) : launch_seed_wide_r<3, 3>(b, ck, prm);
+    return R == 2 ? launch_seed_wide_r<2, 2>(b, ck, prm) : launch_seed_wide_r<3, 3>(b, ck, prm);
 }
 
-template <int RA, int RB, bool ZG>
-int launch_align_wide_zg(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
-    using Src = cr::RbfCoords<RA>;
-    const int entries = ck.max_aln;
+// both stages in one launch (k_pair_wide)
+template <int RA, int RB, int D, bool ZG, bool SC>
+int launch_pair_wide_t(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
+    const int seed_entries = std::min(ck.n_max, ck.m_max), align_entries = ck.max_aln;
     const int waves = plan_of(b).strips(ck.n_max);
-    const size_t lds = sizeof(double) * std::max(cr::sweep_wide_lds_doubles<cr::kSwScore | cr::kDtw, Src>(waves, ck.m_max),
-                                                 (size_t)cr::kExpDoubles + cr::trace_lds_doubles(RA, entries));
-    int rc = allow_lds(cr::k_align_wide<RA, RB, ZG>, lds);
+    const size_t seed_fill = ZG ? cr::sweep_cols_team_lds_doubles(waves) : cr::sweep_wide_lds_doubles<cr::kSwTrace, cr::RbfTensor<RA, D>>(waves, ck.m_max);
+    const size_t second = SC ? cr::sweep_cols_score_team_lds_doubles<cr::RbfCoords<RA>>(waves)
+                             : std::max(cr::sweep_wide_lds_doubles<cr::kSwScore | cr::kDtw, cr::RbfCoords<RA>>(waves, ck.m_max),
+                                        (size_t)cr::kExpDoubles + cr::trace_lds_doubles(RA, align_entries));
+    const size_t lds = sizeof(double) * std::max(std::max(seed_fill, (size_t)cr::kExpDoubles + cr::trace_lds_doubles(RA, seed_entries)), second);
+    int rc = allow_lds(cr::k_pair_wide<RA, RB, D, ZG, SC>, lds);
     if (rc) return rc;
-    CR_LAUNCH((cr::k_align_wide<RA, RB, ZG>), dim3((unsigned)ck.count), dim3(waves * cr::kWave), lds,
-                       b->launch_stream ? b->launch_stream : b->ctx->stream, b->pairs.p + ck.first, b->coords.p, b->xf.p + ck.first,
-                       b->seed_score.p + ck.first, prm.gamma_coords, prm.sw_gap, prm.gap_open, prm.gap_extend, entries,
-                       b->wide_sync, b->wide_na, b->bits.p, b->aln.p, b->res.p + ck.first, host_out_for(b, ck));
+    CR_LAUNCH((cr::k_pair_wide<RA, RB, D, ZG, SC>), dim3((unsigned)ck.count), dim3(waves * cr::kWave), lds,
+              b->launch_stream ? b->launch_stream : b->ctx->stream, b->pairs.p + ck.first, b->tensors.p, (int)b->d, b->coords.p,
+              prm.gamma_tensor, prm.gamma_coords, prm.sw_gap, prm.gap_open, prm.gap_extend, seed_entries, align_entries, b->wide_sync,
+              b->wide_na, b->dirs.p, b->bits.p, b->xf.p + ck.first, b->seed_score.p + ck.first, b->aln.p, b->res.p + ck.first,
+              host_out_for(b, ck));
     CR_HIP(hipGetLastError());
     return CR_OK;
 }
 
-int launch_align_wide(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
-    const bool zg = prm.sw_gap == 0.0;
-    if (b->r_b != b->r_seed) return zg ? launch_align_wide_zg<3, 2, true>(b, ck, prm) : launch_align_wide_zg<3, 2, false>(b, ck, prm);
-    switch (R) {
-        case 1: return zg ? launch_align_wide_zg<1, 1, true>(b, ck, prm) : launch_align_wide_zg<1, 1, false>(b, ck, prm);
-        case 2: return zg ? launch_align_wide_zg<2, 2, true>(b, ck, prm) : launch_align_wide_zg<2, 2, false>(b, ck, prm);
-        default: return zg ? launch_align_wide_zg<3, 3, true>(b, ck, prm) : launch_align_wide_zg<3, 3, false>(b, ck, prm);
+template <int RA, int RB, int D>
+int launch_pair_wide_d(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, bool scores) {
+    if (prm.sw_gap != 0.0) return launch_pair_wide_t<RA, RB, D, false, false>(b, ck, prm);
+    return scores ? launch_pair_wide_t<RA, RB, D, true, true>(b, ck, prm) : launch_pair_wide_t<RA, RB, D, true, false>(b, ck, prm);
+}
+
+template <int RA, int RB>
+int launch_pair_wide_r(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, bool scores) {
+    switch (b->d_pad) {
+        case 4: return launch_pair_wide_d<RA, RB, 4>(b, ck, prm, scores);
+        case 8: return launch_pair_wide_d<RA, RB, 8>(b, ck, prm, scores);
+        case 10: return launch_pair_wide_d<RA, RB, 10>(b, ck, prm, scores);
+        case 16: return launch_pair_wide_d<RA, RB, 16>(b, ck, prm, scores);
+        default: return fail(CR_ERR_ARGUMENT, "unsupported tensor width");
     }
+}
+
+int launch_pair_wide(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, bool scores) {
+    if (b->r_b != b->r_seed) return launch_pair_wide_r<3, 2>(b, ck, prm, scores);
+    return b->r_seed == 2 ? launch_pair_wide_r<2, 2>(b, ck, prm, scores) : launch_pair_wide_r<3, 3>(b, ck, prm, scores);
 }
 
 // Can a pair list with these maxima run on the wide kernels with this strip plan?  (strips <= 16 waves, the columns
 // of the tensor sweep -- the larger of the two -- resident in LDS next to the edge rings)
 bool wide_fits(const StripPlan& p, int n_max, int m_max, int d_pad) {
-    if (p.ra < 1 || p.ra > 3 || p.rb < 1 || p.rb > p.ra || d_pad > 16) return false;   // (the wide seed kernels are built for widths up to 16)
+    if (p.ra < 2 || p.ra > 3 || p.rb < 2 || p.rb > p.ra || d_pad > 16) return false;   // (the wide kernels are built for 2 or 3 rows per lane, widths up to 16)
     if (p.ra != p.rb && !(p.ra == 3 && p.rb == 2)) return false;                        // (the one mixed instance)
     const int waves = p.strips(n_max);
     if (waves > cr::kWideMaxWaves) return false;
@@ -1193,13 +1208,25 @@ static int run_batch(cr_batch* b, const cr_params* params, double* d_sw_out, boo
         hipStream_t st = ck.lane == 0 ? ctx->stream : ctx->side[(size_t)ck.lane - 1];
         b->launch_stream = st;
         if (prof) (void)hipEventRecord((*evl)[evi++], st);
-        rc = b->wide_sync ? launch_seed_wide(ck.r, b, ck, prm) : b->team ? launch_seed_team(ck.r, b, ck, prm) : launch_seed_r(ck.r, b, ck, prm);
+        if (b->wide_sync) {
+            // the wide layout: both stages of a pair in ONE launch (k_pair_wide) -- the stage split of the events is
+            // (everything, 0)
+            rc = launch_pair_wide(b, ck, prm, scores_only && prm.sw_gap == 0.0);
+            if (!rc && prof) {
+                (void)hipEventRecord((*evl)[evi++], st);
+                (void)hipEventRecord((*evl)[evi++], st);
+            }
+            b->launch_stream = nullptr;
+            if (rc) return rc;
+            continue;
+        }
+        rc = b->team ? launch_seed_team(ck.r, b, ck, prm) : launch_seed_r(ck.r, b, ck, prm);
         if (!rc && prof) (void)hipEventRecord((*evl)[evi++], st);
         if (!rc) {
             // scores only (gap 0): the column sweep without decisions -- one wave per pair, or one wave per strip for the
             // few-pair batches (team / wide layouts: strips_of(n_max, R) <= 16 waves)
             if (scores_only && prm.sw_gap == 0.0) rc = b->team ? launch_score_team_r(ck.r, b, ck, prm) : launch_score_r(ck.r, b, ck, prm);
-            else rc = b->wide_sync ? launch_align_wide(ck.r, b, ck, prm) : b->team ? launch_align_team(ck.r, b, ck, prm) : launch_align_r(ck.r, b, ck, prm);
+            else rc = b->team ? launch_align_team(ck.r, b, ck, prm) : launch_align_r(ck.r, b, ck, prm);
         }
         if (!rc && prof) (void)hipEventRecord((*evl)[evi++], st);
         b->launch_stream = nullptr;

@@ -49,13 +49,17 @@
 #define CR_ILP_SEED_WIDE_D(X, RA, RB) \
     X(RA, RB, 4, true) X(RA, RB, 4, false) X(RA, RB, 8, true) X(RA, RB, 8, false) X(RA, RB, 10, true) X(RA, RB, 10, false) \
     X(RA, RB, 16, true) X(RA, RB, 16, false)
-#define CR_ILP_SEED_WIDE_INSTANCES(X) CR_ILP_SEED_WIDE_D(X, 1, 1) CR_ILP_SEED_WIDE_D(X, 2, 2) CR_ILP_SEED_WIDE_D(X, 3, 3) CR_ILP_SEED_WIDE_D(X, 3, 2)
-#define CR_ILP_ALIGN_WIDE_INSTANCES(X) \
-    X(1, 1, true) X(1, 1, false) X(2, 2, true) X(2, 2, false) X(3, 3, true) X(3, 3, false) X(3, 2, true) X(3, 2, false)
+#define CR_ILP_SEED_WIDE_INSTANCES(X) CR_ILP_SEED_WIDE_D(X, 2, 2) CR_ILP_SEED_WIDE_D(X, 3, 3) CR_ILP_SEED_WIDE_D(X, 3, 2)
 #define CR_SEED_WIDE_SIGNATURE(RA, RB, D, ZG)                                                                                   \
     __global__ void cr::k_seed_wide<RA, RB, D, ZG>(const cr::PairDesc*, const double*, int, const double*, double, double, int, \
                                                    int, int, uint32_t*, cr::Transform*, double*);
-#define CR_ALIGN_WIDE_SIGNATURE(RA, RB, ZG)                                                                                      \
-    __global__ void cr::k_align_wide<RA, RB, ZG>(const cr::PairDesc*, const double*, const cr::Transform*, const double*, double, \
-                                                 double, double, double, int, int, int, uint32_t*, int32_t*, cr::PairResult*,    \
-                                                 const cr::HostOut);
+// both stages of a pair in one launch (k_pair_wide; SCORES only with gap 0)
+#define CR_ILP_PAIR_WIDE_D(X, RA, RB) \
+    X(RA, RB, 4, true, false) X(RA, RB, 4, false, false) X(RA, RB, 4, true, true) X(RA, RB, 8, true, false) X(RA, RB, 8, false, false) \
+    X(RA, RB, 8, true, true) X(RA, RB, 10, true, false) X(RA, RB, 10, false, false) X(RA, RB, 10, true, true) \
+    X(RA, RB, 16, true, false) X(RA, RB, 16, false, false) X(RA, RB, 16, true, true)
+#define CR_ILP_PAIR_WIDE_INSTANCES(X) CR_ILP_PAIR_WIDE_D(X, 2, 2) CR_ILP_PAIR_WIDE_D(X, 3, 3) CR_ILP_PAIR_WIDE_D(X, 3, 2)
+#define CR_PAIR_WIDE_SIGNATURE(RA, RB, D, ZG, SC)                                                                               \
+    __global__ void cr::k_pair_wide<RA, RB, D, ZG, SC>(const cr::PairDesc*, const double*, int, const double*, double, double,  \
+                                                       double, double, double, int, int, int, int, uint32_t*, uint32_t*,        \
+                                                       cr::Transform*, double*, int32_t*, cr::PairResult*, const cr::HostOut);

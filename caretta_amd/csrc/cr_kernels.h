@@ -1753,24 +1753,17 @@ struct Walker {
     int r0, c0, bs, amax;     // block key (wave-uniform): anchor cell, strip (-1: empty), deepest row offset held
     int s, l, q;              // position of the current row (wave-uniform): strip, fill lane, row slot
     int rs, base, slot0;      // of strip s (wave-uniform): rows per lane, first row, row slots before it
-    // A second block, requested when a block is loaded and consumed when the walk leaves that block: the 16 rows above
-    // it, anchored one block further along the diagonal (the direction a structural alignment mostly takes).  Its load
-    // is in flight while the walk crosses the current block, so a correct guess costs no memory round trip.
-    uint32_t nblk;
-    int nlax;
-    int nr0, nc0, ns, namax;  // its key; ns = -1: none
-
     CR_D void init(const uint32_t* __restrict__ w, int tb, int lane, int na = 0) {
         words = w;
         TB = tb;
         nA = na;
         ax = lane >> 2;
         wx = lane & 3;
-        blk = nblk = 0;
-        lax = nlax = 0;
-        r0 = c0 = nr0 = nc0 = 0;
-        bs = ns = -1;             // no strip: the first lookup fills the block
-        amax = namax = -1;
+        blk = 0;
+        lax = 0;
+        r0 = c0 = 0;
+        bs = -1;                  // no strip: the first lookup fills the block
+        amax = -1;
         s = l = q = 0;
         rs = R;
         base = slot0 = 0;
@@ -1822,47 +1815,24 @@ struct Walker {
         const int tb = ((c + la * SKEW) >> kLog) - wx;
         return (rv && tb >= 0) ? words[((int64_t)slot0 * TB + (int64_t)tb * rs + qa) * kWave + la] : 0u;
     }
+    // (Requesting the block above along the diagonal while the walk crosses this one was measured: 225 k -> 218 k cycles
+    // per 1200-row walk, and 2 % more time for the headline kernels -- a walk step is bound by its ~100 dependent scalar
+    // instructions, not by the load; not kept.)
     CR_D void refill(int r, int c) {
-        // the block requested ahead: taken when it is the current strip's, starts at this row, and its words reach the
-        // column (words only extend to the left of an anchor)
-        bool hit = false;
-        if (ns == s && nr0 == r && c <= nc0) {
-            const int w = ((nc0 + l * SKEW) >> kLog) - ((c + l * SKEW) >> kLog);
-            hit = w < kBlockWords;
-        }
-        if (hit) {
-            blk = nblk;
-            lax = nlax;
-            r0 = nr0;
-            c0 = nc0;
-            amax = namax;
-        } else {
-            r0 = r;
-            c0 = c;
-            amax = r - base < kBlockRows - 1 ? r - base : kBlockRows - 1;
-            blk = load_block(r, c, lax);
-        }
+        r0 = r;
+        c0 = c;
         bs = s;
-        // request the block above this one, one block along the diagonal from the anchor in use
-        const int pr = r0 - kBlockRows, pc = c0 - kBlockRows;
-        if (pr >= base && pc >= 0) {
-            ns = s;
-            nr0 = pr;
-            nc0 = pc;
-            namax = pr - base < kBlockRows - 1 ? pr - base : kBlockRows - 1;
-            nblk = load_block(pr, pc, nlax);
-        } else {
-            ns = -1;
-        }
+        amax = r - base < kBlockRows - 1 ? r - base : kBlockRows - 1;
+        blk = load_block(r, c, lax);
     }
     // decision field of cell (r, c); (s, l, q) must be the position of row r
     CR_D uint32_t get(int r, int c) {
         int a = r0 - r;
         int w = ((c0 + l * SKEW) >> kLog) - ((c + l * SKEW) >> kLog);
-        if (!(s == bs && a <= amax && w < kBlockWords && w >= 0)) {
+        if (!(s == bs && a <= amax && w < kBlockWords)) {
             refill(r, c);
-            a = r0 - r;
-            w = ((c0 + l * SKEW) >> kLog) - ((c + l * SKEW) >> kLog);
+            a = 0;
+            w = 0;
         }
         const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)blk, a * 4 + w);
         return (word >> (((c + l * SKEW) & kStepMask) * BITS)) & kFieldMask;
@@ -2803,6 +2773,105 @@ __global__ __launch_bounds__(kWideMaxWaves* kWave) void k_align_wide(const PairD
     if (threadIdx.x == 0) {
         res[blockIdx.x] = r;
         if (hout.res) hout.res[hout.dst(blockIdx.x)] = r;
+    }
+    CR_STAMP(7);
+}
+
+// Both stages of a pair in ONE launch of the wide layout: seed fill -> (wave 0) seed walk + Kabsch -> align fill (or the
+// score sweep alone, SCORES) -> (wave 0) DTW walk + Kabsch + metrics.  With one pair per CU (one GPU's share of a sharded
+// long-chain family) two launches meant that every CU waited for the slowest pair of the seed launch before any of
+// them started its alignment fill, and a launch gap on top: 252 pairs of 1200 x 1200 took 2.46 ms where the phases of
+// the median pair add up to 2.32.  The seed superposition reaches the second fill through LDS.
+template <int RA, int RB, int D, bool ZG, bool SCORES>
+__global__ __launch_bounds__(kWideMaxWaves* kWave) void k_pair_wide(const PairDesc* __restrict__ pairs,
+                                                                   const double* __restrict__ tensors, int d,
+                                                                   const double* __restrict__ coords, double gamma_tensor,
+                                                                   double gamma_coords, double sw_gap, double gap_open,
+                                                                   double gap_extend, int seed_entries, int align_entries,
+                                                                   int sync_every, int nA, uint32_t* __restrict__ dirs,
+                                                                   uint32_t* __restrict__ bits, Transform* __restrict__ xf,
+                                                                   double* __restrict__ seed_score, int32_t* __restrict__ aln,
+                                                                   PairResult* __restrict__ res, const HostOut hout) {
+    extern __shared__ double lds[];
+    __shared__ Transform s_tr;
+    CR_STAMP(0);
+    const PairDesc pd = pairs[blockIdx.x];
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const WidePlan<RA, RB> plan{nA};
+    const StripGeom geom = plan.geom(w, pd.n);
+    SeedMax sm;
+    AlignEnd e;
+    {
+        AlignEnd unused;
+        auto fill = [&](auto rtag) {
+            constexpr int R = decltype(rtag)::value;
+            RbfTensor<R, D> src;
+            src.rows_g = tensors + pd.off_i * d;
+            src.cols_g = tensors + pd.off_j * d;
+            src.d = d;
+            src.neg_gamma = -gamma_tensor;
+            SweepParams prm{sw_gap, 0.0, 0.0};
+            if constexpr (ZG) sweep_cols_team<R, D>(src, pd.n, pd.m, lds, dirs + pd.dirs_off, sm, geom);
+            else sweep_wide<R, kSwTrace>(src, pd.n, pd.m, prm, lds, sync_every, dirs + pd.dirs_off, nullptr, sm, unused, geom);
+        };
+        if (plan.wave_in_a(w)) fill(std::integral_constant<int, RA>{});
+        else if constexpr (RA != RB) fill(std::integral_constant<int, RB>{});
+    }
+    if (threadIdx.x < kWave) {                         // wave 0 alone; the others wait at the barrier below
+        CR_STAMP(1);
+        Transform tr;
+        seed_trace<RA, ZG ? 0 : 1, RB>(pd, seed_entries, coords, dirs, sm, lds + kExpDoubles, tr, nA);
+        if (threadIdx.x == 0) {
+            xf[blockIdx.x] = tr;
+            seed_score[blockIdx.x] = sm.score;
+            s_tr = tr;
+        }
+        CR_STAMP(3);
+    }
+    __syncthreads();
+    CR_STAMP(4);
+    double sw_only = 0.0;
+    {
+        SeedMax unused;
+        auto fill = [&](auto rtag) {
+            constexpr int R = decltype(rtag)::value;
+            RbfCoords<R> src;
+            src.rows_g = coords + pd.off_i * 3;
+            src.cols_g = coords + pd.off_j * 3;
+            src.xf = &s_tr;
+            src.neg_gamma = -gamma_coords;
+            if constexpr (SCORES) {
+                sw_only = sweep_cols_score_team<R>(src, pd.n, pd.m, lds, geom);
+            } else {
+                SweepParams prm{sw_gap, gap_open, gap_extend};
+                sweep_wide<R, kSwScore | kDtw | (ZG ? kZeroGap : 0)>(src, pd.n, pd.m, prm, lds, sync_every, nullptr, bits + pd.bt_off, unused, e, geom);
+            }
+        };
+        if (plan.wave_in_a(w)) fill(std::integral_constant<int, RA>{});
+        else if constexpr (RA != RB) fill(std::integral_constant<int, RB>{});
+    }
+    if (threadIdx.x >= kWave) return;                  // wave 0 goes on alone (wave_sync, no s_barrier from here on)
+    CR_STAMP(5);
+    PairResult r;
+    if constexpr (SCORES) {
+        r.sw = sw_only;
+        r.dtw_score = 0.0;
+#pragma unroll
+        for (int x = 0; x < 9; x++) r.R[x] = 0.0;
+#pragma unroll
+        for (int x = 0; x < 3; x++) r.t[x] = 0.0;
+        r.rmsd = r.coverage = r.tm = 0.0;
+        r.aln_len = r.aln_start = 0;
+        r.flags = 0;
+    } else {
+        align_trace<RA, RB>(pd, align_entries, coords, bits, e, lds + kExpDoubles, aln, r, hout, nA);
+    }
+    r.seed_score = sm.score;
+    r.seed_len = s_tr.seed_len;
+    r.flags |= s_tr.flags;
+    if (threadIdx.x == 0) {
+        res[blockIdx.x] = r;
+        if (!SCORES && hout.res) hout.res[hout.dst(blockIdx.x)] = r;
     }
     CR_STAMP(7);
 }

@@ -23,6 +23,6 @@ CR_ILP_NODE_TEAM_INSTANCES(CR_X)
 #define CR_X(RA, RB, D, ZG) template CR_SEED_WIDE_SIGNATURE(RA, RB, D, ZG)
 CR_ILP_SEED_WIDE_INSTANCES(CR_X)
 #undef CR_X
-#define CR_X(RA, RB, ZG) template CR_ALIGN_WIDE_SIGNATURE(RA, RB, ZG)
-CR_ILP_ALIGN_WIDE_INSTANCES(CR_X)
+#define CR_X(RA, RB, D, ZG, SC) template CR_PAIR_WIDE_SIGNATURE(RA, RB, D, ZG, SC)
+CR_ILP_PAIR_WIDE_INSTANCES(CR_X)
 #undef CR_X
