@@ -471,7 +471,7 @@ struct SweepParams {
 // max(a, b) is v_max_f64: value-identical to the reference's compare-and-keep for non-NaN data.
 template <int R, int MODE, class Src>
 CR_D void dp_column(const Src& src, DpState<R>& st, const SweepParams& prm, const ExpEntry* tab, int c, int rowbase,
-                    int n, int sh2, int sh4, double h_top, double m0_top, double m1_top) {
+                    int n, int sh2, int sh4, double h_top, double m0_top, double m1_top, const double* ready = nullptr) {
     constexpr bool SW = (MODE & (kSwTrace | kSwScore)) != 0;
     constexpr bool TRACE = (MODE & kSwTrace) != 0;
     constexpr bool DTW = (MODE & kDtw) != 0;
@@ -484,7 +484,8 @@ CR_D void dp_column(const Src& src, DpState<R>& st, const SweepParams& prm, cons
     bool b2[R];
 #pragma unroll
     for (int q = 0; q < R; q++) {
-        const double sc = src.score(q, tab);
+        // `ready`: the scores of this column, formed one step ahead (sweep_wide with few rows per lane)
+        const double sc = ready ? ready[q] : src.score(q, tab);
         if constexpr (SW) dg[q] = (q == 0 ? st.h_diag : st.h_left[q - 1]) + sc;
         if constexpr (DTW) {
             c1[q] = (q == 0 ? st.m1_diag : st.m1_left[q - 1]) + sc;
@@ -1461,6 +1462,19 @@ CR_D void sweep_wide(Src& src, const int n, const int m, const SweepParams prm, 
 #pragma unroll
     for (int q = 0; q < R; q++) st.swbits[q] = st.dtbits[q] = 0;
 
+    // Few rows per lane: a step is one long chain of dependent FP64 instructions (squared distance -> exp -> recurrences,
+    // ~10 cycles each for a wave that has its SIMD to itself) with nothing to interleave.  The scores do not depend on the
+    // recurrence, so they are formed ONE COLUMN AHEAD: the chain of column c + 1's scores runs beside the recurrence of
+    // column c, and the step becomes issue-bound.  (Every lane's first column is column 0: its scores are formed here.)
+    constexpr bool AHEAD = R <= 2;
+    double sc_cur[R];
+    __syncthreads();                                       // the resident columns and the exp table are complete (every
+                                                           // wave, whatever its rows per lane: barriers must pair up)
+    if constexpr (AHEAD) {
+        src.fetch_resident(res, stride, 0);
+#pragma unroll
+        for (int q = 0; q < R; q++) sc_cur[q] = src.score(q, tab);
+    }
     const int G = lag * (nstrips - 1) + m + kWave - 1;
     int until_sync = 0;
     for (int g = 0; g < G; g++) {
@@ -1492,8 +1506,18 @@ CR_D void sweep_wide(Src& src, const int n, const int m, const SweepParams prm, 
         const int sh2 = (t & 15) * 2, sh4 = (t & 7) * 4;
 
         if (active) {
-            src.fetch_resident(res, stride, c);
-            dp_column<R, MODE>(src, st, prm, tab, c, rowbase, n, sh2, sh4, h_top, m0_top, m1_top);
+            if constexpr (AHEAD) {
+                double sc_next[R];
+                src.fetch_resident(res, stride, c + 1 < m ? c + 1 : c);
+#pragma unroll
+                for (int q = 0; q < R; q++) sc_next[q] = src.score(q, tab);
+                dp_column<R, MODE>(src, st, prm, tab, c, rowbase, n, sh2, sh4, h_top, m0_top, m1_top, sc_cur);
+#pragma unroll
+                for (int q = 0; q < R; q++) sc_cur[q] = sc_next[q];
+            } else {
+                src.fetch_resident(res, stride, c);
+                dp_column<R, MODE>(src, st, prm, tab, c, rowbase, n, sh2, sh4, h_top, m0_top, m1_top);
+            }
             if (w + 1 < nstrips && lane == kWave - 1) {
                 if constexpr (SW) edge_out[c & (kWideEdge - 1)] = st.h_left[R - 1];
                 if constexpr (DTW) {

@@ -1172,3 +1172,31 @@ def test_streamed_run_writes_what_fetch_copies(ctx):
             bad = np.zeros(len(pairs), dtype=_capi.PAIR_RESULT_DTYPE)
             _capi.check(batch._lib.cr_batch_run_stream_i32(batch._h, C.byref(engine.make_params()), _capi.ptr(bad), None, 0, None))
         batch.close()
+
+
+def test_wide_strip_plans_vs_oracle(ctx, oracle, monkeypatch):
+    """The wide layout (one workgroup per pair, one wave per strip, both stages in one launch) with strips of UNEQUAL rows
+    per lane -- 3 in the first nA strips, 2 in the others, CARETTA_WIDE=RA,RB,nA,B -- on ragged lengths, so that pairs of one
+    launch end in different strips and zones; every output bit-identical to the oracle, full pipeline and scores only,
+    with and without a Smith-Waterman gap (skewed seed sweep)."""
+    from caretta_amd import engine
+    from oracle.pyoracle import default_params
+    fam = synthetic.make_family(5, 700, seed=6061, ragged=True, clades=1)
+    cuts = [700, 130, 450, 577, 193]
+    for s, cut in zip(fam, cuts):
+        s.coordinates, s.tensors = s.coordinates[:cut].copy(), s.tensors[:cut].copy()
+    coords, tensors, offsets = synthetic.pack(fam)
+    pairs = np.vstack([engine.all_pairs(5), engine.all_pairs(5)[:, ::-1]])
+    ref = {gap: oracle.pairwise_batch(coords, tensors, offsets, pairs, params=default_params(sw_gap=gap), nthreads=8) for gap in (0.0, 0.05)}
+    for plan in ("3,2,1,8", "3,2,2,8", "3,2,3,2", "2,2,0,8", "3,3,0,4"):
+        monkeypatch.setenv("CARETTA_WIDE", plan)
+        batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
+        for gap in (0.0, 0.05):
+            prm = engine.make_params(sw_gap=gap)
+            batch.run(prm)
+            res, aln = batch.fetch()
+            assert_bit_identical(res, aln, *ref[gap])
+            batch.run(prm, scores_only=True)
+            sw, flags = batch.fetch_scores()
+            assert np.array_equal(sw, ref[gap][0]["sw"])
+        batch.close()

@@ -36,7 +36,7 @@ WORKLOADS = {
 
 
 def grid(length):
-    plans = [(1, 1, 0, 8), (2, 2, 0, 8), (3, 3, 0, 8), (2, 2, 0, 4), (3, 3, 0, 4)]
+    plans = [(2, 2, 0, 8), (3, 3, 0, 8), (2, 2, 0, 2), (3, 3, 0, 2)]
     for na in range(1, 8):
         if na * 192 < length:
             plans.append((3, 2, na, 8))
