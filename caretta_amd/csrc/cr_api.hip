@@ -617,10 +617,11 @@ int launch_pair_wide_t(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& 
     const int seed_entries = std::min(ck.n_max, ck.m_max), align_entries = ck.max_aln;
     const int waves = plan_of(b).strips(ck.n_max);
     const size_t seed_fill = ZG ? cr::sweep_cols_team_lds_doubles(waves) : cr::sweep_wide_lds_doubles<cr::kSwTrace, cr::RbfTensor<RA, D>>(waves, ck.m_max);
+    // (the sums behind the walks are taken by the whole workgroup: a term tile next to the entries)
     const size_t second = SC ? cr::sweep_cols_score_team_lds_doubles<cr::RbfCoords<RA>>(waves)
                              : std::max(cr::sweep_wide_lds_doubles<cr::kSwScore | cr::kDtw, cr::RbfCoords<RA>>(waves, ck.m_max),
-                                        (size_t)cr::kExpDoubles + cr::trace_lds_doubles(RA, align_entries));
-    const size_t lds = sizeof(double) * std::max(std::max(seed_fill, (size_t)cr::kExpDoubles + cr::trace_lds_doubles(RA, seed_entries)), second);
+                                        (size_t)cr::kExpDoubles + cr::trace_team_lds_doubles(align_entries));
+    const size_t lds = sizeof(double) * std::max(std::max(seed_fill, (size_t)cr::kExpDoubles + cr::trace_team_lds_doubles(seed_entries)), second);
     int rc = allow_lds(cr::k_pair_wide<RA, RB, D, ZG, SC>, lds);
     if (rc) return rc;
     CR_LAUNCH((cr::k_pair_wide<RA, RB, D, ZG, SC>), dim3((unsigned)ck.count), dim3(waves * cr::kWave), lds,
@@ -664,7 +665,7 @@ bool wide_fits(const StripPlan& p, int n_max, int m_max, int d_pad) {
     // (sized for sw_gap != 0, where the tensor sweep needs its columns resident too; the parameters come with cr_batch_run)
     const size_t seed = cr::kExpDoubles + (size_t)d_pad * m_max + (size_t)waves * (cr::kWideEdge + 8);
     const size_t align = cr::kExpDoubles + (size_t)3 * m_max + (size_t)waves * (3 * cr::kWideEdge + 8);
-    const size_t trace = cr::kExpDoubles + cr::trace_lds_doubles(p.ra, n_max + m_max);
+    const size_t trace = cr::kExpDoubles + cr::trace_team_lds_doubles(n_max + m_max);
     return sizeof(double) * std::max(std::max(seed, align), trace) <= 160 * 1024;
 }
 

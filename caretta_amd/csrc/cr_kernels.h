@@ -1861,22 +1861,49 @@ struct Walker {
         const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)blk, a * 4 + w);
         return (word >> (((c + l * SKEW) & kStepMask) * BITS)) & kFieldMask;
     }
-    // Number of consecutive cells (r - k, c - k), k = 0, 1, ..., whose decision field satisfies `diag`, as far as the
-    // block holds them (at least 1 when the caller has just seen diag(get(r, c))).
-    template <class Pred>
-    CR_D int diag_run(int r, int c, Pred diag) {
+    // Number of consecutive cells (r - k, c - k * DC), k = 0, 1, ..., whose decision field satisfies `pred`, as far as the
+    // block holds them (DC = 1: a diagonal run, DC = 0: a vertical one).  `more`: the cell behind the run is in the block
+    // too (so the run ended because that cell's field does not satisfy `pred`, not because the block did).
+    template <int DC, class Pred>
+    CR_D int run_up(int r, int c, Pred pred, bool& more) {
         const int a_cur = r0 - r;
         const int k = ax - a_cur;
-        const int col = c - k;
+        const int col = c - k * DC;
         const int t = col + lax * SKEW;
         const int wneed = ((c0 + lax * SKEW) >> kLog) - (t >> kLog);
         const uint32_t f = (blk >> ((t & kStepMask) * BITS)) & kFieldMask;
-        const bool cont = k >= 0 && ax <= amax && col >= 0 && wneed == wx && diag(f);
-        uint64_t mk = __ballot(cont);
-        mk = (mk | (mk >> 1) | (mk >> 2) | (mk >> 3)) & 0x1111111111111111ull;     // bit 4a: row a continues
+        const bool have = k >= 0 && ax <= amax && col >= 0 && wneed == wx;
+        uint64_t mh = __ballot(have), mk = __ballot(have && pred(f));
+        mh = (mh | (mh >> 1) | (mh >> 2) | (mh >> 3)) & 0x1111111111111111ull;     // bit 4a: row a's cell is held
+        mk = (mk | (mk >> 1) | (mk >> 2) | (mk >> 3)) & 0x1111111111111111ull;     // bit 4a: ... and continues the run
         const uint64_t stop = ~(mk >> (4 * a_cur)) & 0x1111111111111111ull;
-        const int rows = stop ? (__builtin_ctzll(stop) >> 2) : 16;
-        return __builtin_amdgcn_readfirstlane(rows);
+        const int rows = __builtin_amdgcn_readfirstlane(stop ? (__builtin_ctzll(stop) >> 2) : 16);
+        more = a_cur + rows < 16 && ((mh >> (4 * (a_cur + rows))) & 1ull);
+        return rows;
+    }
+    template <class Pred>
+    CR_D int diag_run(int r, int c, Pred diag) {
+        bool more;
+        return run_up<1>(r, c, diag, more);
+    }
+    // The same along the row: cells (r, c - k), k = 0, 1, ... (a horizontal gap run).  Lane k looks at cell k: the word it
+    // needs is one of the four the block holds for row r and comes over with one ds_bpermute.  (s, l, q) must be the
+    // position of row r and the block must hold (r, c) -- the caller has just read it.
+    template <class Pred>
+    CR_D int run_left(int r, int c, Pred pred, bool& more) {
+        const int lane = ax * 4 + wx;
+        const int a_cur = r0 - r;
+        const int top = (c0 + l * SKEW) >> kLog;              // newest word the block holds for this row
+        const int col = c - lane;
+        const int t = col + l * SKEW;
+        const int w = top - (t >> kLog);
+        const bool have = col >= 0 && w < kBlockWords;
+        const uint32_t word = (uint32_t)__builtin_amdgcn_ds_bpermute((a_cur * 4 + (have ? w : 0)) * 4, (int)blk);
+        const uint32_t f = (word >> ((t & kStepMask) * BITS)) & kFieldMask;
+        const uint64_t mh = __ballot(have), mk = __ballot(have && pred(f));
+        const int cells = __builtin_amdgcn_readfirstlane(~mk ? __builtin_ctzll(~mk) : 64);
+        more = cells < 64 && ((mh >> cells) & 1ull);
+        return cells;
     }
 };
 
@@ -2002,12 +2029,12 @@ __host__ __device__ inline size_t trace_lds_doubles(int /*R*/, int max_entries) 
 // Stage 2: SW traceback on the stored decisions, common positions, seed Kabsch
 // (dynamic_time_warping.py:249-278, helper.py:13-42, superposition_functions.py:39-60).
 // Wave-uniform; `lds` is this stage's LDS.  Returns the transform in every lane.
+// The walk of stage 2 alone: the aligned pairs into plist[cap - k, cap) (cap = min(n, m)), their number, the length of the
+// local alignment, kFlagSeedAllZero.  One wave.
 template <int R, int SKEW = 1, int RB = R>
-CR_D void seed_trace(const PairDesc& pd, int max_entries, const double* __restrict__ coords,
-                     const uint32_t* __restrict__ dirs, const SeedMax sm, double* lds, Transform& tr, const int nA = 0) {
-    const int lane = threadIdx.x;
-    uint32_t* plist = reinterpret_cast<uint32_t*>(lds);          // aligned pairs, filled back-to-front
-    double* scratch = lds + ((size_t)max_entries + 3) / 4 * 2;   // 16-byte aligned, after the list
+CR_D void seed_walk(const PairDesc& pd, const uint32_t* __restrict__ dirs, const SeedMax sm, uint32_t* plist, const int nA,
+                    int& k_out, int& len_out, uint32_t& flags_out) {
+    const int lane = threadIdx.x & (kWave - 1);
     const int cap = pd.n < pd.m ? pd.n : pd.m;
     uint32_t flags = 0;
     int k = 0, len = 0;
@@ -2031,16 +2058,35 @@ CR_D void seed_trace(const PairDesc& pd, int max_entries, const double* __restri
                 i -= run;
                 j -= run;
                 if (i > 0) wk.set_row(i - 1);
-            } else if (code == 2) {
-                len++;
-                j--;
-            } else {
-                len++;
-                i--;
-                wk.row_up();
+            } else if (code == 2) {                              // a run of gaps along the row: all of it at once
+                bool more;
+                const int run = wk.run_left(i - 1, j - 1, [](uint32_t f) { return f == 2u; }, more);
+                len += run;
+                j -= run;
+            } else {                                             // ... and along the column
+                bool more;
+                const int run = wk.template run_up<0>(i - 1, j - 1, [](uint32_t f) { return f == 3u; }, more);
+                len += run;
+                i -= run;
+                if (i > 0) wk.set_row(i - 1);
             }
         }
     }
+    k_out = k;
+    len_out = len;
+    flags_out = flags;
+}
+
+template <int R, int SKEW = 1, int RB = R>
+CR_D void seed_trace(const PairDesc& pd, int max_entries, const double* __restrict__ coords,
+                     const uint32_t* __restrict__ dirs, const SeedMax sm, double* lds, Transform& tr, const int nA = 0) {
+    const int lane = threadIdx.x;
+    uint32_t* plist = reinterpret_cast<uint32_t*>(lds);          // aligned pairs, filled back-to-front
+    double* scratch = lds + ((size_t)max_entries + 3) / 4 * 2;   // 16-byte aligned, after the list
+    const int cap = pd.n < pd.m ? pd.n : pd.m;
+    uint32_t flags = 0;
+    int k = 0, len = 0;
+    seed_walk<R, SKEW, RB>(pd, dirs, sm, plist, nA, k, len, flags);
     wave_sync();
     CR_STAMP(2);
 #pragma unroll
@@ -2112,6 +2158,148 @@ CR_D void rmsd_tm_ordered(const double* __restrict__ Xi, const double* __restric
     tm = t1 > t2 ? t1 : t2;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same sums with the whole WORKGROUP at work (one pair per workgroup: the wide layout).  After a fill all waves of the
+// workgroup are still there and wave 0 has walked: every thread forms the terms of its columns -- kSumTile columns per
+// round, each thread gathering the coordinates of its own -- into LDS, then ONE thread per accumulator adds the round's
+// terms in position order (the rounding sequence of the sequential loop, as above).  What is left on the critical path
+// is the chain of dependent additions itself; the gathers of all columns are in flight together.
+// `terms`: kSumTile * kMaxAcc doubles of LDS; `red`: 16 doubles.  Every thread of the workgroup must call these (they
+// contain barriers); results in every thread.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSumTile = 1024;
+constexpr int kSumSlack = 8 * kMaxAcc;     // doubles behind the term tile that chain_sum may read (never add)
+
+// acc + p[0] + p[stride] + ... + p[(cnt - 1) * stride], added in this order by ONE thread.  The chain of dependent
+// additions is the critical path of a sum that has to round like a sequential loop; the LDS reads are kept off it: two
+// register blocks of 8 in turn, each read one block ahead of its additions (the last read-ahead runs up to 8 elements
+// past the end: read, never added).
+CR_D double chain_sum(const double* p, int stride, int cnt, double acc) {
+    int x = 0;
+    if (cnt >= 16) {
+        double a[8], b[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) a[k] = p[k * stride];
+        for (; x + 16 <= cnt; x += 16) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) b[k] = p[(x + 8 + k) * stride];
+            __builtin_amdgcn_sched_barrier(0);          // (the scheduler would sink the reads below the adds)
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc += a[k];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 8; k++) a[k] = p[(x + 16 + k) * stride];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc += b[k];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    for (; x < cnt; x++) acc += p[x * stride];
+    return acc;
+}
+
+template <int NACC, class TermFn>
+CR_D void ordered_sums_team(const double* __restrict__ Xi, const double* __restrict__ Xj, const uint32_t* entries, int count,
+                            double* terms, double* red, TermFn term) {
+    const int tid = threadIdx.x, nth = blockDim.x;
+    double acc = 0.0;
+    for (int base = 0; base < count; base += kSumTile) {
+        const int cnt = count - base < kSumTile ? count - base : kSumTile;
+        for (int e = tid; e < cnt; e += nth) {
+            const ColumnXYZ col = load_column(Xi, Xj, entries, base + e, count);
+            double tv[NACC];
+            term(col, tv);
+#pragma unroll
+            for (int a = 0; a < NACC; a++) terms[e * NACC + a] = tv[a];
+        }
+        __syncthreads();
+        if (tid < NACC) acc = chain_sum(terms + tid, NACC, cnt, acc);
+        __syncthreads();
+    }
+    if (tid < NACC) red[tid] = acc;
+    __syncthreads();
+}
+
+CR_D void kabsch_team(const double* __restrict__ Xi, const double* __restrict__ Xj, const uint32_t* entries, int count, int k,
+                      double* terms, double* red, double* c1, double* c2, double* R, double* t) {
+    ordered_sums_team<6>(Xi, Xj, entries, count, terms, red, [&](const ColumnXYZ& c, double* out) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            out[a] = c.pair ? c.a[a] : 0.0;
+            out[3 + a] = c.pair ? c.b[a] : 0.0;
+        }
+    });
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        c1[a] = red[a] / (double)k;
+        c2[a] = red[3 + a] / (double)k;
+    }
+    __syncthreads();                                   // `red` is written again below
+    ordered_sums_team<9>(Xi, Xj, entries, count, terms, red, [&](const ColumnXYZ& col, double* out) {
+        const double a[3] = {col.b[0] - c2[0], col.b[1] - c2[1], col.b[2] - c2[2]};
+        const double b[3] = {col.a[0] - c1[0], col.a[1] - c1[1], col.a[2] - c1[2]};
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) out[3 * r + c] = col.pair ? a[r] * b[c] : 0.0;
+    });
+    double C[9];
+#pragma unroll
+    for (int a = 0; a < 9; a++) C[a] = red[a];
+    __syncthreads();
+    kabsch_from_correlation(C, c1, c2, R, t);          // every thread computes the same 3x3 SVD
+}
+
+template <bool MOVE>
+CR_D void rmsd_tm_team(const double* __restrict__ Xi, const double* __restrict__ Xj, const uint32_t* ent, int count, int k,
+                       int len1, int len2, const double* R, const double* t, double* terms, double* red, double& rmsd, double& tm) {
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const double d1 = 1.24 * (double)(len1 - 15) / 3.0 - 1.8;
+    const double d2 = 1.24 * (double)(len2 - 15) / 3.0 - 1.8;
+    double acc = 0.0;
+    for (int base = 0; base < count; base += kSumTile) {
+        const int cnt = count - base < kSumTile ? count - base : kSumTile;
+        for (int e = tid; e < cnt; e += nth) {
+            const ColumnXYZ cur = load_column(Xi, Xj, ent, base + e, count);
+            double mv[3] = {cur.b[0], cur.b[1], cur.b[2]};
+            if constexpr (MOVE) {
+                rot3(cur.b, R, mv);
+                mv[0] = mv[0] + t[0];
+                mv[1] = mv[1] + t[1];
+                mv[2] = mv[2] + t[2];
+            }
+            const double e0 = cur.a[0] - mv[0], e1 = cur.a[1] - mv[1], e2 = cur.a[2] - mv[2];
+            const double sg = (e0 + e1) + e2;
+            const double q1 = sg / d1, q2 = sg / d2;
+            // three regions: the squared differences (three per column, in the order they are added), the two TM sums
+            terms[e * 3 + 0] = cur.pair ? e0 * e0 : 0.0;
+            terms[e * 3 + 1] = cur.pair ? e1 * e1 : 0.0;
+            terms[e * 3 + 2] = cur.pair ? e2 * e2 : 0.0;
+            terms[3 * kSumTile + e] = cur.pair ? 1.0 / (1.0 + q1 * q1) : 0.0;
+            terms[4 * kSumTile + kSumSlack + e] = cur.pair ? 1.0 / (1.0 + q2 * q2) : 0.0;
+        }
+        __syncthreads();
+        if (tid == 0) acc = chain_sum(terms, 1, 3 * cnt, acc);
+        else if (tid == 1) acc = chain_sum(terms + 3 * kSumTile, 1, cnt, acc);
+        else if (tid == 2) acc = chain_sum(terms + 4 * kSumTile + kSumSlack, 1, cnt, acc);
+        __syncthreads();
+    }
+    if (tid < 3) red[tid] = acc;
+    __syncthreads();
+    const double ss = red[0], sum1 = red[1], sum2 = red[2];
+    rmsd = sqrt(ss / (double)k);
+    const double t1 = (1.0 / (double)len1) * sum1;
+    const double t2 = (1.0 / (double)len2) * sum2;
+    tm = t1 > t2 ? t1 : t2;
+    __syncthreads();
+}
+
+// LDS (doubles) of a trace stage whose sums are taken by the whole workgroup: entries | term tile | reduction slots
+__host__ __device__ inline size_t trace_team_lds_doubles(int max_entries) {
+    return ((size_t)max_entries + 3) / 4 * 2 + (size_t)kSumTile * kMaxAcc + kSumSlack + 16;
+}
+
 // DTW traceback (dynamic_time_warping.py:90-144) on the packed decisions: leaves the alignment columns
 // as packed entries in lds[first .. cap) (cap = n + m), writes the rows to HBM (back-to-front in
 // [aln, aln + 2*cap)), returns the number of columns and of aligned pairs.  Wave-uniform.
@@ -2146,16 +2334,26 @@ CR_D void dtw_walk(int n0, int m0, int max_entries, const uint32_t* __restrict__
             dir = 1;
             if (n > 0) wk.set_row(n - 1);
         } else if (layer == 0) {
-            dir = (int)(nib & 1u);
-            n--;
-            wk.row_up();
-            idx++;
-            if (lane == 0) arow[cap - idx] = pack_entry(n, -1);
+            // The vertical gap layer (:122-127): every cell it passes is consumed and its bit 0 says whether the walk stays in
+            // the layer.  A whole run at once: the leading cells of the column whose bit is 0, plus the cell that ends the
+            // run (bit 1: back to layer 1) when the block holds it.
+            bool more;
+            int run = wk.template run_up<0>(n - 1, m - 1, [](uint32_t f) { return (f & 1u) == 0u; }, more);
+            dir = more ? 1 : 0;
+            run += more ? 1 : 0;
+            if (lane < run) arow[cap - idx - 1 - lane] = pack_entry(n - 1 - lane, -1);
+            idx += run;
+            n -= run;
+            if (n > 0) wk.set_row(n - 1);
         } else {
-            dir = (int)((nib >> 3) & 1u) + 1;
-            m--;
-            idx++;
-            if (lane == 0) arow[cap - idx] = pack_entry(-1, m);
+            // the horizontal gap layer (:138-143): bit 3 set = stay in it
+            bool more;
+            int run = wk.run_left(n - 1, m - 1, [](uint32_t f) { return (f & 8u) != 0u; }, more);
+            dir = more ? 1 : 2;
+            run += more ? 1 : 0;
+            if (lane < run) arow[cap - idx - 1 - lane] = pack_entry(-1, m - 1 - lane);
+            idx += run;
+            m -= run;
         }
     }
     // border runs (dynamic_time_warping.py:108-117): only one of n, m is still positive
@@ -2178,6 +2376,21 @@ CR_D void dtw_walk(int n0, int m0, int max_entries, const uint32_t* __restrict__
 
 // Stage 4: DTW traceback, common positions, Kabsch on the original coordinates, RMSD / coverage / TM
 // (multiple_alignment.py:1033-1054, :59-70).  Wave-uniform.
+// the alignment rows of this block's pair straight into the caller's page-locked array (one wave; `ent`: the idx packed
+// columns).  Only the aln_len entries of each row cross the link: what lies behind them in the caller's array is not touched.
+CR_D void stream_rows(const HostOut& hout, const uint32_t* ent, int idx, int lane) {
+    if (!hout.aln) return;
+    int32_t* o1 = hout.aln + (int64_t)hout.dst(blockIdx.x) * 2 * hout.stride;
+    int32_t* o2 = o1 + hout.stride;
+    for (int x = lane; x < idx; x += kWave) {
+        const uint32_t u = ent[x];
+        const int i = (u & 0xffffu) == kGap16 ? -1 : (int)(u & 0xffffu);
+        const int j = (u >> 16) == kGap16 ? -1 : (int)(u >> 16);
+        __builtin_nontemporal_store(i, o1 + x);
+        __builtin_nontemporal_store(j, o2 + x);
+    }
+}
+
 template <int R, int RB = R>
 CR_D void align_trace(const PairDesc& pd, int max_entries, const double* __restrict__ coords,
                       const uint32_t* __restrict__ bits, const AlignEnd e, double* lds,
@@ -2190,18 +2403,7 @@ CR_D void align_trace(const PairDesc& pd, int max_entries, const double* __restr
     dtw_walk<R, RB>(pd.n, pd.m, max_entries, bits + pd.bt_off, e.start_layer, lds, aln + pd.aln_off, idx, k, nA);
     CR_STAMP(6);
     const int first = cap - idx;
-    if (hout.aln) {                                   // the rows straight into the caller's page-locked array
-        int32_t* o1 = hout.aln + (int64_t)hout.dst(blockIdx.x) * 2 * hout.stride;
-        int32_t* o2 = o1 + hout.stride;
-        // (only the aln_len entries of each row cross the link: what lies behind them in the caller's array is not touched)
-        for (int x = lane; x < idx; x += kWave) {
-            const uint32_t u = arow[first + x];
-            const int i = (u & 0xffffu) == kGap16 ? -1 : (int)(u & 0xffffu);
-            const int j = (u >> 16) == kGap16 ? -1 : (int)(u >> 16);
-            __builtin_nontemporal_store(i, o1 + x);
-            __builtin_nontemporal_store(j, o2 + x);
-        }
-    }
+    stream_rows(hout, arow + first, idx, lane);
     r.sw = e.sw;
     r.dtw_score = e.dtw_score;
 #pragma unroll
@@ -2841,10 +3043,40 @@ __global__ __launch_bounds__(kWideMaxWaves* kWave) void k_pair_wide(const PairDe
         if (plan.wave_in_a(w)) fill(std::integral_constant<int, RA>{});
         else if constexpr (RA != RB) fill(std::integral_constant<int, RB>{});
     }
-    if (threadIdx.x < kWave) {                         // wave 0 alone; the others wait at the barrier below
+    // wave 0 walks (the others wait at the barrier); the position-ordered sums behind the walk are taken by everybody
+    __shared__ int s_walk[4];
+    uint32_t* const seed_list = reinterpret_cast<uint32_t*>(lds + kExpDoubles);
+    double* const seed_terms = lds + kExpDoubles + ((size_t)seed_entries + 3) / 4 * 2;
+    if (threadIdx.x < kWave) {
         CR_STAMP(1);
+        int k, len;
+        uint32_t fl;
+        seed_walk<RA, ZG ? 0 : 1, RB>(pd, dirs, sm, seed_list, nA, k, len, fl);
+        if (threadIdx.x == 0) {
+            s_walk[0] = k;
+            s_walk[1] = len;
+            s_walk[2] = (int)fl;
+        }
+        CR_STAMP(2);
+    }
+    __syncthreads();
+    {
+        const int k = s_walk[0];
         Transform tr;
-        seed_trace<RA, ZG ? 0 : 1, RB>(pd, seed_entries, coords, dirs, sm, lds + kExpDoubles, tr, nA);
+#pragma unroll
+        for (int x = 0; x < 3; x++) tr.c1[x] = tr.c2[x] = 0.0;
+#pragma unroll
+        for (int x = 0; x < 9; x++) tr.R[x] = (x % 4 == 0) ? 1.0 : 0.0;
+        tr.flags = (uint32_t)s_walk[2];
+        tr.seed_len = s_walk[1];
+        if (k <= 3) {
+            tr.flags |= kFlagSeedSkipped;
+        } else {
+            double t[3];
+            const int cap = pd.n < pd.m ? pd.n : pd.m;
+            kabsch_team(coords + pd.off_i * 3, coords + pd.off_j * 3, seed_list + (cap - k), k, k, seed_terms, seed_terms + kSumTile * kMaxAcc + kSumSlack,
+                        tr.c1, tr.c2, tr.R, t);
+        }
         if (threadIdx.x == 0) {
             xf[blockIdx.x] = tr;
             seed_score[blockIdx.x] = sm.score;
@@ -2874,21 +3106,45 @@ __global__ __launch_bounds__(kWideMaxWaves* kWave) void k_pair_wide(const PairDe
         if (plan.wave_in_a(w)) fill(std::integral_constant<int, RA>{});
         else if constexpr (RA != RB) fill(std::integral_constant<int, RB>{});
     }
-    if (threadIdx.x >= kWave) return;                  // wave 0 goes on alone (wave_sync, no s_barrier from here on)
     CR_STAMP(5);
     PairResult r;
-    if constexpr (SCORES) {
-        r.sw = sw_only;
-        r.dtw_score = 0.0;
+    r.sw = SCORES ? sw_only : e.sw;
+    r.dtw_score = SCORES ? 0.0 : e.dtw_score;
 #pragma unroll
-        for (int x = 0; x < 9; x++) r.R[x] = 0.0;
+    for (int x = 0; x < 9; x++) r.R[x] = 0.0;
 #pragma unroll
-        for (int x = 0; x < 3; x++) r.t[x] = 0.0;
-        r.rmsd = r.coverage = r.tm = 0.0;
-        r.aln_len = r.aln_start = 0;
-        r.flags = 0;
-    } else {
-        align_trace<RA, RB>(pd, align_entries, coords, bits, e, lds + kExpDoubles, aln, r, hout, nA);
+    for (int x = 0; x < 3; x++) r.t[x] = 0.0;
+    r.rmsd = r.coverage = r.tm = 0.0;
+    r.aln_len = r.aln_start = 0;
+    r.flags = 0;
+    if constexpr (!SCORES) {
+        uint32_t* const arow = reinterpret_cast<uint32_t*>(lds + kExpDoubles);
+        double* const terms = lds + kExpDoubles + ((size_t)align_entries + 3) / 4 * 2;
+        const int cap = pd.n + pd.m;
+        if (threadIdx.x < kWave) {                     // wave 0 walks, the others wait at the barrier
+            int idx, k;
+            dtw_walk<RA, RB>(pd.n, pd.m, align_entries, bits + pd.bt_off, e.start_layer, lds + kExpDoubles, aln + pd.aln_off, idx, k, nA);
+            stream_rows(hout, arow + (cap - idx), idx, (int)threadIdx.x);
+            if (threadIdx.x == 0) {
+                s_walk[0] = idx;
+                s_walk[1] = k;
+            }
+            CR_STAMP(6);
+        }
+        __syncthreads();
+        const int idx = s_walk[0], k = s_walk[1], first = cap - idx;
+        r.aln_len = idx;
+        r.aln_start = first;
+        if (k < 3) {
+            r.flags |= kFlagMetricsSkipped;
+        } else {
+            const double* Xi = coords + pd.off_i * 3;
+            const double* Xj = coords + pd.off_j * 3;
+            double c1[3], c2[3];
+            kabsch_team(Xi, Xj, arow + first, idx, k, terms, terms + kSumTile * kMaxAcc + kSumSlack, c1, c2, r.R, r.t);
+            rmsd_tm_team<true>(Xi, Xj, arow + first, idx, k, pd.n, pd.m, r.R, r.t, terms, terms + kSumTile * kMaxAcc + kSumSlack, r.rmsd, r.tm);
+            r.coverage = (double)k / (double)idx;
+        }
     }
     r.seed_score = sm.score;
     r.seed_len = s_tr.seed_len;
