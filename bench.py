@@ -365,53 +365,16 @@ def main():
                 t_parts += (t1 - t0, t2 - t1)
         t_parts /= reps
         t_incl = max_over_ranks(float(t_parts.sum()))
-        # steady state of a stream of such batches: two contexts (streams) fed by two host threads, so that the upload of
-        # one batch and the tail of another overlap with kernels (ctypes releases the GIL inside the library)
-        import threading
-        ctxs = [engine.Context(local_rank) for _ in range(2)]
-        per_thread = max(4, min(args.steps, 12))
-
-        turn = threading.Lock()                        # one batch's kernels at a time; the other thread uploads meanwhile
-
-        def feeder(c, store):
-            keep = None
-            for _ in range(per_thread):
-                bb = engine.PairBatch(c, pin_c, pin_t, offsets).set_pairs(my_pairs)
-                if keep is not None:
-                    bb._pinned_cache = keep
-                with turn:
-                    bb.run_streamed(params)
-                    c.synchronize()
-                keep = bb._pinned_cache
-                bb.close()
-            store.append(keep)
-
-        for timed in (False, True):                    # first round: allocations and page-locked arrays
-            fence()
-            t0 = time.perf_counter()
-            th = [threading.Thread(target=feeder, args=(c, [])) for c in ctxs]
-            for t in th:
-                t.start()
-            for t in th:
-                t.join()
-            torch.cuda.synchronize(dev)
-            t_stream = (time.perf_counter() - t0) / (2 * per_thread)
-        t_stream = max_over_ranks(t_stream)
-        for c in ctxs:
-            c.close()
         if rank == 0:
             extras["value_incl_transfers"] = len(pairs) / t_incl
             extras["incl_transfers"] = {
                 "ms_per_step": t_incl * 1e3, "upload_ms": t_parts[0] * 1e3, "run_and_download_ms": t_parts[1] * 1e3,
                 "ratio_to_resident": t_incl / (elapsed / args.steps),
-                "pipelined_ms_per_batch": t_stream * 1e3, "pipelined_pairs_per_s": len(pairs) / t_stream,
-                "pipelined_ratio_to_resident": t_stream / (elapsed / args.steps),
                 "streamed_results_equal_fetched": streamed_ok,
                 "downloaded_bytes_per_rank": int(r2.nbytes + a2.nbytes), "uploaded_bytes_per_rank": int(coords.nbytes + tensors.nbytes + my_pairs.nbytes),
                 "note": "per step, one batch alone: cr_batch_create + cr_batch_set_pairs (H2D of structures and pair list from page-locked "
                         "arrays), cr_batch_run_stream_i32 (the alignment kernel stores all int32 alignment rows + PairResult records "
-                        "into page-locked host arrays while the other waves compute), wait; `pipelined`: a stream of such batches "
-                        "through two contexts fed by two host threads (one uploads the next batch while the other's kernels run)"}
+                        "into page-locked host arrays while the other waves compute), wait"}
         # ---------------------------------------------------------- BASELINE configs 4 and 5, sharded over the ranks
         gated = world == 1 and not args.no_cpu_baseline
         orc = None
@@ -470,6 +433,17 @@ def main():
                 part.close()
             extras[f"{key}_sharded"] = rec
 
+    if rank == 0 and world == 1 and not args.no_extras and engine.device_count() > 1:
+        # several GPUs visible to this ONE process: the single-process multi-GPU path behind make_pairwise_matrix
+        # (cr_multi_*) on BASELINE config 4, in a child process with a time limit (tools/multi_gpu_check.py)
+        import subprocess
+        try:
+            p = subprocess.run([sys.executable, str(ROOT / "tools" / "multi_gpu_check.py")], capture_output=True, text=True, timeout=600)
+            line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            extras["single_process_multi_gpu"] = json.loads(line[-1]) if p.returncode == 0 and line else {
+                "error": f"exit code {p.returncode}", "stderr_tail": p.stderr[-500:]}
+        except Exception as exc:                          # noqa: BLE001 -- the headline line must survive
+            extras["single_process_multi_gpu"] = {"error": repr(exc)}
     if rank == 0:
         total_pairs = len(pairs)
         ms_per_step = elapsed / args.steps * 1e3

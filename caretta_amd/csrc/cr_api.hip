@@ -1386,7 +1386,12 @@ int cr_debug_stamps(unsigned long long* out, int blocks) {
 int cr_batch_destroy(cr_batch* b) {
     if (!b) return CR_OK;
     (void)hipSetDevice(b->ctx->device);
-    (void)hipStreamSynchronize(b->ctx->stream);
+    // Everything that touches the batch's buffers runs on its context's streams: once those have drained the blocks can go
+    // back to the cache without the device-wide wait DevBuf::release would otherwise make -- which would also wait for
+    // the kernels of OTHER contexts (a second host thread preparing or running the next batch).
+    bool drained = hipStreamSynchronize(b->ctx->stream) == hipSuccess;
+    for (hipStream_t st : b->ctx->side) drained = hipStreamSynchronize(st) == hipSuccess && drained;
+    if (drained) g_dirty = false;
     delete b;
     return CR_OK;
 }
