@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerate the measured files of profiles/<round> on the GPU box:  gpurun -- 'bash tools/refresh_profiles.sh r02'
 # (writes under gpurun_out/<round>/; copy what is to be judged into profiles/<round>/).
-R=${1:-r02}
+R=${1:-r03}
 set -x
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R
@@ -16,6 +16,10 @@ bash tools/pmc_profile.sh ${R}_pmc --steps 3 --warmup 1 --no-cpu-baseline --no-e
 python tools/bench_msa.py 128 300 > $O/msa_128.txt 2>&1
 python tools/bench_msa.py 512 300 > $O/msa_512.txt 2>&1
 python tools/config5_share_time.py > $O/config5_share.txt 2>&1
+python tools/calibrate_wide.py c5share p120x900 p120x600 p105x1500 > $O/calibrate_wide.txt 2>&1
+python tools/stamps.py run c5share c2 one300 > $O/stamps.txt 2>&1
+./tools/valu_latency.bin > $O/valu_latency.txt 2>&1
+python tools/multi_gpu_check.py 512 300 2>/dev/null | grep '^{' > $O/multi_gpu_check_1device.json
 python tools/dropin_latency.py > $O/dropin_latency.txt 2>&1
 python tools/nj_device_time.py > $O/nj_device_time.txt 2>&1
 python tools/explicit_batch_rate.py > $O/explicit_batch_rate.txt 2>&1
