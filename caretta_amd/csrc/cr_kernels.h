@@ -963,7 +963,7 @@ CR_D void sweep_cols(RbfTensor<R, D>& src, const int n, const int m, double* lds
 // The row above a strip arrives through an LDS ring written by the previous strip's last lane (one double per column,
 // two chunks deep); the waves meet at one barrier per phase.  LDS (doubles): exp table | NW rings of 2 * kColChunk |
 // NW * 4 reduction slots.  Results in every lane of every wave.
-constexpr int kColChunk = 16;
+constexpr int kColChunk = 8;
 
 template <int R, int D>
 CR_D void sweep_cols_team(RbfTensor<R, D>& src, const int n, const int m, double* lds,
@@ -1008,7 +1008,8 @@ CR_D void sweep_cols_team(RbfTensor<R, D>& src, const int n, const int m, double
                 st.template step<FULL, TOP>(src, tab, j, j + 1 < m ? j + 1 : j, TOP ? lane_value(top_vec, j - j0) : 0.0);
                 if (hand_out && lane == kWave - 1) ring_out[(c & 1) * kColChunk + (j - j0)] = st.hprev[R - 1];
             }
-            st.flush(sw_dirs, ((int64_t)geom.slot0 * TB + (int64_t)c * R) * kWave + lane);      // one chunk = one decision word per row
+            if (((jend - 1) & 15) == 15 || jend == m)                            // a decision word holds 16 columns
+                st.flush(sw_dirs, ((int64_t)geom.slot0 * TB + (int64_t)((jend - 1) >> 4) * R) * kWave + lane);
         }
     };
     if (w == 0) {
