@@ -227,6 +227,7 @@ struct ExplicitStream {
     static constexpr bool kNonNegative = false;
     static constexpr bool kMaskRows = true;
     static constexpr bool kStreams = true;
+    static constexpr bool kNoExp = true;                  // explicit scores: no exp table in LDS
     static constexpr int kBlk = 8;                        // doubles per aligned block
     static constexpr int kLoads = 4;                      // load instructions per row slot and boundary (16 owners each)
     static constexpr int kRingDoubles = R * 2 * kBlk * kWave + R * kWave;     // block rings | stream offsets of every lane
@@ -417,7 +418,7 @@ int launch_stream(cr_explicit_batch* b, const cr::ExplicitProblem* probs, const 
 
 template <int MODE>
 int launch_stream_r(int R, cr_explicit_batch* b, const cr::ExplicitProblem* probs, const cr::SweepParams& prm, uint32_t* bits) {
-    return R == 2 ? launch_stream<2, MODE>(b, probs, prm, bits) : R == 3 ? launch_stream<3, MODE>(b, probs, prm, bits)
+    return R == 1 ? launch_stream<1, MODE>(b, probs, prm, bits) : R == 2 ? launch_stream<2, MODE>(b, probs, prm, bits) : R == 3 ? launch_stream<3, MODE>(b, probs, prm, bits)
          : R == 4 ? launch_stream<4, MODE>(b, probs, prm, bits) : launch_stream<5, MODE>(b, probs, prm, bits);
 }
 
@@ -455,10 +456,17 @@ int cr_explicit_batch_create(cr_context* ctx, const double* S, int64_t s_elems, 
     bool has_minus1 = false, all_ident = true, all_ident_sw = true;
     int n_all = 0;
     for (int64_t p = 0; p < count; p++) n_all = std::max<int>(n_all, problems[p].n);
-    // rows per lane of the streaming kernels: 2 (a stream costs 1 KB of LDS per lane-row pair of blocks: with 2 rows six
-    // waves share a CU; measured on 8128 x 300 x 300: R = 2 / 3 / 5 -> 1.92 / 2.07 / 2.37 ms (SW, gap 0.1), 2.52 / 2.68 /
-    // 2.89 ms (DTW)); CARETTA_FORCE_R overrides
-    const int r_stream = std::getenv("CARETTA_FORCE_R") ? rows_per_lane(std::max(n_all, 1)) : 2;
+    // rows per lane of the streaming kernels: 1.  A stream costs 1 KB of LDS per lane-row pair of blocks, so the rows per
+    // lane set the waves per CU: 1 row -> 12 waves (three per SIMD: FP64 at the full issue rate), 2 -> 7, 3 -> 4; and 300 rows
+    // are 4.7 strips of 64 but 2.3 of 128.  Measured on 8128 x 300 x 300 (without the exp table these providers never read):
+    // R = 1 / 2 / 3 -> 1.52 / 1.76 / 2.13 ms (SW, gap 0.1: 3.84 TB/s), 2.22 / 2.31 / 2.69 ms (DTW); CARETTA_STREAM_R overrides
+    // (a list too short to give every CU its twelve waves is bound by the strips one wave walks one after the other: 2 rows
+    // per lane halve them -- 600 x 1200 x 1200: 4.2 vs 5.8 ms)
+    int r_stream = std::getenv("CARETTA_FORCE_R") ? rows_per_lane(std::max(n_all, 1)) : (count >= 3072 ? 1 : 2);
+    if (const char* env = std::getenv("CARETTA_STREAM_R")) {        // calibration
+        const int r = std::atoi(env);
+        if (r >= 1 && r <= 5) r_stream = r;
+    }
     int64_t bits_off_s = 0;
     int64_t hand_off = 0, bits_off = 0, aln_off = 0;
     int m_max = 0, n_max = 0, m_max_sw = 0;
@@ -648,7 +656,7 @@ int cr_dtw_align_batch(cr_explicit_batch* b, double gap_open, double gap_extend,
         CR_HIP(b->aln.ensure((size_t)aln_total));
         CR_HIP(b->trace.ensure((size_t)b->count));
         if (!stream) rc = launch_trace<kExplicitR, false>(b, entries);
-        else rc = R == 2 ? launch_trace<2, true>(b, entries) : R == 3 ? launch_trace<3, true>(b, entries)
+        else rc = R == 1 ? launch_trace<1, true>(b, entries) : R == 2 ? launch_trace<2, true>(b, entries) : R == 3 ? launch_trace<3, true>(b, entries)
                 : R == 4 ? launch_trace<4, true>(b, entries) : launch_trace<5, true>(b, entries);
         if (rc) return rc;
     }

@@ -425,6 +425,13 @@ struct is_streaming : std::false_type {};
 template <class S>
 struct is_streaming<S, std::void_t<decltype(S::kStreams)>> : std::bool_constant<S::kStreams> {};
 
+// doubles of LDS in front of a sweep's rings: the exp table, for providers that evaluate an RBF (explicit score matrices
+// declare `static constexpr bool kNoExp = true` and get the 2 KB back: one more wave per CU for the streaming sweep)
+template <class S, class = void>
+struct exp_doubles : std::integral_constant<int, kExpDoubles> {};
+template <class S>
+struct exp_doubles<S, std::void_t<decltype(S::kNoExp)>> : std::integral_constant<int, S::kNoExp ? 0 : kExpDoubles> {};
+
 // Registers a lane carries from column to column of its R rows.
 template <int R>
 struct DpState {
@@ -578,13 +585,13 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
     constexpr int NB = (SW ? 1 : 0) + (DTW ? 2 : 0);   // values handed from strip to strip per column
     const int lane = threadIdx.x;
     const ExpEntry* tab = reinterpret_cast<const ExpEntry*>(lds);
-    double* ring = lds + kExpDoubles;
+    double* ring = lds + exp_doubles<Src>::value;
     // A strip's last row is handed to the next strip through HBM (hand_g: NB planes of m doubles, L2
     // resident), staged on both sides through small LDS rings with coalesced transfers every 64 steps.
     double* hin = ring + Src::kRingDoubles;            // [NB][64]  row above lane 0, current 64 columns
     double* hout = hin + NB * kWave;                   // [NB][128] last row of lane 63, most recent columns
 
-    load_exp_table(lds, lane);
+    if constexpr (exp_doubles<Src>::value != 0) load_exp_table(lds, lane);
     src.init_ring(ring, lane);
     __syncthreads();
 
@@ -1191,7 +1198,7 @@ __host__ __device__ inline size_t sweep_cols_score_team_lds_doubles(int waves) {
 template <int R, int MODE, class Src>
 __host__ __device__ inline size_t sweep_lds_doubles(int n_max, int m_max) {
     constexpr int NB = ((MODE & (kSwTrace | kSwScore)) ? 1 : 0) + ((MODE & kDtw) ? 2 : 0);
-    size_t v = kExpDoubles + Src::kRingDoubles;
+    size_t v = exp_doubles<Src>::value + Src::kRingDoubles;
     if (strips_of(n_max, R) > 1) v += (size_t)NB * (kWave + kRing);
     return v;
 }
