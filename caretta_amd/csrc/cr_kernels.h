@@ -1821,21 +1821,6 @@ struct Walker {
             slot0 = nA * R + sb * RB;
         }
     }
-    CR_D void row_up() {
-        if (q > 0) {
-            q--;
-        } else if (l > 0) {
-            l--;
-            q = rs - 1;
-        } else {                                      // last row of the strip above
-            s--;
-            l = kWave - 1;
-            if (kMixed) rs = s < nA ? R : RB;
-            base -= kWave * rs;
-            slot0 -= rs;
-            q = rs - 1;
-        }
-    }
     // the word of lane (ax, wx) in the block of the current strip anchored at (r, c); `la_out`: the fill lane of its row
     CR_D uint32_t load_block(int r, int c, int& la_out) const {
         const int rel = r - ax - base;                    // this lane's row, relative to the strip
@@ -2966,49 +2951,6 @@ __global__ __launch_bounds__(kWideMaxWaves* kWave) void k_seed_wide(const PairDe
         seed_score[blockIdx.x] = sm.score;
     }
     CR_STAMP(3);
-}
-
-template <int RA, int RB, bool ZG>
-__global__ __launch_bounds__(kWideMaxWaves* kWave) void k_align_wide(const PairDesc* __restrict__ pairs,
-                                                                    const double* __restrict__ coords,
-                                                                    const Transform* __restrict__ xf,
-                                                                    const double* __restrict__ seed_score, double gamma,
-                                                                    double sw_gap, double gap_open, double gap_extend,
-                                                                    int max_entries, int sync_every, int nA,
-                                                                    uint32_t* __restrict__ bits,
-                                                                    int32_t* __restrict__ aln, PairResult* __restrict__ res, const HostOut hout) {
-    extern __shared__ double lds[];
-    CR_STAMP(4);
-    const PairDesc pd = pairs[blockIdx.x];
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const WidePlan<RA, RB> plan{nA};
-    const StripGeom geom = plan.geom(w, pd.n);
-    SeedMax unused;
-    AlignEnd e;
-    auto fill = [&](auto rtag) {
-        constexpr int R = decltype(rtag)::value;
-        RbfCoords<R> src;
-        src.rows_g = coords + pd.off_i * 3;
-        src.cols_g = coords + pd.off_j * 3;
-        src.xf = xf + blockIdx.x;
-        src.neg_gamma = -gamma;
-        SweepParams prm{sw_gap, gap_open, gap_extend};
-        sweep_wide<R, kSwScore | kDtw | (ZG ? kZeroGap : 0)>(src, pd.n, pd.m, prm, lds, sync_every, nullptr, bits + pd.bt_off, unused, e, geom);
-    };
-    if (plan.wave_in_a(w)) fill(std::integral_constant<int, RA>{});
-    else if constexpr (RA != RB) fill(std::integral_constant<int, RB>{});
-    if (threadIdx.x >= kWave) return;                  // wave 0 goes on alone (wave_sync, no s_barrier from here on)
-    CR_STAMP(5);
-    PairResult r;
-    align_trace<RA, RB>(pd, max_entries, coords, bits, e, lds + kExpDoubles, aln, r, hout, nA);
-    r.seed_score = seed_score[blockIdx.x];
-    r.seed_len = xf[blockIdx.x].seed_len;
-    r.flags |= xf[blockIdx.x].flags;
-    if (threadIdx.x == 0) {
-        res[blockIdx.x] = r;
-        if (hout.res) hout.res[hout.dst(blockIdx.x)] = r;
-    }
-    CR_STAMP(7);
 }
 
 // Both stages of a pair in ONE launch of the wide layout: seed fill -> (wave 0) seed walk + Kabsch -> align fill (or the
