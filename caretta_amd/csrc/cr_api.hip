@@ -666,7 +666,8 @@ bool wide_fits(const StripPlan& p, int n_max, int m_max, int d_pad) {
     const size_t seed = cr::kExpDoubles + (size_t)d_pad * m_max + (size_t)waves * (cr::kWideEdge + 8);
     const size_t align = cr::kExpDoubles + (size_t)3 * m_max + (size_t)waves * (3 * cr::kWideEdge + 8);
     const size_t trace = cr::kExpDoubles + cr::trace_team_lds_doubles(n_max + m_max);
-    return sizeof(double) * std::max(std::max(seed, align), trace) <= 160 * 1024;
+    // (1 KB less than the CU's 160 KB: k_pair_wide also has a few hundred bytes of static LDS)
+    return sizeof(double) * std::max(std::max(seed, align), trace) <= 159 * 1024;
 }
 
 // The strip plan of a wide launch.  A workgroup's waves are dealt round robin to the CU's four SIMDs; a SIMD issues one

@@ -1200,3 +1200,22 @@ def test_wide_strip_plans_vs_oracle(ctx, oracle, monkeypatch):
             sw, flags = batch.fetch_scores()
             assert np.array_equal(sw, ref[gap][0]["sw"])
         batch.close()
+
+
+def test_wide_layout_at_the_lds_limit(ctx, oracle):
+    """A pair list whose resident tensor columns (Smith-Waterman gap != 0: the skewed seed sweep keeps all m columns of
+    width 16 in LDS) fill the CU's 160 KB to the last byte: the fused wide kernel's static LDS must still fit (found by
+    tests/fuzz_parity.py), results bit-identical to the oracle."""
+    from caretta_amd import engine
+    from oracle.pyoracle import default_params
+    for m in (1245, 1246, 1247, 1260):
+        a = synthetic.make_family(1, 500, dim=16, seed=7071, clades=1)[0]
+        b = synthetic.make_family(1, m, dim=16, seed=7072, clades=1)[0]
+        coords, tensors, offsets = synthetic.pack([a, b])
+        pairs = np.array([[0, 1]], dtype=np.int32)
+        batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
+        batch.run(engine.make_params(sw_gap=0.05))
+        res, aln = batch.fetch()
+        batch.close()
+        ref, ref_aln = oracle.pairwise_batch(coords, tensors, offsets, pairs, params=default_params(sw_gap=0.05))
+        assert_bit_identical(res, aln, ref, ref_aln)

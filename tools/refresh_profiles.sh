@@ -1,5 +1,5 @@
 #!/bin/bash
-# Regenerate the measured files of profiles/<round> on the GPU box:  gpurun -- 'bash tools/refresh_profiles.sh r02'
+# Regenerate the measured files of profiles/<round> on the GPU box:  gpurun -- 'bash tools/refresh_profiles.sh r03'
 # (writes under gpurun_out/<round>/; copy what is to be judged into profiles/<round>/).
 R=${1:-r03}
 set -x
@@ -13,6 +13,7 @@ export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace -o kt -- python3 bench.py --no-cpu-baseline --no-extras --steps 20 > $O/ktrace.log 2>&1
 ls $O/ktrace
 bash tools/pmc_profile.sh ${R}_pmc --steps 3 --warmup 1 --no-cpu-baseline --no-extras
+bash tools/pmc_share.sh ${R}_pmc_c5share > $O/pmc_c5share.log 2>&1
 python tools/bench_msa.py 128 300 > $O/msa_128.txt 2>&1
 python tools/bench_msa.py 512 300 > $O/msa_512.txt 2>&1
 python tools/config5_share_time.py > $O/config5_share.txt 2>&1
