@@ -254,6 +254,8 @@ struct cr_batch {
     int64_t P = 0, d = 0, total = 0;
     std::vector<int64_t> offsets;
     DevBuf<double> coords, tensors;
+    DevBuf<int64_t> d_offsets;          // offsets on the device (pair descriptors of equal-length lists are built there)
+    DevBuf<int32_t> d_ij;               // the caller's (i, j) list on the device (the same fast path)
     // pair list
     int64_t npairs = 0;
     int r_seed = 5, r_align = 5, d_pad = 0;
@@ -960,8 +962,14 @@ int cr_batch_create(cr_context* ctx, const double* coords, const double* tensors
         return fail(e == hipErrorOutOfMemory ? CR_ERR_MEMORY : CR_ERR_HIP,
                     std::string("allocating structures: ") + hipGetErrorString(e));
     }
+    if (e == hipSuccess) e = b->d_offsets.ensure((size_t)num_structures + 1);
+    if (e != hipSuccess) {
+        delete b;
+        return fail(e == hipErrorOutOfMemory ? CR_ERR_MEMORY : CR_ERR_HIP, std::string("allocating structures: ") + hipGetErrorString(e));
+    }
     int up = upload_async(ctx, b->coords.p, coords, sizeof(double) * b->total * 3);
     if (!up) up = upload_async(ctx, b->tensors.p, tensors, sizeof(double) * b->total * d);
+    if (!up) up = upload_async(ctx, b->d_offsets.p, b->offsets.data(), sizeof(int64_t) * ((size_t)num_structures + 1));
     if (!up && hipStreamSynchronize(ctx->stream) != hipSuccess) up = fail(CR_ERR_HIP, "uploading structures");
     if (up) {
         delete b;
@@ -977,7 +985,6 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     if (rc) return rc;
     CR_REQUIRE(npairs >= 0 && (npairs == 0 || pairs != nullptr), "bad pair list");
     CR_REQUIRE(npairs < (int64_t)std::numeric_limits<int32_t>::max(), "too many pairs for one batch");
-    b->h_pairs.resize((size_t)npairs);
     b->npairs = npairs;
     b->ran = false;
     b->n_max = b->m_max = 0;
@@ -1033,9 +1040,54 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
         const long long mb = std::atoll(env);
         if (mb > 0) budget_words = (int64_t)mb * 1024 * 1024 / 4;
     }
+    // Structures of equal length (every BASELINE configuration): nothing to sort, every pair has the same footprint, and the
+    // descriptors are built on the device from the (i, j) list (k_make_pairs_uniform) -- at 130 816 pairs the host side of
+    // this call drops from 3.2 to under 1 ms.
+    bool equal_lengths = npairs > 0;
+    for (int64_t s = 1; s < b->P && equal_lengths; s++)
+        equal_lengths = b->offsets[(size_t)s + 1] - b->offsets[(size_t)s] == b->offsets[1] - b->offsets[0];
+    if (equal_lengths) {
+        const int n = b->n_max, R = b->r_seed;
+        const int64_t slots = b->wide_sync ? plan_of(b).slots(n) : cr::strips_of(n, R) * R;
+        const int64_t dw = slots * cr::tblocks(n, 16) * cr::kWave, bw = slots * cr::tblocks(n, 8) * cr::kWave;
+        const int64_t hand_per = cr::strips_of(n, R) > 1 ? 3 * (int64_t)n : 0;
+        const int64_t per_chunk = std::max<int64_t>(1, std::min<int64_t>(npairs, budget_words / (dw + bw)));
+        b->h_pairs.clear();
+        b->order.clear();
+        b->reordered = false;
+        b->chunks.clear();
+        for (int64_t first = 0; first < npairs; first += per_chunk) {
+            cr_batch::Chunk ck{first, std::min(per_chunk, npairs - first), n, n, 2 * n};
+            ck.r = R;
+            ck.lane = 0;
+            b->chunks.push_back(ck);
+        }
+        b->max_aln = 2 * (int64_t)n;
+        b->aln_elems = npairs * 4 * (int64_t)n;
+        const double nm = (double)n * n, npm = 2.0 * n;
+        b->alg_bytes = (double)npairs * (8.0 * (3 + b->d) * npm + nm / 4 + nm / 2 + 16.0 * npm + 136.0);   // SURVEY.md 8(d) B_alg
+        b->cells = (double)npairs * nm;
+        hipError_t e = b->pairs.ensure((size_t)npairs);
+        if (e == hipSuccess) e = b->dirs.ensure((size_t)(per_chunk * dw));
+        if (e == hipSuccess) e = b->bits.ensure((size_t)(per_chunk * bw));
+        if (e == hipSuccess) e = b->hand.ensure((size_t)(per_chunk * hand_per));
+        if (e == hipSuccess) e = b->aln.ensure((size_t)b->aln_elems);
+        if (e == hipSuccess) e = b->xf.ensure((size_t)npairs);
+        if (e == hipSuccess) e = b->seed_score.ensure((size_t)npairs);
+        if (e == hipSuccess) e = b->res.ensure((size_t)npairs);
+        if (e == hipSuccess) e = b->d_ij.ensure((size_t)npairs * 2);
+        if (e != hipSuccess)
+            return fail(e == hipErrorOutOfMemory ? CR_ERR_MEMORY : CR_ERR_HIP, std::string("allocating pair scratch: ") + hipGetErrorString(e));
+        if ((rc = upload_async(b->ctx, b->d_ij.p, pairs, sizeof(int32_t) * 2 * (size_t)npairs))) return rc;
+        CR_LAUNCH(cr::k_make_pairs_uniform, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, b->ctx->stream, b->d_ij.p, b->d_offsets.p, n, dw,
+                  bw, hand_per, per_chunk, b->pairs.p, npairs);
+        CR_HIP(hipGetLastError());
+        return CR_OK;
+    }
     // Launch order: the pairs with the most DP cells first, so that the last wave slots to drain hold short pairs
     // (waves are dispatched in block order; with ragged structures the caller's order would leave long pairs for
     // the tail).  Stable, so equal-length inputs keep the caller's order and nothing is permuted.
+    b->h_pairs.resize((size_t)npairs);
     b->order.resize((size_t)npairs);
     for (int64_t p = 0; p < npairs; p++) b->order[(size_t)p] = (int32_t)p;
     std::vector<int64_t> cost_of((size_t)npairs);               // sort keys, computed once per pair

@@ -154,12 +154,32 @@ def _progressive_node(s1: Protein, s2: Protein, w1, w2, mult1, mult2, name_int, 
     return a1[:k].copy(), a2[:k].copy(), node, wn[:k].reshape(-1, 1).copy()
 
 
-def pack_proteins(proteins: typing.Sequence[Protein]):
+_staging = {}          # per thread: page-locked packing buffers of pack_proteins(staging=True), reused from call to call
+
+
+def pack_proteins(proteins: typing.Sequence[Protein], staging: bool = False):
+    """-> (coords (total, 3), tensors (total, d), offsets (P + 1)) float64 / int64, the layout cr_batch_create takes.
+    ``staging``: pack into page-locked arrays kept by this module (one set per thread, reused by the next call): the
+    upload is then a plain DMA, without the library's own staging copy -- for callers that upload at once and do not
+    keep the arrays (make_pairwise_matrix)."""
     lens = [len(p) for p in proteins]
     offsets = np.zeros(len(proteins) + 1, dtype=np.int64)
     offsets[1:] = np.cumsum(lens)
-    coords = np.ascontiguousarray(np.vstack([f64(p.coordinates) for p in proteins]))
-    tensors = np.ascontiguousarray(np.vstack([f64(p.tensors) for p in proteins]))
+    total, d = int(offsets[-1]), int(np.shape(proteins[0].tensors)[1])
+    if staging:
+        import threading
+        from .engine import pinned_empty
+        key = threading.get_ident()
+        have = _staging.get(key)
+        if have is None or have[0].shape[0] < total or have[1].shape[1] != d:
+            grow = max(total, 1) + max(total, 1) // 4
+            have = (pinned_empty((grow, 3), np.float64), pinned_empty((grow, d), np.float64))
+            _staging[key] = have
+        coords, tensors = have[0][:total], have[1][:total]
+    else:
+        coords, tensors = np.empty((total, 3)), np.empty((total, d))
+    np.concatenate([np.asarray(p.coordinates) for p in proteins], axis=0, out=coords)
+    np.concatenate([np.asarray(p.tensors) for p in proteins], axis=0, out=tensors)
     return coords, tensors, offsets
 
 
@@ -263,7 +283,7 @@ class MultipleAlignment:
         if prm:
             raise TypeError(f"unknown score_function parameters {sorted(prm)}")
         ctx = context or default_context()
-        coords, tensors, offsets = pack_proteins(self.sequences)
+        coords, tensors, offsets = pack_proteins(self.sequences, staging=True)
         batch = PairBatch(ctx, coords, tensors, offsets)
         try:
             pairs = all_pairs(len(self.sequences)) if pairs is None else np.asarray(pairs, np.int32).reshape(-1, 2)

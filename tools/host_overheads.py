@@ -31,12 +31,12 @@ def main():
         pairs = all_pairs(num)
         batch.set_pairs(pairs)
         t.append(time.perf_counter())
-        batch.run(params)
+        batch.run(params, scores_only=True)        # what make_pairwise_matrix runs
         ctx.synchronize()
         t.append(time.perf_counter())
-        res, _ = batch.fetch(False)
+        sw, flags = batch.fetch_scores()
         t.append(time.perf_counter())
-        m = assemble_matrix(pairs, res["sw"], num)
+        m = assemble_matrix(pairs, sw, num)
         t.append(time.perf_counter())
         batch.close()
         t.append(time.perf_counter())
