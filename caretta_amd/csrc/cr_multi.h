@@ -112,6 +112,10 @@ struct cr_multi {
         DevBuf<uint32_t> local_flags, gathered_flags;
     };
     std::vector<PerDevice*> dev;
+    // The device list names a device twice (only accepted with CARETTA_MULTI_ALLOW_DUPLICATES=1; RCCL refuses such a
+    // communicator): the shares are gathered with device copies instead.  This is how a one-GPU box runs the deal, the
+    // host threads, the share layout and the scatter with MORE THAN ONE share (tests); it is not a product path.
+    bool loopback = false;
     float last_ms[3] = {0.f, 0.f, 0.f};      // wall ms of the last call: compute (all devices), all-gather, download + scatter
 };
 
@@ -129,15 +133,17 @@ int cr_partition_pairs(const int64_t* lengths, int64_t P, int world, int rank, i
 
 int cr_multi_destroy(cr_multi* m) {
     if (!m) return CR_OK;
-    RcclApi* api = rccl_api();
     for (size_t g = 0; g < m->ctx.size(); g++) {
         if (m->ctx[g]) {
             (void)hipSetDevice(m->devices[g]);
             (void)hipStreamSynchronize(m->ctx[g]->stream);
         }
     }
-    for (void* c : m->comm)
-        if (c && api->CommDestroy) (void)api->CommDestroy(c);
+    if (!m->comm.empty()) {
+        RcclApi* api = rccl_api();
+        for (void* c : m->comm)
+            if (c && api->CommDestroy) (void)api->CommDestroy(c);
+    }
     for (size_t g = 0; g < m->dev.size(); g++) {
         (void)hipSetDevice(m->devices[g]);
         delete m->dev[g];
@@ -158,11 +164,14 @@ int cr_multi_create(const int* devices, int ndev, cr_multi** out) {
     if (devices == nullptr || ndev <= 0) {
         for (int g = 0; g < visible; g++) m->devices.push_back(g);
     } else {
+        const bool allow_twice = std::getenv("CARETTA_MULTI_ALLOW_DUPLICATES") != nullptr;
         for (int g = 0; g < ndev; g++) {
-            if (devices[g] < 0 || devices[g] >= visible || std::count(devices, devices + g, devices[g])) {
+            const bool twice = std::count(devices, devices + g, devices[g]) != 0;
+            if (devices[g] < 0 || devices[g] >= visible || (twice && !allow_twice)) {
                 delete m;
                 return fail(CR_ERR_ARGUMENT, "device list: indices must be distinct and visible");
             }
+            m->loopback = m->loopback || twice;
             m->devices.push_back(devices[g]);
         }
     }
@@ -297,12 +306,35 @@ int cr_multi_pairwise_scores(cr_multi* m, const double* coords, const double* te
     const auto t1 = std::chrono::steady_clock::now();
 
     // ---- one grouped all-gather: every device ends up with every share ------------------------------------------
-    RcclApi* api = rccl_api();
-    if (!api->error.empty()) {
+    if (m->loopback) {
+        // (test mode, see cr_multi::loopback) the same data movement with copies: wait for every share, then every
+        // "device" collects all of them
+        auto copy_all = [&]() -> int {
+            for (int g = 0; g < G; g++) {
+                CR_HIP(hipSetDevice(m->devices[(size_t)g]));
+                CR_HIP(hipStreamSynchronize(m->ctx[(size_t)g]->stream));
+            }
+            for (int g = 0; g < G; g++)
+                for (int r = 0; r < G; r++) {
+                    CR_HIP(hipMemcpyAsync(m->dev[(size_t)g]->gathered.p + (size_t)r * shard, m->dev[(size_t)r]->local.p, sizeof(double) * (size_t)shard,
+                                          hipMemcpyDeviceToDevice, m->ctx[(size_t)g]->stream));
+                    CR_HIP(hipMemcpyAsync(m->dev[(size_t)g]->gathered_flags.p + (size_t)r * shard, m->dev[(size_t)r]->local_flags.p,
+                                          sizeof(uint32_t) * (size_t)shard, hipMemcpyDeviceToDevice, m->ctx[(size_t)g]->stream));
+                }
+            return CR_OK;
+        };
+        const int rc_copy = copy_all();
+        if (rc_copy) {
+            cleanup();
+            return rc_copy;
+        }
+    }
+    RcclApi* api = m->loopback ? nullptr : rccl_api();
+    if (api && !api->error.empty()) {
         cleanup();
         return fail(CR_ERR_HIP, api->error);
     }
-    if (m->comm.empty()) {
+    if (api && m->comm.empty()) {
         m->comm.assign((size_t)G, nullptr);
         const int r = api->CommInitAll(m->comm.data(), G, m->devices.data());
         if (r != 0) {
@@ -322,7 +354,7 @@ int cr_multi_pairwise_scores(cr_multi* m, const double* coords, const double* te
         CR_RCCL(api, api->GroupEnd());
         return CR_OK;
     };
-    int rc = gather();
+    int rc = api ? gather() : CR_OK;
     if (rc) {
         cleanup();
         return rc;

@@ -1140,6 +1140,28 @@ def test_single_process_multi_device_path_equals_the_batch(ctx):
     with pytest.raises(TypeError):
         msa._pairwise_matrix_multi(multi, dict(gamma_tensor=7.0, gamma_coords=0.03))
     multi.close()
+    # More than one share on the one GPU of the box: the device list may name a device twice when
+    # CARETTA_MULTI_ALLOW_DUPLICATES is set; the shares are then gathered with device copies (RCCL refuses such a
+    # communicator), everything else -- the deal, a host thread and a context per share, the share layout, the scatter back
+    # to pair order -- is the product path.  3 and 4 shares, ragged and equal lengths, pair counts that do not divide.
+    import os
+    os.environ["CARETTA_MULTI_ALLOW_DUPLICATES"] = "1"
+    try:
+        for shares in (3, 4):
+            multi = engine.MultiDevice([0] * shares)
+            assert multi.num_devices == shares
+            for fam in (synthetic.make_family(11, 70, seed=4041, ragged=True, clades=2), synthetic.make_family(23, 150, seed=4044)):
+                coords, tensors, offsets = synthetic.pack(fam)
+                pairs = engine.all_pairs(len(fam))
+                batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
+                batch.run(engine.make_params(), scores_only=True)
+                sw_ref, flags_ref = batch.fetch_scores()
+                batch.close()
+                sw, flags = multi.pairwise_scores(coords, tensors, offsets, engine.make_params())
+                assert np.array_equal(sw, sw_ref) and np.array_equal(flags, flags_ref)
+            multi.close()
+    finally:
+        del os.environ["CARETTA_MULTI_ALLOW_DUPLICATES"]
 
 
 def test_streamed_run_writes_what_fetch_copies(ctx):
