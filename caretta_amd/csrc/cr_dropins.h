@@ -373,7 +373,7 @@ int launch_node_team_r(hipStream_t stream, int count, int n_max, int m_max, int 
                        const double* coords, const double* tensors, int d, const double* weights,
                        const cr::NodeDesc* nodes, const cr::Transform* xf, const cr_params& prm, double gamma_weight,
                        uint32_t* bits, double* hand, int32_t* aln, double* xn, double* tn, double* wn, cr::NodeOut* out) {
-    const size_t lds = sizeof(double) * std::max(cr::sweep_team_lds_doubles<R, cr::kDtw, cr::RbfNode<R>>(cr::kTeamWaves),
+    const size_t lds = sizeof(double) * std::max(cr::sweep_wide_lds_doubles<cr::kDtw, cr::RbfNode<R>>(cr::kTeamWaves, m_max),
                                                  (size_t)cr::kExpDoubles + cr::trace_lds_doubles(R, entries));
     int rc = allow_lds(cr::k_node_team<R>, lds);
     if (rc) return rc;

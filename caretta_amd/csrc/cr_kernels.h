@@ -2637,7 +2637,10 @@ CR_D void node_body(const PairDesc* __restrict__ pairs, const double* coords,
         src.mult2 = mult2;
         src.neg_gamma_w = -gamma_weight;
         SweepParams prm{0.0, gap_open, gap_extend};
-        if constexpr (TEAM) sweep_team<R, kDtw>(src, pd.n, pd.m, prm, lds, nullptr, bits, unused, e);
+        // one wave per strip: the wide sweep (all columns of the node resident in LDS, a barrier every 8 steps instead of
+        // every step, the scores one column ahead with 1 or 2 rows per lane)
+        if constexpr (TEAM) sweep_wide<R, kDtw>(src, pd.n, pd.m, prm, lds, 8, nullptr, bits, unused, e,
+                                                WidePlan<R>{0}.geom(__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), pd.n));
         else sweep<R, kDtw>(src, pd.n, pd.m, prm, lds, nullptr, bits, hand, unused, e);
     }
     if constexpr (TEAM) {
