@@ -1007,14 +1007,15 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     const bool few = npairs > 0 && npairs <= team_limit && !std::getenv("CARETTA_NO_TEAM");
     b->team = few && b->n_max > 3 * cr::kWave && b->n_max <= 5 * cr::kTeamWaves * cr::kWave;
     if (b->team) b->r_seed = b->r_align = (b->n_max + cr::kTeamWaves * cr::kWave - 1) / (cr::kTeamWaves * cr::kWave);
-    // Above 384 rows the wide kernels (one wave per strip of 2 or 3 rows per lane, up to 16 waves per pair, a barrier
-    // every 8 steps) beat the four-wave teams: two waves per SIMD issue FP64 at the full rate where a lone wave gets
-    // about 60 % of it.  Measured (tools/calibrate_wide.py): 120 pairs of 600: 1.14 -> 1.05 ms (R = 2), 252 pairs of
-    // 1200 (one GPU's share of BASELINE config 5 on 8 GPUs): 2.95 -> 2.72 ms (R = 3); 66 pairs of 300: no gain.
+    // The wide layout (one workgroup per pair: one wave per strip of 2 or 3 rows per lane, up to 16 waves, a barrier every
+    // 8 steps, both stages in one launch, the sums behind the walks taken by the whole workgroup) beats the four-wave
+    // teams wherever those apply.  Measured (tools/calibrate_wide.py, round 3): 252 pairs of 1200 (one GPU's share of
+    // BASELINE config 5 on 8 GPUs) 2.74 -> 2.18 ms, 120 pairs of 600 0.96 -> 0.93, 66 pairs of 300 0.411 -> 0.391, one pair
+    // of 300 0.394 -> 0.379.
     b->wide_sync = 0;
     b->wide_na = 0;
     // (also beyond the 1280 rows the four-wave teams reach: 105 pairs of 1500 take 13.5 ms one wave per pair, 3.3 ms wide)
-    if (few && b->n_max > 6 * cr::kWave && !g_no_wide && !std::getenv("CARETTA_NO_WIDE")) {
+    if (few && b->n_max > 3 * cr::kWave && !g_no_wide && !std::getenv("CARETTA_NO_WIDE")) {
         const StripPlan p = choose_wide_plan(b->n_max, b->m_max, b->d_pad, 8);
         if (p.ra) {
             b->team = true;                                         // same layout rules as the team kernels: one group, one plan
