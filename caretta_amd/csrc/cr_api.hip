@@ -1455,6 +1455,7 @@ int cr_batch_destroy(cr_batch* b) {
 }  // extern "C"
 
 #include "cr_dropins.h"
+#include "cr_staged.h"
 #include "cr_progressive.h"
 #include "cr_explicit_batch.h"
 #include "cr_nj_device.h"

@@ -90,6 +90,13 @@ CR_D void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// Workgroup barrier for hand-offs that go through LDS only (the edge rings between the strips of a pair): waits for this
+// wave's LDS operations and not for its global stores.  __syncthreads() carries a release fence, which on gfx950 is
+// s_waitcnt vmcnt(0): every barrier of a sweep then waited for the decision words (and, with staged scores, for the
+// score lines requested a block ahead) to reach memory -- 300 .. 900 cycles per barrier that nothing needs; the words
+// are made visible to the traceback once, by the fence behind the sweep.
+CR_D void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // value of `v` in lane `src_lane` (wave-uniform index), broadcast to every lane
 CR_D double lane_value(double v, int src_lane) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_lane),
@@ -201,11 +208,14 @@ struct RbfTensor {
     // wide sweep: all m columns resident in LDS, feature-major planes of `stride` doubles (consecutive lanes read
     // consecutive doubles of a plane: conflict-free ds_read_b64)
     static constexpr int kColDoubles = D;
-    CR_D void load_resident(double* res, int stride, int m, int tid, int nth) {
-        const int total = m * d;
+    CR_D void load_resident(double* res, int stride, int m, int tid, int nth) { load_resident_range(res, stride, 0, m, tid, nth); }
+    // columns [c0, c1) only, column c at index c - c0 of every plane (the score staging kernels, cr_staged.h)
+    CR_D void load_resident_range(double* res, int stride, int c0, int c1, int tid, int nth) {
+        const int total = (c1 - c0) * d;
+        const double* __restrict__ from = cols_g + (int64_t)c0 * d;
         for (int e = tid; e < total; e += nth) {
             const int c = e / d, k = e - c * d;
-            res[k * stride + c] = cols_g[e];
+            res[k * stride + c] = from[e];
         }
         for (int e = tid; e < (D - d) * stride; e += nth) res[d * stride + e] = 0.0;   // padded features
     }
@@ -282,9 +292,10 @@ struct RbfCoords {
         col[2] = ring[2 * kRing + slot];
     }
     static constexpr int kColDoubles = 3;
-    CR_D void load_resident(double* res, int stride, int m, int tid, int nth) {
+    CR_D void load_resident(double* res, int stride, int m, int tid, int nth) { load_resident_range(res, stride, 0, m, tid, nth); }
+    CR_D void load_resident_range(double* res, int stride, int c0, int c1, int tid, int nth) {
         const bool raw = xf->flags & kFlagSeedSkipped;
-        for (int c = tid; c < m; c += nth) {
+        for (int c = c0 + tid; c < c1; c += nth) {
             const double v[3] = {cols_g[(int64_t)c * 3], cols_g[(int64_t)c * 3 + 1], cols_g[(int64_t)c * 3 + 2]};
             double o[3];
             if (raw) {
@@ -293,9 +304,9 @@ struct RbfCoords {
                 const double w[3] = {v[0] - xf->c2[0], v[1] - xf->c2[1], v[2] - xf->c2[2]};
                 rot3(w, xf->R, o);
             }
-            res[c] = o[0];
-            res[stride + c] = o[1];
-            res[2 * stride + c] = o[2];
+            res[c - c0] = o[0];
+            res[stride + c - c0] = o[1];
+            res[2 * stride + c - c0] = o[2];
         }
     }
     CR_D void fetch_resident(const double* res, int stride, int c) {
@@ -342,9 +353,10 @@ struct RbfNode {
         wcol = ring[3 * kRing + slot];
     }
     static constexpr int kColDoubles = 4;
-    CR_D void load_resident(double* res, int stride, int m, int tid, int nth) {
-        xyz.load_resident(res, stride, m, tid, nth);
-        for (int c = tid; c < m; c += nth) res[3 * stride + c] = w_cols[c] * mult2;
+    CR_D void load_resident(double* res, int stride, int m, int tid, int nth) { load_resident_range(res, stride, 0, m, tid, nth); }
+    CR_D void load_resident_range(double* res, int stride, int c0, int c1, int tid, int nth) {
+        xyz.load_resident_range(res, stride, c0, c1, tid, nth);
+        for (int c = c0 + tid; c < c1; c += nth) res[3 * stride + c - c0] = w_cols[c] * mult2;
     }
     CR_D void fetch_resident(const double* res, int stride, int c) {
         xyz.fetch_resident(res, stride, c);
@@ -1431,131 +1443,14 @@ constexpr int kWideEdge = 64;
 constexpr int kWideMaxWaves = 16;
 constexpr int kWideMaxSync = 32;
 
-template <int R, int MODE, class Src>
-CR_D void sweep_wide(Src& src, const int n, const int m, const SweepParams prm, double* lds, const int sync_every,
-                     uint32_t* __restrict__ sw_dirs, uint32_t* __restrict__ dtw_bits, SeedMax& seed_out,
-                     AlignEnd& end_out, const StripGeom geom) {
-    constexpr bool SW = (MODE & (kSwTrace | kSwScore)) != 0;
+// The end of a one-wave-per-strip sweep: per-wave results, then across the waves through LDS (as sweep_team).
+// `red`: 8 doubles per wave.
+template <int R, int MODE>
+CR_D void wide_finish(const DpState<R>& st, const bool mine, const int w, const int lane, const int rowbase, const StripGeom geom,
+                      double* red, SeedMax& seed_out, AlignEnd& end_out) {
     constexpr bool TRACE = (MODE & kSwTrace) != 0;
     constexpr bool DTW = (MODE & kDtw) != 0;
-    constexpr int NB = (SW ? 1 : 0) + (DTW ? 2 : 0);
-    const int lane = threadIdx.x & (kWave - 1);
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int NW = (int)(blockDim.x >> 6);
-    const int stride = m;
-    const ExpEntry* tab = reinterpret_cast<const ExpEntry*>(lds);
-    double* res = lds + kExpDoubles;
-    double* edges = res + (size_t)Src::kColDoubles * stride;
-    double* edge_out = edges + w * (NB * kWideEdge);
-    const double* edge_in = edges + (w > 0 ? w - 1 : 0) * (NB * kWideEdge);
-    double* red = edges + NW * (NB * kWideEdge);
-
-    load_exp_table(lds, threadIdx.x);
-    src.load_resident(res, stride, m, (int)threadIdx.x, (int)blockDim.x);
-
-    const int nstrips = geom.nstrips;                    // <= NW, guaranteed by the launcher
-    const int TB_SW = tblocks(m, 16), TB_DTW = tblocks(m, 8);
-    const double col0_m2 = kMinF64 - prm.gap_open;
-    const bool mine = w < nstrips;
-    const int rowbase = geom.rowbase0 + lane * R;
-    const int rows_here = n - geom.rowbase0;
-    const int lanes_here = rows_here >= kWave * R ? kWave : (rows_here + R - 1) / R;
-    const int T = mine ? m + lanes_here - 1 : 0;
-    const int lag = kWave - 1 + sync_every;
-
-    DpState<R> st;
-    st.sw_max = 0.0;
-    if (mine) src.load_rows(rowbase, n);
-    st.reset_column0(col0_m2);
-#pragma unroll
-    for (int q = 0; q < R; q++) st.swbits[q] = st.dtbits[q] = 0;
-
-    // Few rows per lane: a step is one long chain of dependent FP64 instructions (squared distance -> exp -> recurrences,
-    // ~10 cycles each for a wave that has its SIMD to itself) with nothing to interleave.  The scores do not depend on the
-    // recurrence, so they are formed ONE COLUMN AHEAD: the chain of column c + 1's scores runs beside the recurrence of
-    // column c, and the step becomes issue-bound.  (Every lane's first column is column 0: its scores are formed here.)
-    constexpr bool AHEAD = R <= 2;
-    double sc_cur[R];
-    __syncthreads();                                       // the resident columns and the exp table are complete (every
-                                                           // wave, whatever its rows per lane: barriers must pair up)
-    if constexpr (AHEAD) {
-        src.fetch_resident(res, stride, 0);
-#pragma unroll
-        for (int q = 0; q < R; q++) sc_cur[q] = src.score(q, tab);
-    }
-    const int G = lag * (nstrips - 1) + m + kWave - 1;
-    int until_sync = 0;
-    for (int g = 0; g < G; g++) {
-        if (until_sync == 0) {
-            __syncthreads();                               // edge values of the last B steps visible to the next strip
-            until_sync = sync_every;
-        }
-        until_sync--;
-        const int t = g - lag * w;
-        const bool live = mine && t >= 0 && t < T;
-        if (!live) continue;
-        const int c = t - lane;
-        const bool active = (unsigned)c < (unsigned)m;
-
-        double h_top0 = 0.0, m0_top0 = col0_m2, m1_top0 = 0.0;
-        if (w > 0 && lane == 0 && active) {
-            if constexpr (SW) h_top0 = edge_in[c & (kWideEdge - 1)];
-            if constexpr (DTW) {
-                m0_top0 = edge_in[(NB - 2) * kWideEdge + (c & (kWideEdge - 1))];
-                m1_top0 = edge_in[(NB - 1) * kWideEdge + (c & (kWideEdge - 1))];
-            }
-        }
-        double h_top = 0.0, m0_top = 0.0, m1_top = 0.0;
-        if constexpr (SW) h_top = wave_shr1(st.h_left[R - 1], h_top0);
-        if constexpr (DTW) {
-            m0_top = wave_shr1(st.m0_left[R - 1], m0_top0);
-            m1_top = wave_shr1(st.m1_left[R - 1], m1_top0);
-        }
-        const int sh2 = (t & 15) * 2, sh4 = (t & 7) * 4;
-
-        if (active) {
-            if constexpr (AHEAD) {
-                double sc_next[R];
-                src.fetch_resident(res, stride, c + 1 < m ? c + 1 : c);
-#pragma unroll
-                for (int q = 0; q < R; q++) sc_next[q] = src.score(q, tab);
-                dp_column<R, MODE>(src, st, prm, tab, c, rowbase, n, sh2, sh4, h_top, m0_top, m1_top, sc_cur);
-#pragma unroll
-                for (int q = 0; q < R; q++) sc_cur[q] = sc_next[q];
-            } else {
-                src.fetch_resident(res, stride, c);
-                dp_column<R, MODE>(src, st, prm, tab, c, rowbase, n, sh2, sh4, h_top, m0_top, m1_top);
-            }
-            if (w + 1 < nstrips && lane == kWave - 1) {
-                if constexpr (SW) edge_out[c & (kWideEdge - 1)] = st.h_left[R - 1];
-                if constexpr (DTW) {
-                    edge_out[(NB - 2) * kWideEdge + (c & (kWideEdge - 1))] = st.m0_left[R - 1];
-                    edge_out[(NB - 1) * kWideEdge + (c & (kWideEdge - 1))] = st.m1_left[R - 1];
-                }
-            }
-        }
-        if constexpr (TRACE) {
-            if ((t & 15) == 15 || t == T - 1) {
-                const int64_t base = ((int64_t)geom.slot0 * TB_SW + (int64_t)(t >> 4) * R) * kWave + lane;
-#pragma unroll
-                for (int q = 0; q < R; q++) {
-                    sw_dirs[base + q * kWave] = st.swbits[q];
-                    st.swbits[q] = 0;
-                }
-            }
-        }
-        if constexpr (DTW) {
-            if ((t & 7) == 7 || t == T - 1) {
-                const int64_t base = ((int64_t)geom.slot0 * TB_DTW + (int64_t)(t >> 3) * R) * kWave + lane;
-#pragma unroll
-                for (int q = 0; q < R; q++) {
-                    dtw_bits[base + q * kWave] = st.dtbits[q];
-                    st.dtbits[q] = 0;
-                }
-            }
-        }
-    }
-
+    const int nstrips = geom.nstrips;
     // ---- per-wave results, then across the waves through LDS (as sweep_team) -------------------------
     double best_v = 0.0;
     int best_i = 0x7fffffff, best_j = 0x7fffffff;
@@ -1640,10 +1535,277 @@ CR_D void sweep_wide(Src& src, const int n, const int m, const SweepParams prm, 
     __syncthreads();
 }
 
+template <int R, int MODE, class Src>
+CR_D void sweep_wide(Src& src, const int n, const int m, const SweepParams prm, double* lds, const int sync_every,
+                     uint32_t* __restrict__ sw_dirs, uint32_t* __restrict__ dtw_bits, SeedMax& seed_out,
+                     AlignEnd& end_out, const StripGeom geom) {
+    constexpr bool SW = (MODE & (kSwTrace | kSwScore)) != 0;
+    constexpr bool TRACE = (MODE & kSwTrace) != 0;
+    constexpr bool DTW = (MODE & kDtw) != 0;
+    constexpr int NB = (SW ? 1 : 0) + (DTW ? 2 : 0);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int NW = (int)(blockDim.x >> 6);
+    const int stride = m;
+    const ExpEntry* tab = reinterpret_cast<const ExpEntry*>(lds);
+    double* res = lds + kExpDoubles;
+    double* edges = res + (size_t)Src::kColDoubles * stride;
+    double* edge_out = edges + w * (NB * kWideEdge);
+    const double* edge_in = edges + (w > 0 ? w - 1 : 0) * (NB * kWideEdge);
+    double* red = edges + NW * (NB * kWideEdge);
+
+    load_exp_table(lds, threadIdx.x);
+    src.load_resident(res, stride, m, (int)threadIdx.x, (int)blockDim.x);
+
+    const int nstrips = geom.nstrips;                    // <= NW, guaranteed by the launcher
+    const int TB_SW = tblocks(m, 16), TB_DTW = tblocks(m, 8);
+    const double col0_m2 = kMinF64 - prm.gap_open;
+    const bool mine = w < nstrips;
+    const int rowbase = geom.rowbase0 + lane * R;
+    const int rows_here = n - geom.rowbase0;
+    const int lanes_here = rows_here >= kWave * R ? kWave : (rows_here + R - 1) / R;
+    const int T = mine ? m + lanes_here - 1 : 0;
+    const int lag = kWave - 1 + sync_every;
+
+    DpState<R> st;
+    st.sw_max = 0.0;
+    if (mine) src.load_rows(rowbase, n);
+    st.reset_column0(col0_m2);
+#pragma unroll
+    for (int q = 0; q < R; q++) st.swbits[q] = st.dtbits[q] = 0;
+
+    // Few rows per lane: a step is one long chain of dependent FP64 instructions (squared distance -> exp -> recurrences,
+    // ~10 cycles each for a wave that has its SIMD to itself) with nothing to interleave.  The scores do not depend on the
+    // recurrence, so they are formed ONE COLUMN AHEAD: the chain of column c + 1's scores runs beside the recurrence of
+    // column c, and the step becomes issue-bound.  (Every lane's first column is column 0: its scores are formed here.)
+    constexpr bool AHEAD = R <= 2;
+    double sc_cur[R];
+    __syncthreads();                                       // the resident columns and the exp table are complete (every
+                                                           // wave, whatever its rows per lane: barriers must pair up)
+    if constexpr (AHEAD) {
+        src.fetch_resident(res, stride, 0);
+#pragma unroll
+        for (int q = 0; q < R; q++) sc_cur[q] = src.score(q, tab);
+    }
+    const int G = lag * (nstrips - 1) + m + kWave - 1;
+    int until_sync = 0;
+    for (int g = 0; g < G; g++) {
+        if (until_sync == 0) {
+            lds_barrier();                                 // edge values of the last B steps visible to the next strip
+            until_sync = sync_every;
+        }
+        until_sync--;
+        const int t = g - lag * w;
+        const bool live = mine && t >= 0 && t < T;
+        if (!live) continue;
+        const int c = t - lane;
+        const bool active = (unsigned)c < (unsigned)m;
+
+        double h_top0 = 0.0, m0_top0 = col0_m2, m1_top0 = 0.0;
+        if (w > 0 && lane == 0 && active) {
+            if constexpr (SW) h_top0 = edge_in[c & (kWideEdge - 1)];
+            if constexpr (DTW) {
+                m0_top0 = edge_in[(NB - 2) * kWideEdge + (c & (kWideEdge - 1))];
+                m1_top0 = edge_in[(NB - 1) * kWideEdge + (c & (kWideEdge - 1))];
+            }
+        }
+        double h_top = 0.0, m0_top = 0.0, m1_top = 0.0;
+        if constexpr (SW) h_top = wave_shr1(st.h_left[R - 1], h_top0);
+        if constexpr (DTW) {
+            m0_top = wave_shr1(st.m0_left[R - 1], m0_top0);
+            m1_top = wave_shr1(st.m1_left[R - 1], m1_top0);
+        }
+        const int sh2 = (t & 15) * 2, sh4 = (t & 7) * 4;
+
+        if (active) {
+            if constexpr (AHEAD) {
+                double sc_next[R];
+                src.fetch_resident(res, stride, c + 1 < m ? c + 1 : c);
+#pragma unroll
+                for (int q = 0; q < R; q++) sc_next[q] = src.score(q, tab);
+                dp_column<R, MODE>(src, st, prm, tab, c, rowbase, n, sh2, sh4, h_top, m0_top, m1_top, sc_cur);
+#pragma unroll
+                for (int q = 0; q < R; q++) sc_cur[q] = sc_next[q];
+            } else {
+                src.fetch_resident(res, stride, c);
+                dp_column<R, MODE>(src, st, prm, tab, c, rowbase, n, sh2, sh4, h_top, m0_top, m1_top);
+            }
+            if (w + 1 < nstrips && lane == kWave - 1) {
+                if constexpr (SW) edge_out[c & (kWideEdge - 1)] = st.h_left[R - 1];
+                if constexpr (DTW) {
+                    edge_out[(NB - 2) * kWideEdge + (c & (kWideEdge - 1))] = st.m0_left[R - 1];
+                    edge_out[(NB - 1) * kWideEdge + (c & (kWideEdge - 1))] = st.m1_left[R - 1];
+                }
+            }
+        }
+        if constexpr (TRACE) {
+            if ((t & 15) == 15 || t == T - 1) {
+                const int64_t base = ((int64_t)geom.slot0 * TB_SW + (int64_t)(t >> 4) * R) * kWave + lane;
+#pragma unroll
+                for (int q = 0; q < R; q++) {
+                    sw_dirs[base + q * kWave] = st.swbits[q];
+                    st.swbits[q] = 0;
+                }
+            }
+        }
+        if constexpr (DTW) {
+            if ((t & 7) == 7 || t == T - 1) {
+                const int64_t base = ((int64_t)geom.slot0 * TB_DTW + (int64_t)(t >> 3) * R) * kWave + lane;
+#pragma unroll
+                for (int q = 0; q < R; q++) {
+                    dtw_bits[base + q * kWave] = st.dtbits[q];
+                    st.dtbits[q] = 0;
+                }
+            }
+        }
+    }
+
+    wide_finish<R, MODE>(st, mine, w, lane, rowbase, geom, red, seed_out, end_out);
+}
+
 template <int MODE, class Src>
 __host__ __device__ inline size_t sweep_wide_lds_doubles(int waves, int m_max) {
     constexpr int NB = ((MODE & (kSwTrace | kSwScore)) ? 1 : 0) + ((MODE & kDtw) ? 2 : 0);
     return kExpDoubles + (size_t)Src::kColDoubles * m_max + (size_t)waves * (NB * kWideEdge + 8);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The wide sweep on scores that another launch has already formed (cr_staged.h), ONE row per lane.
+//
+// When a launch has few workgroups -- a level of the progressive alignment, a short pair list -- the fused kernels are
+// bound by the instruction issue of the few waves that hold the recurrence, and 50 of a seed step's 59 instructions (30
+// of an alignment step's 49) are the score, which does not depend on the recurrence at all.  A staging launch forms the
+// scores on every CU of the chip in the SAME arithmetic (the provider's own score()), and this sweep is left with the
+// recurrence.
+// Layout of one strip (64 rows): element t * 64 + lane = S(row lane, column t - lane), t = 0 .. m + 62: the line a wave
+// needs at step t is one coalesced 512-byte read.  The loop runs in blocks of kStagedBlock = 16 steps, unrolled: the
+// block's 16 lines sit in registers, requested one block (16 steps: the scores are in L2 / MALL, 200 .. 900 cycles away)
+// ahead; shifts, word boundaries and the one barrier of a block are fixed at compile time.  The strips lag each other by
+// 80 steps (a multiple of the block, >= 63 + 16), so every wave's blocks are the workgroup's blocks.
+// The strip region has staged_steps(m_max) lines: the request one block past the last step stays inside it.
+// LDS (doubles): NW edge rings of NB * kWideEdge | NW * 8.  Decision words: the layout of every other skewed sweep.
+// ---------------------------------------------------------------------------------------------
+constexpr int kStagedBlock = 16;
+constexpr int kStagedLagBlocks = 5;
+constexpr int kStagedMaxWaves = 8;       // 512 rows: two blocks of score lines in registers need more than the 128 VGPRs of
+                                         // a 16-wave workgroup
+CR_HD int staged_steps(int m_max) { return (m_max + kWave - 1 + kStagedBlock - 1) / kStagedBlock * kStagedBlock + 2 * kStagedBlock; }
+
+struct StagedScore {                               // what dp_column sees: the score of the lane's cell of this step
+    static constexpr bool kNonNegative = true;     // RBF scores (the staging kernels write what the RBF providers return)
+    static constexpr bool kMaskRows = false;       // rows past n were staged as the exact zeros the RBF gives them
+    double v;
+    CR_D double score(int, const ExpEntry*) const { return v; }
+};
+
+template <int MODE>
+CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int m, const SweepParams prm, double* lds,
+                       uint32_t* __restrict__ sw_dirs, uint32_t* __restrict__ dtw_bits, SeedMax& seed_out,
+                       AlignEnd& end_out, const StripGeom geom) {
+    constexpr bool SW = (MODE & (kSwTrace | kSwScore)) != 0;
+    constexpr bool TRACE = (MODE & kSwTrace) != 0;
+    constexpr bool DTW = (MODE & kDtw) != 0;
+    constexpr int NB = (SW ? 1 : 0) + (DTW ? 2 : 0);
+    constexpr int B = kStagedBlock;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int NW = (int)(blockDim.x >> 6);
+    double* edges = lds;
+    double* edge_out = edges + w * (NB * kWideEdge);
+    const double* edge_in = edges + (w > 0 ? w - 1 : 0) * (NB * kWideEdge);
+    double* red = edges + NW * (NB * kWideEdge);
+
+    const int nstrips = geom.nstrips;                    // <= NW, guaranteed by the launcher
+    const int TB_SW = tblocks(m, 16), TB_DTW = tblocks(m, 8);
+    const double col0_m2 = kMinF64 - prm.gap_open;
+    const bool mine = w < nstrips;
+    const int rowbase = geom.rowbase0 + lane;
+    const int rows_here = n - geom.rowbase0;
+    const int lanes_here = rows_here >= kWave ? kWave : rows_here;
+    const int my_blocks = mine ? (m + lanes_here - 1 + B - 1) / B : 0;
+
+    DpState<1> st;
+    st.sw_max = 0.0;
+    st.reset_column0(col0_m2);
+    st.swbits[0] = st.dtbits[0] = 0;
+    StagedScore src;
+    const double* __restrict__ line = strip + lane;
+    double cur[B], nxt[B], nx2[B];
+    if (mine) {
+#pragma unroll
+        for (int k = 0; k < B; k++) {
+            nxt[k] = line[k * kWave];
+            nx2[k] = line[(B + k) * kWave];
+        }
+    }
+    const int GB = kStagedLagBlocks * (nstrips - 1) + (m + kWave - 1 + B - 1) / B;
+#pragma unroll 1
+    for (int gb = 0; gb < GB; gb++) {
+        lds_barrier();                                     // edge values of the last block visible to the next strip
+        const int tb = gb - kStagedLagBlocks * w;
+        if (tb < 0 || tb >= my_blocks) continue;
+        const double* __restrict__ ahead = line + (int64_t)(tb + 2) * (B * kWave);
+#pragma unroll
+        for (int k = 0; k < B; k++) {
+            cur[k] = nxt[k];
+            nxt[k] = nx2[k];
+            nx2[k] = ahead[k * kWave];
+        }
+        // the row above the strip for this block's 16 steps (lane 0's column is t itself): one LDS read, lane k = step k
+        double ev_h = 0.0, ev_m0 = col0_m2, ev_m1 = 0.0;
+        if (w > 0) {
+            const int slot = (tb * B + (lane & (B - 1))) & (kWideEdge - 1);
+            if constexpr (SW) ev_h = edge_in[slot];
+            if constexpr (DTW) {
+                ev_m0 = edge_in[(NB - 2) * kWideEdge + slot];
+                ev_m1 = edge_in[(NB - 1) * kWideEdge + slot];
+            }
+        }
+        auto steps = [&](auto all_tag) {
+            constexpr bool ALL = decltype(all_tag)::value;    // every lane's column of every step of the block is inside [0, m)
+            static_for<0, B>([&](auto k_tag) {
+                constexpr int k = decltype(k_tag)::value;
+                const int c = tb * B + k - lane;
+                const bool active = ALL || (unsigned)c < (unsigned)m;
+                double h_top = 0.0, m0_top = 0.0, m1_top = 0.0;
+                if constexpr (SW) h_top = wave_shr1_fill_from<k>(st.h_left[0], ev_h);
+                if constexpr (DTW) {
+                    m0_top = wave_shr1_fill_from<k>(st.m0_left[0], ev_m0);
+                    m1_top = wave_shr1_fill_from<k>(st.m1_left[0], ev_m1);
+                }
+                if (active) {
+                    src.v = cur[k];
+                    dp_column<1, MODE>(src, st, prm, nullptr, c, rowbase, n, k * 2, (k & 7) * 4, h_top, m0_top, m1_top);
+                    if (w + 1 < nstrips && lane == kWave - 1) {
+                        if constexpr (SW) edge_out[c & (kWideEdge - 1)] = st.h_left[0];
+                        if constexpr (DTW) {
+                            edge_out[(NB - 2) * kWideEdge + (c & (kWideEdge - 1))] = st.m0_left[0];
+                            edge_out[(NB - 1) * kWideEdge + (c & (kWideEdge - 1))] = st.m1_left[0];
+                        }
+                    }
+                }
+                if constexpr (DTW) {
+                    if ((k & 7) == 7 && tb * 2 + (k >> 3) < TB_DTW) {
+                        dtw_bits[((int64_t)geom.slot0 * TB_DTW + tb * 2 + (k >> 3)) * kWave + lane] = st.dtbits[0];
+                        st.dtbits[0] = 0;
+                    }
+                }
+            });
+        };
+        if (tb * B >= kWave - 1 && tb * B + B - 1 < m) steps(std::true_type{});
+        else steps(std::false_type{});
+        if constexpr (TRACE) {
+            sw_dirs[((int64_t)geom.slot0 * TB_SW + tb) * kWave + lane] = st.swbits[0];
+            st.swbits[0] = 0;
+        }
+    }
+    wide_finish<1, MODE>(st, mine, w, lane, rowbase, geom, red, seed_out, end_out);
+}
+
+template <int MODE>
+__host__ __device__ inline size_t sweep_staged_lds_doubles(int waves) {
+    constexpr int NB = ((MODE & (kSwTrace | kSwScore)) ? 1 : 0) + ((MODE & kDtw) ? 2 : 0);
+    return (size_t)waves * (NB * kWideEdge + 8);
 }
 
 CR_D uint32_t lookup_bits(const uint32_t* __restrict__ words, int R, int TB, int per_word_log2, int bits,
@@ -2600,6 +2762,11 @@ struct NodeDesc {
 // One wave per tree node; blockIdx.x indexes pairs / nodes / xf / out.  The children are read from
 // coords / tensors / weights at pd.off_i, pd.off_j; the node is written to Xn / Tn / Wn at out_off (the
 // output arrays may be the input arrays: a level of the guide tree appends to the arena it reads from).
+template <int R>
+CR_D void node_finish(const PairDesc& pd, const NodeDesc& nd, const Transform* xf, const AlignEnd& e, const double* coords,
+                      const double* tensors, int d, const double* weights, int max_entries, const uint32_t* __restrict__ bits,
+                      int32_t* __restrict__ aln, double* lds, double* Xn, double* Tn, double* Wn, NodeOut* out);
+
 template <int R, bool TEAM>
 CR_D void node_body(const PairDesc* __restrict__ pairs, const double* coords,
                                                const double* tensors, int d, const double* weights,
@@ -2611,7 +2778,6 @@ CR_D void node_body(const PairDesc* __restrict__ pairs, const double* coords,
                                                double* Xn_base, double* Tn_base, double* Wn_base,
                                                NodeOut* __restrict__ outs) {
     extern __shared__ double lds[];
-    const int lane = threadIdx.x;
     const PairDesc pd = pairs[blockIdx.x];
     const NodeDesc nd = nodes[blockIdx.x];
     const Transform* xf = xfs + blockIdx.x;
@@ -2648,10 +2814,20 @@ CR_D void node_body(const PairDesc* __restrict__ pairs, const double* coords,
     } else {
         drain_stores();
     }
+    node_finish<R>(pd, nd, xf, e, coords, tensors, d, weights, max_entries, bits, aln, lds, Xn, Tn, Wn, out);
+}
+
+// The part of a node behind its fill (one wave): DTW traceback, superposition on the aligned positions, the merged node.
+template <int R>
+CR_D void node_finish(const PairDesc& pd, const NodeDesc& nd, const Transform* xf, const AlignEnd& e, const double* coords,
+                      const double* tensors, int d, const double* weights, int max_entries, const uint32_t* __restrict__ bits,
+                      int32_t* __restrict__ aln, double* lds, double* Xn, double* Tn, double* Wn, NodeOut* out) {
+    const int lane = threadIdx.x;
     double* tl = lds + kExpDoubles;
     const int cap = pd.n + pd.m;
     int idx, k;
     dtw_walk<R>(pd.n, pd.m, max_entries, bits, e.start_layer, tl, aln, idx, k);
+    CR_STAMP(6);
     const int first = cap - idx;
     const uint32_t* ent = reinterpret_cast<const uint32_t*>(tl) + first;
     double* scratch = tl + ((size_t)max_entries + 3) / 4 * 2;

@@ -16,6 +16,7 @@ struct cr_progressive {
     int64_t P = 0, d = 0;
     cr_batch scratch;                        // k_seed launch state: arena (coords, tensors) + decision scratch
     DevBuf<double> weights;                  // arena, one double per row
+    DevBuf<double> staged;                   // scores of one level formed ahead of its sweeps (cr_staged.h)
     int64_t used = 0, capacity = 0;          // arena rows
     DevBuf<cr::NodeDesc> d_nodes;
     DevBuf<cr::NodeOut> d_outs;
@@ -160,7 +161,19 @@ int run_tree_planned(cr_progressive* h, const std::vector<std::vector<int64_t>>&
     for (int64_t s = 0; s < P; s++) longest = std::max(longest, h->len[(size_t)s]);
     const int bound = (int)std::min<int64_t>(5 * cr::kTeamWaves * cr::kWave, (longest * 3 + 1) / 2 + 8);
     if (bound <= 3 * cr::kWave || longest > bound || std::getenv("CARETTA_NO_TEAM")) return 1;
-    const int R = (bound + cr::kTeamWaves * cr::kWave - 1) / (cr::kTeamWaves * cr::kWave);
+    int64_t widest_level = 0;
+    for (int64_t lv = 1; lv <= h->levels; lv++) widest_level = std::max<int64_t>(widest_level, (int64_t)by_level[(size_t)lv].size());
+    // Scores formed by their own launches (cr_staged.h) while one row per lane fits the 8 waves of its workgroups and the
+    // widest level's scores fit a tenth of the device memory; CARETTA_STAGED=0: the fused kernels
+    const cr::StagedShape shape = staged_shape(bound, bound);
+    const char* staged_env = std::getenv("CARETTA_STAGED");
+    bool staged = bound <= cr::kStagedMaxWaves * cr::kWave && widest_level <= 65535 && !(staged_env && staged_env[0] == '0');
+    if (staged) {
+        size_t free_b = 0, total_b = 0;
+        CR_HIP(hipMemGetInfo(&free_b, &total_b));
+        staged = (double)widest_level * (double)shape.pair_doubles() * sizeof(double) <= (double)total_b / 10.0;
+    }
+    const int R = staged ? 1 : (bound + cr::kTeamWaves * cr::kWave - 1) / (cr::kTeamWaves * cr::kWave);
 
     // static plan: every internal node in level order
     std::vector<cr::PlanNode> plan;
@@ -200,6 +213,7 @@ int run_tree_planned(cr_progressive* h, const std::vector<std::vector<int64_t>>&
     CR_HIP(b.dirs.ensure((size_t)dirs_words));
     CR_HIP(b.bits.ensure((size_t)bits_words));
     CR_HIP(b.aln.ensure((size_t)aln_total));
+    if (staged) CR_HIP(h->staged.ensure((size_t)(max_count * shape.pair_doubles())));
     CR_UPLOAD(h->ctx, d_plan.p, plan.data(), sizeof(cr::PlanNode) * plan.size());
     CR_UPLOAD(h->ctx, d_len.p, h->len.data(), sizeof(int64_t) * (size_t)(2 * P - 1));
     CR_UPLOAD(h->ctx, d_off.p, h->off.data(), sizeof(int64_t) * (size_t)(2 * P - 1));
@@ -215,6 +229,19 @@ int run_tree_planned(cr_progressive* h, const std::vector<std::vector<int64_t>>&
         CR_HIP(hipGetLastError());
         if (count == 0) break;
         const cr_batch::Chunk ck{first, count, bound, bound, 2 * bound};
+        if (staged) {
+            // scores (every CU) -> SW sweep + seed superposition -> node scores in that frame (every CU) -> DTW sweep + node
+            if ((rc = launch_stage_tensor(&b, ck, prm, h->staged.p, shape))) return rc;
+            if ((rc = launch_seed_staged(&b, ck, prm, h->staged.p, shape))) return rc;
+            if ((rc = launch_stage_node(stream, (int)count, bound, b.pairs.p + first, b.coords.p, h->weights.p, h->d_nodes.p + first,
+                                        b.xf.p + first, prm, gamma_weight, h->staged.p, shape)))
+                return rc;
+            if ((rc = launch_node_staged(stream, (int)count, 2 * bound, b.pairs.p + first, b.coords.p, b.tensors.p, (int)h->d,
+                                         h->weights.p, h->d_nodes.p + first, b.xf.p + first, prm, h->staged.p, shape, b.bits.p,
+                                         b.aln.p, b.coords.p, b.tensors.p, h->weights.p, h->d_outs.p + first)))
+                return rc;
+            continue;
+        }
         if ((rc = launch_seed_team(R, &b, ck, prm))) return rc;
         if ((rc = launch_node_team(R, stream, (int)count, bound, bound, 2 * bound, b.pairs.p + first, b.coords.p, b.tensors.p,
                                    (int)h->d, h->weights.p, h->d_nodes.p + first, b.xf.p + first, prm, gamma_weight, b.bits.p,

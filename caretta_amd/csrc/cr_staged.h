@@ -1,0 +1,248 @@
+// Launches with few workgroups (a level of the progressive alignment): the scores are formed by their own launch on every
+// CU of the chip and the sweep that holds the recurrence reads them back (cr::Staged, cr_kernels.h).
+//
+// Why: one tree level is 1 .. P/2 nodes, every node one workgroup, and its levels come one after the other
+// (multiple_alignment.py:193-234 needs both children).  In the fused kernels the 4 .. 8 waves of a node form the scores AND
+// run the recurrence; a wave that has its SIMD to itself issues an FP64-rate instruction every ~6.5 cycles
+// (profiles/r03/valu_latency.txt), so a level took 0.49 ms whether it held 64 nodes or one, and 250 of the chip's 256
+// CUs idled.  The score of a cell does not depend on the recurrence: 50 of the 59 instructions of a seed cell (tensor RBF,
+// d = 10) and 55 of the ~80 of a node cell (two RBFs) go to a launch that has as many workgroups as there are (strip, 16
+// step) pieces, and the sweep keeps ~15 / ~25 instructions per cell, with one row per lane (the shortest pipeline).
+// The arithmetic is the providers' own score() -- the values are the same doubles, so every result is bit-identical to the
+// fused kernels (tests/test_gpu_parity.py::test_progressive_staged_equals_fused).
+//
+// Layout: cr::sweep_staged.  One pair = `waves` strips of `steps` lines of 64 doubles; 8 bytes per cell are written once and
+// read once (L2 / MALL resident: one level of 64 nodes of 450 columns is 140 MB).
+// Included by cr_api.hip after cr_dropins.h.
+#pragma once
+
+namespace cr {
+
+struct StagedShape {       // the same for every pair of a launch (sized for the launch's length bound)
+    int waves;             // strips per pair
+    int steps;             // score lines per strip: staged_steps(m bound)
+    CR_HD int64_t strip_doubles() const { return (int64_t)steps * kWave; }
+    CR_HD int64_t pair_doubles() const { return (int64_t)waves * steps * kWave; }
+};
+
+// One workgroup = the steps [t0, t0 + tc) of every strip of one pair (wave w = strip w = rows 64 w ..), i.e. the columns
+// [t0 - 63, t0 + tc) of the pair, which go through LDS once for all strips.
+template <class Src>
+CR_D void stage_block(Src& src, const int n, const int m, const int tc, double* __restrict__ pair_base,
+                      const StagedShape shape, double* lds) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int t0 = (int)blockIdx.x * tc;
+    if (t0 >= m + kWave - 1) return;                       // (whole workgroup) past the last step of this pair
+    const int c_lo = t0 - (kWave - 1) > 0 ? t0 - (kWave - 1) : 0;
+    const int c_hi = t0 + tc < m ? t0 + tc : m;
+    const int stride = tc + kWave - 1;
+    const ExpEntry* tab = reinterpret_cast<const ExpEntry*>(lds);
+    double* res = lds + kExpDoubles;
+    load_exp_table(lds, threadIdx.x);
+    src.load_resident_range(res, stride, c_lo, c_hi, (int)threadIdx.x, (int)blockDim.x);
+    const bool mine = w * kWave < n;
+    if (mine) src.load_rows(w * kWave + lane, n);          // rows past n: the far-away features whose score is exactly 0
+    __syncthreads();
+    if (!mine) return;
+    double* __restrict__ out = pair_base + (int64_t)w * shape.strip_doubles() + lane;
+    const int t1 = t0 + tc < m + kWave - 1 ? t0 + tc : m + kWave - 1;
+    for (int t = t0; t < t1; t++) {
+        const int c = t - lane;
+        if ((unsigned)c < (unsigned)m) {
+            src.fetch_resident(res, stride, c - c_lo);
+            out[(int64_t)t * kWave] = src.score(0, tab);
+        }
+    }
+}
+
+__host__ __device__ inline size_t stage_lds_doubles(int col_doubles, int tc) {
+    return kExpDoubles + (size_t)col_doubles * (tc + kWave - 1);
+}
+
+// tensor RBF of a pair's two structures / a node's two children (multiple_alignment.py:328-335)
+template <int D>
+__global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_stage_tensor(const PairDesc* __restrict__ pairs,
+                                                                      const double* __restrict__ tensors, int d,
+                                                                      double gamma, int tc, double* __restrict__ staged,
+                                                                      const StagedShape shape) {
+    extern __shared__ double lds[];
+    const PairDesc pd = pairs[blockIdx.y];
+    RbfTensor<1, D> src;
+    src.rows_g = tensors + pd.off_i * d;
+    src.cols_g = tensors + pd.off_j * d;
+    src.d = d;
+    src.neg_gamma = -gamma;
+    stage_block(src, pd.n, pd.m, tc, staged + (int64_t)blockIdx.y * shape.pair_doubles(), shape, lds);
+}
+
+// node score of the progressive alignment (multiple_alignment.py:204-210) in the frame of the node's seed superposition
+template <class Dummy = void>
+__global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_stage_node_t(const PairDesc* __restrict__ pairs,
+                                                                      const double* __restrict__ coords,
+                                                                      const double* __restrict__ weights,
+                                                                      const NodeDesc* __restrict__ nodes,
+                                                                      const Transform* __restrict__ xfs,
+                                                                      double gamma_coords, double gamma_weight, int tc,
+                                                                      double* __restrict__ staged, const StagedShape shape) {
+    extern __shared__ double lds[];
+    const PairDesc pd = pairs[blockIdx.y];
+    const NodeDesc nd = nodes[blockIdx.y];
+    RbfNode<1> src;
+    src.xyz.rows_g = coords + pd.off_i * 3;
+    src.xyz.cols_g = coords + pd.off_j * 3;
+    src.xyz.xf = xfs + blockIdx.y;
+    src.xyz.neg_gamma = -gamma_coords;
+    src.w_rows = weights + pd.off_i;
+    src.w_cols = weights + pd.off_j;
+    src.mult1 = nd.mult1;
+    src.mult2 = nd.mult2;
+    src.neg_gamma_w = -gamma_weight;
+    stage_block(src, pd.n, pd.m, tc, staged + (int64_t)blockIdx.y * shape.pair_doubles(), shape, lds);
+}
+constexpr auto k_stage_node = k_stage_node_t<>;
+
+// Seed stage on staged scores: SW fill with one wave per strip, then (wave 0) traceback + seed Kabsch, as k_seed_wide.
+template <bool ZG>
+__global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_seed_staged(const PairDesc* __restrict__ pairs,
+                                                                     const double* __restrict__ coords, double sw_gap,
+                                                                     int max_entries, const double* __restrict__ staged,
+                                                                     const StagedShape shape, uint32_t* __restrict__ dirs,
+                                                                     Transform* __restrict__ xf,
+                                                                     double* __restrict__ seed_score) {
+    extern __shared__ double lds[];
+    CR_STAMP(0);
+    const PairDesc pd = pairs[blockIdx.x];
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    SeedMax sm;
+    AlignEnd unused;
+    {
+        SweepParams prm{sw_gap, 0.0, 0.0};
+        sweep_staged<kSwTrace | (ZG ? kZeroGap : 0)>(staged + (int64_t)blockIdx.x * shape.pair_doubles() + (int64_t)w * shape.strip_doubles(),
+                                                     pd.n, pd.m, prm, lds, dirs + pd.dirs_off, nullptr, sm, unused,
+                                                     WidePlan<1>{0}.geom(w, pd.n));
+    }
+    if (threadIdx.x >= kWave) return;                  // wave 0 goes on alone (wave_sync, no s_barrier from here on)
+    CR_STAMP(1);
+    Transform tr;
+    seed_trace<1, 1>(pd, max_entries, coords, dirs, sm, lds + kExpDoubles, tr);
+    if (threadIdx.x == 0) {
+        xf[blockIdx.x] = tr;
+        seed_score[blockIdx.x] = sm.score;
+    }
+    CR_STAMP(3);
+}
+
+// Node stage on staged scores: affine DTW fill with one wave per strip, then (wave 0) node_finish, as k_node_team.
+template <class Dummy = void>
+__global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_node_staged_t(const PairDesc* __restrict__ pairs, const double* coords,
+                                                                     const double* tensors, int d, const double* weights,
+                                                                     const NodeDesc* __restrict__ nodes,
+                                                                     const Transform* __restrict__ xfs, double gap_open,
+                                                                     double gap_extend, int max_entries,
+                                                                     const double* __restrict__ staged, const StagedShape shape,
+                                                                     uint32_t* __restrict__ bits_base,
+                                                                     int32_t* __restrict__ aln_base, double* Xn_base,
+                                                                     double* Tn_base, double* Wn_base,
+                                                                     NodeOut* __restrict__ outs) {
+    extern __shared__ double lds[];
+    CR_STAMP(4);
+    const PairDesc pd = pairs[blockIdx.x];
+    const NodeDesc nd = nodes[blockIdx.x];
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t* bits = bits_base + pd.bt_off;
+    SeedMax unused;
+    AlignEnd e;
+    {
+        SweepParams prm{0.0, gap_open, gap_extend};
+        sweep_staged<kDtw>(staged + (int64_t)blockIdx.x * shape.pair_doubles() + (int64_t)w * shape.strip_doubles(), pd.n, pd.m,
+                           prm, lds, nullptr, bits, unused, e, WidePlan<1>{0}.geom(w, pd.n));
+    }
+    if (threadIdx.x >= kWave) return;                  // wave 0 goes on alone (wave_sync, no s_barrier from here on)
+    CR_STAMP(5);
+    node_finish<1>(pd, nd, xfs + blockIdx.x, e, coords, tensors, d, weights, max_entries, bits, aln_base + pd.aln_off, lds,
+                   Xn_base + nd.out_off * 3, Tn_base + nd.out_off * d, Wn_base + nd.out_off, outs + blockIdx.x);
+    CR_STAMP(7);
+}
+constexpr auto k_node_staged = k_node_staged_t<>;
+
+}  // namespace cr
+
+#ifndef CR_KERNELS_TEMPLATES_ONLY      // the launchers (cr_api.hip)
+namespace {
+
+constexpr int kStageSteps = 16;            // steps of every strip per staging workgroup
+
+inline cr::StagedShape staged_shape(int n_bound, int m_bound) {
+    cr::StagedShape s;
+    s.waves = (n_bound + cr::kWave - 1) / cr::kWave;
+    s.steps = cr::staged_steps(m_bound);
+    return s;
+}
+
+template <int D>
+int launch_stage_tensor_d(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, double* staged, const cr::StagedShape shape) {
+    const size_t lds = sizeof(double) * cr::stage_lds_doubles(D, kStageSteps);
+    int rc = allow_lds(cr::k_stage_tensor<D>, lds);
+    if (rc) return rc;
+    const unsigned chunks = (unsigned)((ck.m_max + cr::kWave - 1 + kStageSteps - 1) / kStageSteps);
+    CR_LAUNCH((cr::k_stage_tensor<D>), dim3(chunks, (unsigned)ck.count), dim3(shape.waves * cr::kWave), lds, b->ctx->stream,
+              b->pairs.p + ck.first, b->tensors.p, (int)b->d, prm.gamma_tensor, kStageSteps, staged, shape);
+    CR_HIP(hipGetLastError());
+    return CR_OK;
+}
+
+int launch_stage_tensor(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, double* staged, const cr::StagedShape shape) {
+    switch (b->d_pad) {
+        case 4: return launch_stage_tensor_d<4>(b, ck, prm, staged, shape);
+        case 8: return launch_stage_tensor_d<8>(b, ck, prm, staged, shape);
+        case 10: return launch_stage_tensor_d<10>(b, ck, prm, staged, shape);
+        case 16: return launch_stage_tensor_d<16>(b, ck, prm, staged, shape);
+        case 24: return launch_stage_tensor_d<24>(b, ck, prm, staged, shape);
+        case 32: return launch_stage_tensor_d<32>(b, ck, prm, staged, shape);
+        default: return fail(CR_ERR_ARGUMENT, "unsupported tensor width");
+    }
+}
+
+int launch_seed_staged(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, const double* staged, const cr::StagedShape shape) {
+    const int entries = std::min(ck.n_max, ck.m_max);
+    const size_t lds = sizeof(double) * std::max(cr::sweep_staged_lds_doubles<cr::kSwTrace>(shape.waves),
+                                                 (size_t)cr::kExpDoubles + cr::trace_lds_doubles(1, entries));
+    auto go = [&](auto kernel) -> int {
+        int rc = allow_lds(kernel, lds);
+        if (rc) return rc;
+        CR_LAUNCH(kernel, dim3((unsigned)ck.count), dim3(shape.waves * cr::kWave), lds, b->ctx->stream, b->pairs.p + ck.first,
+                  b->coords.p, prm.sw_gap, entries, staged, shape, b->dirs.p, b->xf.p + ck.first, b->seed_score.p + ck.first);
+        CR_HIP(hipGetLastError());
+        return CR_OK;
+    };
+    return prm.sw_gap == 0.0 ? go(cr::k_seed_staged<true>) : go(cr::k_seed_staged<false>);
+}
+
+int launch_stage_node(hipStream_t stream, int count, int m_max, const cr::PairDesc* pairs, const double* coords,
+                      const double* weights, const cr::NodeDesc* nodes, const cr::Transform* xf, const cr_params& prm,
+                      double gamma_weight, double* staged, const cr::StagedShape shape) {
+    const size_t lds = sizeof(double) * cr::stage_lds_doubles(cr::RbfNode<1>::kColDoubles, kStageSteps);
+    const unsigned chunks = (unsigned)((m_max + cr::kWave - 1 + kStageSteps - 1) / kStageSteps);
+    CR_LAUNCH(cr::k_stage_node, dim3(chunks, (unsigned)count), dim3(shape.waves * cr::kWave), lds, stream, pairs, coords, weights,
+              nodes, xf, prm.gamma_coords, gamma_weight, kStageSteps, staged, shape);
+    CR_HIP(hipGetLastError());
+    return CR_OK;
+}
+
+int launch_node_staged(hipStream_t stream, int count, int entries, const cr::PairDesc* pairs, const double* coords,
+                       const double* tensors, int d, const double* weights, const cr::NodeDesc* nodes, const cr::Transform* xf,
+                       const cr_params& prm, const double* staged, const cr::StagedShape shape, uint32_t* bits, int32_t* aln,
+                       double* xn, double* tn, double* wn, cr::NodeOut* out) {
+    const size_t lds = sizeof(double) * std::max(cr::sweep_staged_lds_doubles<cr::kDtw>(shape.waves),
+                                                 (size_t)cr::kExpDoubles + cr::trace_lds_doubles(1, entries));
+    int rc = allow_lds(cr::k_node_staged, lds);
+    if (rc) return rc;
+    CR_LAUNCH(cr::k_node_staged, dim3((unsigned)count), dim3(shape.waves * cr::kWave), lds, stream, pairs, coords, tensors, d,
+              weights, nodes, xf, prm.gap_open, prm.gap_extend, entries, staged, shape, bits, aln, xn, tn, wn, out);
+    CR_HIP(hipGetLastError());
+    return CR_OK;
+}
+
+}  // namespace
+#endif

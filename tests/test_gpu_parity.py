@@ -786,6 +786,45 @@ def test_progressive_resident_vs_oracle_and_single_node(oracle, num, length, rag
     assert np.array_equal(np.array([aln[q] for q in order]), rows[-1])
 
 
+@pytest.mark.parametrize("num,length,ragged,seed", [(12, 300, False, 21), (5, 335, False, 22), (7, 200, True, 23), (9, 140, True, 24)])
+def test_progressive_staged_scores_equal_fused(oracle, monkeypatch, num, length, ragged, seed):
+    """The tree levels whose scores are formed by their own launches (cr_staged.h) against the fused kernels
+    (CARETTA_STAGED=0): alignments, node coordinates / tensors / weights and flags bit for bit; 335-residue leaves size the
+    launches for 511 rows (all 8 waves of the staged sweep), ragged 140-residue ones for 218 (4 waves, most nodes fewer).
+    The root join also against the oracle."""
+    from caretta_amd import multiple_alignment as ma, neighbor_joining as nj
+    fam = synthetic.make_family(num, length, seed=seed, ragged=ragged, clades=2)
+    prm = dict(flexible=False, gamma_tensor=7.0, gamma_coords=0.03, verbose=False)
+    runs = []
+    for staged in ("1", "0"):
+        monkeypatch.setenv("CARETTA_STAGED", staged)
+        prots = [ma.Protein(s.name, s.tensors, s.coordinates, "") for s in fam]
+        msa = ma.MultipleAlignment(prots)
+        if not runs:
+            m = msa.make_pairwise_matrix(prm)
+            tree, _ = nj.neighbor_joining(m.max() - m)
+        aln = msa.progressive_align(tree, 1.0, 0.01, 1.0, 1.0, prm, dict(flexible=False, verbose=False))
+        runs.append((msa, aln))
+    (a, aln_a), (b, aln_b) = runs
+    assert np.array_equal(a.node_table, b.node_table)
+    for q in aln_a:
+        assert np.array_equal(aln_a[q], aln_b[q])
+    for k in range(num, 2 * num - 1):
+        assert np.array_equal(a.final_sequences[k].coordinates, b.final_sequences[k].coordinates)
+        assert np.array_equal(a.final_sequences[k].tensors, b.final_sequences[k].tensors)
+        assert np.array_equal(a.final_consensus_weights[k], b.final_consensus_weights[k])
+    n1, n2 = _replay_tree(a, tree, num)[-1]
+    members = a.node_table[:, 5]
+    size = lambda x: 1 if x < num else int(members[x - num])
+    tot = size(n1) + size(n2)
+    s1, s2 = a.final_sequences[n1], a.final_sequences[n2]
+    _, _, xn, tn, wn, _ = oracle.progressive_node(s1.coordinates, s1.tensors, a.final_consensus_weights[n1], s2.coordinates, s2.tensors,
+                                                  a.final_consensus_weights[n2], size(n2) / (2 * tot), size(n1) / (2 * tot))
+    root = a.final_sequences[2 * num - 2]
+    assert np.array_equal(xn, root.coordinates) and np.array_equal(tn, root.tensors)
+    assert np.array_equal(wn, a.final_consensus_weights[2 * num - 2])
+
+
 def test_gamma_too_small_is_rejected(ctx):
     """gamma = 0 would make the scores of the padding rows 1.0 instead of 0.0: the fused kernels refuse it."""
     from caretta_amd import engine, synthetic as syn

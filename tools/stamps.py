@@ -38,6 +38,24 @@ def run(names):
     ctx = engine.Context(0)
     prm = engine.make_params()
     for name in names:
+        if name.startswith("tree"):            # progressive alignment of treeP structures of 300: the ROOT node's launches
+            from caretta_amd import multiple_alignment as ma, neighbor_joining as nj
+            num = int(name[4:])
+            fam = synthetic.make_family(num, 300, seed=20242)
+            prots = [ma.Protein(s.name, s.tensors, s.coordinates, s.sequence) for s in fam]
+            msa = ma.MultipleAlignment(prots)
+            p = dict(flexible=False, gamma_tensor=7.0, gamma_coords=0.03, verbose=False)
+            m = msa.make_pairwise_matrix(p)
+            tree, _ = nj.neighbor_joining(m.max() - m)
+            msa.progressive_align(tree, 1.0, 0.01, 1.0, 1.0, p, dict(flexible=False, verbose=False))
+            st = np.zeros((1, 8), dtype=np.uint64)
+            _capi.check(lib.cr_debug_stamps(st.ctypes.data_as(C.c_void_p), 1))
+            d = np.diff(st.astype(np.int64), axis=1)[0]
+            print(f"{name} root node (width {len(next(iter(msa.final_alignments['int-final'].values()))) if hasattr(msa, 'final_alignments') else '?'}, "
+                  f"CARETTA_STAGED={os.environ.get('CARETTA_STAGED', '-')}): shader-clock cycles\n"
+                  f"  seed : fill {d[0]:9d}  walk {d[1]:9d}  kabsch/rest {d[2]:9d}\n"
+                  f"  node : fill {d[4]:9d}  walk {d[5]:9d}  superposition/merge {d[6]:9d}", flush=True)
+            continue
         num, length, seed, stride = WORKLOADS[name]
         fam = synthetic.make_family(num, length, seed=seed)
         coords, tensors, offsets = synthetic.pack(fam)
