@@ -1683,7 +1683,7 @@ __host__ __device__ inline size_t sweep_wide_lds_doubles(int waves, int m_max) {
 // ahead; shifts, word boundaries and the one barrier of a block are fixed at compile time.  The strips lag each other by
 // 80 steps (a multiple of the block, >= 63 + 16), so every wave's blocks are the workgroup's blocks.
 // The strip region has staged_steps(m_max) lines: the request one block past the last step stays inside it.
-// LDS (doubles): NW edge rings of NB * kWideEdge | NW * 8.  Decision words: the layout of every other skewed sweep.
+// LDS (doubles): NW + 1 hand-off rings of NB * kWideEdge | NW * 8 | NW dumps.  Decision words: as every other skewed sweep.
 // ---------------------------------------------------------------------------------------------
 constexpr int kStagedBlock = 16;
 constexpr int kStagedLagBlocks = 5;
@@ -1698,6 +1698,126 @@ struct StagedScore {                               // what dp_column sees: the s
     CR_D double score(int, const ExpEntry*) const { return v; }
 };
 
+// The seed's Smith-Waterman with gap 0 on staged scores: the COLUMN sweep of sweep_cols_team (one step per column, the
+// `up` dependency a prefix maximum across the lanes, strips kColChunk columns apart instead of 80 steps) with the score
+// read instead of formed.  Layout of a strip: element c * 64 + lane = S(row lane, column c) (not skewed).  A chunk's 8
+// lines sit in registers, requested two chunks ahead.  LDS (doubles): NW rings of 2 * kColChunk | NW * 4.
+// Decision words: the column sweeps' layout (Walker SKEW = 0).
+CR_D void sweep_cols_staged(const double* __restrict__ strip, const int n, const int m, double* lds,
+                            uint32_t* __restrict__ sw_dirs, SeedMax& seed_out, const StripGeom geom) {
+    constexpr int C = kColChunk;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int NW = (int)(blockDim.x >> 6);
+    double* ring_out = lds + w * (2 * C);
+    const double* ring_in = lds + (w > 0 ? w - 1 : 0) * (2 * C);
+    double* red = lds + NW * (2 * C);
+    const int nstrips = geom.nstrips;                    // <= NW, guaranteed by the launcher
+    const int TB = (m + 15) >> 4;
+    const bool mine = w < nstrips;
+    const int rowbase = geom.rowbase0 + lane;
+    const bool hand_out = w + 1 < nstrips;
+    const int chunks = (m + C - 1) / C;
+    const int phases = chunks + nstrips - 1;
+    double hprev = 0.0, eprev = 0.0;
+    int rowfirst = 0;
+    uint32_t bits = 0;
+    const double* __restrict__ line = strip + lane;
+    double cur[C], nxt[C], nx2[C];
+    if (mine) {
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+            nxt[k] = line[k * kWave];
+            nx2[k] = line[(C + k) * kWave];
+        }
+    }
+    auto run = [&](auto top_tag) {
+        constexpr bool TOP = decltype(top_tag)::value;
+#pragma unroll 1
+        for (int g = 0; g < phases; g++) {
+            lds_barrier();                                 // the chunk written in phase g - 1 is visible to the strip below
+            const int c = g - w;
+            if (!mine || c < 0 || c >= chunks) continue;
+            const double* __restrict__ ahead = line + (int64_t)(c + 2) * (C * kWave);
+#pragma unroll
+            for (int k = 0; k < C; k++) {
+                cur[k] = nxt[k];
+                nxt[k] = nx2[k];
+                nx2[k] = ahead[k * kWave];
+            }
+            double top_vec = 0.0;                          // the row above the strip for this chunk: lane x = column j0 + x
+            if (TOP && lane < C) top_vec = ring_in[(c & 1) * C + lane];
+            const int j0 = c * C;
+            auto columns = [&](auto all_tag) {
+                constexpr bool ALL = decltype(all_tag)::value;
+                static_for<0, C>([&](auto k_tag) {
+                    constexpr int k = decltype(k_tag)::value;
+                    const int j = j0 + k;
+                    if (ALL || j < m) {
+                        // dynamic_time_warping.py:226-247 with gap 0, as ColSweep::step
+                        const double dg = eprev + cur[k];
+                        const double b = vmax(dg, hprev);
+                        double e = wave_shr1(wave_scan_max(b), 0.0);
+                        if constexpr (TOP) e = vmax(e, lane_value(top_vec, k));
+                        const double h = vmax(b, e);
+                        const bool same = h == hprev;
+                        uint32_t code = (h == dg) ? 1u : same ? 2u : 3u;
+                        code = (h > 0.0) ? code : 0u;
+                        bits |= code << ((j & 15) * 2);
+                        rowfirst = same ? rowfirst : j;
+                        hprev = h;
+                        eprev = e;
+                        if (hand_out && lane == kWave - 1) ring_out[(c & 1) * C + k] = h;
+                    }
+                });
+            };
+            if (j0 + C <= m) columns(std::true_type{});
+            else columns(std::false_type{});
+            const int jend = j0 + C < m ? j0 + C : m;
+            if (((jend - 1) & 15) == 15 || jend == m) {    // a decision word holds 16 columns
+                sw_dirs[((int64_t)geom.slot0 * TB + (int64_t)((jend - 1) >> 4)) * kWave + lane] = bits;
+                bits = 0;
+            }
+        }
+    };
+    if (w == 0) run(std::false_type{});
+    else run(std::true_type{});
+
+    double best_v = 0.0;
+    int best_i = 0x7fffffff, best_j = 0x7fffffff;
+    if (mine && hprev > 0.0) {                             // the row's maximum is its last value (non-decreasing rows)
+        best_v = hprev;
+        best_i = rowbase;
+        best_j = rowfirst;
+    }
+    wave_first_max(best_v, best_i, best_j);
+    if (lane == 0) {
+        red[w * 4 + 0] = best_v;
+        red[w * 4 + 1] = (double)best_i;
+        red[w * 4 + 2] = (double)best_j;
+    }
+    __threadfence();                                   // decision words of every wave visible to wave 0's walk
+    __syncthreads();
+    best_v = 0.0;
+    best_i = best_j = 0x7fffffff;
+    for (int x = 0; x < nstrips; x++) {
+        const double ov = red[x * 4 + 0];
+        const int oi = (int)red[x * 4 + 1], oj = (int)red[x * 4 + 2];
+        const bool take = ov > best_v || (ov == best_v && (oi < best_i || (oi == best_i && oj < best_j)));
+        best_v = take ? ov : best_v;
+        best_i = take ? oi : best_i;
+        best_j = take ? oj : best_j;
+    }
+    seed_out.score = best_v;
+    seed_out.i = best_v > 0.0 ? best_i + 1 : 0;
+    seed_out.j = best_v > 0.0 ? best_j + 1 : 0;
+    __syncthreads();
+}
+
+__host__ __device__ inline size_t sweep_cols_staged_lds_doubles(int waves) { return (size_t)waves * (2 * kColChunk + 4); }
+
+constexpr int kStagedDump = 2 * kWideEdge + kStagedBlock;     // doubles per wave that take the hand-off writes of lanes 0 .. 62
+
 template <int MODE>
 CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int m, const SweepParams prm, double* lds,
                        uint32_t* __restrict__ sw_dirs, uint32_t* __restrict__ dtw_bits, SeedMax& seed_out,
@@ -1707,13 +1827,16 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
     constexpr bool DTW = (MODE & kDtw) != 0;
     constexpr int NB = (SW ? 1 : 0) + (DTW ? 2 : 0);
     constexpr int B = kStagedBlock;
+    constexpr int PH = 0, PM0 = (NB - 2) * kWideEdge, PM1 = (NB - 1) * kWideEdge;   // planes of a ring
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int NW = (int)(blockDim.x >> 6);
-    double* edges = lds;
-    double* edge_out = edges + w * (NB * kWideEdge);
-    const double* edge_in = edges + (w > 0 ? w - 1 : 0) * (NB * kWideEdge);
-    double* red = edges + NW * (NB * kWideEdge);
+    // Hand-off rings, indexed by the WRITER's step (t & 63: a block's 16 slots are contiguous): ring 0 holds the DP border
+    // above row 0 (constants), ring w + 1 the last row of strip w.  Strip w reads ring w: no special case for the first.
+    const double* ring_in = lds + w * (NB * kWideEdge);
+    double* ring_out = lds + (w + 1) * (NB * kWideEdge);
+    double* red = lds + (NW + 1) * (NB * kWideEdge);
+    double* dump = red + NW * 8 + w * kStagedDump;
 
     const int nstrips = geom.nstrips;                    // <= NW, guaranteed by the launcher
     const int TB_SW = tblocks(m, 16), TB_DTW = tblocks(m, 8);
@@ -1723,6 +1846,7 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
     const int rows_here = n - geom.rowbase0;
     const int lanes_here = rows_here >= kWave ? kWave : rows_here;
     const int my_blocks = mine ? (m + lanes_here - 1 + B - 1) / B : 0;
+    for (int x = threadIdx.x; x < NB * kWideEdge; x += blockDim.x) lds[x] = (DTW && x / kWideEdge == NB - 2) ? col0_m2 : 0.0;
 
     DpState<1> st;
     st.sw_max = 0.0;
@@ -1741,7 +1865,7 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
     const int GB = kStagedLagBlocks * (nstrips - 1) + (m + kWave - 1 + B - 1) / B;
 #pragma unroll 1
     for (int gb = 0; gb < GB; gb++) {
-        lds_barrier();                                     // edge values of the last block visible to the next strip
+        lds_barrier();                                     // hand-off values of the last block visible to the next strip
         const int tb = gb - kStagedLagBlocks * w;
         if (tb < 0 || tb >= my_blocks) continue;
         const double* __restrict__ ahead = line + (int64_t)(tb + 2) * (B * kWave);
@@ -1751,15 +1875,20 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
             nxt[k] = nx2[k];
             nx2[k] = ahead[k * kWave];
         }
-        // the row above the strip for this block's 16 steps (lane 0's column is t itself): one LDS read, lane k = step k
-        double ev_h = 0.0, ev_m0 = col0_m2, ev_m1 = 0.0;
-        if (w > 0) {
-            const int slot = (tb * B + (lane & (B - 1))) & (kWideEdge - 1);
-            if constexpr (SW) ev_h = edge_in[slot];
-            if constexpr (DTW) {
-                ev_m0 = edge_in[(NB - 2) * kWideEdge + slot];
-                ev_m1 = edge_in[(NB - 1) * kWideEdge + slot];
-            }
+        // The row above the strip.  Lane 0's column at step t is t itself, written by the strip above at ITS step t + 63:
+        // slot (t - 1) & 63.  Every lane reads it (one address: a broadcast) and hands it to the shift as lane 0's fill;
+        // the read of step k + 1 is issued before the arithmetic of step k.
+        const int q4 = (tb & 3) * B;
+        const double* fills = ring_in + q4 - 1;            // step k >= 1: fills[k]
+        const int slot0 = (tb * B - 1) & (kWideEdge - 1);
+        // the strip's last row: lane 63 writes its values of step k to slot q4 + k of the ring, the other lanes write theirs
+        // to a dump (one LDS instruction per step with no EXEC juggling)
+        double* wr = (lane == kWave - 1 && w + 1 < nstrips) ? ring_out + q4 : dump + lane;
+        double f_h = 0.0, f_m0 = 0.0, f_m1 = 0.0;
+        if constexpr (SW) f_h = ring_in[PH + slot0];
+        if constexpr (DTW) {
+            f_m0 = ring_in[PM0 + slot0];
+            f_m1 = ring_in[PM1 + slot0];
         }
         auto steps = [&](auto all_tag) {
             constexpr bool ALL = decltype(all_tag)::value;    // every lane's column of every step of the block is inside [0, m)
@@ -1767,23 +1896,32 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
                 constexpr int k = decltype(k_tag)::value;
                 const int c = tb * B + k - lane;
                 const bool active = ALL || (unsigned)c < (unsigned)m;
+                double g_h = 0.0, g_m0 = 0.0, g_m1 = 0.0;
+                if constexpr (k + 1 < B) {
+                    if constexpr (SW) g_h = fills[PH + k + 1];
+                    if constexpr (DTW) {
+                        g_m0 = fills[PM0 + k + 1];
+                        g_m1 = fills[PM1 + k + 1];
+                    }
+                }
                 double h_top = 0.0, m0_top = 0.0, m1_top = 0.0;
-                if constexpr (SW) h_top = wave_shr1_fill_from<k>(st.h_left[0], ev_h);
+                if constexpr (SW) h_top = wave_shr1(st.h_left[0], f_h);
                 if constexpr (DTW) {
-                    m0_top = wave_shr1_fill_from<k>(st.m0_left[0], ev_m0);
-                    m1_top = wave_shr1_fill_from<k>(st.m1_left[0], ev_m1);
+                    m0_top = wave_shr1(st.m0_left[0], f_m0);
+                    m1_top = wave_shr1(st.m1_left[0], f_m1);
                 }
                 if (active) {
                     src.v = cur[k];
                     dp_column<1, MODE>(src, st, prm, nullptr, c, rowbase, n, k * 2, (k & 7) * 4, h_top, m0_top, m1_top);
-                    if (w + 1 < nstrips && lane == kWave - 1) {
-                        if constexpr (SW) edge_out[c & (kWideEdge - 1)] = st.h_left[0];
-                        if constexpr (DTW) {
-                            edge_out[(NB - 2) * kWideEdge + (c & (kWideEdge - 1))] = st.m0_left[0];
-                            edge_out[(NB - 1) * kWideEdge + (c & (kWideEdge - 1))] = st.m1_left[0];
-                        }
+                    if constexpr (SW) wr[PH + k] = st.h_left[0];
+                    if constexpr (DTW) {
+                        wr[PM0 + k] = st.m0_left[0];
+                        wr[PM1 + k] = st.m1_left[0];
                     }
                 }
+                f_h = g_h;
+                f_m0 = g_m0;
+                f_m1 = g_m1;
                 if constexpr (DTW) {
                     if ((k & 7) == 7 && tb * 2 + (k >> 3) < TB_DTW) {
                         dtw_bits[((int64_t)geom.slot0 * TB_DTW + tb * 2 + (k >> 3)) * kWave + lane] = st.dtbits[0];
@@ -1805,7 +1943,7 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
 template <int MODE>
 __host__ __device__ inline size_t sweep_staged_lds_doubles(int waves) {
     constexpr int NB = ((MODE & (kSwTrace | kSwScore)) ? 1 : 0) + ((MODE & kDtw) ? 2 : 0);
-    return (size_t)waves * (NB * kWideEdge + 8);
+    return (size_t)(waves + 1) * (NB * kWideEdge) + (size_t)waves * (8 + kStagedDump);
 }
 
 CR_D uint32_t lookup_bits(const uint32_t* __restrict__ words, int R, int TB, int per_word_log2, int bits,

@@ -25,18 +25,20 @@ struct StagedShape {       // the same for every pair of a launch (sized for the
     CR_HD int64_t pair_doubles() const { return (int64_t)waves * steps * kWave; }
 };
 
-// One workgroup = the steps [t0, t0 + tc) of every strip of one pair (wave w = strip w = rows 64 w ..), i.e. the columns
-// [t0 - 63, t0 + tc) of the pair, which go through LDS once for all strips.
-template <class Src>
+// One workgroup = the steps [t0, t0 + tc) of every strip of one pair (wave w = strip w = rows 64 w ..).  SKEW: the layout of
+// sweep_staged -- line t holds column t - lane, the workgroup needs the columns [t0 - 63, t0 + tc), which go through LDS
+// once for all strips; otherwise the layout of sweep_cols_staged -- line t holds column t for every lane.
+template <bool SKEW, class Src>
 CR_D void stage_block(Src& src, const int n, const int m, const int tc, double* __restrict__ pair_base,
                       const StagedShape shape, double* lds) {
+    constexpr int kBack = SKEW ? kWave - 1 : 0;
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int t0 = (int)blockIdx.x * tc;
-    if (t0 >= m + kWave - 1) return;                       // (whole workgroup) past the last step of this pair
-    const int c_lo = t0 - (kWave - 1) > 0 ? t0 - (kWave - 1) : 0;
+    if (t0 >= m + kBack) return;                           // (whole workgroup) past the last step of this pair
+    const int c_lo = t0 - kBack > 0 ? t0 - kBack : 0;
     const int c_hi = t0 + tc < m ? t0 + tc : m;
-    const int stride = tc + kWave - 1;
+    const int stride = tc + kBack;
     const ExpEntry* tab = reinterpret_cast<const ExpEntry*>(lds);
     double* res = lds + kExpDoubles;
     load_exp_table(lds, threadIdx.x);
@@ -46,9 +48,9 @@ CR_D void stage_block(Src& src, const int n, const int m, const int tc, double* 
     __syncthreads();
     if (!mine) return;
     double* __restrict__ out = pair_base + (int64_t)w * shape.strip_doubles() + lane;
-    const int t1 = t0 + tc < m + kWave - 1 ? t0 + tc : m + kWave - 1;
+    const int t1 = t0 + tc < m + kBack ? t0 + tc : m + kBack;
     for (int t = t0; t < t1; t++) {
-        const int c = t - lane;
+        const int c = SKEW ? t - lane : t;
         if ((unsigned)c < (unsigned)m) {
             src.fetch_resident(res, stride, c - c_lo);
             out[(int64_t)t * kWave] = src.score(0, tab);
@@ -61,7 +63,7 @@ __host__ __device__ inline size_t stage_lds_doubles(int col_doubles, int tc) {
 }
 
 // tensor RBF of a pair's two structures / a node's two children (multiple_alignment.py:328-335)
-template <int D>
+template <int D, bool SKEW>
 __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_stage_tensor(const PairDesc* __restrict__ pairs,
                                                                       const double* __restrict__ tensors, int d,
                                                                       double gamma, int tc, double* __restrict__ staged,
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_stage_tensor(const P
     src.cols_g = tensors + pd.off_j * d;
     src.d = d;
     src.neg_gamma = -gamma;
-    stage_block(src, pd.n, pd.m, tc, staged + (int64_t)blockIdx.y * shape.pair_doubles(), shape, lds);
+    stage_block<SKEW>(src, pd.n, pd.m, tc, staged + (int64_t)blockIdx.y * shape.pair_doubles(), shape, lds);
 }
 
 // node score of the progressive alignment (multiple_alignment.py:204-210) in the frame of the node's seed superposition
@@ -98,11 +100,12 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_stage_node_t(const P
     src.mult1 = nd.mult1;
     src.mult2 = nd.mult2;
     src.neg_gamma_w = -gamma_weight;
-    stage_block(src, pd.n, pd.m, tc, staged + (int64_t)blockIdx.y * shape.pair_doubles(), shape, lds);
+    stage_block<true>(src, pd.n, pd.m, tc, staged + (int64_t)blockIdx.y * shape.pair_doubles(), shape, lds);
 }
 constexpr auto k_stage_node = k_stage_node_t<>;
 
-// Seed stage on staged scores: SW fill with one wave per strip, then (wave 0) traceback + seed Kabsch, as k_seed_wide.
+// Seed stage on staged scores: SW fill with one wave per strip (gap 0: the column sweep on the unskewed layout), then
+// (wave 0) traceback + seed Kabsch, as k_seed_wide.
 template <bool ZG>
 __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_seed_staged(const PairDesc* __restrict__ pairs,
                                                                      const double* __restrict__ coords, double sw_gap,
@@ -117,15 +120,16 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_seed_staged(const Pa
     SeedMax sm;
     AlignEnd unused;
     {
+        const double* strip = staged + (int64_t)blockIdx.x * shape.pair_doubles() + (int64_t)w * shape.strip_doubles();
+        const StripGeom geom = WidePlan<1>{0}.geom(w, pd.n);
         SweepParams prm{sw_gap, 0.0, 0.0};
-        sweep_staged<kSwTrace | (ZG ? kZeroGap : 0)>(staged + (int64_t)blockIdx.x * shape.pair_doubles() + (int64_t)w * shape.strip_doubles(),
-                                                     pd.n, pd.m, prm, lds, dirs + pd.dirs_off, nullptr, sm, unused,
-                                                     WidePlan<1>{0}.geom(w, pd.n));
+        if constexpr (ZG) sweep_cols_staged(strip, pd.n, pd.m, lds, dirs + pd.dirs_off, sm, geom);
+        else sweep_staged<kSwTrace>(strip, pd.n, pd.m, prm, lds, dirs + pd.dirs_off, nullptr, sm, unused, geom);
     }
     if (threadIdx.x >= kWave) return;                  // wave 0 goes on alone (wave_sync, no s_barrier from here on)
     CR_STAMP(1);
     Transform tr;
-    seed_trace<1, 1>(pd, max_entries, coords, dirs, sm, lds + kExpDoubles, tr);
+    seed_trace<1, ZG ? 0 : 1>(pd, max_entries, coords, dirs, sm, lds + kExpDoubles, tr);
     if (threadIdx.x == 0) {
         xf[blockIdx.x] = tr;
         seed_score[blockIdx.x] = sm.score;
@@ -183,13 +187,15 @@ inline cr::StagedShape staged_shape(int n_bound, int m_bound) {
 template <int D>
 int launch_stage_tensor_d(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, double* staged, const cr::StagedShape shape) {
     const size_t lds = sizeof(double) * cr::stage_lds_doubles(D, kStageSteps);
-    int rc = allow_lds(cr::k_stage_tensor<D>, lds);
-    if (rc) return rc;
-    const unsigned chunks = (unsigned)((ck.m_max + cr::kWave - 1 + kStageSteps - 1) / kStageSteps);
-    CR_LAUNCH((cr::k_stage_tensor<D>), dim3(chunks, (unsigned)ck.count), dim3(shape.waves * cr::kWave), lds, b->ctx->stream,
-              b->pairs.p + ck.first, b->tensors.p, (int)b->d, prm.gamma_tensor, kStageSteps, staged, shape);
-    CR_HIP(hipGetLastError());
-    return CR_OK;
+    const bool skew = prm.sw_gap != 0.0;                   // gap 0: the seed is a column sweep (k_seed_staged<true>)
+    const unsigned chunks = (unsigned)((ck.m_max + (skew ? cr::kWave - 1 : 0) + kStageSteps - 1) / kStageSteps);
+    auto go = [&](auto kernel) -> int {
+        CR_LAUNCH(kernel, dim3(chunks, (unsigned)ck.count), dim3(shape.waves * cr::kWave), lds, b->ctx->stream,
+                  b->pairs.p + ck.first, b->tensors.p, (int)b->d, prm.gamma_tensor, kStageSteps, staged, shape);
+        CR_HIP(hipGetLastError());
+        return CR_OK;
+    };
+    return skew ? go(cr::k_stage_tensor<D, true>) : go(cr::k_stage_tensor<D, false>);
 }
 
 int launch_stage_tensor(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, double* staged, const cr::StagedShape shape) {
@@ -206,8 +212,8 @@ int launch_stage_tensor(cr_batch* b, const cr_batch::Chunk& ck, const cr_params&
 
 int launch_seed_staged(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, const double* staged, const cr::StagedShape shape) {
     const int entries = std::min(ck.n_max, ck.m_max);
-    const size_t lds = sizeof(double) * std::max(cr::sweep_staged_lds_doubles<cr::kSwTrace>(shape.waves),
-                                                 (size_t)cr::kExpDoubles + cr::trace_lds_doubles(1, entries));
+    const size_t fill = prm.sw_gap == 0.0 ? cr::sweep_cols_staged_lds_doubles(shape.waves) : cr::sweep_staged_lds_doubles<cr::kSwTrace>(shape.waves);
+    const size_t lds = sizeof(double) * std::max(fill, (size_t)cr::kExpDoubles + cr::trace_lds_doubles(1, entries));
     auto go = [&](auto kernel) -> int {
         int rc = allow_lds(kernel, lds);
         if (rc) return rc;
