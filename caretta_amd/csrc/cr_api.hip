@@ -262,6 +262,8 @@ struct cr_batch {
     bool team = false;                  // few pairs: one workgroup of kTeamWaves waves per pair (k_seed_team / k_align_team)
     int wide_sync = 0;                  // > 0: the wide kernels (one wave per strip, up to 16 waves per pair) with a barrier every wide_sync steps
     int r_b = 5, wide_na = 0;           // wide kernels: strips [0, wide_na) have r_seed rows per lane, the others r_b (r_b == r_seed: all alike)
+    bool staged = false;                // scores formed by their own launches, sweeps with one row per lane (cr_staged.h)
+    DevBuf<double> staged_scores;       // ... one chunk's scores
     int n_max = 0, m_max = 0;
     int64_t max_aln = 0;
     std::vector<cr::PairDesc> h_pairs;  // in LAUNCH order: most cells first (order[k] = index in the caller's list)
@@ -577,6 +579,12 @@ int launch_align_team(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_pa
     }
 }
 
+}  // namespace
+
+#include "cr_staged.h"      // scores formed by their own launches: kernels and launchers
+
+namespace {
+
 // ---- wide kernels: one wave per strip, up to kWideMaxWaves waves per pair, columns resident in LDS ----------
 template <int RA, int RB, int D, bool ZG>
 int launch_seed_wide_zg(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
@@ -709,6 +717,8 @@ StripPlan choose_wide_plan(int n_max, int m_max, int d_pad, int sync_every) {
 }
 
 constexpr int64_t kTeamPairLimit = 256;
+// Pair lists of at most this many 64-row strips run on staged scores (cr_batch_set_pairs): one wave per SIMD of the chip.
+constexpr int64_t kStagedWaveLimit = 1024;
 constexpr int kGroupLanes = 4;             // streams that row-per-lane groups are spread over
 int launch_seed_team(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm);   // cr_dropins.h
 
@@ -1036,6 +1046,29 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
             b->wide_na = ra == rb ? 0 : na;
         }
     }
+    // Lists so short that one wave per 64-row strip still leaves SIMDs idle (a single pair, 66 pairs of 300, 248 pairs of
+    // 150) are bound by the instruction issue of lone waves, most of it the RBF scores: those are formed by their own
+    // launches on every CU and the sweeps keep the recurrence, one row per lane (cr_staged.h).  Measured
+    // (tools/calibrate_staged.py, full pipeline, fused -> staged): one pair of 300 0.382 -> 0.253 ms, 66 pairs of 300
+    // 0.395 -> 0.299, 248 pairs of 150 0.218 -> 0.191, 120 pairs of 450 0.614 -> 0.529; 496 pairs of 150 (1 488 strips for
+    // 1 024 SIMDs) 0.232 -> 0.275: hence at most kStagedWaveLimit strips.
+    b->staged = false;
+    {
+        const char* env = std::getenv("CARETTA_STAGED");
+        int64_t wave_limit = kStagedWaveLimit;
+        if (const char* lim = std::getenv("CARETTA_STAGED_WAVES")) wave_limit = std::atoll(lim);   // calibration
+        const int64_t strips1 = (b->n_max + cr::kWave - 1) / cr::kWave;
+        const cr::StagedShape shape = staged_shape(std::max(b->n_max, 1), std::max(b->m_max, 1));
+        if (npairs > 0 && !g_no_wide && !(env && env[0] == '0') && !std::getenv("CARETTA_NO_TEAM") && !std::getenv("CARETTA_WIDE") &&
+            !std::getenv("CARETTA_NO_WIDE") && b->n_max <= cr::kStagedMaxWaves * cr::kWave && npairs * strips1 <= wave_limit &&
+            (double)npairs * (double)shape.pair_doubles() * sizeof(double) <= 2.0 * 1024 * 1024 * 1024) {
+            b->staged = true;
+            b->team = true;                                         // one group, one plan: the team kernels' layout rules
+            b->wide_sync = 0;
+            b->wide_na = 0;
+            b->r_seed = b->r_align = 1;
+        }
+    }
     if (!b->wide_sync) b->r_b = b->r_seed;
     // scratch budget per chunk (decision words); CARETTA_SCRATCH_MB overrides the 8 GiB default
     int64_t budget_words = (int64_t)8192 * 1024 * 1024 / 4;
@@ -1079,6 +1112,7 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
         if (e == hipSuccess) e = b->seed_score.ensure((size_t)npairs);
         if (e == hipSuccess) e = b->res.ensure((size_t)npairs);
         if (e == hipSuccess) e = b->d_ij.ensure((size_t)npairs * 2);
+        if (e == hipSuccess && b->staged) e = b->staged_scores.ensure((size_t)(per_chunk * staged_shape(b->n_max, b->m_max).pair_doubles()));
         if (e != hipSuccess)
             return fail(e == hipErrorOutOfMemory ? CR_ERR_MEMORY : CR_ERR_HIP, std::string("allocating pair scratch: ") + hipGetErrorString(e));
         if ((rc = upload_async(b->ctx, b->d_ij.p, pairs, sizeof(int32_t) * 2 * (size_t)npairs))) return rc;
@@ -1210,6 +1244,11 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     if (e == hipSuccess) e = b->seed_score.ensure((size_t)npairs);
     if (e == hipSuccess) e = b->res.ensure((size_t)npairs);
     if (e == hipSuccess && b->reordered) e = b->d_order.ensure((size_t)npairs);
+    if (e == hipSuccess && b->staged) {
+        int64_t most = 0;
+        for (const cr_batch::Chunk& c : b->chunks) most = std::max(most, c.count);
+        e = b->staged_scores.ensure((size_t)(most * staged_shape(b->n_max, b->m_max).pair_doubles()));
+    }
     if (e != hipSuccess)
         return fail(e == hipErrorOutOfMemory ? CR_ERR_MEMORY : CR_ERR_HIP,
                     std::string("allocating pair scratch: ") + hipGetErrorString(e));
@@ -1265,6 +1304,20 @@ static int run_batch(cr_batch* b, const cr_params* params, double* d_sw_out, boo
         hipStream_t st = ck.lane == 0 ? ctx->stream : ctx->side[(size_t)ck.lane - 1];
         b->launch_stream = st;
         if (prof) (void)hipEventRecord((*evl)[evi++], st);
+        if (b->staged) {
+            // scores (every CU) -> SW sweep + seed superposition -> coordinate scores in that frame (every CU) -> SW score +
+            // DTW sweep + metrics (or the SW score alone); the staged scores of a chunk are reused by the next in stream order
+            const cr::StagedShape shape = staged_shape(b->n_max, b->m_max);
+            rc = launch_stage_tensor(b, ck, prm, b->staged_scores.p, shape);
+            if (!rc) rc = launch_seed_staged(b, ck, prm, b->staged_scores.p, shape);
+            if (!rc && prof) (void)hipEventRecord((*evl)[evi++], st);
+            if (!rc) rc = launch_stage_coords(b, ck, prm, b->staged_scores.p, shape);
+            if (!rc) rc = launch_align_staged(b, ck, prm, b->staged_scores.p, shape, scores_only && prm.sw_gap == 0.0);
+            if (!rc && prof) (void)hipEventRecord((*evl)[evi++], st);
+            b->launch_stream = nullptr;
+            if (rc) return rc;
+            continue;
+        }
         if (b->wide_sync) {
             // the wide layout: both stages of a pair in ONE launch (k_pair_wide) -- the stage split of the events is
             // (everything, 0)
@@ -1455,7 +1508,6 @@ int cr_batch_destroy(cr_batch* b) {
 }  // extern "C"
 
 #include "cr_dropins.h"
-#include "cr_staged.h"
 #include "cr_progressive.h"
 #include "cr_explicit_batch.h"
 #include "cr_nj_device.h"

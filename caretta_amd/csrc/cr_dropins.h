@@ -426,6 +426,11 @@ int launch_seed_team(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_par
 
 // the seed kernel that matches the batch's layout (cr_batch_set_pairs chose team / rows per lane)
 int launch_seed_auto(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
+    if (b->staged) {
+        const cr::StagedShape shape = staged_shape(b->n_max, b->m_max);
+        const int rc = launch_stage_tensor(b, ck, prm, b->staged_scores.p, shape);
+        return rc ? rc : launch_seed_staged(b, ck, prm, b->staged_scores.p, shape);
+    }
     if (b->wide_sync) return launch_seed_wide(b->r_seed, b, ck, prm);
     if (b->team) return launch_seed_team(b->r_seed, b, ck, prm);
     return launch_seed_r(b->r_seed, b, ck, prm);

@@ -104,8 +104,26 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_stage_node_t(const P
 }
 constexpr auto k_stage_node = k_stage_node_t<>;
 
+// coordinate RBF of a pair in the frame of its seed superposition (multiple_alignment.py:158-170, Protein.score_function)
+template <class Dummy = void>
+__global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_stage_coords_t(const PairDesc* __restrict__ pairs,
+                                                                        const double* __restrict__ coords,
+                                                                        const Transform* __restrict__ xfs, double gamma,
+                                                                        int tc, double* __restrict__ staged,
+                                                                        const StagedShape shape) {
+    extern __shared__ double lds[];
+    const PairDesc pd = pairs[blockIdx.y];
+    RbfCoords<1> src;
+    src.rows_g = coords + pd.off_i * 3;
+    src.cols_g = coords + pd.off_j * 3;
+    src.xf = xfs + blockIdx.y;
+    src.neg_gamma = -gamma;
+    stage_block<true>(src, pd.n, pd.m, tc, staged + (int64_t)blockIdx.y * shape.pair_doubles(), shape, lds);
+}
+constexpr auto k_stage_coords = k_stage_coords_t<>;
+
 // Seed stage on staged scores: SW fill with one wave per strip (gap 0: the column sweep on the unskewed layout), then
-// (wave 0) traceback + seed Kabsch, as k_seed_wide.
+// traceback (wave 0) + seed Kabsch (the ordered sums by the whole workgroup), as the first half of k_pair_wide.
 template <bool ZG>
 __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_seed_staged(const PairDesc* __restrict__ pairs,
                                                                      const double* __restrict__ coords, double sw_gap,
@@ -126,10 +144,39 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_seed_staged(const Pa
         if constexpr (ZG) sweep_cols_staged(strip, pd.n, pd.m, lds, dirs + pd.dirs_off, sm, geom);
         else sweep_staged<kSwTrace>(strip, pd.n, pd.m, prm, lds, dirs + pd.dirs_off, nullptr, sm, unused, geom);
     }
-    if (threadIdx.x >= kWave) return;                  // wave 0 goes on alone (wave_sync, no s_barrier from here on)
-    CR_STAMP(1);
+    // wave 0 walks (the others wait at the barrier); the position-ordered sums behind the walk are taken by everybody
+    __shared__ int s_walk[4];
+    uint32_t* const seed_list = reinterpret_cast<uint32_t*>(lds + kExpDoubles);
+    double* const terms = lds + kExpDoubles + ((size_t)max_entries + 3) / 4 * 2;
+    if (threadIdx.x < kWave) {
+        CR_STAMP(1);
+        int k, len;
+        uint32_t fl;
+        seed_walk<1, ZG ? 0 : 1>(pd, dirs, sm, seed_list, 0, k, len, fl);
+        if (threadIdx.x == 0) {
+            s_walk[0] = k;
+            s_walk[1] = len;
+            s_walk[2] = (int)fl;
+        }
+        CR_STAMP(2);
+    }
+    __syncthreads();
+    const int k = s_walk[0];
     Transform tr;
-    seed_trace<1, ZG ? 0 : 1>(pd, max_entries, coords, dirs, sm, lds + kExpDoubles, tr);
+#pragma unroll
+    for (int x = 0; x < 3; x++) tr.c1[x] = tr.c2[x] = 0.0;
+#pragma unroll
+    for (int x = 0; x < 9; x++) tr.R[x] = (x % 4 == 0) ? 1.0 : 0.0;
+    tr.flags = (uint32_t)s_walk[2];
+    tr.seed_len = s_walk[1];
+    if (k <= 3) {
+        tr.flags |= kFlagSeedSkipped;
+    } else {
+        double t[3];
+        const int cap = pd.n < pd.m ? pd.n : pd.m;
+        kabsch_team(coords + pd.off_i * 3, coords + pd.off_j * 3, seed_list + (cap - k), k, k, terms, terms + kSumTile * kMaxAcc + kSumSlack,
+                    tr.c1, tr.c2, tr.R, t);
+    }
     if (threadIdx.x == 0) {
         xf[blockIdx.x] = tr;
         seed_score[blockIdx.x] = sm.score;
@@ -137,7 +184,8 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_seed_staged(const Pa
     CR_STAMP(3);
 }
 
-// Node stage on staged scores: affine DTW fill with one wave per strip, then (wave 0) node_finish, as k_node_team.
+// Node stage on staged scores: affine DTW fill with one wave per strip, then the traceback (wave 0) and, by the whole
+// workgroup, what node_finish does behind it: the superposition on the aligned positions and the merged node.
 template <class Dummy = void>
 __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_node_staged_t(const PairDesc* __restrict__ pairs, const double* coords,
                                                                      const double* tensors, int d, const double* weights,
@@ -162,20 +210,166 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_node_staged_t(const 
         sweep_staged<kDtw>(staged + (int64_t)blockIdx.x * shape.pair_doubles() + (int64_t)w * shape.strip_doubles(), pd.n, pd.m,
                            prm, lds, nullptr, bits, unused, e, WidePlan<1>{0}.geom(w, pd.n));
     }
-    if (threadIdx.x >= kWave) return;                  // wave 0 goes on alone (wave_sync, no s_barrier from here on)
-    CR_STAMP(5);
-    node_finish<1>(pd, nd, xfs + blockIdx.x, e, coords, tensors, d, weights, max_entries, bits, aln_base + pd.aln_off, lds,
-                   Xn_base + nd.out_off * 3, Tn_base + nd.out_off * d, Wn_base + nd.out_off, outs + blockIdx.x);
+    // wave 0 walks; superposition sums and the merged node by the whole workgroup (node_finish with all hands)
+    __shared__ int s_walk[4];
+    uint32_t* const arow = reinterpret_cast<uint32_t*>(lds + kExpDoubles);
+    double* const terms = lds + kExpDoubles + ((size_t)max_entries + 3) / 4 * 2;
+    const int cap = pd.n + pd.m;
+    if (threadIdx.x < kWave) {
+        CR_STAMP(5);
+        int idx, k;
+        dtw_walk<1>(pd.n, pd.m, max_entries, bits, e.start_layer, lds + kExpDoubles, aln_base + pd.aln_off, idx, k);
+        if (threadIdx.x == 0) {
+            s_walk[0] = idx;
+            s_walk[1] = k;
+        }
+        CR_STAMP(6);
+    }
+    __syncthreads();
+    const int idx = s_walk[0], k = s_walk[1], first = cap - idx;
+    const uint32_t* ent = arow + first;
+    const double* X1 = coords + pd.off_i * 3;
+    const double* X2 = coords + pd.off_j * 3;
+    const double* T1 = tensors + pd.off_i * d;
+    const double* T2 = tensors + pd.off_j * d;
+    const double* W1 = weights + pd.off_i;
+    const double* W2 = weights + pd.off_j;
+    double* Xn = Xn_base + nd.out_off * 3;
+    double* Tn = Tn_base + nd.out_off * d;
+    double* Wn = Wn_base + nd.out_off;
+    uint32_t flags = xfs[blockIdx.x].flags;
+    double c1[3] = {0, 0, 0}, c2[3] = {0, 0, 0}, Rm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3];
+    const bool superpose = k > 3;                        // multiple_alignment.py:364
+    if (superpose) kabsch_team(X1, X2, ent, idx, k, terms, terms + kSumTile * kMaxAcc + kSumSlack, c1, c2, Rm, t);
+    else flags |= 8u;
+    // Protein.mean_function (:351-381) and get_mean_weights (:73-82), one alignment column per thread
+    for (int x = threadIdx.x; x < idx; x += blockDim.x) {
+        const uint32_t u = ent[x];
+        const uint32_t i = u & 0xffffu, j = u >> 16;
+        const bool has1 = i != kGap16, has2 = j != kGap16;
+        double a[3] = {0, 0, 0}, b[3] = {0, 0, 0};
+        if (has1)
+            for (int c = 0; c < 3; c++) a[c] = superpose ? X1[(int64_t)i * 3 + c] - c1[c] : X1[(int64_t)i * 3 + c];
+        if (has2) {
+            if (superpose) {
+                const double v[3] = {X2[(int64_t)j * 3] - c2[0], X2[(int64_t)j * 3 + 1] - c2[1], X2[(int64_t)j * 3 + 2] - c2[2]};
+                rot3(v, Rm, b);
+            } else {
+                for (int c = 0; c < 3; c++) b[c] = X2[(int64_t)j * 3 + c];
+            }
+        }
+        const int64_t o = first + x;
+        for (int c = 0; c < 3; c++) Xn[o * 3 + c] = !has1 ? b[c] : (!has2 ? a[c] : (a[c] + b[c]) / 2);
+        for (int c = 0; c < d; c++) {
+            const double ta = has1 ? T1[(int64_t)i * d + c] : 0.0, tb = has2 ? T2[(int64_t)j * d + c] : 0.0;
+            Tn[o * d + c] = !has1 ? tb : (!has2 ? ta : (ta + tb) / 2);
+        }
+        double wsum = 0.0;
+        if (has1) wsum += W1[i];
+        if (has2) wsum += W2[j];
+        Wn[o] = wsum;
+    }
+    if (threadIdx.x == 0) {
+        NodeOut no;
+        no.len = idx;
+        no.first = first;
+        no.flags = flags;
+        no.pad = 0;
+        outs[blockIdx.x] = no;
+    }
     CR_STAMP(7);
 }
 constexpr auto k_node_staged = k_node_staged_t<>;
+
+// Alignment stage of a pair on staged scores: SW score + affine DTW fill with one wave per strip, then the traceback (wave 0)
+// and Kabsch, RMSD / coverage / TM (the whole workgroup), as the second half of k_pair_wide.  SCORES (gap 0 only): the SW
+// score alone, as k_score_team.
+template <bool ZG, bool SCORES>
+__global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_align_staged(const PairDesc* __restrict__ pairs,
+                                                                      const double* __restrict__ coords,
+                                                                      const Transform* __restrict__ xf,
+                                                                      const double* __restrict__ seed_score, double sw_gap,
+                                                                      double gap_open, double gap_extend, int max_entries,
+                                                                      const double* __restrict__ staged, const StagedShape shape,
+                                                                      uint32_t* __restrict__ bits, int32_t* __restrict__ aln,
+                                                                      PairResult* __restrict__ res, const HostOut hout) {
+    extern __shared__ double lds[];
+    CR_STAMP(4);
+    const PairDesc pd = pairs[blockIdx.x];
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const double* strip = staged + (int64_t)blockIdx.x * shape.pair_doubles() + (int64_t)w * shape.strip_doubles();
+    const StripGeom geom = WidePlan<1>{0}.geom(w, pd.n);
+    SeedMax unused;
+    AlignEnd e;
+    SweepParams prm{sw_gap, gap_open, gap_extend};
+    if constexpr (SCORES) sweep_staged<kSwScore | kZeroGap>(strip, pd.n, pd.m, prm, lds, nullptr, nullptr, unused, e, geom);
+    else sweep_staged<kSwScore | kDtw | (ZG ? kZeroGap : 0)>(strip, pd.n, pd.m, prm, lds, nullptr, bits + pd.bt_off, unused, e, geom);
+    PairResult r;
+    r.sw = e.sw;
+    r.dtw_score = SCORES ? 0.0 : e.dtw_score;
+#pragma unroll
+    for (int x = 0; x < 9; x++) r.R[x] = 0.0;
+#pragma unroll
+    for (int x = 0; x < 3; x++) r.t[x] = 0.0;
+    r.rmsd = r.coverage = r.tm = 0.0;
+    r.aln_len = r.aln_start = 0;
+    r.flags = 0;
+    if constexpr (!SCORES) {
+        // wave 0 walks (the others wait at the barrier); Kabsch and the metrics by the whole workgroup, as k_pair_wide
+        __shared__ int s_walk[4];
+        uint32_t* const arow = reinterpret_cast<uint32_t*>(lds + kExpDoubles);
+        double* const terms = lds + kExpDoubles + ((size_t)max_entries + 3) / 4 * 2;
+        const int cap = pd.n + pd.m;
+        if (threadIdx.x < kWave) {
+            CR_STAMP(5);
+            int idx, k;
+            dtw_walk<1>(pd.n, pd.m, max_entries, bits + pd.bt_off, e.start_layer, lds + kExpDoubles, aln + pd.aln_off, idx, k);
+            stream_rows(hout, arow + (cap - idx), idx, (int)threadIdx.x);
+            if (threadIdx.x == 0) {
+                s_walk[0] = idx;
+                s_walk[1] = k;
+            }
+            CR_STAMP(6);
+        }
+        __syncthreads();
+        const int idx = s_walk[0], k = s_walk[1], first = cap - idx;
+        r.aln_len = idx;
+        r.aln_start = first;
+        if (k < 3) {
+            r.flags |= kFlagMetricsSkipped;
+        } else {
+            const double* Xi = coords + pd.off_i * 3;
+            const double* Xj = coords + pd.off_j * 3;
+            double c1[3], c2[3];
+            kabsch_team(Xi, Xj, arow + first, idx, k, terms, terms + kSumTile * kMaxAcc + kSumSlack, c1, c2, r.R, r.t);
+            rmsd_tm_team<true>(Xi, Xj, arow + first, idx, k, pd.n, pd.m, r.R, r.t, terms, terms + kSumTile * kMaxAcc + kSumSlack, r.rmsd, r.tm);
+            r.coverage = (double)k / (double)idx;
+        }
+    }
+    r.seed_score = seed_score[blockIdx.x];
+    r.seed_len = xf[blockIdx.x].seed_len;
+    r.flags |= xf[blockIdx.x].flags;
+    if (threadIdx.x == 0) {
+        res[blockIdx.x] = r;
+        if (!SCORES && hout.res) hout.res[hout.dst(blockIdx.x)] = r;
+    }
+    CR_STAMP(7);
+}
 
 }  // namespace cr
 
 #ifndef CR_KERNELS_TEMPLATES_ONLY      // the launchers (cr_api.hip)
 namespace {
 
-constexpr int kStageSteps = 16;            // steps of every strip per staging workgroup
+constexpr int kStageSteps = 16;            // steps of every strip per staging workgroup, at least
+
+// Steps per staging workgroup: 16 while that makes at most ~2 000 workgroups (a tree level, a handful of pairs: as many
+// CUs as possible), up to 64 for longer lists (every workgroup pays for its exp table, its rows and its column window
+// before it forms a score: 496 pairs of 150 staged in 37 us with 16 steps per workgroup)
+inline int stage_steps(int64_t count, int steps_total) {
+    const int64_t groups16 = count * ((steps_total + kStageSteps - 1) / kStageSteps);
+    return kStageSteps * (int)std::min<int64_t>(4, std::max<int64_t>(1, groups16 / 2048));
+}
 
 inline cr::StagedShape staged_shape(int n_bound, int m_bound) {
     cr::StagedShape s;
@@ -186,12 +380,13 @@ inline cr::StagedShape staged_shape(int n_bound, int m_bound) {
 
 template <int D>
 int launch_stage_tensor_d(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, double* staged, const cr::StagedShape shape) {
-    const size_t lds = sizeof(double) * cr::stage_lds_doubles(D, kStageSteps);
     const bool skew = prm.sw_gap != 0.0;                   // gap 0: the seed is a column sweep (k_seed_staged<true>)
-    const unsigned chunks = (unsigned)((ck.m_max + (skew ? cr::kWave - 1 : 0) + kStageSteps - 1) / kStageSteps);
+    const int steps = ck.m_max + (skew ? cr::kWave - 1 : 0), tc = stage_steps(ck.count, steps);
+    const size_t lds = sizeof(double) * cr::stage_lds_doubles(D, tc);
+    const unsigned chunks = (unsigned)((steps + tc - 1) / tc);
     auto go = [&](auto kernel) -> int {
-        CR_LAUNCH(kernel, dim3(chunks, (unsigned)ck.count), dim3(shape.waves * cr::kWave), lds, b->ctx->stream,
-                  b->pairs.p + ck.first, b->tensors.p, (int)b->d, prm.gamma_tensor, kStageSteps, staged, shape);
+        CR_LAUNCH(kernel, dim3(chunks, (unsigned)ck.count), dim3(shape.waves * cr::kWave), lds, b->launch_stream ? b->launch_stream : b->ctx->stream,
+                  b->pairs.p + ck.first, b->tensors.p, (int)b->d, prm.gamma_tensor, tc, staged, shape);
         CR_HIP(hipGetLastError());
         return CR_OK;
     };
@@ -213,11 +408,11 @@ int launch_stage_tensor(cr_batch* b, const cr_batch::Chunk& ck, const cr_params&
 int launch_seed_staged(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, const double* staged, const cr::StagedShape shape) {
     const int entries = std::min(ck.n_max, ck.m_max);
     const size_t fill = prm.sw_gap == 0.0 ? cr::sweep_cols_staged_lds_doubles(shape.waves) : cr::sweep_staged_lds_doubles<cr::kSwTrace>(shape.waves);
-    const size_t lds = sizeof(double) * std::max(fill, (size_t)cr::kExpDoubles + cr::trace_lds_doubles(1, entries));
+    const size_t lds = sizeof(double) * std::max(fill, (size_t)cr::kExpDoubles + cr::trace_team_lds_doubles(entries));
     auto go = [&](auto kernel) -> int {
         int rc = allow_lds(kernel, lds);
         if (rc) return rc;
-        CR_LAUNCH(kernel, dim3((unsigned)ck.count), dim3(shape.waves * cr::kWave), lds, b->ctx->stream, b->pairs.p + ck.first,
+        CR_LAUNCH(kernel, dim3((unsigned)ck.count), dim3(shape.waves * cr::kWave), lds, b->launch_stream ? b->launch_stream : b->ctx->stream, b->pairs.p + ck.first,
                   b->coords.p, prm.sw_gap, entries, staged, shape, b->dirs.p, b->xf.p + ck.first, b->seed_score.p + ck.first);
         CR_HIP(hipGetLastError());
         return CR_OK;
@@ -225,13 +420,46 @@ int launch_seed_staged(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& 
     return prm.sw_gap == 0.0 ? go(cr::k_seed_staged<true>) : go(cr::k_seed_staged<false>);
 }
 
+// the pair batch (cr_batch_run on a list short enough to be latency bound, cr_batch_set_pairs): coordinate scores in the
+// frame of the seed superposition, then the alignment stage (or, scores only with gap 0, the SW score alone)
+int launch_stage_coords(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, double* staged, const cr::StagedShape shape) {
+    const int steps = ck.m_max + cr::kWave - 1, tc = stage_steps(ck.count, steps);
+    const size_t lds = sizeof(double) * cr::stage_lds_doubles(cr::RbfCoords<1>::kColDoubles, tc);
+    const unsigned chunks = (unsigned)((steps + tc - 1) / tc);
+    CR_LAUNCH(cr::k_stage_coords, dim3(chunks, (unsigned)ck.count), dim3(shape.waves * cr::kWave), lds,
+              b->launch_stream ? b->launch_stream : b->ctx->stream, b->pairs.p + ck.first, b->coords.p, b->xf.p + ck.first,
+              prm.gamma_coords, tc, staged, shape);
+    CR_HIP(hipGetLastError());
+    return CR_OK;
+}
+
+int launch_align_staged(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, const double* staged, const cr::StagedShape shape,
+                        bool scores) {
+    const int entries = ck.max_aln;
+    const bool zg = prm.sw_gap == 0.0;
+    const size_t fill = scores ? cr::sweep_staged_lds_doubles<cr::kSwScore>(shape.waves) : cr::sweep_staged_lds_doubles<cr::kSwScore | cr::kDtw>(shape.waves);
+    const size_t lds = sizeof(double) * std::max(fill, scores ? (size_t)0 : (size_t)cr::kExpDoubles + cr::trace_team_lds_doubles(entries));
+    auto go = [&](auto kernel) -> int {
+        int rc = allow_lds(kernel, lds);
+        if (rc) return rc;
+        CR_LAUNCH(kernel, dim3((unsigned)ck.count), dim3(shape.waves * cr::kWave), lds, b->launch_stream ? b->launch_stream : b->ctx->stream,
+                  b->pairs.p + ck.first, b->coords.p, b->xf.p + ck.first, b->seed_score.p + ck.first, prm.sw_gap, prm.gap_open,
+                  prm.gap_extend, entries, staged, shape, b->bits.p, b->aln.p, b->res.p + ck.first, host_out_for(b, ck));
+        CR_HIP(hipGetLastError());
+        return CR_OK;
+    };
+    if (scores) return go(cr::k_align_staged<true, true>);
+    return zg ? go(cr::k_align_staged<true, false>) : go(cr::k_align_staged<false, false>);
+}
+
 int launch_stage_node(hipStream_t stream, int count, int m_max, const cr::PairDesc* pairs, const double* coords,
                       const double* weights, const cr::NodeDesc* nodes, const cr::Transform* xf, const cr_params& prm,
                       double gamma_weight, double* staged, const cr::StagedShape shape) {
-    const size_t lds = sizeof(double) * cr::stage_lds_doubles(cr::RbfNode<1>::kColDoubles, kStageSteps);
-    const unsigned chunks = (unsigned)((m_max + cr::kWave - 1 + kStageSteps - 1) / kStageSteps);
+    const int steps = m_max + cr::kWave - 1, tc = stage_steps(count, steps);
+    const size_t lds = sizeof(double) * cr::stage_lds_doubles(cr::RbfNode<1>::kColDoubles, tc);
+    const unsigned chunks = (unsigned)((steps + tc - 1) / tc);
     CR_LAUNCH(cr::k_stage_node, dim3(chunks, (unsigned)count), dim3(shape.waves * cr::kWave), lds, stream, pairs, coords, weights,
-              nodes, xf, prm.gamma_coords, gamma_weight, kStageSteps, staged, shape);
+              nodes, xf, prm.gamma_coords, gamma_weight, tc, staged, shape);
     CR_HIP(hipGetLastError());
     return CR_OK;
 }
@@ -241,7 +469,7 @@ int launch_node_staged(hipStream_t stream, int count, int entries, const cr::Pai
                        const cr_params& prm, const double* staged, const cr::StagedShape shape, uint32_t* bits, int32_t* aln,
                        double* xn, double* tn, double* wn, cr::NodeOut* out) {
     const size_t lds = sizeof(double) * std::max(cr::sweep_staged_lds_doubles<cr::kDtw>(shape.waves),
-                                                 (size_t)cr::kExpDoubles + cr::trace_lds_doubles(1, entries));
+                                                 (size_t)cr::kExpDoubles + cr::trace_team_lds_doubles(entries));
     int rc = allow_lds(cr::k_node_staged, lds);
     if (rc) return rc;
     CR_LAUNCH(cr::k_node_staged, dim3((unsigned)count), dim3(shape.waves * cr::kWave), lds, stream, pairs, coords, tensors, d,

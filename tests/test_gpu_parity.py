@@ -1263,6 +1263,46 @@ def test_wide_strip_plans_vs_oracle(ctx, oracle, monkeypatch):
         batch.close()
 
 
+@pytest.mark.parametrize("dim,seed", [(10, 8081), (4, 8082), (16, 8083)])
+def test_staged_pair_batches_vs_oracle_and_fused(ctx, oracle, monkeypatch, dim, seed):
+    """Short pair lists run on STAGED scores (cr_staged.h: the RBF scores formed by their own launches, the sweeps with one
+    row per lane).  Ragged lengths from 1 to 512 rows (1 .. 8 waves per pair, partial last strips, fewer columns than a
+    block), both orientations of every pair, with and without a Smith-Waterman gap (column sweep / skewed sweep of the
+    seed), full pipeline, scores only and the streamed run: bit-identical to the oracle and to the fused kernels
+    (CARETTA_STAGED=0: teams and wide layout)."""
+    from caretta_amd import engine
+    from oracle.pyoracle import default_params
+    fam = synthetic.make_family(8, 512, dim=dim, seed=seed, ragged=True, clades=2)
+    cuts = [512, 1, 449, 64, 65, 300, 7, 130]
+    for s, cut in zip(fam, cuts):
+        s.coordinates, s.tensors = s.coordinates[:cut].copy(), s.tensors[:cut].copy()
+    coords, tensors, offsets = synthetic.pack(fam)
+    pairs = np.vstack([engine.all_pairs(8), engine.all_pairs(8)[:, ::-1]])
+    for gap in (0.0, 0.05):
+        prm = engine.make_params(sw_gap=gap)
+        ref, ref_aln = oracle.pairwise_batch(coords, tensors, offsets, pairs, params=default_params(sw_gap=gap), nthreads=8)
+        got = {}
+        for staged in ("1", "0"):
+            monkeypatch.setenv("CARETTA_STAGED", staged)
+            batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
+            batch.run(prm)
+            res, aln = batch.fetch()
+            assert_bit_identical(res, aln, ref, ref_aln)
+            batch.run(prm, scores_only=True)
+            sw, flags = batch.fetch_scores()
+            assert np.array_equal(sw, ref["sw"])
+            res_s, aln_s = batch.run_streamed(prm)
+            ctx.synchronize()
+            assert res_s.tobytes() == res.tobytes()
+            for p in range(len(pairs)):
+                ln = int(res["aln_len"][p])
+                assert np.array_equal(aln_s[p, :, :ln], aln[p, :, :ln])
+            got[staged] = (res.tobytes(), aln.copy(), sw.copy(), flags.copy())
+            batch.close()
+        assert got["1"][0] == got["0"][0] and np.array_equal(got["1"][1], got["0"][1])
+        assert np.array_equal(got["1"][2], got["0"][2]) and np.array_equal(got["1"][3], got["0"][3])
+
+
 def test_wide_layout_at_the_lds_limit(ctx, oracle):
     """A pair list whose resident tensor columns (Smith-Waterman gap != 0: the skewed seed sweep keeps all m columns of
     width 16 in LDS) fill the CU's 160 KB to the last byte: the fused wide kernel's static LDS must still fit (found by
