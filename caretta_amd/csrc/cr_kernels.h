@@ -2916,6 +2916,7 @@ CR_D void node_body(const PairDesc* __restrict__ pairs, const double* coords,
                                                double* Xn_base, double* Tn_base, double* Wn_base,
                                                NodeOut* __restrict__ outs) {
     extern __shared__ double lds[];
+    CR_STAMP(4);
     const PairDesc pd = pairs[blockIdx.x];
     const NodeDesc nd = nodes[blockIdx.x];
     const Transform* xf = xfs + blockIdx.x;
@@ -2952,7 +2953,9 @@ CR_D void node_body(const PairDesc* __restrict__ pairs, const double* coords,
     } else {
         drain_stores();
     }
+    CR_STAMP(5);
     node_finish<R>(pd, nd, xf, e, coords, tensors, d, weights, max_entries, bits, aln, lds, Xn, Tn, Wn, out);
+    CR_STAMP(7);
 }
 
 // The part of a node behind its fill (one wave): DTW traceback, superposition on the aligned positions, the merged node.

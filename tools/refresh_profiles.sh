@@ -18,7 +18,10 @@ python tools/bench_msa.py 128 300 > $O/msa_128.txt 2>&1
 python tools/bench_msa.py 512 300 > $O/msa_512.txt 2>&1
 python tools/config5_share_time.py > $O/config5_share.txt 2>&1
 python tools/calibrate_wide.py c5share p120x900 p120x600 p105x1500 > $O/calibrate_wide.txt 2>&1
-python tools/stamps.py run c5share c2 one300 > $O/stamps.txt 2>&1
+python tools/stamps.py run c5share c2 one300 tree128 > $O/stamps.txt 2>&1
+CARETTA_STAGED=0 python tools/stamps.py run tree128 one300 > $O/stamps_fused.txt 2>&1
+python tools/calibrate_staged.py c2 c2half one300 p64x300 p120x450 > $O/calibrate_staged.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/msa_ktrace -o kt -- python3 tools/bench_msa.py 128 300 > $O/msa_ktrace.log 2>&1
 ./tools/valu_latency.bin > $O/valu_latency.txt 2>&1
 python tools/multi_gpu_check.py 512 300 2>/dev/null | grep '^{' > $O/multi_gpu_check_1device.json
 python tools/dropin_latency.py > $O/dropin_latency.txt 2>&1
