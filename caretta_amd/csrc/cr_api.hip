@@ -1061,7 +1061,9 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
         const cr::StagedShape shape = staged_shape(std::max(b->n_max, 1), std::max(b->m_max, 1));
         if (npairs > 0 && !g_no_wide && !(env && env[0] == '0') && !std::getenv("CARETTA_NO_TEAM") && !std::getenv("CARETTA_WIDE") &&
             !std::getenv("CARETTA_NO_WIDE") && b->n_max <= cr::kStagedMaxWaves * cr::kWave && npairs * strips1 <= wave_limit &&
-            (double)npairs * (double)shape.pair_doubles() * sizeof(double) <= 2.0 * 1024 * 1024 * 1024) {
+            (double)npairs * (double)shape.pair_doubles() * sizeof(double) <= 2.0 * 1024 * 1024 * 1024 &&
+            // (the alignment columns of a pair and the term tile of the workgroup-wide sums share the LDS)
+            sizeof(double) * ((size_t)cr::kExpDoubles + cr::trace_team_lds_doubles(b->n_max + b->m_max)) <= 159 * 1024) {
             b->staged = true;
             b->team = true;                                         // one group, one plan: the team kernels' layout rules
             b->wide_sync = 0;

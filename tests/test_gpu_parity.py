@@ -1303,6 +1303,23 @@ def test_staged_pair_batches_vs_oracle_and_fused(ctx, oracle, monkeypatch, dim, 
         assert np.array_equal(got["1"][2], got["0"][2]) and np.array_equal(got["1"][3], got["0"][3])
 
 
+def test_short_list_with_a_very_long_structure_leaves_the_staged_path(ctx, oracle):
+    """One pair of 64 x 22 000 residues: a single strip, so the list qualifies for staged scores -- but the workgroup-wide
+    sums of that path share the LDS with the n + m alignment columns, which do not fit beside the term tile; the fused
+    kernel (whose limit is n + m <= 39 000) has to take it.  Both orientations, bit-identical to the oracle."""
+    from caretta_amd import engine
+    a = synthetic.make_family(1, 64, seed=9091, clades=1)[0]
+    b = synthetic.make_family(1, 22000, seed=9092, clades=1)[0]
+    coords, tensors, offsets = synthetic.pack([a, b])
+    for pairs in (np.array([[0, 1]], dtype=np.int32), np.array([[1, 0]], dtype=np.int32)):
+        batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
+        batch.run(engine.make_params())
+        res, aln = batch.fetch()
+        batch.close()
+        ref, ref_aln = oracle.pairwise_batch(coords, tensors, offsets, pairs)
+        assert_bit_identical(res, aln, ref, ref_aln)
+
+
 def test_wide_layout_at_the_lds_limit(ctx, oracle):
     """A pair list whose resident tensor columns (Smith-Waterman gap != 0: the skewed seed sweep keeps all m columns of
     width 16 in LDS) fill the CU's 160 KB to the last byte: the fused wide kernel's static LDS must still fit (found by
