@@ -21,6 +21,8 @@ Besides `value` (device-resident rate, SURVEY.md 8(d) and the driver's contract)
                          at N=1 also `share_of_8`: one GPU's share of the 8-GPU split run on this GPU;
   matrix_only          : the P x P matrix entries alone (cr_batch_run_scores), what make_pairwise_matrix -> NJ consumes;
   nj_gate              : neighbor-joining bipartitions of the GPU matrix = those of the all-core oracle matrix (N=1);
+  msa                  : the consumers behind the matrix at N=1: neighbor joining and the progressive alignment of the guide
+                         tree (ms), every tree node replayed by the oracle (node_gate);
   roofline, cpu_baseline : as the contract asks (roofline.frac from SURVEY 8(d)'s algorithmic bytes).
 """
 from __future__ import annotations
@@ -432,6 +434,44 @@ def main():
                     rec.update(config_gate(orc, part.coords, part.tensors, part.offsets, part.pairs, full_scores, r_p, a_p, part.mine))
                 part.close()
             extras[f"{key}_sharded"] = rec
+
+    if rank == 0 and world == 1 and not args.no_extras and args.workload == "headline":
+        # ---------------------------------------------------------- the consumers behind the matrix (SURVEY 8f, rows f-1,
+        # a19): neighbor joining of max(M) - M and the progressive alignment of the guide tree, whole tree resident in HBM
+        from caretta_amd import multiple_alignment as ma, neighbor_joining as nj
+        fam = synthetic.make_family(num, length, dim=dim, seed=seed)
+        prots = [ma.Protein(s.name, s.tensors, s.coordinates, s.sequence) for s in fam]
+        msa = ma.MultipleAlignment(prots)
+        sp = dict(flexible=False, gamma_tensor=params.gamma_tensor, gamma_coords=params.gamma_coords, verbose=False)
+        t_nj = t_pa = float("inf")
+        for _ in range(3):
+            t0 = time.perf_counter()
+            tree, _bl = nj.neighbor_joining(matrix.max() - matrix)
+            t1 = time.perf_counter()
+            aligned = msa.progressive_align(tree, params.gap_open, params.gap_extend, 1.0, 1.0, sp, dict(flexible=False, verbose=False))
+            t2 = time.perf_counter()
+            t_nj, t_pa = min(t_nj, t1 - t0), min(t_pa, t2 - t1)
+        rec = {"structures": num, "residues": length, "neighbor_joining_ms": t_nj * 1e3, "progressive_alignment_ms": t_pa * 1e3,
+               "tree_levels": int(msa.node_table[:, 3].max()), "msa_width": int(len(next(iter(aligned.values())))),
+               "note": "MultipleAlignment.progressive_align on the tree of the headline matrix (cr_progressive_align: per tree "
+                       "level the RBF scores of all nodes by their own launches, SW / affine-DTW sweeps on them, node merge)"}
+        if gated:
+            # every join replayed by the oracle on the GPU's own child nodes: node coordinates, tensors, weights bit-identical
+            tr = np.asarray(tree).astype(np.int64)
+            joins = [(int(tr[x, 0]), int(tr[x + 1, 0])) for x in range(0, tr.shape[0] - 1, 2)] + [(int(tr[-1, 0]), int(tr[-1, 1]))]
+            sizes, bad = [1] * num, 0
+            for k, (n1, n2) in enumerate(joins):
+                tot = sizes[n1] + sizes[n2]
+                s1, s2 = msa.final_sequences[n1], msa.final_sequences[n2]
+                _a1, _a2, xn, tn, wn, _f = orc.progressive_node(s1.coordinates, s1.tensors, msa.final_consensus_weights[n1], s2.coordinates,
+                                                               s2.tensors, msa.final_consensus_weights[n2], sizes[n2] / (2 * tot), sizes[n1] / (2 * tot))
+                node = msa.final_sequences[num + k]
+                bad += int(not (np.array_equal(xn, node.coordinates) and np.array_equal(tn, node.tensors)
+                                and np.array_equal(wn, msa.final_consensus_weights[num + k])))
+                sizes.append(tot)
+            rec["node_gate"] = {"nodes": len(joins), "mismatches": bad, "what": "every tree node replayed by the C oracle on the GPU's "
+                                "own children: node coordinates, tensors and consensus weights bit-identical"}
+        extras["msa"] = rec
 
     if rank == 0 and world == 1 and not args.no_extras and engine.device_count() > 1:
         # several GPUs visible to this ONE process: the single-process multi-GPU path behind make_pairwise_matrix

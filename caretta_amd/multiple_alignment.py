@@ -421,7 +421,8 @@ class MultipleAlignment:
         nodes, alignments and attributes, computed level by level of the guide tree with everything resident in HBM."""
         lib = _capi.load()
         P = len(self.sequences)
-        coords, tensors, offsets = pack_proteins(self.sequences)
+        # (page-locked packing buffers: cr_progressive_align has uploaded them when it returns)
+        coords, tensors, offsets = pack_proteins(self.sequences, staging=True)
         d = tensors.shape[1]
         prm = make_params(gamma_tensor=score_function_params.get("gamma_tensor", 0.03),
                           gamma_coords=score_function_params.get("gamma_coords", 0.03),
