@@ -1679,10 +1679,10 @@ __host__ __device__ inline size_t sweep_wide_lds_doubles(int waves, int m_max) {
 // recurrence.
 // Layout of one strip (64 rows): element t * 64 + lane = S(row lane, column t - lane), t = 0 .. m + 62: the line a wave
 // needs at step t is one coalesced 512-byte read.  The loop runs in blocks of kStagedBlock = 16 steps, unrolled: the
-// block's 16 lines sit in registers, requested one block (16 steps: the scores are in L2 / MALL, 200 .. 900 cycles away)
-// ahead; shifts, word boundaries and the one barrier of a block are fixed at compile time.  The strips lag each other by
-// 80 steps (a multiple of the block, >= 63 + 16), so every wave's blocks are the workgroup's blocks.
-// The strip region has staged_steps(m_max) lines: the request one block past the last step stays inside it.
+// block's 16 lines sit in registers, requested TWO blocks ahead (the scores are in L2 / MALL, 200 .. 900 cycles away;
+// 48 lines in flight per wave); shifts, word boundaries and the one barrier of a block are fixed at compile time.  The
+// strips lag each other by 80 steps (a multiple of the block, >= 63 + 16), so every wave's blocks are the workgroup's
+// blocks.  The strip region has staged_steps(m_max) lines: the requests two blocks past the last step stay inside it.
 // LDS (doubles): NW + 1 hand-off rings of NB * kWideEdge | NW * 8 | NW dumps.  Decision words: as every other skewed sweep.
 // ---------------------------------------------------------------------------------------------
 constexpr int kStagedBlock = 16;
