@@ -1050,17 +1050,20 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     // 150) are bound by the instruction issue of lone waves, most of it the RBF scores: those are formed by their own
     // launches on every CU and the sweeps keep the recurrence, one row per lane (cr_staged.h).  Measured
     // (tools/calibrate_staged.py, full pipeline, fused -> staged): one pair of 300 0.382 -> 0.253 ms, 66 pairs of 300
-    // 0.395 -> 0.299, 248 pairs of 150 0.218 -> 0.191, 120 pairs of 450 0.614 -> 0.529; 496 pairs of 150 (1 488 strips for
-    // 1 024 SIMDs) 0.232 -> 0.275: hence at most kStagedWaveLimit strips.
+    // 0.395 -> 0.299, 248 pairs of 150 0.218 -> 0.191, 120 pairs of 450 0.614 -> 0.529; with two rows per lane (513 .. 1024
+    // rows, against the wide layout): 28 pairs of 1000 1.62 -> 1.11, 28 of 750 1.18 -> 0.78, 120 of 750 1.22 -> 1.05, 120 of
+    // 900 1.52 -> 1.41; 496 pairs of 150 (1 488 strips for 1 024 SIMDs) 0.232 -> 0.275: hence at most kStagedWaveLimit strips.
     b->staged = false;
     {
         const char* env = std::getenv("CARETTA_STAGED");
         int64_t wave_limit = kStagedWaveLimit;
         if (const char* lim = std::getenv("CARETTA_STAGED_WAVES")) wave_limit = std::atoll(lim);   // calibration
-        const int64_t strips1 = (b->n_max + cr::kWave - 1) / cr::kWave;
         const cr::StagedShape shape = staged_shape(std::max(b->n_max, 1), std::max(b->m_max, 1));
+        const int64_t strips1 = shape.waves;
+        int row_limit = cr::kStagedMaxRows;                        // one row per lane up to 512 rows, two up to 1024
+        if (const char* lim = std::getenv("CARETTA_STAGED_ROWS")) row_limit = std::min(std::atoi(lim), cr::kStagedMaxRows);   // calibration
         if (npairs > 0 && !g_no_wide && !(env && env[0] == '0') && !std::getenv("CARETTA_NO_TEAM") && !std::getenv("CARETTA_WIDE") &&
-            !std::getenv("CARETTA_NO_WIDE") && b->n_max <= cr::kStagedMaxWaves * cr::kWave && npairs * strips1 <= wave_limit &&
+            !std::getenv("CARETTA_NO_WIDE") && b->n_max <= row_limit && npairs * strips1 <= wave_limit &&
             (double)npairs * (double)shape.pair_doubles() * sizeof(double) <= 2.0 * 1024 * 1024 * 1024 &&
             // (the alignment columns of a pair and the term tile of the workgroup-wide sums share the LDS)
             sizeof(double) * ((size_t)cr::kExpDoubles + cr::trace_team_lds_doubles(b->n_max + b->m_max)) <= 159 * 1024) {
@@ -1068,7 +1071,7 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
             b->team = true;                                         // one group, one plan: the team kernels' layout rules
             b->wide_sync = 0;
             b->wide_na = 0;
-            b->r_seed = b->r_align = 1;
+            b->r_seed = b->r_align = shape.r;
         }
     }
     if (!b->wide_sync) b->r_b = b->r_seed;

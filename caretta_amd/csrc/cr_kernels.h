@@ -1670,7 +1670,7 @@ __host__ __device__ inline size_t sweep_wide_lds_doubles(int waves, int m_max) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// The wide sweep on scores that another launch has already formed (cr_staged.h), ONE row per lane.
+// The wide sweep on scores that another launch has already formed (cr_staged.h), ONE row per lane (two above 512 rows).
 //
 // When a launch has few workgroups -- a level of the progressive alignment, a short pair list -- the fused kernels are
 // bound by the instruction issue of the few waves that hold the recurrence, and 50 of a seed step's 59 instructions (30
@@ -1687,15 +1687,17 @@ __host__ __device__ inline size_t sweep_wide_lds_doubles(int waves, int m_max) {
 // ---------------------------------------------------------------------------------------------
 constexpr int kStagedBlock = 16;
 constexpr int kStagedLagBlocks = 5;
-constexpr int kStagedMaxWaves = 8;       // 512 rows: two blocks of score lines in registers need more than the 128 VGPRs of
-                                         // a 16-wave workgroup
+constexpr int kStagedMaxWaves = 8;       // the blocks of score lines in registers need more than the 128 VGPRs of a 16-wave
+                                         // workgroup: up to 512 rows with one row per lane, up to 1024 with two
+constexpr int kStagedMaxRows = kStagedMaxWaves * kWave * 2;
 CR_HD int staged_steps(int m_max) { return (m_max + kWave - 1 + kStagedBlock - 1) / kStagedBlock * kStagedBlock + 2 * kStagedBlock; }
 
-struct StagedScore {                               // what dp_column sees: the score of the lane's cell of this step
+template <int R>
+struct StagedScore {                               // what dp_column sees: the scores of the lane's cells of this step
     static constexpr bool kNonNegative = true;     // RBF scores (the staging kernels write what the RBF providers return)
     static constexpr bool kMaskRows = false;       // rows past n were staged as the exact zeros the RBF gives them
-    double v;
-    CR_D double score(int, const ExpEntry*) const { return v; }
+    double v[R];
+    CR_D double score(int q, const ExpEntry*) const { return v[q]; }
 };
 
 // The seed's Smith-Waterman with gap 0 on staged scores: the COLUMN sweep of sweep_cols_team (one step per column, the
@@ -1703,6 +1705,7 @@ struct StagedScore {                               // what dp_column sees: the s
 // read instead of formed.  Layout of a strip: element c * 64 + lane = S(row lane, column c) (not skewed).  A chunk's 8
 // lines sit in registers, requested two chunks ahead.  LDS (doubles): NW rings of 2 * kColChunk | NW * 4.
 // Decision words: the column sweeps' layout (Walker SKEW = 0).
+template <int R>
 CR_D void sweep_cols_staged(const double* __restrict__ strip, const int n, const int m, double* lds,
                             uint32_t* __restrict__ sw_dirs, SeedMax& seed_out, const StripGeom geom) {
     constexpr int C = kColChunk;
@@ -1715,21 +1718,29 @@ CR_D void sweep_cols_staged(const double* __restrict__ strip, const int n, const
     const int nstrips = geom.nstrips;                    // <= NW, guaranteed by the launcher
     const int TB = (m + 15) >> 4;
     const bool mine = w < nstrips;
-    const int rowbase = geom.rowbase0 + lane;
+    const int rowbase = geom.rowbase0 + lane * R;
     const bool hand_out = w + 1 < nstrips;
     const int chunks = (m + C - 1) / C;
     const int phases = chunks + nstrips - 1;
-    double hprev = 0.0, eprev = 0.0;
-    int rowfirst = 0;
-    uint32_t bits = 0;
-    const double* __restrict__ line = strip + lane;
-    double cur[C], nxt[C], nx2[C];
+    double hprev[R], eprev = 0.0;
+    int rowfirst[R];
+    uint32_t bits[R];
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+        hprev[q] = 0.0;
+        rowfirst[q] = 0;
+        bits[q] = 0;
+    }
+    const double* __restrict__ line = strip + lane;      // line c: R sub-lines of 64 doubles (row slot q, lane)
+    double cur[C][R], nxt[C][R], nx2[C][R];
     if (mine) {
 #pragma unroll
-        for (int k = 0; k < C; k++) {
-            nxt[k] = line[k * kWave];
-            nx2[k] = line[(C + k) * kWave];
-        }
+        for (int k = 0; k < C; k++)
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                nxt[k][q] = line[(k * R + q) * kWave];
+                nx2[k][q] = line[((C + k) * R + q) * kWave];
+            }
     }
     auto run = [&](auto top_tag) {
         constexpr bool TOP = decltype(top_tag)::value;
@@ -1738,13 +1749,15 @@ CR_D void sweep_cols_staged(const double* __restrict__ strip, const int n, const
             lds_barrier();                                 // the chunk written in phase g - 1 is visible to the strip below
             const int c = g - w;
             if (!mine || c < 0 || c >= chunks) continue;
-            const double* __restrict__ ahead = line + (int64_t)(c + 2) * (C * kWave);
+            const double* __restrict__ ahead = line + (int64_t)(c + 2) * (C * R * kWave);
 #pragma unroll
-            for (int k = 0; k < C; k++) {
-                cur[k] = nxt[k];
-                nxt[k] = nx2[k];
-                nx2[k] = ahead[k * kWave];
-            }
+            for (int k = 0; k < C; k++)
+#pragma unroll
+                for (int q = 0; q < R; q++) {
+                    cur[k][q] = nxt[k][q];
+                    nxt[k][q] = nx2[k][q];
+                    nx2[k][q] = ahead[(k * R + q) * kWave];
+                }
             double top_vec = 0.0;                          // the row above the strip for this chunk: lane x = column j0 + x
             if (TOP && lane < C) top_vec = ring_in[(c & 1) * C + lane];
             const int j0 = c * C;
@@ -1755,19 +1768,27 @@ CR_D void sweep_cols_staged(const double* __restrict__ strip, const int n, const
                     const int j = j0 + k;
                     if (ALL || j < m) {
                         // dynamic_time_warping.py:226-247 with gap 0, as ColSweep::step
-                        const double dg = eprev + cur[k];
-                        const double b = vmax(dg, hprev);
-                        double e = wave_shr1(wave_scan_max(b), 0.0);
+                        double dg[R], p[R];
+#pragma unroll
+                        for (int q = 0; q < R; q++) {
+                            dg[q] = (q == 0 ? eprev : hprev[q - 1]) + cur[k][q];
+                            const double b = vmax(dg[q], hprev[q]);
+                            p[q] = q == 0 ? b : vmax(p[q - 1], b);
+                        }
+                        double e = wave_shr1(wave_scan_max(p[R - 1]), 0.0);
                         if constexpr (TOP) e = vmax(e, lane_value(top_vec, k));
-                        const double h = vmax(b, e);
-                        const bool same = h == hprev;
-                        uint32_t code = (h == dg) ? 1u : same ? 2u : 3u;
-                        code = (h > 0.0) ? code : 0u;
-                        bits |= code << ((j & 15) * 2);
-                        rowfirst = same ? rowfirst : j;
-                        hprev = h;
+#pragma unroll
+                        for (int q = 0; q < R; q++) {
+                            const double h = vmax(p[q], e);
+                            const bool same = h == hprev[q];
+                            uint32_t code = (h == dg[q]) ? 1u : same ? 2u : 3u;
+                            code = (h > 0.0) ? code : 0u;
+                            bits[q] |= code << ((j & 15) * 2);
+                            rowfirst[q] = same ? rowfirst[q] : j;
+                            hprev[q] = h;
+                        }
                         eprev = e;
-                        if (hand_out && lane == kWave - 1) ring_out[(c & 1) * C + k] = h;
+                        if (hand_out && lane == kWave - 1) ring_out[(c & 1) * C + k] = hprev[R - 1];
                     }
                 });
             };
@@ -1775,8 +1796,12 @@ CR_D void sweep_cols_staged(const double* __restrict__ strip, const int n, const
             else columns(std::false_type{});
             const int jend = j0 + C < m ? j0 + C : m;
             if (((jend - 1) & 15) == 15 || jend == m) {    // a decision word holds 16 columns
-                sw_dirs[((int64_t)geom.slot0 * TB + (int64_t)((jend - 1) >> 4)) * kWave + lane] = bits;
-                bits = 0;
+                const int64_t base = ((int64_t)geom.slot0 * TB + (int64_t)((jend - 1) >> 4) * R) * kWave + lane;
+#pragma unroll
+                for (int q = 0; q < R; q++) {
+                    sw_dirs[base + q * kWave] = bits[q];
+                    bits[q] = 0;
+                }
             }
         }
     };
@@ -1785,10 +1810,14 @@ CR_D void sweep_cols_staged(const double* __restrict__ strip, const int n, const
 
     double best_v = 0.0;
     int best_i = 0x7fffffff, best_j = 0x7fffffff;
-    if (mine && hprev > 0.0) {                             // the row's maximum is its last value (non-decreasing rows)
-        best_v = hprev;
-        best_i = rowbase;
-        best_j = rowfirst;
+    if (mine) {                                            // a row's maximum is its last value (non-decreasing rows)
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const bool gt = hprev[q] > best_v;
+            best_v = gt ? hprev[q] : best_v;
+            best_i = gt ? rowbase + q : best_i;
+            best_j = gt ? rowfirst[q] : best_j;
+        }
     }
     wave_first_max(best_v, best_i, best_j);
     if (lane == 0) {
@@ -1818,7 +1847,7 @@ __host__ __device__ inline size_t sweep_cols_staged_lds_doubles(int waves) { ret
 
 constexpr int kStagedDump = 2 * kWideEdge + kStagedBlock;     // doubles per wave that take the hand-off writes of lanes 0 .. 62
 
-template <int MODE>
+template <int R, int MODE>
 CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int m, const SweepParams prm, double* lds,
                        uint32_t* __restrict__ sw_dirs, uint32_t* __restrict__ dtw_bits, SeedMax& seed_out,
                        AlignEnd& end_out, const StripGeom geom) {
@@ -1827,6 +1856,7 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
     constexpr bool DTW = (MODE & kDtw) != 0;
     constexpr int NB = (SW ? 1 : 0) + (DTW ? 2 : 0);
     constexpr int B = kStagedBlock;
+    constexpr bool FAR = R == 1;                          // score lines two blocks ahead (R = 2: one, the registers are taken)
     constexpr int PH = 0, PM0 = (NB - 2) * kWideEdge, PM1 = (NB - 1) * kWideEdge;   // planes of a ring
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1842,25 +1872,28 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
     const int TB_SW = tblocks(m, 16), TB_DTW = tblocks(m, 8);
     const double col0_m2 = kMinF64 - prm.gap_open;
     const bool mine = w < nstrips;
-    const int rowbase = geom.rowbase0 + lane;
+    const int rowbase = geom.rowbase0 + lane * R;
     const int rows_here = n - geom.rowbase0;
-    const int lanes_here = rows_here >= kWave ? kWave : rows_here;
+    const int lanes_here = rows_here >= kWave * R ? kWave : (rows_here + R - 1) / R;
     const int my_blocks = mine ? (m + lanes_here - 1 + B - 1) / B : 0;
     for (int x = threadIdx.x; x < NB * kWideEdge; x += blockDim.x) lds[x] = (DTW && x / kWideEdge == NB - 2) ? col0_m2 : 0.0;
 
-    DpState<1> st;
+    DpState<R> st;
     st.sw_max = 0.0;
     st.reset_column0(col0_m2);
-    st.swbits[0] = st.dtbits[0] = 0;
-    StagedScore src;
-    const double* __restrict__ line = strip + lane;
-    double cur[B], nxt[B], nx2[B];
+#pragma unroll
+    for (int q = 0; q < R; q++) st.swbits[q] = st.dtbits[q] = 0;
+    StagedScore<R> src;
+    const double* __restrict__ line = strip + lane;      // line t: R sub-lines of 64 doubles (row slot q, lane)
+    double cur[B][R], nxt[B][R], nx2[FAR ? B : 1][R];
     if (mine) {
 #pragma unroll
-        for (int k = 0; k < B; k++) {
-            nxt[k] = line[k * kWave];
-            nx2[k] = line[(B + k) * kWave];
-        }
+        for (int k = 0; k < B; k++)
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                nxt[k][q] = line[(k * R + q) * kWave];
+                if constexpr (FAR) nx2[k][q] = line[((B + k) * R + q) * kWave];
+            }
     }
     const int GB = kStagedLagBlocks * (nstrips - 1) + (m + kWave - 1 + B - 1) / B;
 #pragma unroll 1
@@ -1868,13 +1901,19 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
         lds_barrier();                                     // hand-off values of the last block visible to the next strip
         const int tb = gb - kStagedLagBlocks * w;
         if (tb < 0 || tb >= my_blocks) continue;
-        const double* __restrict__ ahead = line + (int64_t)(tb + 2) * (B * kWave);
+        const double* __restrict__ ahead = line + (int64_t)(tb + (FAR ? 2 : 1)) * (B * R * kWave);
 #pragma unroll
-        for (int k = 0; k < B; k++) {
-            cur[k] = nxt[k];
-            nxt[k] = nx2[k];
-            nx2[k] = ahead[k * kWave];
-        }
+        for (int k = 0; k < B; k++)
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                cur[k][q] = nxt[k][q];
+                if constexpr (FAR) {
+                    nxt[k][q] = nx2[k][q];
+                    nx2[k][q] = ahead[(k * R + q) * kWave];
+                } else {
+                    nxt[k][q] = ahead[(k * R + q) * kWave];
+                }
+            }
         // The row above the strip.  Lane 0's column at step t is t itself, written by the strip above at ITS step t + 63:
         // slot (t - 1) & 63.  Every lane reads it (one address: a broadcast) and hands it to the shift as lane 0's fill;
         // the read of step k + 1 is issued before the arithmetic of step k.
@@ -1905,18 +1944,19 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
                     }
                 }
                 double h_top = 0.0, m0_top = 0.0, m1_top = 0.0;
-                if constexpr (SW) h_top = wave_shr1(st.h_left[0], f_h);
+                if constexpr (SW) h_top = wave_shr1(st.h_left[R - 1], f_h);
                 if constexpr (DTW) {
-                    m0_top = wave_shr1(st.m0_left[0], f_m0);
-                    m1_top = wave_shr1(st.m1_left[0], f_m1);
+                    m0_top = wave_shr1(st.m0_left[R - 1], f_m0);
+                    m1_top = wave_shr1(st.m1_left[R - 1], f_m1);
                 }
                 if (active) {
-                    src.v = cur[k];
-                    dp_column<1, MODE>(src, st, prm, nullptr, c, rowbase, n, k * 2, (k & 7) * 4, h_top, m0_top, m1_top);
-                    if constexpr (SW) wr[PH + k] = st.h_left[0];
+#pragma unroll
+                    for (int q = 0; q < R; q++) src.v[q] = cur[k][q];
+                    dp_column<R, MODE>(src, st, prm, nullptr, c, rowbase, n, k * 2, (k & 7) * 4, h_top, m0_top, m1_top);
+                    if constexpr (SW) wr[PH + k] = st.h_left[R - 1];
                     if constexpr (DTW) {
-                        wr[PM0 + k] = st.m0_left[0];
-                        wr[PM1 + k] = st.m1_left[0];
+                        wr[PM0 + k] = st.m0_left[R - 1];
+                        wr[PM1 + k] = st.m1_left[R - 1];
                     }
                 }
                 f_h = g_h;
@@ -1924,8 +1964,12 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
                 f_m1 = g_m1;
                 if constexpr (DTW) {
                     if ((k & 7) == 7 && tb * 2 + (k >> 3) < TB_DTW) {
-                        dtw_bits[((int64_t)geom.slot0 * TB_DTW + tb * 2 + (k >> 3)) * kWave + lane] = st.dtbits[0];
-                        st.dtbits[0] = 0;
+                        const int64_t base = ((int64_t)geom.slot0 * TB_DTW + (int64_t)(tb * 2 + (k >> 3)) * R) * kWave + lane;
+#pragma unroll
+                        for (int q = 0; q < R; q++) {
+                            dtw_bits[base + q * kWave] = st.dtbits[q];
+                            st.dtbits[q] = 0;
+                        }
                     }
                 }
             });
@@ -1933,11 +1977,15 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
         if (tb * B >= kWave - 1 && tb * B + B - 1 < m) steps(std::true_type{});
         else steps(std::false_type{});
         if constexpr (TRACE) {
-            sw_dirs[((int64_t)geom.slot0 * TB_SW + tb) * kWave + lane] = st.swbits[0];
-            st.swbits[0] = 0;
+            const int64_t base = ((int64_t)geom.slot0 * TB_SW + (int64_t)tb * R) * kWave + lane;
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                sw_dirs[base + q * kWave] = st.swbits[q];
+                st.swbits[q] = 0;
+            }
         }
     }
-    wide_finish<1, MODE>(st, mine, w, lane, rowbase, geom, red, seed_out, end_out);
+    wide_finish<R, MODE>(st, mine, w, lane, rowbase, geom, red, seed_out, end_out);
 }
 
 template <int MODE>

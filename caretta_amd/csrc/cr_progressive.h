@@ -163,17 +163,17 @@ int run_tree_planned(cr_progressive* h, const std::vector<std::vector<int64_t>>&
     if (bound <= 3 * cr::kWave || longest > bound || std::getenv("CARETTA_NO_TEAM")) return 1;
     int64_t widest_level = 0;
     for (int64_t lv = 1; lv <= h->levels; lv++) widest_level = std::max<int64_t>(widest_level, (int64_t)by_level[(size_t)lv].size());
-    // Scores formed by their own launches (cr_staged.h) while one row per lane fits the 8 waves of its workgroups and the
-    // widest level's scores fit a tenth of the device memory; CARETTA_STAGED=0: the fused kernels
+    // Scores formed by their own launches (cr_staged.h) while one or two rows per lane fit the 8 waves of its workgroups
+    // (1024 rows) and the widest level's scores fit a tenth of the device memory; CARETTA_STAGED=0: the fused kernels
     const cr::StagedShape shape = staged_shape(bound, bound);
     const char* staged_env = std::getenv("CARETTA_STAGED");
-    bool staged = bound <= cr::kStagedMaxWaves * cr::kWave && widest_level <= 65535 && !(staged_env && staged_env[0] == '0');
+    bool staged = bound <= cr::kStagedMaxRows && widest_level <= 65535 && !(staged_env && staged_env[0] == '0');
     if (staged) {
         size_t free_b = 0, total_b = 0;
         CR_HIP(hipMemGetInfo(&free_b, &total_b));
         staged = (double)widest_level * (double)shape.pair_doubles() * sizeof(double) <= (double)total_b / 10.0;
     }
-    const int R = staged ? 1 : (bound + cr::kTeamWaves * cr::kWave - 1) / (cr::kTeamWaves * cr::kWave);
+    const int R = staged ? shape.r : (bound + cr::kTeamWaves * cr::kWave - 1) / (cr::kTeamWaves * cr::kWave);
 
     // static plan: every internal node in level order
     std::vector<cr::PlanNode> plan;

@@ -21,14 +21,15 @@ namespace cr {
 struct StagedShape {       // the same for every pair of a launch (sized for the launch's length bound)
     int waves;             // strips per pair
     int steps;             // score lines per strip: staged_steps(m bound)
-    CR_HD int64_t strip_doubles() const { return (int64_t)steps * kWave; }
-    CR_HD int64_t pair_doubles() const { return (int64_t)waves * steps * kWave; }
+    int r;                 // rows per lane: 1 up to 512 rows, 2 up to 1024 (a line is r sub-lines of 64 doubles)
+    CR_HD int64_t strip_doubles() const { return (int64_t)steps * r * kWave; }
+    CR_HD int64_t pair_doubles() const { return (int64_t)waves * strip_doubles(); }
 };
 
-// One workgroup = the steps [t0, t0 + tc) of every strip of one pair (wave w = strip w = rows 64 w ..).  SKEW: the layout of
+// One workgroup = the steps [t0, t0 + tc) of every strip of one pair (wave w = strip w = rows 64 R w ..; lane l: R rows).  SKEW: the layout of
 // sweep_staged -- line t holds column t - lane, the workgroup needs the columns [t0 - 63, t0 + tc), which go through LDS
 // once for all strips; otherwise the layout of sweep_cols_staged -- line t holds column t for every lane.
-template <bool SKEW, class Src>
+template <bool SKEW, int R, class Src>
 CR_D void stage_block(Src& src, const int n, const int m, const int tc, double* __restrict__ pair_base,
                       const StagedShape shape, double* lds) {
     constexpr int kBack = SKEW ? kWave - 1 : 0;
@@ -43,8 +44,8 @@ CR_D void stage_block(Src& src, const int n, const int m, const int tc, double* 
     double* res = lds + kExpDoubles;
     load_exp_table(lds, threadIdx.x);
     src.load_resident_range(res, stride, c_lo, c_hi, (int)threadIdx.x, (int)blockDim.x);
-    const bool mine = w * kWave < n;
-    if (mine) src.load_rows(w * kWave + lane, n);          // rows past n: the far-away features whose score is exactly 0
+    const bool mine = w * kWave * R < n;
+    if (mine) src.load_rows((w * kWave + lane) * R, n);    // rows past n: the far-away features whose score is exactly 0
     __syncthreads();
     if (!mine) return;
     double* __restrict__ out = pair_base + (int64_t)w * shape.strip_doubles() + lane;
@@ -53,7 +54,8 @@ CR_D void stage_block(Src& src, const int n, const int m, const int tc, double* 
         const int c = SKEW ? t - lane : t;
         if ((unsigned)c < (unsigned)m) {
             src.fetch_resident(res, stride, c - c_lo);
-            out[(int64_t)t * kWave] = src.score(0, tab);
+#pragma unroll
+            for (int q = 0; q < R; q++) out[((int64_t)t * R + q) * kWave] = src.score(q, tab);
         }
     }
 }
@@ -63,24 +65,24 @@ __host__ __device__ inline size_t stage_lds_doubles(int col_doubles, int tc) {
 }
 
 // tensor RBF of a pair's two structures / a node's two children (multiple_alignment.py:328-335)
-template <int D, bool SKEW>
+template <int D, bool SKEW, int R>
 __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_stage_tensor(const PairDesc* __restrict__ pairs,
                                                                       const double* __restrict__ tensors, int d,
                                                                       double gamma, int tc, double* __restrict__ staged,
                                                                       const StagedShape shape) {
     extern __shared__ double lds[];
     const PairDesc pd = pairs[blockIdx.y];
-    RbfTensor<1, D> src;
+    RbfTensor<R, D> src;
     src.rows_g = tensors + pd.off_i * d;
     src.cols_g = tensors + pd.off_j * d;
     src.d = d;
     src.neg_gamma = -gamma;
-    stage_block<SKEW>(src, pd.n, pd.m, tc, staged + (int64_t)blockIdx.y * shape.pair_doubles(), shape, lds);
+    stage_block<SKEW, R>(src, pd.n, pd.m, tc, staged + (int64_t)blockIdx.y * shape.pair_doubles(), shape, lds);
 }
 
 // node score of the progressive alignment (multiple_alignment.py:204-210) in the frame of the node's seed superposition
-template <class Dummy = void>
-__global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_stage_node_t(const PairDesc* __restrict__ pairs,
+template <int R>
+__global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_stage_node(const PairDesc* __restrict__ pairs,
                                                                       const double* __restrict__ coords,
                                                                       const double* __restrict__ weights,
                                                                       const NodeDesc* __restrict__ nodes,
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_stage_node_t(const P
     extern __shared__ double lds[];
     const PairDesc pd = pairs[blockIdx.y];
     const NodeDesc nd = nodes[blockIdx.y];
-    RbfNode<1> src;
+    RbfNode<R> src;
     src.xyz.rows_g = coords + pd.off_i * 3;
     src.xyz.cols_g = coords + pd.off_j * 3;
     src.xyz.xf = xfs + blockIdx.y;
@@ -100,31 +102,29 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_stage_node_t(const P
     src.mult1 = nd.mult1;
     src.mult2 = nd.mult2;
     src.neg_gamma_w = -gamma_weight;
-    stage_block<true>(src, pd.n, pd.m, tc, staged + (int64_t)blockIdx.y * shape.pair_doubles(), shape, lds);
+    stage_block<true, R>(src, pd.n, pd.m, tc, staged + (int64_t)blockIdx.y * shape.pair_doubles(), shape, lds);
 }
-constexpr auto k_stage_node = k_stage_node_t<>;
 
 // coordinate RBF of a pair in the frame of its seed superposition (multiple_alignment.py:158-170, Protein.score_function)
-template <class Dummy = void>
-__global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_stage_coords_t(const PairDesc* __restrict__ pairs,
+template <int R>
+__global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_stage_coords(const PairDesc* __restrict__ pairs,
                                                                         const double* __restrict__ coords,
                                                                         const Transform* __restrict__ xfs, double gamma,
                                                                         int tc, double* __restrict__ staged,
                                                                         const StagedShape shape) {
     extern __shared__ double lds[];
     const PairDesc pd = pairs[blockIdx.y];
-    RbfCoords<1> src;
+    RbfCoords<R> src;
     src.rows_g = coords + pd.off_i * 3;
     src.cols_g = coords + pd.off_j * 3;
     src.xf = xfs + blockIdx.y;
     src.neg_gamma = -gamma;
-    stage_block<true>(src, pd.n, pd.m, tc, staged + (int64_t)blockIdx.y * shape.pair_doubles(), shape, lds);
+    stage_block<true, R>(src, pd.n, pd.m, tc, staged + (int64_t)blockIdx.y * shape.pair_doubles(), shape, lds);
 }
-constexpr auto k_stage_coords = k_stage_coords_t<>;
 
 // Seed stage on staged scores: SW fill with one wave per strip (gap 0: the column sweep on the unskewed layout), then
 // traceback (wave 0) + seed Kabsch (the ordered sums by the whole workgroup), as the first half of k_pair_wide.
-template <bool ZG>
+template <bool ZG, int R>
 __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_seed_staged(const PairDesc* __restrict__ pairs,
                                                                      const double* __restrict__ coords, double sw_gap,
                                                                      int max_entries, const double* __restrict__ staged,
@@ -139,10 +139,10 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_seed_staged(const Pa
     AlignEnd unused;
     {
         const double* strip = staged + (int64_t)blockIdx.x * shape.pair_doubles() + (int64_t)w * shape.strip_doubles();
-        const StripGeom geom = WidePlan<1>{0}.geom(w, pd.n);
+        const StripGeom geom = WidePlan<R>{0}.geom(w, pd.n);
         SweepParams prm{sw_gap, 0.0, 0.0};
-        if constexpr (ZG) sweep_cols_staged(strip, pd.n, pd.m, lds, dirs + pd.dirs_off, sm, geom);
-        else sweep_staged<kSwTrace>(strip, pd.n, pd.m, prm, lds, dirs + pd.dirs_off, nullptr, sm, unused, geom);
+        if constexpr (ZG) sweep_cols_staged<R>(strip, pd.n, pd.m, lds, dirs + pd.dirs_off, sm, geom);
+        else sweep_staged<R, kSwTrace>(strip, pd.n, pd.m, prm, lds, dirs + pd.dirs_off, nullptr, sm, unused, geom);
     }
     // wave 0 walks (the others wait at the barrier); the position-ordered sums behind the walk are taken by everybody
     __shared__ int s_walk[4];
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_seed_staged(const Pa
         CR_STAMP(1);
         int k, len;
         uint32_t fl;
-        seed_walk<1, ZG ? 0 : 1>(pd, dirs, sm, seed_list, 0, k, len, fl);
+        seed_walk<R, ZG ? 0 : 1>(pd, dirs, sm, seed_list, 0, k, len, fl);
         if (threadIdx.x == 0) {
             s_walk[0] = k;
             s_walk[1] = len;
@@ -186,8 +186,8 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_seed_staged(const Pa
 
 // Node stage on staged scores: affine DTW fill with one wave per strip, then the traceback (wave 0) and, by the whole
 // workgroup, what node_finish does behind it: the superposition on the aligned positions and the merged node.
-template <class Dummy = void>
-__global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_node_staged_t(const PairDesc* __restrict__ pairs, const double* coords,
+template <int R>
+__global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_node_staged(const PairDesc* __restrict__ pairs, const double* coords,
                                                                      const double* tensors, int d, const double* weights,
                                                                      const NodeDesc* __restrict__ nodes,
                                                                      const Transform* __restrict__ xfs, double gap_open,
@@ -207,8 +207,8 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_node_staged_t(const 
     AlignEnd e;
     {
         SweepParams prm{0.0, gap_open, gap_extend};
-        sweep_staged<kDtw>(staged + (int64_t)blockIdx.x * shape.pair_doubles() + (int64_t)w * shape.strip_doubles(), pd.n, pd.m,
-                           prm, lds, nullptr, bits, unused, e, WidePlan<1>{0}.geom(w, pd.n));
+        sweep_staged<R, kDtw>(staged + (int64_t)blockIdx.x * shape.pair_doubles() + (int64_t)w * shape.strip_doubles(), pd.n, pd.m,
+                              prm, lds, nullptr, bits, unused, e, WidePlan<R>{0}.geom(w, pd.n));
     }
     // wave 0 walks; superposition sums and the merged node by the whole workgroup (node_finish with all hands)
     __shared__ int s_walk[4];
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_node_staged_t(const 
     if (threadIdx.x < kWave) {
         CR_STAMP(5);
         int idx, k;
-        dtw_walk<1>(pd.n, pd.m, max_entries, bits, e.start_layer, lds + kExpDoubles, aln_base + pd.aln_off, idx, k);
+        dtw_walk<R>(pd.n, pd.m, max_entries, bits, e.start_layer, lds + kExpDoubles, aln_base + pd.aln_off, idx, k);
         if (threadIdx.x == 0) {
             s_walk[0] = idx;
             s_walk[1] = k;
@@ -279,12 +279,11 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_node_staged_t(const 
     }
     CR_STAMP(7);
 }
-constexpr auto k_node_staged = k_node_staged_t<>;
 
 // Alignment stage of a pair on staged scores: SW score + affine DTW fill with one wave per strip, then the traceback (wave 0)
 // and Kabsch, RMSD / coverage / TM (the whole workgroup), as the second half of k_pair_wide.  SCORES (gap 0 only): the SW
 // score alone, as k_score_team.
-template <bool ZG, bool SCORES>
+template <bool ZG, bool SCORES, int R>
 __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_align_staged(const PairDesc* __restrict__ pairs,
                                                                       const double* __restrict__ coords,
                                                                       const Transform* __restrict__ xf,
@@ -298,12 +297,12 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_align_staged(const P
     const PairDesc pd = pairs[blockIdx.x];
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const double* strip = staged + (int64_t)blockIdx.x * shape.pair_doubles() + (int64_t)w * shape.strip_doubles();
-    const StripGeom geom = WidePlan<1>{0}.geom(w, pd.n);
+    const StripGeom geom = WidePlan<R>{0}.geom(w, pd.n);
     SeedMax unused;
     AlignEnd e;
     SweepParams prm{sw_gap, gap_open, gap_extend};
-    if constexpr (SCORES) sweep_staged<kSwScore | kZeroGap>(strip, pd.n, pd.m, prm, lds, nullptr, nullptr, unused, e, geom);
-    else sweep_staged<kSwScore | kDtw | (ZG ? kZeroGap : 0)>(strip, pd.n, pd.m, prm, lds, nullptr, bits + pd.bt_off, unused, e, geom);
+    if constexpr (SCORES) sweep_staged<R, kSwScore | kZeroGap>(strip, pd.n, pd.m, prm, lds, nullptr, nullptr, unused, e, geom);
+    else sweep_staged<R, kSwScore | kDtw | (ZG ? kZeroGap : 0)>(strip, pd.n, pd.m, prm, lds, nullptr, bits + pd.bt_off, unused, e, geom);
     PairResult r;
     r.sw = e.sw;
     r.dtw_score = SCORES ? 0.0 : e.dtw_score;
@@ -323,7 +322,7 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_align_staged(const P
         if (threadIdx.x < kWave) {
             CR_STAMP(5);
             int idx, k;
-            dtw_walk<1>(pd.n, pd.m, max_entries, bits + pd.bt_off, e.start_layer, lds + kExpDoubles, aln + pd.aln_off, idx, k);
+            dtw_walk<R>(pd.n, pd.m, max_entries, bits + pd.bt_off, e.start_layer, lds + kExpDoubles, aln + pd.aln_off, idx, k);
             stream_rows(hout, arow + (cap - idx), idx, (int)threadIdx.x);
             if (threadIdx.x == 0) {
                 s_walk[0] = idx;
@@ -373,10 +372,12 @@ inline int stage_steps(int64_t count, int steps_total) {
 
 inline cr::StagedShape staged_shape(int n_bound, int m_bound) {
     cr::StagedShape s;
-    s.waves = (n_bound + cr::kWave - 1) / cr::kWave;
+    s.r = n_bound <= cr::kStagedMaxWaves * cr::kWave ? 1 : 2;
+    s.waves = (n_bound + cr::kWave * s.r - 1) / (cr::kWave * s.r);
     s.steps = cr::staged_steps(m_bound);
     return s;
 }
+
 
 template <int D>
 int launch_stage_tensor_d(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, double* staged, const cr::StagedShape shape) {
@@ -390,7 +391,8 @@ int launch_stage_tensor_d(cr_batch* b, const cr_batch::Chunk& ck, const cr_param
         CR_HIP(hipGetLastError());
         return CR_OK;
     };
-    return skew ? go(cr::k_stage_tensor<D, true>) : go(cr::k_stage_tensor<D, false>);
+    if (shape.r == 1) return skew ? go(cr::k_stage_tensor<D, true, 1>) : go(cr::k_stage_tensor<D, false, 1>);
+    return skew ? go(cr::k_stage_tensor<D, true, 2>) : go(cr::k_stage_tensor<D, false, 2>);
 }
 
 int launch_stage_tensor(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, double* staged, const cr::StagedShape shape) {
@@ -417,7 +419,8 @@ int launch_seed_staged(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& 
         CR_HIP(hipGetLastError());
         return CR_OK;
     };
-    return prm.sw_gap == 0.0 ? go(cr::k_seed_staged<true>) : go(cr::k_seed_staged<false>);
+    if (shape.r == 1) return prm.sw_gap == 0.0 ? go(cr::k_seed_staged<true, 1>) : go(cr::k_seed_staged<false, 1>);
+    return prm.sw_gap == 0.0 ? go(cr::k_seed_staged<true, 2>) : go(cr::k_seed_staged<false, 2>);
 }
 
 // the pair batch (cr_batch_run on a list short enough to be latency bound, cr_batch_set_pairs): coordinate scores in the
@@ -426,11 +429,14 @@ int launch_stage_coords(cr_batch* b, const cr_batch::Chunk& ck, const cr_params&
     const int steps = ck.m_max + cr::kWave - 1, tc = stage_steps(ck.count, steps);
     const size_t lds = sizeof(double) * cr::stage_lds_doubles(cr::RbfCoords<1>::kColDoubles, tc);
     const unsigned chunks = (unsigned)((steps + tc - 1) / tc);
-    CR_LAUNCH(cr::k_stage_coords, dim3(chunks, (unsigned)ck.count), dim3(shape.waves * cr::kWave), lds,
-              b->launch_stream ? b->launch_stream : b->ctx->stream, b->pairs.p + ck.first, b->coords.p, b->xf.p + ck.first,
-              prm.gamma_coords, tc, staged, shape);
-    CR_HIP(hipGetLastError());
-    return CR_OK;
+    auto go = [&](auto kernel) -> int {
+        CR_LAUNCH(kernel, dim3(chunks, (unsigned)ck.count), dim3(shape.waves * cr::kWave), lds,
+                  b->launch_stream ? b->launch_stream : b->ctx->stream, b->pairs.p + ck.first, b->coords.p, b->xf.p + ck.first,
+                  prm.gamma_coords, tc, staged, shape);
+        CR_HIP(hipGetLastError());
+        return CR_OK;
+    };
+    return shape.r == 1 ? go(cr::k_stage_coords<1>) : go(cr::k_stage_coords<2>);
 }
 
 int launch_align_staged(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, const double* staged, const cr::StagedShape shape,
@@ -448,8 +454,12 @@ int launch_align_staged(cr_batch* b, const cr_batch::Chunk& ck, const cr_params&
         CR_HIP(hipGetLastError());
         return CR_OK;
     };
-    if (scores) return go(cr::k_align_staged<true, true>);
-    return zg ? go(cr::k_align_staged<true, false>) : go(cr::k_align_staged<false, false>);
+    if (shape.r == 1) {
+        if (scores) return go(cr::k_align_staged<true, true, 1>);
+        return zg ? go(cr::k_align_staged<true, false, 1>) : go(cr::k_align_staged<false, false, 1>);
+    }
+    if (scores) return go(cr::k_align_staged<true, true, 2>);
+    return zg ? go(cr::k_align_staged<true, false, 2>) : go(cr::k_align_staged<false, false, 2>);
 }
 
 int launch_stage_node(hipStream_t stream, int count, int m_max, const cr::PairDesc* pairs, const double* coords,
@@ -458,10 +468,13 @@ int launch_stage_node(hipStream_t stream, int count, int m_max, const cr::PairDe
     const int steps = m_max + cr::kWave - 1, tc = stage_steps(count, steps);
     const size_t lds = sizeof(double) * cr::stage_lds_doubles(cr::RbfNode<1>::kColDoubles, tc);
     const unsigned chunks = (unsigned)((steps + tc - 1) / tc);
-    CR_LAUNCH(cr::k_stage_node, dim3(chunks, (unsigned)count), dim3(shape.waves * cr::kWave), lds, stream, pairs, coords, weights,
-              nodes, xf, prm.gamma_coords, gamma_weight, tc, staged, shape);
-    CR_HIP(hipGetLastError());
-    return CR_OK;
+    auto go = [&](auto kernel) -> int {
+        CR_LAUNCH(kernel, dim3(chunks, (unsigned)count), dim3(shape.waves * cr::kWave), lds, stream, pairs, coords, weights, nodes, xf,
+                  prm.gamma_coords, gamma_weight, tc, staged, shape);
+        CR_HIP(hipGetLastError());
+        return CR_OK;
+    };
+    return shape.r == 1 ? go(cr::k_stage_node<1>) : go(cr::k_stage_node<2>);
 }
 
 int launch_node_staged(hipStream_t stream, int count, int entries, const cr::PairDesc* pairs, const double* coords,
@@ -470,12 +483,15 @@ int launch_node_staged(hipStream_t stream, int count, int entries, const cr::Pai
                        double* xn, double* tn, double* wn, cr::NodeOut* out) {
     const size_t lds = sizeof(double) * std::max(cr::sweep_staged_lds_doubles<cr::kDtw>(shape.waves),
                                                  (size_t)cr::kExpDoubles + cr::trace_team_lds_doubles(entries));
-    int rc = allow_lds(cr::k_node_staged, lds);
-    if (rc) return rc;
-    CR_LAUNCH(cr::k_node_staged, dim3((unsigned)count), dim3(shape.waves * cr::kWave), lds, stream, pairs, coords, tensors, d,
-              weights, nodes, xf, prm.gap_open, prm.gap_extend, entries, staged, shape, bits, aln, xn, tn, wn, out);
-    CR_HIP(hipGetLastError());
-    return CR_OK;
+    auto go = [&](auto kernel) -> int {
+        int rc = allow_lds(kernel, lds);
+        if (rc) return rc;
+        CR_LAUNCH(kernel, dim3((unsigned)count), dim3(shape.waves * cr::kWave), lds, stream, pairs, coords, tensors, d, weights, nodes,
+                  xf, prm.gap_open, prm.gap_extend, entries, staged, shape, bits, aln, xn, tn, wn, out);
+        CR_HIP(hipGetLastError());
+        return CR_OK;
+    };
+    return shape.r == 1 ? go(cr::k_node_staged<1>) : go(cr::k_node_staged<2>);
 }
 
 }  // namespace

@@ -786,11 +786,13 @@ def test_progressive_resident_vs_oracle_and_single_node(oracle, num, length, rag
     assert np.array_equal(np.array([aln[q] for q in order]), rows[-1])
 
 
-@pytest.mark.parametrize("num,length,ragged,seed", [(12, 300, False, 21), (5, 335, False, 22), (7, 200, True, 23), (9, 140, True, 24)])
+@pytest.mark.parametrize("num,length,ragged,seed", [(12, 300, False, 21), (5, 335, False, 22), (7, 200, True, 23), (9, 140, True, 24),
+                                                    (5, 600, True, 25), (3, 675, False, 26), (4, 400, False, 27)])
 def test_progressive_staged_scores_equal_fused(oracle, monkeypatch, num, length, ragged, seed):
     """The tree levels whose scores are formed by their own launches (cr_staged.h) against the fused kernels
     (CARETTA_STAGED=0): alignments, node coordinates / tensors / weights and flags bit for bit; 335-residue leaves size the
-    launches for 511 rows (all 8 waves of the staged sweep), ragged 140-residue ones for 218 (4 waves, most nodes fewer).
+    launches for 511 rows (all 8 waves of the staged sweep with one row per lane), ragged 140-residue ones for 218 (4 waves,
+    most nodes fewer); 400 / 600 / 675-residue leaves for 608 / 908 / 1021 rows: TWO rows per lane, 5 / 8 / 8 waves.
     The root join also against the oracle."""
     from caretta_amd import multiple_alignment as ma, neighbor_joining as nj
     fam = synthetic.make_family(num, length, seed=seed, ragged=ragged, clades=2)
@@ -1206,12 +1208,13 @@ def test_single_process_multi_device_path_equals_the_batch(ctx):
 def test_streamed_run_writes_what_fetch_copies(ctx):
     """cr_batch_run_stream_i32: the alignment kernels store rows and records straight into page-locked host arrays.  Same
     bytes as cr_batch_fetch_i32 afterwards, for every kernel family: one wave per pair (ragged: launch order differs from
-    the caller's), the four-wave teams, the wide layout; pageable arrays are refused."""
+    the caller's), the staged sweeps (one and two rows per lane), the wide layout; pageable arrays are refused."""
     from caretta_amd import _capi, engine
     cases = [(synthetic.make_family(12, 90, seed=5051, ragged=True, clades=2), None),
              (synthetic.make_family(20, 150, seed=5052), None),
              (synthetic.make_family(4, 300, seed=5053, clades=1), None),               # 6 pairs of 300 rows: teams
-             (synthetic.make_family(3, 700, seed=5054, clades=1), None)]               # 700 rows: wide kernels
+             (synthetic.make_family(3, 700, seed=5054, clades=1), None),               # 700 rows: staged, two rows per lane
+             (synthetic.make_family(3, 1100, seed=5055, clades=1), None)]              # 1100 rows: wide kernels
     for fam, _ in cases:
         coords, tensors, offsets = synthetic.pack(fam)
         pairs = engine.all_pairs(len(fam))
@@ -1303,6 +1306,29 @@ def test_staged_pair_batches_vs_oracle_and_fused(ctx, oracle, monkeypatch, dim, 
         assert np.array_equal(got["1"][2], got["0"][2]) and np.array_equal(got["1"][3], got["0"][3])
 
 
+def test_staged_pair_batches_two_rows_per_lane(ctx, oracle, monkeypatch):
+    """The staged sweeps with TWO rows per lane (513 .. 1024 rows): ragged pairs of 513 .. 1024 rows, both orientations,
+    gap 0 and 0.05, full pipeline and scores only, bit-identical to the oracle."""
+    from caretta_amd import engine
+    from oracle.pyoracle import default_params
+    fam = synthetic.make_family(4, 1024, seed=8181, ragged=True, clades=1)
+    for s, cut in zip(fam, [1024, 513, 700, 90]):
+        s.coordinates, s.tensors = s.coordinates[:cut].copy(), s.tensors[:cut].copy()
+    coords, tensors, offsets = synthetic.pack(fam)
+    pairs = np.vstack([engine.all_pairs(4), engine.all_pairs(4)[:, ::-1]])
+    for gap in (0.0, 0.05):
+        prm = engine.make_params(sw_gap=gap)
+        ref, ref_aln = oracle.pairwise_batch(coords, tensors, offsets, pairs, params=default_params(sw_gap=gap), nthreads=8)
+        batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
+        batch.run(prm)
+        res, aln = batch.fetch()
+        assert_bit_identical(res, aln, ref, ref_aln)
+        batch.run(prm, scores_only=True)
+        sw, flags = batch.fetch_scores()
+        assert np.array_equal(sw, ref["sw"])
+        batch.close()
+
+
 def test_short_list_with_a_very_long_structure_leaves_the_staged_path(ctx, oracle):
     """One pair of 64 x 22 000 residues: a single strip, so the list qualifies for staged scores -- but the workgroup-wide
     sums of that path share the LDS with the n + m alignment columns, which do not fit beside the term tile; the fused
@@ -1320,12 +1346,14 @@ def test_short_list_with_a_very_long_structure_leaves_the_staged_path(ctx, oracl
         assert_bit_identical(res, aln, ref, ref_aln)
 
 
-def test_wide_layout_at_the_lds_limit(ctx, oracle):
+def test_wide_layout_at_the_lds_limit(ctx, oracle, monkeypatch):
     """A pair list whose resident tensor columns (Smith-Waterman gap != 0: the skewed seed sweep keeps all m columns of
     width 16 in LDS) fill the CU's 160 KB to the last byte: the fused wide kernel's static LDS must still fit (found by
-    tests/fuzz_parity.py), results bit-identical to the oracle."""
+    tests/fuzz_parity.py), results bit-identical to the oracle.  (CARETTA_STAGED=0: one pair of 500 rows would otherwise run
+    on staged scores.)"""
     from caretta_amd import engine
     from oracle.pyoracle import default_params
+    monkeypatch.setenv("CARETTA_STAGED", "0")
     for m in (1245, 1246, 1247, 1260):
         a = synthetic.make_family(1, 500, dim=16, seed=7071, clades=1)[0]
         b = synthetic.make_family(1, m, dim=16, seed=7072, clades=1)[0]

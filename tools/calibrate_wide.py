@@ -32,6 +32,9 @@ WORKLOADS = {
     "p120x900": (16, 900, 13, 1),
     "p105x1500": (15, 1500, 14, 1),
     "p120x450": (16, 450, 15, 1),
+    "p120x750": (16, 750, 16, 1),
+    "p28x750": (8, 750, 17, 1),
+    "p28x1000": (8, 1000, 18, 1),
 }
 
 
