@@ -297,14 +297,47 @@ struct ExplicitRun {
     DevBuf<cr::SeedMax> seed;
     DevBuf<cr::AlignEnd> end;
     DevBuf<cr::TraceOut> tout;
+    DevBuf<double> staged;              // the matrix in the staged sweep's step order (cr_staged.h)
+    int r = 0;                          // rows per lane of the decision words
+    bool walked = false;                // dtw_align's traceback already ran (inside the staged kernel)
 };
+static_assert(sizeof(cr::TraceOut) == sizeof(cr::StagedTrace), "trace records differ");
 
 constexpr int kExplicitR = 2;     // 128 rows per strip: the strip's tile (128 x 129 doubles) fits the LDS
 
 // shared body of the three explicit-matrix drop-ins
+// One matrix of up to 1024 rows: gathered into the staged sweep's step order by its own launch (every CU), then ONE
+// workgroup with a wave per 64 (128) rows instead of one wave for everything; dtw_align's traceback by the walker of the
+// pairwise kernels in the same launch.  300 x 300: dtw_align 0.63 -> see profiles/r03/dropin_latency.txt.
+template <int R, int MODE>
+int run_explicit_staged(cr_context* ctx, int64_t n, int64_t m, int64_t s_cols, cr::SweepParams prm, ExplicitRun& r, bool walk,
+                        const cr::StagedShape shape) {
+    CR_HIP(r.staged.ensure((size_t)shape.pair_doubles()));
+    const int steps = (int)m + cr::kWave - 1, tc = kStageSteps;
+    CR_LAUNCH(cr::k_stage_explicit<R>, dim3((unsigned)((steps + tc - 1) / tc)), dim3(shape.waves * cr::kWave), 0, ctx->stream, r.s1.p,
+              (int)n, r.s2.p, (int)m, r.S.p, s_cols, tc, r.staged.p, shape);
+    CR_HIP(hipGetLastError());
+    const int entries = (int)(n + m);
+    const size_t lds = sizeof(double) * std::max(cr::sweep_staged_lds_doubles<MODE>(shape.waves), walk ? cr::trace_lds_doubles(R, entries) : (size_t)0);
+    auto go = [&](auto kernel) -> int {
+        int rc = allow_lds(kernel, lds);
+        if (rc) return rc;
+        CR_LAUNCH(kernel, dim3(1), dim3(shape.waves * cr::kWave), lds, ctx->stream, (int)n, (int)m, prm, r.staged.p, shape, r.dirs.p,
+                  r.bits.p, r.seed.p, r.end.p, entries, r.aln.p, reinterpret_cast<cr::StagedTrace*>(r.tout.p));
+        CR_HIP(hipGetLastError());
+        return CR_OK;
+    };
+    r.r = R;
+    r.walked = walk;
+    if constexpr ((MODE & cr::kDtw) != 0) {
+        if (walk) return go(cr::k_explicit_staged<R, MODE, true>);
+    }
+    return go(cr::k_explicit_staged<R, MODE, false>);
+}
+
 template <int MODE>
 int run_explicit(cr_context* ctx, const int64_t* seq1, int64_t n, const int64_t* seq2, int64_t m, const double* S,
-                 int64_t s_rows, int64_t s_cols, cr::SweepParams prm, ExplicitRun& r) {
+                 int64_t s_rows, int64_t s_cols, cr::SweepParams prm, ExplicitRun& r, bool walk = false) {
     int rc = set_device(ctx);
     if (rc) return rc;
     CR_REQUIRE(seq1 && seq2 && S, "null input array");
@@ -317,8 +350,10 @@ int run_explicit(cr_context* ctx, const int64_t* seq1, int64_t n, const int64_t*
     if ((rc = upload(r.s1, h1.data(), (size_t)n, ctx))) return rc;
     if ((rc = upload(r.s2, h2.data(), (size_t)m, ctx))) return rc;
     constexpr int R = kExplicitR;
-    const size_t nd = (size_t)cr::strips_of((int)n, R) * cr::tblocks((int)m, 16) * R * cr::kWave;
-    const size_t nb = (size_t)cr::strips_of((int)n, R) * cr::tblocks((int)m, 8) * R * cr::kWave;
+    // (sized for either layout: strips of 64 R' rows hold ceil(n / 64 R') R' row slots, at most ceil(n / 64) + 1)
+    const size_t slots = (size_t)((n + cr::kWave - 1) / cr::kWave) + 2;
+    const size_t nd = slots * cr::tblocks((int)m, 16) * cr::kWave;
+    const size_t nb = slots * cr::tblocks((int)m, 8) * cr::kWave;
     CR_HIP(r.dirs.ensure((MODE & cr::kSwTrace) ? nd : 1));
     CR_HIP(r.bits.ensure((MODE & cr::kDtw) ? nb : 1));
     CR_HIP(r.hand.ensure(3 * (size_t)m));
@@ -326,6 +361,17 @@ int run_explicit(cr_context* ctx, const int64_t* seq1, int64_t n, const int64_t*
     CR_HIP(r.end.ensure(1));
     CR_HIP(r.tout.ensure(1));
     CR_HIP(r.aln.ensure(2 * (size_t)(n + m)));
+    r.r = R;
+    r.walked = false;
+    {
+        const char* env = std::getenv("CARETTA_STAGED");
+        const cr::StagedShape shape = staged_shape((int)std::min<int64_t>(n, cr::kStagedMaxRows), (int)m);
+        if (n <= cr::kStagedMaxRows && !(env && env[0] == '0') &&
+            (double)shape.pair_doubles() * sizeof(double) <= 2.0 * 1024 * 1024 * 1024 &&
+            (!walk || sizeof(double) * cr::trace_lds_doubles(2, (int)(n + m)) <= 159 * 1024))
+            return shape.r == 1 ? run_explicit_staged<1, MODE>(ctx, n, m, s_cols, prm, r, walk, shape)
+                                : run_explicit_staged<2, MODE>(ctx, n, m, s_cols, prm, r, walk, shape);
+    }
     const size_t lds = cr::sweep_lds_doubles<R, MODE, cr::Explicit<R>>((int)n, (int)m) * sizeof(double);
     if ((rc = allow_lds(cr::k_explicit<R, MODE>, lds))) return rc;
     CR_LAUNCH((cr::k_explicit<R, MODE>), dim3(1), dim3(cr::kWave), lds, ctx->stream, r.s1.p, (int)n, r.s2.p,
@@ -535,9 +581,12 @@ int cr_progressive_node(cr_context* ctx, const double* coords_1, const double* t
         cr_batch* b;
         ~Guard() { cr_batch_destroy(b); }
     } guard{b};
-    g_no_wide = true;                        // the node kernel exists as a single-wave and a four-wave team kernel only
-    rc = cr_batch_set_pairs(b, pair, 1);
-    g_no_wide = false;
+    rc = cr_batch_set_pairs(b, pair, 1);     // on staged scores up to 1024 rows (cr_staged.h) ...
+    if (!rc && !b->staged) {                 // ... else single-wave or four-wave team kernels: the node kernel has no wide version
+        g_no_wide = true;
+        rc = cr_batch_set_pairs(b, pair, 1);
+        g_no_wide = false;
+    }
     if (rc) return rc;
     const cr_params prm = *params;
     CR_REQUIRE(gamma_ok(prm.gamma_tensor) && gamma_ok(prm.gamma_coords) && std::isfinite(prm.gap_open) && std::isfinite(prm.gap_extend) &&
@@ -559,11 +608,20 @@ int cr_progressive_node(cr_context* ctx, const double* coords_1, const double* t
     const cr::NodeDesc hnd{mult1, mult2, 0};
     DevBuf<cr::NodeDesc> dnd;
     if ((rc = upload(dnd, &hnd, 1, ctx))) return rc;
-    rc = b->team ? launch_node_team(R, ctx->stream, 1, (int)n, (int)m, entries, b->pairs.p, b->coords.p, b->tensors.p, (int)d,
-                                    dw.p, dnd.p, b->xf.p, prm, gamma_weight, b->bits.p, b->hand.p, b->aln.p, dxn.p, dtn.p, dwn.p,
-                                    dout.p)
-                 : launch_node(R, ctx->stream, 1, (int)n, (int)m, entries, b->pairs.p, b->coords.p, b->tensors.p, (int)d, dw.p,
-                               dnd.p, b->xf.p, prm, gamma_weight, b->bits.p, b->hand.p, b->aln.p, dxn.p, dtn.p, dwn.p, dout.p);
+    if (b->staged) {
+        const cr::StagedShape shape = staged_shape(b->n_max, b->m_max);
+        rc = launch_stage_node(ctx->stream, 1, (int)m, b->pairs.p, b->coords.p, dw.p, dnd.p, b->xf.p, prm, gamma_weight,
+                               b->staged_scores.p, shape);
+        if (!rc)
+            rc = launch_node_staged(ctx->stream, 1, entries, b->pairs.p, b->coords.p, b->tensors.p, (int)d, dw.p, dnd.p, b->xf.p, prm,
+                                    b->staged_scores.p, shape, b->bits.p, b->aln.p, dxn.p, dtn.p, dwn.p, dout.p);
+    } else {
+        rc = b->team ? launch_node_team(R, ctx->stream, 1, (int)n, (int)m, entries, b->pairs.p, b->coords.p, b->tensors.p, (int)d,
+                                        dw.p, dnd.p, b->xf.p, prm, gamma_weight, b->bits.p, b->hand.p, b->aln.p, dxn.p, dtn.p,
+                                        dwn.p, dout.p)
+                     : launch_node(R, ctx->stream, 1, (int)n, (int)m, entries, b->pairs.p, b->coords.p, b->tensors.p, (int)d, dw.p,
+                                   dnd.p, b->xf.p, prm, gamma_weight, b->bits.p, b->hand.p, b->aln.p, dxn.p, dtn.p, dwn.p, dout.p);
+    }
     if (rc) return rc;
     CR_HIP(hipGetLastError());
     cr::NodeOut no;
@@ -588,11 +646,11 @@ int cr_dtw_align(cr_context* ctx, const int64_t* seq1, int64_t n, const int64_t*
                  int64_t* aln_len, double* score) {
     ExplicitRun r;
     cr::SweepParams prm{0.0, gap_open, gap_extend};
-    int rc = run_explicit<cr::kDtw>(ctx, seq1, n, seq2, m, S, s_rows, s_cols, prm, r);
+    int rc = run_explicit<cr::kDtw>(ctx, seq1, n, seq2, m, S, s_rows, s_cols, prm, r, aln1 && aln2);
     if (rc) return rc;
     cr::AlignEnd e;
-    if (aln1 && aln2) {
-        CR_LAUNCH(cr::k_dtw_trace_full, dim3(1), dim3(1), 0, ctx->stream, (int)n, (int)m, kExplicitR, r.bits.p,
+    if (aln1 && aln2 && !r.walked) {
+        CR_LAUNCH(cr::k_dtw_trace_full, dim3(1), dim3(1), 0, ctx->stream, (int)n, (int)m, r.r, r.bits.p,
                            r.end.p, r.aln.p, r.tout.p);
         CR_HIP(hipGetLastError());
     }
@@ -630,7 +688,7 @@ int cr_smith_waterman(cr_context* ctx, const int64_t* seq1, int64_t n, const int
     cr::SweepParams prm{gap, 0.0, 0.0};
     int rc = run_explicit<cr::kSwTrace>(ctx, seq1, n, seq2, m, S, s_rows, s_cols, prm, r);
     if (rc) return rc;
-    CR_LAUNCH(cr::k_sw_trace_full, dim3(1), dim3(1), 0, ctx->stream, (int)n, (int)m, kExplicitR, r.dirs.p,
+    CR_LAUNCH(cr::k_sw_trace_full, dim3(1), dim3(1), 0, ctx->stream, (int)n, (int)m, r.r, r.dirs.p,
                        r.seed.p, r.aln.p, r.tout.p);
     CR_HIP(hipGetLastError());
     cr::SeedMax sm;

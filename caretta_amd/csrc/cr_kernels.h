@@ -1692,10 +1692,11 @@ constexpr int kStagedMaxWaves = 8;       // the blocks of score lines in registe
 constexpr int kStagedMaxRows = kStagedMaxWaves * kWave * 2;
 CR_HD int staged_steps(int m_max) { return (m_max + kWave - 1 + kStagedBlock - 1) / kStagedBlock * kStagedBlock + 2 * kStagedBlock; }
 
-template <int R>
+template <int R, bool RBF = true>
 struct StagedScore {                               // what dp_column sees: the scores of the lane's cells of this step
-    static constexpr bool kNonNegative = true;     // RBF scores (the staging kernels write what the RBF providers return)
-    static constexpr bool kMaskRows = false;       // rows past n were staged as the exact zeros the RBF gives them
+    static constexpr bool kNonNegative = RBF;      // RBF scores (the staging kernels write what the RBF providers return);
+                                                   // explicit score matrices (cr_dropins.h) may hold anything
+    static constexpr bool kMaskRows = !RBF;        // RBF: rows past n were staged as the exact zeros the RBF gives them
     double v[R];
     CR_D double score(int q, const ExpEntry*) const { return v[q]; }
 };
@@ -1847,7 +1848,7 @@ __host__ __device__ inline size_t sweep_cols_staged_lds_doubles(int waves) { ret
 
 constexpr int kStagedDump = 2 * kWideEdge + kStagedBlock;     // doubles per wave that take the hand-off writes of lanes 0 .. 62
 
-template <int R, int MODE>
+template <int R, int MODE, bool RBF = true>
 CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int m, const SweepParams prm, double* lds,
                        uint32_t* __restrict__ sw_dirs, uint32_t* __restrict__ dtw_bits, SeedMax& seed_out,
                        AlignEnd& end_out, const StripGeom geom) {
@@ -1883,7 +1884,7 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
     st.reset_column0(col0_m2);
 #pragma unroll
     for (int q = 0; q < R; q++) st.swbits[q] = st.dtbits[q] = 0;
-    StagedScore<R> src;
+    StagedScore<R, RBF> src;
     const double* __restrict__ line = strip + lane;      // line t: R sub-lines of 64 doubles (row slot q, lane)
     double cur[B][R], nxt[B][R], nx2[FAR ? B : 1][R];
     if (mine) {

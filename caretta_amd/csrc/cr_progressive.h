@@ -151,7 +151,8 @@ int run_level(cr_progressive* h, const std::vector<int64_t>& ids, const cr_param
 // The whole tree without host round trips.  Launch shapes (rows per lane, LDS, scratch) are sized for a length
 // bound of 1.5 x the longest leaf; a one-thread planning kernel per level (cr::k_plan_level) turns the lengths the
 // previous level produced into this level's descriptors on the device.  Returns 1 when the bound does not apply
-// (team kernels need 192 < bound <= 1280) or a node outgrew it: the caller then runs the level-by-level path.
+// (staged scores: bound <= 1024; team kernels: 192 < bound <= 1280) or a node outgrew it: the caller then runs the
+// level-by-level path.
 int run_tree_planned(cr_progressive* h, const std::vector<std::vector<int64_t>>& by_level, const cr_params& prm,
                      double gamma_weight) {
     cr_batch& b = h->scratch;
@@ -160,7 +161,7 @@ int run_tree_planned(cr_progressive* h, const std::vector<std::vector<int64_t>>&
     int64_t longest = 0;
     for (int64_t s = 0; s < P; s++) longest = std::max(longest, h->len[(size_t)s]);
     const int bound = (int)std::min<int64_t>(5 * cr::kTeamWaves * cr::kWave, (longest * 3 + 1) / 2 + 8);
-    if (bound <= 3 * cr::kWave || longest > bound || std::getenv("CARETTA_NO_TEAM")) return 1;
+    if (longest > bound || std::getenv("CARETTA_NO_TEAM")) return 1;
     int64_t widest_level = 0;
     for (int64_t lv = 1; lv <= h->levels; lv++) widest_level = std::max<int64_t>(widest_level, (int64_t)by_level[(size_t)lv].size());
     // Scores formed by their own launches (cr_staged.h) while one or two rows per lane fit the 8 waves of its workgroups
@@ -173,6 +174,7 @@ int run_tree_planned(cr_progressive* h, const std::vector<std::vector<int64_t>>&
         CR_HIP(hipMemGetInfo(&free_b, &total_b));
         staged = (double)widest_level * (double)shape.pair_doubles() * sizeof(double) <= (double)total_b / 10.0;
     }
+    if (!staged && bound <= 3 * cr::kWave) return 1;     // (the four-wave team kernels need more than 192 rows)
     const int R = staged ? shape.r : (bound + cr::kTeamWaves * cr::kWave - 1) / (cr::kTeamWaves * cr::kWave);
 
     // static plan: every internal node in level order

@@ -355,6 +355,71 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_align_staged(const P
     CR_STAMP(7);
 }
 
+// Explicit score matrix S[seq1[i], seq2[j]] (dynamic_time_warping.py:24-26,79) into the skewed step order: the
+// single-call dtw_align / smith_waterman(_score) drop-ins then run the multi-wave staged sweep instead of one wave
+// (index sequences, alphabet mode included: the gather happens here, once).
+template <int R>
+__global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_stage_explicit(const int32_t* __restrict__ seq1, int n,
+                                                                        const int32_t* __restrict__ seq2, int m,
+                                                                        const double* __restrict__ S, int64_t s_cols, int tc,
+                                                                        double* __restrict__ staged, const StagedShape shape) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (w * kWave * R >= n) return;
+    int64_t rowoff[R];
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+        const int row = (w * kWave + lane) * R + q;
+        rowoff[q] = row < n ? (int64_t)seq1[row] * s_cols : (int64_t)-1;
+    }
+    double* __restrict__ out = staged + (int64_t)w * shape.strip_doubles() + lane;
+    const int t0 = (int)blockIdx.x * tc;
+    const int t1 = t0 + tc < m + kWave - 1 ? t0 + tc : m + kWave - 1;
+    for (int t = t0; t < t1; t++) {
+        const int c = t - lane;
+        if ((unsigned)c < (unsigned)m) {
+            const int64_t col = seq2[c];
+#pragma unroll
+            for (int q = 0; q < R; q++) out[((int64_t)t * R + q) * kWave] = rowoff[q] >= 0 ? S[rowoff[q] + col] : 0.0;
+        }
+    }
+}
+
+struct StagedTrace {          // = cr::TraceOut of cr_dropins.h (defined behind this header)
+    int32_t len, start;
+};
+
+// The DP of the explicit-matrix drop-ins on staged scores: one workgroup, one wave per strip; WALK: dtw_align's
+// traceback by wave 0 on the register-resident decision blocks (rows back to front in aln[0 .. cap), aln[cap .. 2 cap)).
+template <int R, int MODE, bool WALK>
+__global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_explicit_staged(int n, int m, SweepParams prm,
+                                                                         const double* __restrict__ staged,
+                                                                         const StagedShape shape, uint32_t* __restrict__ dirs,
+                                                                         uint32_t* __restrict__ bits, SeedMax* __restrict__ seed,
+                                                                         AlignEnd* __restrict__ end, int max_entries,
+                                                                         int32_t* __restrict__ aln, StagedTrace* __restrict__ tout) {
+    extern __shared__ double lds[];
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    SeedMax sm;
+    AlignEnd ae;
+    ae.sw = ae.dtw_score = 0.0;
+    ae.start_layer = ae.pad = 0;
+    sweep_staged<R, MODE, false>(staged + (int64_t)w * shape.strip_doubles(), n, m, prm, lds, dirs, bits, sm, ae, WidePlan<R>{0}.geom(w, n));
+    if (threadIdx.x >= kWave) return;                  // wave 0 goes on alone (wave_sync, no s_barrier from here on)
+    if (threadIdx.x == 0) {
+        if constexpr ((MODE & kSwTrace) != 0) *seed = sm;
+        if constexpr ((MODE & (kSwScore | kDtw)) != 0) *end = ae;
+    }
+    if constexpr (WALK) {
+        int len, pairs;
+        dtw_walk<R>(n, m, max_entries, bits, ae.start_layer, lds, aln, len, pairs);
+        if (threadIdx.x == 0) {
+            tout->len = len;
+            tout->start = n + m - len;
+        }
+    }
+}
+
 }  // namespace cr
 
 #ifndef CR_KERNELS_TEMPLATES_ONLY      // the launchers (cr_api.hip)

@@ -281,11 +281,15 @@ def test_plugin_pairwise_matrix_runs_batched(oracle):
     assert np.array_equal(got, want)
 
 
-def test_dp_multistrip_vs_oracle(oracle):
-    """n > 320 rows: strips hand their last row over through LDS."""
+@pytest.mark.parametrize("staged", ["1", "0"])
+def test_dp_multistrip_vs_oracle(oracle, monkeypatch, staged):
+    """n > 64 rows: several strips.  Up to 1024 rows the single-call drop-ins gather the matrix into the staged sweep's
+    step order and run one wave per strip (one or two rows per lane; cr_staged.h), beyond that -- and with
+    CARETTA_STAGED=0 -- one wave takes the strips in turn and hands the last row over through LDS."""
     from caretta_amd import dynamic_time_warping as dtw
+    monkeypatch.setenv("CARETTA_STAGED", staged)
     rng = np.random.default_rng(5)
-    for n, m in [(321, 50), (700, 333), (1000, 64), (64, 1000)]:
+    for n, m in [(321, 50), (700, 333), (1000, 64), (64, 1000), (1024, 7), (513, 200), (1025, 90), (130, 3)]:
         s = rng.uniform(size=(n, m)) ** 3
         a, b = np.arange(n), np.arange(m)
         r1 = dtw.dtw_align(a, b, s, 1.0, 0.01)
@@ -295,6 +299,16 @@ def test_dp_multistrip_vs_oracle(oracle):
         o2 = oracle.smith_waterman(a, b, s - 0.3, 0.1)
         assert np.array_equal(r2[0], o2[0]) and np.array_equal(r2[1], o2[1]) and r2[2] == o2[2]
         assert dtw.smith_waterman_score(a, b, s - 0.3, 0.1) == oracle.smith_waterman_score(a, b, s - 0.3, 0.1)
+        assert dtw.dtw_align_score(a, b, s, 0.5, 0.5) == oracle.dtw_align_score(a, b, s, 0.5, 0.5)
+    # alphabet mode: index sequences into a small substitution matrix (gathered by the staging launch)
+    sub = rng.normal(size=(21, 23))
+    for n, m in [(400, 380), (90, 700)]:
+        a, b = rng.integers(0, 21, size=n), rng.integers(0, 23, size=m)
+        r1, o1 = dtw.dtw_align(a, b, sub, 1.0, 0.1), oracle.dtw_align(a, b, sub, 1.0, 0.1)
+        assert np.array_equal(r1[0], o1[0]) and np.array_equal(r1[1], o1[1]) and r1[2] == o1[2]
+        r2, o2 = dtw.smith_waterman(a, b, sub, 0.5), oracle.smith_waterman(a, b, sub, 0.5)
+        assert np.array_equal(r2[0], o2[0]) and np.array_equal(r2[1], o2[1]) and r2[2] == o2[2]
+        assert dtw.smith_waterman_score(a, b, sub, 0.0) == oracle.smith_waterman_score(a, b, sub, 0.0)
 
 
 # ------------------------------------------------------------------------------- Kabsch & metrics
