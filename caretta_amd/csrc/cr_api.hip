@@ -1052,7 +1052,9 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     // (tools/calibrate_staged.py, full pipeline, fused -> staged): one pair of 300 0.382 -> 0.253 ms, 66 pairs of 300
     // 0.395 -> 0.299, 248 pairs of 150 0.218 -> 0.191, 120 pairs of 450 0.614 -> 0.529; with two rows per lane (513 .. 1024
     // rows, against the wide layout): 28 pairs of 1000 1.62 -> 1.11, 28 of 750 1.18 -> 0.78, 120 of 750 1.22 -> 1.05, 120 of
-    // 900 1.52 -> 1.41; 496 pairs of 150 (1 488 strips for 1 024 SIMDs) 0.232 -> 0.275: hence at most kStagedWaveLimit strips.
+    // 900 1.52 -> 1.41; three / four rows per lane: 28 pairs of 1500 2.98 -> 2.20, 105 of 1500 3.01 -> 2.92, 6 of 2000 (no
+    // wide plan: one wave per pair) 21.5 -> 2.85; 496 pairs of 150 (1 488 strips for 1 024 SIMDs) 0.232 -> 0.275: hence at
+    // most kStagedWaveLimit strips.
     b->staged = false;
     {
         const char* env = std::getenv("CARETTA_STAGED");
@@ -1060,7 +1062,7 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
         if (const char* lim = std::getenv("CARETTA_STAGED_WAVES")) wave_limit = std::atoll(lim);   // calibration
         const cr::StagedShape shape = staged_shape(std::max(b->n_max, 1), std::max(b->m_max, 1));
         const int64_t strips1 = shape.waves;
-        int row_limit = cr::kStagedMaxRows;                        // one row per lane up to 512 rows, two up to 1024
+        int row_limit = cr::kStagedMaxRows;                        // one row per lane up to 512 rows ... four up to 2048
         if (const char* lim = std::getenv("CARETTA_STAGED_ROWS")) row_limit = std::min(std::atoi(lim), cr::kStagedMaxRows);   // calibration
         if (npairs > 0 && !g_no_wide && !(env && env[0] == '0') && !std::getenv("CARETTA_NO_TEAM") && !std::getenv("CARETTA_WIDE") &&
             !std::getenv("CARETTA_NO_WIDE") && b->n_max <= row_limit && npairs * strips1 <= wave_limit &&

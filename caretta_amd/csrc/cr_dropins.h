@@ -350,8 +350,8 @@ int run_explicit(cr_context* ctx, const int64_t* seq1, int64_t n, const int64_t*
     if ((rc = upload(r.s1, h1.data(), (size_t)n, ctx))) return rc;
     if ((rc = upload(r.s2, h2.data(), (size_t)m, ctx))) return rc;
     constexpr int R = kExplicitR;
-    // (sized for either layout: strips of 64 R' rows hold ceil(n / 64 R') R' row slots, at most ceil(n / 64) + 1)
-    const size_t slots = (size_t)((n + cr::kWave - 1) / cr::kWave) + 2;
+    // (sized for either layout: strips of 64 R' rows hold ceil(n / 64 R') R' row slots, at most ceil(n / 64) + 3)
+    const size_t slots = (size_t)((n + cr::kWave - 1) / cr::kWave) + 4;
     const size_t nd = slots * cr::tblocks((int)m, 16) * cr::kWave;
     const size_t nb = slots * cr::tblocks((int)m, 8) * cr::kWave;
     CR_HIP(r.dirs.ensure((MODE & cr::kSwTrace) ? nd : 1));
@@ -368,9 +368,8 @@ int run_explicit(cr_context* ctx, const int64_t* seq1, int64_t n, const int64_t*
         const cr::StagedShape shape = staged_shape((int)std::min<int64_t>(n, cr::kStagedMaxRows), (int)m);
         if (n <= cr::kStagedMaxRows && !(env && env[0] == '0') &&
             (double)shape.pair_doubles() * sizeof(double) <= 2.0 * 1024 * 1024 * 1024 &&
-            (!walk || sizeof(double) * cr::trace_lds_doubles(2, (int)(n + m)) <= 159 * 1024))
-            return shape.r == 1 ? run_explicit_staged<1, MODE>(ctx, n, m, s_cols, prm, r, walk, shape)
-                                : run_explicit_staged<2, MODE>(ctx, n, m, s_cols, prm, r, walk, shape);
+            (!walk || sizeof(double) * cr::trace_lds_doubles(shape.r, (int)(n + m)) <= 159 * 1024))
+            return by_rows(shape.r, [&](auto rt) { return run_explicit_staged<decltype(rt)::value, MODE>(ctx, n, m, s_cols, prm, r, walk, shape); });
     }
     const size_t lds = cr::sweep_lds_doubles<R, MODE, cr::Explicit<R>>((int)n, (int)m) * sizeof(double);
     if ((rc = allow_lds(cr::k_explicit<R, MODE>, lds))) return rc;

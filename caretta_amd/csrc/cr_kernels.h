@@ -1670,7 +1670,8 @@ __host__ __device__ inline size_t sweep_wide_lds_doubles(int waves, int m_max) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// The wide sweep on scores that another launch has already formed (cr_staged.h), ONE row per lane (two above 512 rows).
+// The wide sweep on scores that another launch has already formed (cr_staged.h): ONE row per lane up to 512 rows, then
+// two, three, four (up to 2048 rows; blocks of 8 steps from three rows on).
 //
 // When a launch has few workgroups -- a level of the progressive alignment, a short pair list -- the fused kernels are
 // bound by the instruction issue of the few waves that hold the recurrence, and 50 of a seed step's 59 instructions (30
@@ -1685,11 +1686,11 @@ __host__ __device__ inline size_t sweep_wide_lds_doubles(int waves, int m_max) {
 // blocks.  The strip region has staged_steps(m_max) lines: the requests two blocks past the last step stay inside it.
 // LDS (doubles): NW + 1 hand-off rings of NB * kWideEdge | NW * 8 | NW dumps.  Decision words: as every other skewed sweep.
 // ---------------------------------------------------------------------------------------------
-constexpr int kStagedBlock = 16;
-constexpr int kStagedLagBlocks = 5;
+constexpr int kStagedBlock = 16;         // steps per block with one or two rows per lane; 8 with three or four (registers)
 constexpr int kStagedMaxWaves = 8;       // the blocks of score lines in registers need more than the 128 VGPRs of a 16-wave
-                                         // workgroup: up to 512 rows with one row per lane, up to 1024 with two
-constexpr int kStagedMaxRows = kStagedMaxWaves * kWave * 2;
+                                         // workgroup: 512 rows per row of a lane
+constexpr int kStagedMaxR = 4;
+constexpr int kStagedMaxRows = kStagedMaxWaves * kWave * kStagedMaxR;
 CR_HD int staged_steps(int m_max) { return (m_max + kWave - 1 + kStagedBlock - 1) / kStagedBlock * kStagedBlock + 2 * kStagedBlock; }
 
 template <int R, bool RBF = true>
@@ -1733,14 +1734,15 @@ CR_D void sweep_cols_staged(const double* __restrict__ strip, const int n, const
         bits[q] = 0;
     }
     const double* __restrict__ line = strip + lane;      // line c: R sub-lines of 64 doubles (row slot q, lane)
-    double cur[C][R], nxt[C][R], nx2[C][R];
+    constexpr bool FAR = R <= 2;                          // score lines two chunks ahead (R >= 3: one, the registers are taken)
+    double cur[C][R], nxt[C][R], nx2[FAR ? C : 1][R];
     if (mine) {
 #pragma unroll
         for (int k = 0; k < C; k++)
 #pragma unroll
             for (int q = 0; q < R; q++) {
                 nxt[k][q] = line[(k * R + q) * kWave];
-                nx2[k][q] = line[((C + k) * R + q) * kWave];
+                if constexpr (FAR) nx2[k][q] = line[((C + k) * R + q) * kWave];
             }
     }
     auto run = [&](auto top_tag) {
@@ -1750,14 +1752,18 @@ CR_D void sweep_cols_staged(const double* __restrict__ strip, const int n, const
             lds_barrier();                                 // the chunk written in phase g - 1 is visible to the strip below
             const int c = g - w;
             if (!mine || c < 0 || c >= chunks) continue;
-            const double* __restrict__ ahead = line + (int64_t)(c + 2) * (C * R * kWave);
+            const double* __restrict__ ahead = line + (int64_t)(c + (FAR ? 2 : 1)) * (C * R * kWave);
 #pragma unroll
             for (int k = 0; k < C; k++)
 #pragma unroll
                 for (int q = 0; q < R; q++) {
                     cur[k][q] = nxt[k][q];
-                    nxt[k][q] = nx2[k][q];
-                    nx2[k][q] = ahead[(k * R + q) * kWave];
+                    if constexpr (FAR) {
+                        nxt[k][q] = nx2[k][q];
+                        nx2[k][q] = ahead[(k * R + q) * kWave];
+                    } else {
+                        nxt[k][q] = ahead[(k * R + q) * kWave];
+                    }
                 }
             double top_vec = 0.0;                          // the row above the strip for this chunk: lane x = column j0 + x
             if (TOP && lane < C) top_vec = ring_in[(c & 1) * C + lane];
@@ -1846,7 +1852,8 @@ CR_D void sweep_cols_staged(const double* __restrict__ strip, const int n, const
 
 __host__ __device__ inline size_t sweep_cols_staged_lds_doubles(int waves) { return (size_t)waves * (2 * kColChunk + 4); }
 
-constexpr int kStagedDump = 2 * kWideEdge + kStagedBlock;     // doubles per wave that take the hand-off writes of lanes 0 .. 62
+// doubles per wave that take the hand-off writes of lanes 0 .. 62: dump[lane + plane * 64 + step], up to three planes
+constexpr int kStagedDump = kWave + 2 * kWideEdge + kStagedBlock;
 
 template <int R, int MODE, bool RBF = true>
 CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int m, const SweepParams prm, double* lds,
@@ -1856,8 +1863,9 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
     constexpr bool TRACE = (MODE & kSwTrace) != 0;
     constexpr bool DTW = (MODE & kDtw) != 0;
     constexpr int NB = (SW ? 1 : 0) + (DTW ? 2 : 0);
-    constexpr int B = kStagedBlock;
-    constexpr bool FAR = R == 1;                          // score lines two blocks ahead (R = 2: one, the registers are taken)
+    constexpr int B = R <= 2 ? kStagedBlock : 8;          // steps per block (the block's R * B score lines sit in registers)
+    constexpr int LAGB = R <= 2 ? 5 : 9;                  // blocks a strip lags the one above: 80 / 72 steps (>= 63 + B)
+    constexpr bool FAR = R == 1;                          // score lines two blocks ahead (R >= 2: one, the registers are taken)
     constexpr int PH = 0, PM0 = (NB - 2) * kWideEdge, PM1 = (NB - 1) * kWideEdge;   // planes of a ring
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1896,11 +1904,11 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
                 if constexpr (FAR) nx2[k][q] = line[((B + k) * R + q) * kWave];
             }
     }
-    const int GB = kStagedLagBlocks * (nstrips - 1) + (m + kWave - 1 + B - 1) / B;
+    const int GB = LAGB * (nstrips - 1) + (m + kWave - 1 + B - 1) / B;
 #pragma unroll 1
     for (int gb = 0; gb < GB; gb++) {
         lds_barrier();                                     // hand-off values of the last block visible to the next strip
-        const int tb = gb - kStagedLagBlocks * w;
+        const int tb = gb - LAGB * w;
         if (tb < 0 || tb >= my_blocks) continue;
         const double* __restrict__ ahead = line + (int64_t)(tb + (FAR ? 2 : 1)) * (B * R * kWave);
 #pragma unroll
@@ -1918,7 +1926,7 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
         // The row above the strip.  Lane 0's column at step t is t itself, written by the strip above at ITS step t + 63:
         // slot (t - 1) & 63.  Every lane reads it (one address: a broadcast) and hands it to the shift as lane 0's fill;
         // the read of step k + 1 is issued before the arithmetic of step k.
-        const int q4 = (tb & 3) * B;
+        const int q4 = (tb & (kWideEdge / B - 1)) * B;
         const double* fills = ring_in + q4 - 1;            // step k >= 1: fills[k]
         const int slot0 = (tb * B - 1) & (kWideEdge - 1);
         // the strip's last row: lane 63 writes its values of step k to slot q4 + k of the ring, the other lanes write theirs
@@ -1953,7 +1961,7 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
                 if (active) {
 #pragma unroll
                     for (int q = 0; q < R; q++) src.v[q] = cur[k][q];
-                    dp_column<R, MODE>(src, st, prm, nullptr, c, rowbase, n, k * 2, (k & 7) * 4, h_top, m0_top, m1_top);
+                    dp_column<R, MODE>(src, st, prm, nullptr, c, rowbase, n, ((tb * B + k) & 15) * 2, (k & 7) * 4, h_top, m0_top, m1_top);
                     if constexpr (SW) wr[PH + k] = st.h_left[R - 1];
                     if constexpr (DTW) {
                         wr[PM0 + k] = st.m0_left[R - 1];
@@ -1964,8 +1972,8 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
                 f_m0 = g_m0;
                 f_m1 = g_m1;
                 if constexpr (DTW) {
-                    if ((k & 7) == 7 && tb * 2 + (k >> 3) < TB_DTW) {
-                        const int64_t base = ((int64_t)geom.slot0 * TB_DTW + (int64_t)(tb * 2 + (k >> 3)) * R) * kWave + lane;
+                    if ((k & 7) == 7 && tb * (B / 8) + (k >> 3) < TB_DTW) {
+                        const int64_t base = ((int64_t)geom.slot0 * TB_DTW + (int64_t)(tb * (B / 8) + (k >> 3)) * R) * kWave + lane;
 #pragma unroll
                         for (int q = 0; q < R; q++) {
                             dtw_bits[base + q * kWave] = st.dtbits[q];
@@ -1978,11 +1986,13 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
         if (tb * B >= kWave - 1 && tb * B + B - 1 < m) steps(std::true_type{});
         else steps(std::false_type{});
         if constexpr (TRACE) {
-            const int64_t base = ((int64_t)geom.slot0 * TB_SW + (int64_t)tb * R) * kWave + lane;
+            if ((((tb + 1) * B) & 15) == 0 || tb == my_blocks - 1) {      // a decision word holds 16 steps
+                const int64_t base = ((int64_t)geom.slot0 * TB_SW + (int64_t)((tb * B) >> 4) * R) * kWave + lane;
 #pragma unroll
-            for (int q = 0; q < R; q++) {
-                sw_dirs[base + q * kWave] = st.swbits[q];
-                st.swbits[q] = 0;
+                for (int q = 0; q < R; q++) {
+                    sw_dirs[base + q * kWave] = st.swbits[q];
+                    st.swbits[q] = 0;
+                }
             }
         }
     }

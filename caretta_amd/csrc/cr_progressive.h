@@ -151,7 +151,7 @@ int run_level(cr_progressive* h, const std::vector<int64_t>& ids, const cr_param
 // The whole tree without host round trips.  Launch shapes (rows per lane, LDS, scratch) are sized for a length
 // bound of 1.5 x the longest leaf; a one-thread planning kernel per level (cr::k_plan_level) turns the lengths the
 // previous level produced into this level's descriptors on the device.  Returns 1 when the bound does not apply
-// (staged scores: bound <= 1024; team kernels: 192 < bound <= 1280) or a node outgrew it: the caller then runs the
+// (staged scores: bound <= 2048; team kernels: 192 < bound <= 1280) or a node outgrew it: the caller then runs the
 // level-by-level path.
 int run_tree_planned(cr_progressive* h, const std::vector<std::vector<int64_t>>& by_level, const cr_params& prm,
                      double gamma_weight) {
@@ -160,12 +160,12 @@ int run_tree_planned(cr_progressive* h, const std::vector<std::vector<int64_t>>&
     const int64_t P = h->P, total = h->used, num_nodes = P - 1;
     int64_t longest = 0;
     for (int64_t s = 0; s < P; s++) longest = std::max(longest, h->len[(size_t)s]);
-    const int bound = (int)std::min<int64_t>(5 * cr::kTeamWaves * cr::kWave, (longest * 3 + 1) / 2 + 8);
+    const int bound = (int)std::min<int64_t>(cr::kStagedMaxRows, (longest * 3 + 1) / 2 + 8);
     if (longest > bound || std::getenv("CARETTA_NO_TEAM")) return 1;
     int64_t widest_level = 0;
     for (int64_t lv = 1; lv <= h->levels; lv++) widest_level = std::max<int64_t>(widest_level, (int64_t)by_level[(size_t)lv].size());
-    // Scores formed by their own launches (cr_staged.h) while one or two rows per lane fit the 8 waves of its workgroups
-    // (1024 rows) and the widest level's scores fit a tenth of the device memory; CARETTA_STAGED=0: the fused kernels
+    // Scores formed by their own launches (cr_staged.h) while up to four rows per lane fit the 8 waves of its workgroups
+    // (2048 rows) and the widest level's scores fit a tenth of the device memory; CARETTA_STAGED=0: the fused kernels
     const cr::StagedShape shape = staged_shape(bound, bound);
     const char* staged_env = std::getenv("CARETTA_STAGED");
     bool staged = bound <= cr::kStagedMaxRows && widest_level <= 65535 && !(staged_env && staged_env[0] == '0');
@@ -174,7 +174,7 @@ int run_tree_planned(cr_progressive* h, const std::vector<std::vector<int64_t>>&
         CR_HIP(hipMemGetInfo(&free_b, &total_b));
         staged = (double)widest_level * (double)shape.pair_doubles() * sizeof(double) <= (double)total_b / 10.0;
     }
-    if (!staged && bound <= 3 * cr::kWave) return 1;     // (the four-wave team kernels need more than 192 rows)
+    if (!staged && (bound <= 3 * cr::kWave || bound > 5 * cr::kTeamWaves * cr::kWave)) return 1;     // (the four-wave team kernels: 193 .. 1280 rows)
     const int R = staged ? shape.r : (bound + cr::kTeamWaves * cr::kWave - 1) / (cr::kTeamWaves * cr::kWave);
 
     // static plan: every internal node in level order

@@ -21,7 +21,7 @@ namespace cr {
 struct StagedShape {       // the same for every pair of a launch (sized for the launch's length bound)
     int waves;             // strips per pair
     int steps;             // score lines per strip: staged_steps(m bound)
-    int r;                 // rows per lane: 1 up to 512 rows, 2 up to 1024 (a line is r sub-lines of 64 doubles)
+    int r;                 // rows per lane: 1 up to 512 rows, 2 up to 1024, 3, 4 up to 2048 (a line is r sub-lines of 64 doubles)
     CR_HD int64_t strip_doubles() const { return (int64_t)steps * r * kWave; }
     CR_HD int64_t pair_doubles() const { return (int64_t)waves * strip_doubles(); }
 };
@@ -141,8 +141,9 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_seed_staged(const Pa
         const double* strip = staged + (int64_t)blockIdx.x * shape.pair_doubles() + (int64_t)w * shape.strip_doubles();
         const StripGeom geom = WidePlan<R>{0}.geom(w, pd.n);
         SweepParams prm{sw_gap, 0.0, 0.0};
-        if constexpr (ZG) sweep_cols_staged<R>(strip, pd.n, pd.m, lds, dirs + pd.dirs_off, sm, geom);
-        else sweep_staged<R, kSwTrace>(strip, pd.n, pd.m, prm, lds, dirs + pd.dirs_off, nullptr, sm, unused, geom);
+        // (three and four rows per lane: the column sweep's chunks of score lines do not fit the registers beside its state)
+        if constexpr (ZG && R <= 2) sweep_cols_staged<R>(strip, pd.n, pd.m, lds, dirs + pd.dirs_off, sm, geom);
+        else sweep_staged<R, kSwTrace | (ZG ? kZeroGap : 0)>(strip, pd.n, pd.m, prm, lds, dirs + pd.dirs_off, nullptr, sm, unused, geom);
     }
     // wave 0 walks (the others wait at the barrier); the position-ordered sums behind the walk are taken by everybody
     __shared__ int s_walk[4];
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_seed_staged(const Pa
         CR_STAMP(1);
         int k, len;
         uint32_t fl;
-        seed_walk<R, ZG ? 0 : 1>(pd, dirs, sm, seed_list, 0, k, len, fl);
+        seed_walk<R, (ZG && R <= 2) ? 0 : 1>(pd, dirs, sm, seed_list, 0, k, len, fl);
         if (threadIdx.x == 0) {
             s_walk[0] = k;
             s_walk[1] = len;
@@ -435,9 +436,21 @@ inline int stage_steps(int64_t count, int steps_total) {
     return kStageSteps * (int)std::min<int64_t>(4, std::max<int64_t>(1, groups16 / 2048));
 }
 
+// f(std::integral_constant<int, R>) for the shape's rows per lane
+template <class F>
+int by_rows(int r, F&& f) {
+    switch (r) {
+        case 1: return f(std::integral_constant<int, 1>{});
+        case 2: return f(std::integral_constant<int, 2>{});
+        case 3: return f(std::integral_constant<int, 3>{});
+        default: return f(std::integral_constant<int, 4>{});
+    }
+}
+
 inline cr::StagedShape staged_shape(int n_bound, int m_bound) {
     cr::StagedShape s;
-    s.r = n_bound <= cr::kStagedMaxWaves * cr::kWave ? 1 : 2;
+    s.r = std::min(cr::kStagedMaxR, (n_bound + cr::kStagedMaxWaves * cr::kWave - 1) / (cr::kStagedMaxWaves * cr::kWave));
+    s.r = std::max(s.r, 1);
     s.waves = (n_bound + cr::kWave * s.r - 1) / (cr::kWave * s.r);
     s.steps = cr::staged_steps(m_bound);
     return s;
@@ -446,7 +459,7 @@ inline cr::StagedShape staged_shape(int n_bound, int m_bound) {
 
 template <int D>
 int launch_stage_tensor_d(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, double* staged, const cr::StagedShape shape) {
-    const bool skew = prm.sw_gap != 0.0;                   // gap 0: the seed is a column sweep (k_seed_staged<true>)
+    const bool skew = prm.sw_gap != 0.0 || shape.r > 2;    // gap 0, one or two rows per lane: the seed is a column sweep
     const int steps = ck.m_max + (skew ? cr::kWave - 1 : 0), tc = stage_steps(ck.count, steps);
     const size_t lds = sizeof(double) * cr::stage_lds_doubles(D, tc);
     const unsigned chunks = (unsigned)((steps + tc - 1) / tc);
@@ -456,8 +469,10 @@ int launch_stage_tensor_d(cr_batch* b, const cr_batch::Chunk& ck, const cr_param
         CR_HIP(hipGetLastError());
         return CR_OK;
     };
-    if (shape.r == 1) return skew ? go(cr::k_stage_tensor<D, true, 1>) : go(cr::k_stage_tensor<D, false, 1>);
-    return skew ? go(cr::k_stage_tensor<D, true, 2>) : go(cr::k_stage_tensor<D, false, 2>);
+    return by_rows(shape.r, [&](auto rt) {
+        constexpr int R = decltype(rt)::value;
+        return skew ? go(cr::k_stage_tensor<D, true, R>) : go(cr::k_stage_tensor<D, false, R>);
+    });
 }
 
 int launch_stage_tensor(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, double* staged, const cr::StagedShape shape) {
@@ -474,7 +489,7 @@ int launch_stage_tensor(cr_batch* b, const cr_batch::Chunk& ck, const cr_params&
 
 int launch_seed_staged(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, const double* staged, const cr::StagedShape shape) {
     const int entries = std::min(ck.n_max, ck.m_max);
-    const size_t fill = prm.sw_gap == 0.0 ? cr::sweep_cols_staged_lds_doubles(shape.waves) : cr::sweep_staged_lds_doubles<cr::kSwTrace>(shape.waves);
+    const size_t fill = std::max(cr::sweep_cols_staged_lds_doubles(shape.waves), cr::sweep_staged_lds_doubles<cr::kSwTrace>(shape.waves));
     const size_t lds = sizeof(double) * std::max(fill, (size_t)cr::kExpDoubles + cr::trace_team_lds_doubles(entries));
     auto go = [&](auto kernel) -> int {
         int rc = allow_lds(kernel, lds);
@@ -484,8 +499,10 @@ int launch_seed_staged(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& 
         CR_HIP(hipGetLastError());
         return CR_OK;
     };
-    if (shape.r == 1) return prm.sw_gap == 0.0 ? go(cr::k_seed_staged<true, 1>) : go(cr::k_seed_staged<false, 1>);
-    return prm.sw_gap == 0.0 ? go(cr::k_seed_staged<true, 2>) : go(cr::k_seed_staged<false, 2>);
+    return by_rows(shape.r, [&](auto rt) {
+        constexpr int R = decltype(rt)::value;
+        return prm.sw_gap == 0.0 ? go(cr::k_seed_staged<true, R>) : go(cr::k_seed_staged<false, R>);
+    });
 }
 
 // the pair batch (cr_batch_run on a list short enough to be latency bound, cr_batch_set_pairs): coordinate scores in the
@@ -501,7 +518,7 @@ int launch_stage_coords(cr_batch* b, const cr_batch::Chunk& ck, const cr_params&
         CR_HIP(hipGetLastError());
         return CR_OK;
     };
-    return shape.r == 1 ? go(cr::k_stage_coords<1>) : go(cr::k_stage_coords<2>);
+    return by_rows(shape.r, [&](auto rt) { return go(cr::k_stage_coords<decltype(rt)::value>); });
 }
 
 int launch_align_staged(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, const double* staged, const cr::StagedShape shape,
@@ -519,12 +536,11 @@ int launch_align_staged(cr_batch* b, const cr_batch::Chunk& ck, const cr_params&
         CR_HIP(hipGetLastError());
         return CR_OK;
     };
-    if (shape.r == 1) {
-        if (scores) return go(cr::k_align_staged<true, true, 1>);
-        return zg ? go(cr::k_align_staged<true, false, 1>) : go(cr::k_align_staged<false, false, 1>);
-    }
-    if (scores) return go(cr::k_align_staged<true, true, 2>);
-    return zg ? go(cr::k_align_staged<true, false, 2>) : go(cr::k_align_staged<false, false, 2>);
+    return by_rows(shape.r, [&](auto rt) {
+        constexpr int R = decltype(rt)::value;
+        if (scores) return go(cr::k_align_staged<true, true, R>);
+        return zg ? go(cr::k_align_staged<true, false, R>) : go(cr::k_align_staged<false, false, R>);
+    });
 }
 
 int launch_stage_node(hipStream_t stream, int count, int m_max, const cr::PairDesc* pairs, const double* coords,
@@ -539,7 +555,7 @@ int launch_stage_node(hipStream_t stream, int count, int m_max, const cr::PairDe
         CR_HIP(hipGetLastError());
         return CR_OK;
     };
-    return shape.r == 1 ? go(cr::k_stage_node<1>) : go(cr::k_stage_node<2>);
+    return by_rows(shape.r, [&](auto rt) { return go(cr::k_stage_node<decltype(rt)::value>); });
 }
 
 int launch_node_staged(hipStream_t stream, int count, int entries, const cr::PairDesc* pairs, const double* coords,
@@ -556,7 +572,7 @@ int launch_node_staged(hipStream_t stream, int count, int entries, const cr::Pai
         CR_HIP(hipGetLastError());
         return CR_OK;
     };
-    return shape.r == 1 ? go(cr::k_node_staged<1>) : go(cr::k_node_staged<2>);
+    return by_rows(shape.r, [&](auto rt) { return go(cr::k_node_staged<decltype(rt)::value>); });
 }
 
 }  // namespace

@@ -429,10 +429,12 @@ class MultipleAlignment:
                           gap_open=gap_open_penalty, gap_extend=gap_extend_penalty)
         tree_u = np.ascontiguousarray(tree, dtype=np.uint64)
         h = C.c_void_p()
+        # the nodes of an earlier call go first: their device blocks (arena, staged scores: hundreds of MB for long
+        # structures) return to the library's cache and are handed to this call instead of being allocated beside them
+        self._drop_pending_nodes()
         check(lib.cr_progressive_align(default_context()._h, ptr(coords), ptr(tensors), ptr(offsets), P, d, ptr(tree_u),
                                        tree_u.shape[0], C.byref(prm), float(consensus_weight), float(gamma_weight),
                                        C.byref(h)))
-        self._drop_pending_nodes()
         try:
             sizes = np.zeros(5, np.int64)
             check(lib.cr_progressive_sizes(h, ptr(sizes)))

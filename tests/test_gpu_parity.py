@@ -289,7 +289,8 @@ def test_dp_multistrip_vs_oracle(oracle, monkeypatch, staged):
     from caretta_amd import dynamic_time_warping as dtw
     monkeypatch.setenv("CARETTA_STAGED", staged)
     rng = np.random.default_rng(5)
-    for n, m in [(321, 50), (700, 333), (1000, 64), (64, 1000), (1024, 7), (513, 200), (1025, 90), (130, 3)]:
+    for n, m in [(321, 50), (700, 333), (1000, 64), (64, 1000), (1024, 7), (513, 200), (1025, 90), (130, 3), (1537, 100), (2048, 33),
+                 (2049, 20)]:
         s = rng.uniform(size=(n, m)) ** 3
         a, b = np.arange(n), np.arange(m)
         r1 = dtw.dtw_align(a, b, s, 1.0, 0.01)
@@ -801,13 +802,15 @@ def test_progressive_resident_vs_oracle_and_single_node(oracle, num, length, rag
 
 
 @pytest.mark.parametrize("num,length,ragged,seed", [(12, 300, False, 21), (5, 335, False, 22), (7, 200, True, 23), (9, 140, True, 24),
-                                                    (5, 600, True, 25), (3, 675, False, 26), (4, 400, False, 27)])
+                                                    (5, 600, True, 25), (3, 675, False, 26), (4, 400, False, 27),
+                                                    (3, 900, False, 28), (3, 1300, True, 29)])
 def test_progressive_staged_scores_equal_fused(oracle, monkeypatch, num, length, ragged, seed):
     """The tree levels whose scores are formed by their own launches (cr_staged.h) against the fused kernels
     (CARETTA_STAGED=0): alignments, node coordinates / tensors / weights and flags bit for bit; 335-residue leaves size the
     launches for 511 rows (all 8 waves of the staged sweep with one row per lane), ragged 140-residue ones for 218 (4 waves,
-    most nodes fewer); 400 / 600 / 675-residue leaves for 608 / 908 / 1021 rows: TWO rows per lane, 5 / 8 / 8 waves.
-    The root join also against the oracle."""
+    most nodes fewer); 400 / 600 / 675-residue leaves for 608 / 908 / 1021 rows: TWO rows per lane, 5 / 8 / 8 waves; 900 /
+    1300-residue leaves for 1358 / 1958 rows: three and four rows per lane (blocks of 8 steps, skewed seed sweep; the
+    comparison run then takes the level-by-level single-wave kernels).  The root join also against the oracle."""
     from caretta_amd import multiple_alignment as ma, neighbor_joining as nj
     fam = synthetic.make_family(num, length, seed=seed, ragged=ragged, clades=2)
     prm = dict(flexible=False, gamma_tensor=7.0, gamma_coords=0.03, verbose=False)
@@ -1228,7 +1231,8 @@ def test_streamed_run_writes_what_fetch_copies(ctx):
              (synthetic.make_family(20, 150, seed=5052), None),
              (synthetic.make_family(4, 300, seed=5053, clades=1), None),               # 6 pairs of 300 rows: teams
              (synthetic.make_family(3, 700, seed=5054, clades=1), None),               # 700 rows: staged, two rows per lane
-             (synthetic.make_family(3, 1100, seed=5055, clades=1), None)]              # 1100 rows: wide kernels
+             (synthetic.make_family(3, 1100, seed=5055, clades=1), None),              # 1100 rows: staged, three rows per lane
+             (synthetic.make_family(3, 2100, seed=5056, clades=1), None)]              # 2100 rows: wide kernels
     for fam, _ in cases:
         coords, tensors, offsets = synthetic.pack(fam)
         pairs = engine.all_pairs(len(fam))
@@ -1320,13 +1324,15 @@ def test_staged_pair_batches_vs_oracle_and_fused(ctx, oracle, monkeypatch, dim, 
         assert np.array_equal(got["1"][2], got["0"][2]) and np.array_equal(got["1"][3], got["0"][3])
 
 
-def test_staged_pair_batches_two_rows_per_lane(ctx, oracle, monkeypatch):
-    """The staged sweeps with TWO rows per lane (513 .. 1024 rows): ragged pairs of 513 .. 1024 rows, both orientations,
-    gap 0 and 0.05, full pipeline and scores only, bit-identical to the oracle."""
+@pytest.mark.parametrize("longest,cuts", [(1024, [1024, 513, 700, 90]), (2048, [2048, 1100, 1537, 300])])
+def test_staged_pair_batches_two_rows_per_lane(ctx, oracle, monkeypatch, longest, cuts):
+    """The staged sweeps with TWO rows per lane (513 .. 1024 rows), three and four (.. 2048 rows; blocks of 8 steps, skewed
+    seed sweep): ragged pairs, both orientations, gap 0 and 0.05, full pipeline and scores only, bit-identical to the
+    oracle."""
     from caretta_amd import engine
     from oracle.pyoracle import default_params
-    fam = synthetic.make_family(4, 1024, seed=8181, ragged=True, clades=1)
-    for s, cut in zip(fam, [1024, 513, 700, 90]):
+    fam = synthetic.make_family(4, longest, seed=8181, ragged=True, clades=1)
+    for s, cut in zip(fam, cuts):
         s.coordinates, s.tensors = s.coordinates[:cut].copy(), s.tensors[:cut].copy()
     coords, tensors, offsets = synthetic.pack(fam)
     pairs = np.vstack([engine.all_pairs(4), engine.all_pairs(4)[:, ::-1]])

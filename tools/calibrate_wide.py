@@ -35,6 +35,8 @@ WORKLOADS = {
     "p120x750": (16, 750, 16, 1),
     "p28x750": (8, 750, 17, 1),
     "p28x1000": (8, 1000, 18, 1),
+    "p28x1500": (8, 1500, 19, 1),
+    "p6x2000": (4, 2000, 20, 1),
 }
 
 
