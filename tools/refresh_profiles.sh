@@ -20,7 +20,8 @@ python tools/config5_share_time.py > $O/config5_share.txt 2>&1
 python tools/calibrate_wide.py c5share p120x900 p120x600 p105x1500 > $O/calibrate_wide.txt 2>&1
 python tools/stamps.py run c5share c2 one300 tree128 > $O/stamps.txt 2>&1
 CARETTA_STAGED=0 python tools/stamps.py run tree128 one300 > $O/stamps_fused.txt 2>&1
-python tools/calibrate_staged.py c2 c2half one300 p64x300 p120x450 > $O/calibrate_staged.txt 2>&1
+python tools/calibrate_staged.py c2 c2half one300 p64x300 p120x450 p120x600 p120x750 p28x750 p28x1000 p120x900 p28x1500 p105x1500 p6x2000 > $O/calibrate_staged.txt 2>&1
+(for a in "128 100" "256 150" "128 300" "512 300" "64 600" "32 900" "16 1300"; do python tools/bench_msa.py $a | tail -1; CARETTA_STAGED=0 python tools/bench_msa.py $a | tail -1 | sed "s/^/   CARETTA_STAGED=0: /"; done) > $O/msa_sizes.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/msa_ktrace -o kt -- python3 tools/bench_msa.py 128 300 > $O/msa_ktrace.log 2>&1
 ./tools/valu_latency.bin > $O/valu_latency.txt 2>&1
 python tools/multi_gpu_check.py 512 300 2>/dev/null | grep '^{' > $O/multi_gpu_check_1device.json
