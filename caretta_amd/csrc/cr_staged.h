@@ -1,19 +1,22 @@
-// Launches with few workgroups (a level of the progressive alignment): the scores are formed by their own launch on every
-// CU of the chip and the sweep that holds the recurrence reads them back (cr::Staged, cr_kernels.h).
+// Launches with few workgroups -- a level of the progressive alignment, a short pair list, a single explicit score matrix:
+// the scores are formed (or gathered) by their own launch on every CU of the chip and the sweeps that hold the recurrence
+// read them back (cr::sweep_staged, cr::sweep_cols_staged in cr_kernels.h).  DESIGN.md section 4.1d.
 //
 // Why: one tree level is 1 .. P/2 nodes, every node one workgroup, and its levels come one after the other
 // (multiple_alignment.py:193-234 needs both children).  In the fused kernels the 4 .. 8 waves of a node form the scores AND
-// run the recurrence; a wave that has its SIMD to itself issues an FP64-rate instruction every ~6.5 cycles
+// run the recurrence; a wave that has its SIMD to itself issues an FP64-rate instruction every 5.5 .. 8.75 cycles
 // (profiles/r03/valu_latency.txt), so a level took 0.49 ms whether it held 64 nodes or one, and 250 of the chip's 256
 // CUs idled.  The score of a cell does not depend on the recurrence: 50 of the 59 instructions of a seed cell (tensor RBF,
-// d = 10) and 55 of the ~80 of a node cell (two RBFs) go to a launch that has as many workgroups as there are (strip, 16
-// step) pieces, and the sweep keeps ~15 / ~25 instructions per cell, with one row per lane (the shortest pipeline).
+// d = 10) and 55 of the ~80 of a node cell (two RBFs) go to a launch that has as many workgroups as there are (pair, 16 .. 64
+// step) pieces, and the sweep keeps ~15 / ~25 instructions per cell, with as few rows per lane as its eight waves allow
+// (one up to 512 rows: the shortest pipeline; up to four, 2048 rows).
 // The arithmetic is the providers' own score() -- the values are the same doubles, so every result is bit-identical to the
-// fused kernels (tests/test_gpu_parity.py::test_progressive_staged_equals_fused).
+// fused kernels (tests/test_gpu_parity.py: test_progressive_staged_scores_equal_fused,
+// test_staged_pair_batches_vs_oracle_and_fused, test_staged_pair_batches_two_rows_per_lane, test_dp_multistrip_vs_oracle).
 //
-// Layout: cr::sweep_staged.  One pair = `waves` strips of `steps` lines of 64 doubles; 8 bytes per cell are written once and
-// read once (L2 / MALL resident: one level of 64 nodes of 450 columns is 140 MB).
-// Included by cr_api.hip after cr_dropins.h.
+// Layout: one pair = `waves` strips of `steps` lines of r * 64 doubles in the consumer's step order; 8 bytes per cell are
+// written once and read once (L2 / MALL resident: one level of 64 nodes of 450 columns is 140 MB).
+// Included by cr_api.hip in front of its launch code (kernels, then the launchers).
 #pragma once
 
 namespace cr {
