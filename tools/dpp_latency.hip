@@ -7,7 +7,7 @@
 #include <vector>
 #define ITER 4096
 template <int KIND>
-__global__ __launch_bounds__(256) void k(double* out, unsigned long long* cyc, double a, double b) {
+__global__ __launch_bounds__(512) void k(double* out, unsigned long long* cyc, double a, double b) {
     double x = a + threadIdx.x;
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < ITER; it++) {

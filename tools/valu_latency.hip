@@ -7,7 +7,7 @@
 #include <vector>
 #define ITER 8192
 template <int C, int OP>
-__global__ __launch_bounds__(256) void k(double* out, unsigned long long* cyc, double a, double b) {
+__global__ __launch_bounds__(512) void k(double* out, unsigned long long* cyc, double a, double b) {
     double x[8];
     for (int i = 0; i < 8; i++) x[i] = a + threadIdx.x + i;
     const unsigned long long t0 = __builtin_readcyclecounter();
