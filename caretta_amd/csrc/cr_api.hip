@@ -24,6 +24,8 @@
 
 #include "cr_kernels.h"
 #include "cr_ilp_instances.h"
+#include "cr_duo.h"
+#include "cr_duo_instances.h"
 
 // compiled in cr_kernels_ilp.hip with another instruction scheduler (the diagnostic stamps build is one translation
 // unit: its stamp buffer is a static __device__ array)
@@ -46,6 +48,9 @@ CR_ILP_SEED_WIDE_INSTANCES(CR_X)
 #define CR_X(RA, RB, D, ZG, SC) extern template CR_PAIR_WIDE_SIGNATURE(RA, RB, D, ZG, SC)
 CR_ILP_PAIR_WIDE_INSTANCES(CR_X)
 #undef CR_X
+#define CR_X(RA, RB, D, SC) extern template CR_PAIR_DUO_SIGNATURE(RA, RB, D, SC)
+CR_DUO_INSTANCES(CR_X)
+#undef CR_X
 #endif
 
 namespace {
@@ -54,6 +59,7 @@ thread_local std::string g_err;
 // Work may be in flight on the device since the last device-wide wait of this thread (set by every API entry and every
 // kernel launch; DevBuf::release waits once and clears it, instead of once per buffer).
 thread_local bool g_dirty = true;
+thread_local bool g_no_duo = false;      // set around cr_batch_set_pairs when a duo batch meets sw_gap != 0 (run_batch)
 thread_local bool g_no_wide = false;     // set around cr_batch_set_pairs by callers whose second kernel has no wide version (cr_progressive_node)
 
 int fail(int code, const std::string& msg) {
@@ -262,6 +268,8 @@ struct cr_batch {
     bool team = false;                  // few pairs: one workgroup of kTeamWaves waves per pair (k_seed_team / k_align_team)
     int wide_sync = 0;                  // > 0: the wide kernels (one wave per strip, up to 16 waves per pair) with a barrier every wide_sync steps
     int r_b = 5, wide_na = 0;           // wide kernels: strips [0, wide_na) have r_seed rows per lane, the others r_b (r_b == r_seed: all alike)
+    std::vector<int32_t> duo_ij;        // ... the caller's pair list (k_pair_duo is built for sw_gap == 0: another gap lays the list out again)
+    bool duo = false;                   // the wide LAYOUT on k_pair_duo (cr_duo.h): 2 .. 4 waves per pair paced by LDS progress words, several pairs per CU
     bool staged = false;                // scores formed by their own launches, sweeps with one row per lane (cr_staged.h)
     DevBuf<double> staged_scores;       // ... one chunk's scores
     int n_max = 0, m_max = 0;
@@ -665,6 +673,62 @@ int launch_pair_wide(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& pr
     return b->r_seed == 2 ? launch_pair_wide_r<2, 2>(b, ck, prm, scores) : launch_pair_wide_r<3, 3>(b, ck, prm, scores);
 }
 
+// ---- mid-size pair lists: the wide layout on small workgroups paced by progress words (cr_duo.h); gap 0 only ----------
+template <int RA, int RB, int D, bool SC>
+int launch_pair_duo_t(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
+    const int seed_entries = std::min(ck.n_max, ck.m_max), align_entries = ck.max_aln;
+    const int waves = plan_of(b).strips(ck.n_max);
+    const size_t seed = std::max(cr::duo_cols_lds_doubles(waves, ck.m_max), (size_t)cr::kExpDoubles + cr::trace_lds_doubles(RA, seed_entries));
+    const size_t second = SC ? cr::duo_score_lds_doubles<cr::RbfCoords<RA>>(waves, ck.m_max)
+                             : std::max(cr::duo_sweep_lds_doubles<cr::kSwScore | cr::kDtw, cr::RbfCoords<RA>>(waves, ck.m_max),
+                                        (size_t)cr::kExpDoubles + cr::trace_lds_doubles(RA, align_entries));
+    size_t lds = sizeof(double) * std::max(seed, second);
+    if (const char* env = std::getenv("CARETTA_MID_LDS_KB")) lds = std::max(lds, (size_t)std::atoi(env) * 1024);   // calibration: pairs per CU
+    int rc = allow_lds(cr::k_pair_duo<RA, RB, D, SC>, lds);
+    if (rc) return rc;
+    CR_LAUNCH((cr::k_pair_duo<RA, RB, D, SC>), dim3((unsigned)ck.count), dim3(waves * cr::kWave), lds,
+              b->launch_stream ? b->launch_stream : b->ctx->stream, b->pairs.p + ck.first, b->tensors.p, (int)b->d, b->coords.p,
+              prm.gamma_tensor, prm.gamma_coords, prm.gap_open, prm.gap_extend, seed_entries, align_entries, b->wide_na, b->dirs.p,
+              b->bits.p, b->xf.p + ck.first, b->seed_score.p + ck.first, b->aln.p, b->res.p + ck.first, host_out_for(b, ck));
+    CR_HIP(hipGetLastError());
+    return CR_OK;
+}
+
+template <int RA, int RB>
+int launch_pair_duo_r(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, bool scores) {
+    switch (b->d_pad) {
+        case 4: return scores ? launch_pair_duo_t<RA, RB, 4, true>(b, ck, prm) : launch_pair_duo_t<RA, RB, 4, false>(b, ck, prm);
+        case 8: return scores ? launch_pair_duo_t<RA, RB, 8, true>(b, ck, prm) : launch_pair_duo_t<RA, RB, 8, false>(b, ck, prm);
+        case 10: return scores ? launch_pair_duo_t<RA, RB, 10, true>(b, ck, prm) : launch_pair_duo_t<RA, RB, 10, false>(b, ck, prm);
+        case 16: return scores ? launch_pair_duo_t<RA, RB, 16, true>(b, ck, prm) : launch_pair_duo_t<RA, RB, 16, false>(b, ck, prm);
+        default: return fail(CR_ERR_ARGUMENT, "unsupported tensor width");
+    }
+}
+
+int launch_pair_duo(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, bool scores) {
+    const int key = b->r_seed * 10 + b->r_b;
+    switch (key) {
+        case 11: return launch_pair_duo_r<1, 1>(b, ck, prm, scores);
+        case 21: return launch_pair_duo_r<2, 1>(b, ck, prm, scores);
+        case 22: return launch_pair_duo_r<2, 2>(b, ck, prm, scores);
+        case 32: return launch_pair_duo_r<3, 2>(b, ck, prm, scores);
+        case 33: return launch_pair_duo_r<3, 3>(b, ck, prm, scores);
+        default: return fail(CR_ERR_STATE, "no k_pair_duo instance for this strip plan");
+    }
+}
+
+// Strip plans k_pair_duo is built for: (RA, RB) of cr_duo_instances.h, at most kDuoMaxWaves strips, columns resident in LDS
+bool duo_fits(const StripPlan& p, int n_max, int m_max, int d_pad) {
+    const int key = p.ra * 10 + p.rb;
+    if (!(key == 11 || key == 21 || key == 22 || key == 32 || key == 33) || d_pad > 16) return false;
+    if (p.ra != p.rb && (p.na < 1 || p.na >= cr::kDuoMaxWaves)) return false;
+    const int waves = p.strips(n_max);
+    if ((waves < 2 && !std::getenv("CARETTA_MID_ANY")) || waves > cr::kDuoMaxWaves) return false;   // (CARETTA_MID_ANY: measurements)
+    const size_t fill = cr::duo_sweep_lds_doubles<cr::kSwScore | cr::kDtw, cr::RbfCoords<1>>(waves, m_max);
+    const size_t trace = cr::kExpDoubles + cr::trace_lds_doubles(1, n_max + m_max);
+    return sizeof(double) * std::max(fill, trace) <= 64 * 1024;
+}
+
 // Can a pair list with these maxima run on the wide kernels with this strip plan?  (strips <= 16 waves, the columns
 // of the tensor sweep -- the larger of the two -- resident in LDS next to the edge rings)
 bool wide_fits(const StripPlan& p, int n_max, int m_max, int d_pad) {
@@ -719,6 +783,10 @@ StripPlan choose_wide_plan(int n_max, int m_max, int d_pad, int sync_every) {
 constexpr int64_t kTeamPairLimit = 256;
 // Pair lists of at most this many 64-row strips run on staged scores (cr_batch_set_pairs): one wave per SIMD of the chip.
 constexpr int64_t kStagedWaveLimit = 1024;
+// Mid-size lists (cr_duo.h): up to this many waves (two strips per pair / more; CARETTA_MID_PAIRS overrides the pair limit
+// they give), columns resident in LDS.
+constexpr int64_t kMidWaveLimit2 = 2600, kMidWaveLimit = 3072;
+constexpr int kMidMaxColumns = 1088;
 constexpr int kGroupLanes = 4;             // streams that row-per-lane groups are spread over
 int launch_seed_team(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm);   // cr_dropins.h
 
@@ -1046,6 +1114,40 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
             b->wide_na = ra == rb ? 0 : na;
         }
     }
+    // Mid-size lists (one GPU's share of the headline configuration on 8 GPUs: 1 016 pairs of 300 x 300): too many pairs for
+    // one pair per CU, too few to give every SIMD two single-wave pairs -- a lone wave issues one FP64-rate instruction per
+    // ~7 cycles.  A pair becomes a small workgroup: 3 rows per lane in strip 0, 2 in the strips behind it (320 rows = two
+    // waves), paced by LDS progress words (cr_duo.h), several pairs per CU, all of them resident at once.  Measured
+    // (tools/c3_share.py, single wave -> this layout, full pipeline / matrix entries only, ms): 1 016 pairs of 300 0.69 -> 0.60 /
+    // 0.51 -> 0.43, 508 of 300 0.69 -> 0.55 / 0.51 -> 0.40, 1 162 of 300 0.92 -> 0.76, 1 355 of 300 0.94 -> 0.95 (the limit for two
+    // strips); three strips: 1 016 of 360 0.99 -> 0.89, of 450 1.51 -> 1.28, 508 of 450 1.50 -> 0.87; five strips: 508 of 600
+    // 2.49 -> 1.37, 1 016 of 600 2.45 -> 3.49 (5 080 waves do not fit the chip at once); 220 rows (one wave of 4 rows per lane
+    // suffices) 0.45 -> 0.47: from 257 rows on.
+    b->duo = false;
+    {
+        const char* mid = std::getenv("CARETTA_MID");
+        StripPlan p{3, 2, 1};
+        if (const char* env = std::getenv("CARETTA_MID_PLAN")) {                                  // calibration: "RA,RB,nA"
+            int ra = 0, rb = 0, na = 0;
+            if (std::sscanf(env, "%d,%d,%d", &ra, &rb, &na) == 3) p = StripPlan{ra, rb, ra == rb ? 0 : na};
+        }
+        const int64_t strips = std::max(p.strips(std::max(b->n_max, 1)), 1);
+        // (every workgroup resident at once -- 16 waves per CU at <= 128 VGPRs --, and at most ~2.5 waves per SIMD for two
+        // strips, 3 for more: beyond that the single-wave kernels fill the SIMDs by themselves)
+        int64_t mid_limit = std::min<int64_t>(256 * (16 / strips), (strips == 2 ? kMidWaveLimit2 : kMidWaveLimit) / strips);
+        if (const char* env = std::getenv("CARETTA_MID_PAIRS")) mid_limit = std::atoll(env);      // calibration
+        if (!b->wide_sync && !b->team && npairs > team_limit && npairs <= mid_limit && !(mid && mid[0] == '0') && !g_no_wide && !g_no_duo &&
+            !std::getenv("CARETTA_NO_TEAM") && !std::getenv("CARETTA_NO_WIDE") && (b->n_max > 4 * cr::kWave || std::getenv("CARETTA_MID_ANY")) &&
+            b->m_max <= kMidMaxColumns && duo_fits(p, b->n_max, b->m_max, b->d_pad)) {
+            b->team = true;                                         // the wide layout: one group, one plan
+            b->duo = true;
+            b->wide_sync = 8;
+            b->r_seed = b->r_align = p.ra;
+            b->r_b = p.rb;
+            b->wide_na = p.na;
+            b->duo_ij.assign(pairs, pairs + 2 * npairs);            // (sw_gap != 0 at run time: the list is laid out again)
+        }
+    }
     // Lists so short that one wave per 64-row strip still leaves SIMDs idle (a single pair, 66 pairs of 300, 248 pairs of
     // 150) are bound by the instruction issue of lone waves, most of it the RBF scores: those are formed by their own
     // launches on every CU and the sweeps keep the recurrence, one row per lane (cr_staged.h).  Measured
@@ -1070,6 +1172,7 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
             // (the alignment columns of a pair and the term tile of the workgroup-wide sums share the LDS)
             sizeof(double) * ((size_t)cr::kExpDoubles + cr::trace_team_lds_doubles(b->n_max + b->m_max)) <= 159 * 1024) {
             b->staged = true;
+            b->duo = false;
             b->team = true;                                         // one group, one plan: the team kernels' layout rules
             b->wide_sync = 0;
             b->wide_na = 0;
@@ -1279,6 +1382,13 @@ static int run_batch(cr_batch* b, const cr_params* params, double* d_sw_out, boo
                "gamma_tensor and gamma_coords must be finite and >= 1e-290 (below that every score is exactly 1.0)");
     CR_REQUIRE(std::isfinite(prm.gap_open) && std::isfinite(prm.gap_extend) && std::isfinite(prm.sw_gap),
                "gap penalties must be finite");
+    if (b->duo && prm.sw_gap != 0.0) {                            // k_pair_duo is the gap-0 pipeline: lay the list out without it
+        const std::vector<int32_t> ij = std::move(b->duo_ij);
+        g_no_duo = true;
+        rc = cr_batch_set_pairs(b, ij.data(), (int64_t)(ij.size() / 2));
+        g_no_duo = false;
+        if (rc) return rc;
+    }
     const bool prof = ctx->slots > 0;
     std::vector<hipEvent_t>* evl = nullptr;
     if (prof) {                                                   // three events per chunk: start, seed done, align done
@@ -1328,7 +1438,7 @@ static int run_batch(cr_batch* b, const cr_params* params, double* d_sw_out, boo
         if (b->wide_sync) {
             // the wide layout: both stages of a pair in ONE launch (k_pair_wide) -- the stage split of the events is
             // (everything, 0)
-            rc = launch_pair_wide(b, ck, prm, scores_only && prm.sw_gap == 0.0);
+            rc = b->duo ? launch_pair_duo(b, ck, prm, scores_only) : launch_pair_wide(b, ck, prm, scores_only && prm.sw_gap == 0.0);
             if (!rc && prof) {
                 (void)hipEventRecord((*evl)[evi++], st);
                 (void)hipEventRecord((*evl)[evi++], st);
@@ -1423,6 +1533,15 @@ int cr_batch_work(cr_batch* b, double* alg_bytes, double* cells) {
     return CR_OK;
 }
 
+int cr_batch_layout(cr_batch* b, int* family, int* rows_a, int* rows_b, int* strips_a) {
+    CR_REQUIRE(b != nullptr, "null batch");
+    if (family) *family = b->staged ? CR_LAYOUT_STAGED : b->duo ? CR_LAYOUT_DUO : b->wide_sync ? CR_LAYOUT_WIDE : b->team ? CR_LAYOUT_TEAM : CR_LAYOUT_SINGLE;
+    if (rows_a) *rows_a = b->r_seed;
+    if (rows_b) *rows_b = b->wide_sync ? b->r_b : b->r_seed;
+    if (strips_a) *strips_a = b->wide_sync ? b->wide_na : 0;
+    return CR_OK;
+}
+
 int cr_batch_max_aln_len(cr_batch* b, int64_t* out) {
     CR_REQUIRE(b != nullptr && out != nullptr, "null argument");
     *out = b->max_aln;
@@ -1491,6 +1610,12 @@ int cr_batch_fetch_scores(cr_batch* b, double* sw, uint32_t* flags) {
 }
 
 #ifdef CR_STAMPS
+// diagnostic build only: the per-wave stamps of k_pair_duo (cr_duo.h), 32 slots per block
+int cr_debug_duo_stamps(unsigned long long* out, int blocks) {
+    CR_HIP(hipDeviceSynchronize());
+    CR_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(cr::g_duo_stamps), sizeof(unsigned long long) * 32 * (size_t)blocks));
+    return CR_OK;
+}
 // diagnostic build only: copy out (and clear) the phase stamps of the first `blocks` blocks
 int cr_debug_stamps(unsigned long long* out, int blocks) {
     CR_HIP(hipDeviceSynchronize());

@@ -1,0 +1,12 @@
+// Instances of k_pair_duo (cr_duo.h), compiled in their own translation unit (cr_kernels_duo.hip); cr_api.hip declares them
+// `extern template`.  (RA, RB): rows per lane of the first nA strips and of the others.
+#pragma once
+
+#define CR_DUO_D(X, RA, RB) \
+    X(RA, RB, 4, false) X(RA, RB, 4, true) X(RA, RB, 8, false) X(RA, RB, 8, true) X(RA, RB, 10, false) X(RA, RB, 10, true) \
+    X(RA, RB, 16, false) X(RA, RB, 16, true)
+#define CR_DUO_INSTANCES(X) CR_DUO_D(X, 1, 1) CR_DUO_D(X, 2, 1) CR_DUO_D(X, 2, 2) CR_DUO_D(X, 3, 2) CR_DUO_D(X, 3, 3)
+#define CR_PAIR_DUO_SIGNATURE(RA, RB, D, SC)                                                                                  \
+    __global__ void cr::k_pair_duo<RA, RB, D, SC>(const cr::PairDesc*, const double*, int, const double*, double, double,     \
+                                                  double, double, int, int, int, uint32_t*, uint32_t*, cr::Transform*, double*, \
+                                                  int32_t*, cr::PairResult*, const cr::HostOut);

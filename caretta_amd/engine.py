@@ -209,6 +209,13 @@ class PairBatch:
         check(self._lib.cr_batch_work(self._h, C.byref(b), C.byref(c)))
         return b.value, c.value
 
+    def layout(self):
+        """(kernel family, rows per lane A, rows per lane B, strips with A) chosen by ``set_pairs`` -- "single" (one wave per
+        pair), "team", "wide" (one workgroup per pair), "staged" (scores by their own launches), "duo" (mid-size lists)."""
+        f, ra, rb, na = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        check(self._lib.cr_batch_layout(self._h, C.byref(f), C.byref(ra), C.byref(rb), C.byref(na)))
+        return ("single", "team", "wide", "staged", "duo")[f.value], ra.value, rb.value, na.value
+
     def close(self):
         if self._h:
             self._lib.cr_batch_destroy(self._h)
@@ -268,20 +275,54 @@ class MultiDevice:
 
 
 _multi = None
+_MULTI_FAILED = object()              # sentinel: the multi-device machinery could not be set up in this process
 MULTI_DEVICE_MIN_PAIRS = 16384        # below this one GPU is not even full (256 CUs x 16 wave slots = 4096 pairs per round)
 
 
+def _inside_multi_rank_job() -> bool:
+    """One process per GPU (torchrun, bench.py's own ranks, any torch.distributed job): every rank sees every GPU, and a
+    MultiDevice in each of them would open WORLD_SIZE x WORLD_SIZE contexts and communicators on the librccl shared with torch."""
+    import os
+    import sys
+    try:
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            return True
+    except ValueError:
+        pass
+    dist = getattr(sys.modules.get("torch"), "distributed", None)      # never imports torch by itself
+    try:
+        return bool(dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+    except Exception:
+        return False
+
+
 def multi_device() -> Optional[MultiDevice]:
-    """The process-wide MultiDevice over all visible GPUs, or None when there is only one (or CARETTA_SINGLE_DEVICE=1)."""
+    """The process-wide MultiDevice over all visible GPUs, or None: one GPU only, CARETTA_SINGLE_DEVICE=1, this process is one
+    rank of a multi-rank job (it owns ONE of the GPUs it sees; CARETTA_MULTI_DEVICE=1 overrides), or setting it up has failed
+    before in this process (``multi_device_failed`` records that; the caller computes on one device)."""
     global _multi
     import os
-    if os.environ.get("CARETTA_SINGLE_DEVICE") == "1":
+    if os.environ.get("CARETTA_SINGLE_DEVICE") == "1" or _multi is _MULTI_FAILED:
+        return None
+    if _inside_multi_rank_job() and os.environ.get("CARETTA_MULTI_DEVICE") != "1":
         return None
     if _multi is None:
         if device_count() < 2:
             return None
         _multi = MultiDevice()
     return _multi
+
+
+def multi_device_failed() -> None:
+    """Remember that the multi-device path does not work here (no usable RCCL, a device that cannot be opened): later
+    calls of ``multi_device`` return None at once instead of computing every share and failing again."""
+    global _multi
+    old, _multi = _multi, _MULTI_FAILED
+    if isinstance(old, MultiDevice):
+        try:
+            old.close()
+        except Exception:
+            pass
 
 
 def partition_pairs(lengths, world: int, rank: int) -> np.ndarray:

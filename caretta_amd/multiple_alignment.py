@@ -335,16 +335,18 @@ class MultipleAlignment:
         if self._all_proteins() and not score_function_params.get("flexible", False):
             from . import engine
             npairs = num * (num - 1) // 2
-            multi = engine.multi_device() if npairs >= engine.MULTI_DEVICE_MIN_PAIRS else None
-            if multi is not None:
-                # several GPUs visible to this process: the pair set dealt over all of them, one RCCL all-gather.  A fault
-                # of the multi-device machinery (communicator set-up, a device that cannot be opened) is not a fault of
-                # the input: say so and compute the same matrix on one device.
+            if npairs >= engine.MULTI_DEVICE_MIN_PAIRS:
+                # several GPUs visible to (and owned by) this process: the pair set dealt over all of them, one RCCL
+                # all-gather.  A fault of the multi-device machinery (communicator set-up, a device that cannot be opened)
+                # is not a fault of the input: say so ONCE, remember it, and compute the same matrix on one device.
                 try:
-                    return self._pairwise_matrix_multi(multi, score_function_params)
+                    multi = engine.multi_device()
+                    if multi is not None:
+                        return self._pairwise_matrix_multi(multi, score_function_params)
                 except _capi.CarettaHipError as exc:
                     import warnings
-                    warnings.warn(f"multi-GPU pairwise matrix failed ({exc}); running on one device", RuntimeWarning)
+                    engine.multi_device_failed()
+                    warnings.warn(f"multi-GPU pairwise matrix failed ({exc}); running on one device from now on", RuntimeWarning)
             out = self.pairwise(score_function_params, want_alignments=False, scores_only=True)
             return assemble_matrix(out.pairs, out.results["sw"], num)
         # third-party SequenceBase plugins: the score matrices come from the plugin's own score_function (its Python),

@@ -1,0 +1,162 @@
+"""GPU parity tests of the mid-size pair-list layout (caretta_amd/csrc/cr_duo.h: one small workgroup per pair, one wave per
+strip, strips paced by LDS progress words) and of the path-selection boundaries of cr_batch_set_pairs.  Everything is compared
+with the C oracle bit for bit, through the C ABI."""
+import numpy as np
+import pytest
+
+from caretta_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from caretta_amd import engine
+    c = engine.Context(0)
+    yield c
+    c.close()
+
+
+def assert_bit_identical(res, aln, ref, ref_aln):
+    assert np.array_equal(res["flags"], ref["flags"])
+    assert np.array_equal(res["aln_len"], ref["aln_len"])
+    assert np.array_equal(res["seed_len"], ref["seed_len"])
+    for p in range(len(res)):
+        ln = int(ref["aln_len"][p])
+        assert np.array_equal(aln[p, :, :ln], ref_aln[p, :, :ln]), f"pair {p}: alignment differs"
+        assert np.all(aln[p, :, ln:] == -2)
+    for key in ("sw", "dtw_score", "seed_score", "rmsd", "coverage", "tm", "R", "t"):
+        assert np.array_equal(res[key], ref[key]), f"{key}: not bit-identical to the oracle"
+
+
+def layout_of(batch):
+    """(kernel family, rows per lane A, rows per lane B, strips with A) the library chose for the batch's pair list."""
+    return batch.layout()
+
+
+def run_all_ways(ctx, oracle, coords, tensors, offsets, pairs, expect, sw_gaps=(0.0,), threads=8):
+    """Full pipeline, matrix entries only and the streamed run of one pair list against the oracle; `expect`: the kernel
+    family cr_batch_set_pairs must have chosen."""
+    from caretta_amd import engine
+    from oracle.pyoracle import default_params
+    batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
+    assert layout_of(batch)[0] == expect, f"layout {layout_of(batch)}, expected {expect}"
+    for gap in sw_gaps:
+        ref, ref_aln = oracle.pairwise_batch(coords, tensors, offsets, pairs, params=default_params(sw_gap=gap), nthreads=threads)
+        prm = engine.make_params(sw_gap=gap)
+        batch.run(prm)
+        res, aln = batch.fetch()
+        assert_bit_identical(res, aln, ref, ref_aln)
+        batch.run(prm, scores_only=True)
+        sw, flags = batch.fetch_scores()
+        assert np.array_equal(sw, ref["sw"])
+        res_s, aln_s = batch.run_streamed(prm)
+        ctx.synchronize()
+        assert res_s.tobytes() == res.tobytes()
+        for p in range(len(pairs)):
+            ln = int(res["aln_len"][p])
+            assert np.array_equal(aln_s[p, :, :ln], aln[p, :, :ln])
+    batch.close()
+
+
+def test_one_of_eight_share_of_the_headline(ctx, oracle):
+    """BASELINE config 3 sharded over 8 GPUs: every 8th of the 8 128 pairs of 128 x 300 (1 016 pairs) is what ONE GPU runs
+    (north star: ">= 6x further scaling at 8 GPUs").  That list runs two waves per pair (k_pair_duo); all 1 016 pairs, every
+    output, against the oracle."""
+    from caretta_amd import engine
+    fam = synthetic.make_family(128, 300, seed=20242)
+    coords, tensors, offsets = synthetic.pack(fam)
+    pairs = engine.all_pairs(128)[::8]
+    assert len(pairs) == 1016
+    run_all_ways(ctx, oracle, coords, tensors, offsets, pairs, "duo")
+
+
+@pytest.mark.parametrize("dim,seed", [(10, 9101), (4, 9102), (16, 9103), (7, 9104)])
+def test_midsize_ragged_lists_vs_oracle(ctx, oracle, dim, seed):
+    """Ragged lengths 40 .. 330 rows, both orientations of every pair (290 .. 400 pairs: beyond the one-pair-per-CU layouts):
+    pairs of one launch end in strip 0 or strip 1, some have fewer rows than one strip; tensor widths that are padded (7)
+    or not; with a Smith-Waterman gap the list is laid out again for the kernels that have a skewed seed sweep."""
+    from caretta_amd import engine
+    fam = synthetic.make_family(15, 330, dim=dim, seed=seed, ragged=True, clades=3)
+    cuts = [330, 300, 257, 320, 321, 193, 192, 64, 65, 40, 288, 129, 310, 256, 191]
+    for s, cut in zip(fam, cuts):
+        s.coordinates, s.tensors = s.coordinates[:cut].copy(), s.tensors[:cut].copy()
+    coords, tensors, offsets = synthetic.pack(fam)
+    fwd = engine.all_pairs(15)
+    pairs = np.vstack([fwd, fwd[:, ::-1], fwd[::2]])             # 105 + 105 + 53 = 263 > 256
+    run_all_ways(ctx, oracle, coords, tensors, offsets, pairs, "duo", sw_gaps=(0.0, 0.05) if dim == 10 else (0.0,))
+
+
+def test_midsize_three_and_more_strips(ctx, oracle):
+    """321 .. 600 rows: three to five waves per pair (3 rows per lane in strip 0, 2 in the others), ragged."""
+    from caretta_amd import engine
+    fam = synthetic.make_family(18, 600, seed=9201, ragged=True, clades=2)
+    cuts = [600, 450, 321, 577, 448, 449, 320, 576, 300, 130, 512, 360, 333, 599, 64, 400, 585, 470]
+    for s, cut in zip(fam, cuts):
+        s.coordinates, s.tensors = s.coordinates[:cut].copy(), s.tensors[:cut].copy()
+    coords, tensors, offsets = synthetic.pack(fam)
+    fwd = engine.all_pairs(18)
+    pairs = np.vstack([fwd, fwd[:, ::-1]])                      # 306 pairs
+    run_all_ways(ctx, oracle, coords, tensors, offsets, pairs, "duo")
+
+
+@pytest.mark.parametrize("npairs,rows,expect", [
+    (256, 193, ("wide", "staged")), (257, 193, ("single",)), (257, 256, ("single",)), (257, 257, ("duo",)), (256, 257, ("wide", "staged")),
+    (1300, 300, ("duo",)), (1301, 300, ("single",)), (1024, 360, ("duo",)), (1025, 360, ("single",)),
+    (256, 192, ("single", "staged")), (204, 300, ("staged",)), (205, 300, ("wide",))])
+def test_path_selection_boundaries(ctx, oracle, npairs, rows, expect):
+    """The pair-count and row-count limits of cr_batch_set_pairs at their boundary values: which kernel family runs on either
+    side, and that both sides give the oracle's results (a sample of the pairs is compared: the lists differ by one pair)."""
+    from caretta_amd import engine
+    num = 2
+    while num * (num - 1) < npairs:
+        num += 1
+    fam = synthetic.make_family(num, rows, seed=7000 + npairs + rows, clades=3)
+    coords, tensors, offsets = synthetic.pack(fam)
+    fwd = engine.all_pairs(num)
+    pairs = np.vstack([fwd, fwd[:, ::-1]])[:npairs]
+    assert len(pairs) == npairs
+    batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
+    assert layout_of(batch)[0] in expect, f"{npairs} pairs of {rows}: layout {layout_of(batch)}, expected one of {expect}"
+    batch.run()
+    res, aln = batch.fetch()
+    batch.close()
+    sample = np.unique(np.concatenate([np.arange(0, npairs, max(1, npairs // 40)), [npairs - 1]]))
+    ref, ref_aln = oracle.pairwise_batch(coords, tensors, offsets, pairs[sample], nthreads=8)
+    assert_bit_identical(res[sample], aln[sample], ref, ref_aln)
+
+
+@pytest.mark.parametrize("rows", [512, 513, 1024, 1025, 2048, 2049])
+def test_row_limits_of_the_staged_sweeps(ctx, oracle, rows):
+    """One, two, three / four rows per lane of the staged sweeps change at 512 and 1024 rows, the staged path ends at 2048:
+    three pairs on either side of each limit."""
+    from caretta_amd import engine
+    fam = synthetic.make_family(3, rows, seed=7100 + rows, clades=1)
+    coords, tensors, offsets = synthetic.pack(fam)
+    pairs = engine.all_pairs(3)
+    batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
+    fam_name, ra, rb, na = layout_of(batch)
+    # (beyond 2048 rows: the wide layout while the columns of the widest sweep fit the LDS -- 10 features x 2049 columns do
+    # not --, else one wave per pair)
+    assert fam_name == "staged" if rows <= 2048 else fam_name in ("wide", "single"), (rows, fam_name)
+    if rows <= 2048:
+        assert ra == (1 if rows <= 512 else 2 if rows <= 1024 else 3 if rows <= 1536 else 4), (rows, ra)
+    batch.run()
+    res, aln = batch.fetch()
+    batch.close()
+    assert_bit_identical(res, aln, *oracle.pairwise_batch(coords, tensors, offsets, pairs, nthreads=3))
+
+
+@pytest.mark.parametrize("dim", [16, 17])
+def test_tensor_width_limit_of_the_one_workgroup_layouts(ctx, oracle, dim):
+    """Widths up to 16 have wide / mid-size instances, 17 and more run one wave per pair (or four-wave teams)."""
+    from caretta_amd import engine
+    fam = synthetic.make_family(24, 300, dim=dim, seed=7200 + dim, clades=2)
+    coords, tensors, offsets = synthetic.pack(fam)
+    pairs = np.vstack([engine.all_pairs(24), engine.all_pairs(24)[:40, ::-1]])       # 316 pairs
+    batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
+    assert layout_of(batch)[0] == ("duo" if dim <= 16 else "single")
+    batch.run()
+    res, aln = batch.fetch()
+    batch.close()
+    assert_bit_identical(res, aln, *oracle.pairwise_batch(coords, tensors, offsets, pairs, nthreads=8))

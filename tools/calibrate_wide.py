@@ -22,6 +22,8 @@ from caretta_amd import engine, synthetic  # noqa: E402
 WORKLOADS = {
     "c5share": (64, 1200, 20244, 8),      # 252 pairs: one GPU's share of BASELINE config 5 on 8 GPUs
     "c5": (64, 1200, 20244, 1),
+    "c3share": (128, 300, 20242, 8),      # 1016 pairs: one GPU's share of the headline configuration on 8 GPUs
+    "c3quarter": (128, 300, 20242, 4),    # 2032 pairs
     "c2": (32, 150, 20241, 1),
     "c2half": (32, 150, 20241, 2),        # 248 pairs: at most one wave per CU
     "c2x4": (64, 150, 20241, 1),          # 2016 pairs: two per SIMD
