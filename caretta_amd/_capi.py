@@ -53,6 +53,7 @@ SIGNATURES = {
     "cr_batch_set_pairs": [_vp, _vp, _i64],
     "cr_batch_run": [_vp, C.POINTER(Params), _vp],
     "cr_batch_run_scores": [_vp, C.POINTER(Params), _vp],
+    "cr_batch_run_tensor_scores": [_vp, C.POINTER(Params), _vp],
     "cr_batch_run_stream_i32": [_vp, C.POINTER(Params), _vp, _vp, _i64, _vp],
     "cr_batch_fetch": [_vp, _vp, _vp, _i64],
     "cr_batch_fetch_i32": [_vp, _vp, _vp, _i64],
@@ -90,6 +91,7 @@ SIGNATURES = {
     "cr_explicit_batch_last_ms": [_vp, C.POINTER(C.c_float)],
     "cr_smith_waterman_score_batch": [_vp, _f64, _vp],
     "cr_dtw_align_batch": [_vp, _f64, _f64, _vp, _i64, _vp, _vp],
+    "cr_smith_waterman_batch": [_vp, _f64, _vp, _i64, _vp, _vp, _vp],
     "cr_paired_svd_superpose": [_vp, _vp, _vp, _i64, _vp, _vp],
     "cr_paired_svd_superpose_with_subset": [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp],
     "cr_apply_rotran": [_vp, _vp, _i64, _vp, _vp, _vp],

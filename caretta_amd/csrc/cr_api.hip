@@ -26,6 +26,7 @@
 #include "cr_ilp_instances.h"
 #include "cr_duo.h"
 #include "cr_duo_instances.h"
+#include "cr_flexible.h"
 
 // compiled in cr_kernels_ilp.hip with another instruction scheduler (the diagnostic stamps build is one translation
 // unit: its stamp buffer is a static __device__ array)
@@ -556,6 +557,35 @@ int launch_score_team_r(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_
 int launch_score_r(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
     return R == 1 ? launch_score<1>(b, ck, prm) : R == 2 ? launch_score<2>(b, ck, prm) : R == 3 ? launch_score<3>(b, ck, prm)
          : R == 4 ? launch_score<4>(b, ck, prm) : launch_score<5>(b, ck, prm);
+}
+
+// flexible=True (cr_flexible.h): the tensor score matrix's smith_waterman_score alone
+template <int R, int D>
+int launch_tensor_score(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
+    const size_t lds = sizeof(double) * (cr::kExpDoubles + cr::RbfTensor<R, D>::kRingDoubles);
+    CR_LAUNCH((cr::k_tensor_score<R, D>), dim3((unsigned)ck.count), dim3(cr::kWave), lds, b->launch_stream ? b->launch_stream : b->ctx->stream,
+              b->pairs.p + ck.first, b->tensors.p, (int)b->d, prm.gamma_tensor, b->hand.p, b->res.p + ck.first);
+    CR_HIP(hipGetLastError());
+    return CR_OK;
+}
+
+template <int R>
+int launch_tensor_score_d(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
+    switch (b->d_pad) {
+        case 4: return launch_tensor_score<R, 4>(b, ck, prm);
+        case 8: return launch_tensor_score<R, 8>(b, ck, prm);
+        case 10: return launch_tensor_score<R, 10>(b, ck, prm);
+        case 16: return launch_tensor_score<R, 16>(b, ck, prm);
+        case 24: return launch_tensor_score<R, 24>(b, ck, prm);
+        case 32: return launch_tensor_score<R, 32>(b, ck, prm);
+        default: return fail(CR_ERR_ARGUMENT, "unsupported tensor width");
+    }
+}
+
+// (rows per lane: at least the layout's, so that a pair that needs several strips here has its hand-off row in b->hand)
+int launch_tensor_score_r(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
+    return R <= 2 ? launch_tensor_score_d<2>(b, ck, prm) : R == 3 ? launch_tensor_score_d<3>(b, ck, prm)
+         : R == 4 ? launch_tensor_score_d<4>(b, ck, prm) : launch_tensor_score_d<5>(b, ck, prm);
 }
 
 // The fused kernels feed rows past the end of a structure features of 1e150 so that their RBF score underflows to
@@ -1501,6 +1531,31 @@ int cr_batch_run_stream_i32(cr_batch* b, const cr_params* params, cr_pair_result
 }
 
 int cr_batch_run_scores(cr_batch* b, const cr_params* params, double* d_sw_out) { return run_batch(b, params, d_sw_out, true); }
+
+int cr_batch_run_tensor_scores(cr_batch* b, const cr_params* params, double* d_sw_out) {
+    CR_REQUIRE(b != nullptr && params != nullptr, "null argument");
+    int rc = set_device(b->ctx);
+    if (rc) return rc;
+    CR_REQUIRE(gamma_ok(params->gamma_tensor), "gamma_tensor must be finite and >= 1e-290 (below that every score is exactly 1.0)");
+    cr_context* ctx = b->ctx;
+    for (const cr_batch::Chunk& ck : b->chunks) {                  // (one stream: a single light launch per chunk)
+        b->launch_stream = ctx->stream;
+        rc = launch_tensor_score_r(ck.r, b, ck, *params);
+        b->launch_stream = nullptr;
+        if (rc) return rc;
+    }
+    if (b->npairs && d_sw_out && b->reordered) {
+        CR_LAUNCH(cr::k_scatter_sw, dim3((unsigned)((b->npairs + 255) / 256)), dim3(256), 0, ctx->stream, b->res.p, b->d_order.p, d_sw_out,
+                  (int)b->npairs);
+        CR_HIP(hipGetLastError());
+    } else if (b->npairs && d_sw_out) {
+        CR_HIP(hipMemcpy2DAsync(d_sw_out, sizeof(double), b->res.p, sizeof(cr::PairResult), sizeof(double), (size_t)b->npairs,
+                                hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    b->ran = true;
+    b->scores_only = true;
+    return CR_OK;
+}
 
 int cr_batch_stage_ms(cr_batch* b, float ms[CR_NUM_STAGES], int* runs_averaged) {
     CR_REQUIRE(b != nullptr && ms != nullptr, "null argument");

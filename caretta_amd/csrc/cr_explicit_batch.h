@@ -365,6 +365,106 @@ __global__ __launch_bounds__(kWave) void k_dtw_trace_batch(const ExplicitProblem
     }
 }
 
+// smith_waterman WITH its traceback (dynamic_time_warping.py:226-278) over the list: the fill with 2-bit decisions and the
+// first maximum in row-major order (kSwTrace), Explicit tile or the streaming provider; `dirs_off`: word offset of every
+// problem's decisions (laid out for this launch's rows per lane).
+template <int R, bool STREAM>
+__global__ __launch_bounds__(kWave) void k_explicit_sw_batch(const ExplicitProblem* __restrict__ probs, const int64_t* __restrict__ dirs_off,
+                                                            const double* __restrict__ S, const int32_t* __restrict__ seqs,
+                                                            SweepParams prm, uint32_t* __restrict__ dirs, double* __restrict__ hand,
+                                                            SeedMax* __restrict__ seeds) {
+    extern __shared__ double lds[];
+    const ExplicitProblem pb = probs[blockIdx.x];
+    SeedMax sm;
+    sm.score = 0.0;
+    sm.i = sm.j = 0;
+    AlignEnd ae;
+    if (pb.m > 0) {
+        if constexpr (STREAM) {
+            ExplicitStream<R> src;
+            src.S = S;
+            src.s_off = pb.s_off;
+            src.seq1 = seqs + pb.seq1_off;
+            src.s_cols = pb.s_cols;
+            src.col0 = pb.col0;
+            src.m_ = pb.m;
+            src.t_ = 0;
+            src.lane_ = threadIdx.x & (kWave - 1);
+            sweep<R, kSwTrace>(src, pb.n, pb.m, prm, lds, dirs + dirs_off[blockIdx.x], nullptr, hand + pb.hand_off, sm, ae);
+        } else {
+            Explicit<R> src;
+            src.S = S + pb.s_off;
+            src.seq1 = seqs + pb.seq1_off;
+            src.seq2 = seqs + pb.seq2_off;
+            src.s_cols = pb.s_cols;
+            sweep<R, kSwTrace>(src, pb.n, pb.m, prm, lds, dirs + dirs_off[blockIdx.x], nullptr, hand + pb.hand_off, sm, ae);
+        }
+    }
+    if (threadIdx.x == 0) seeds[blockIdx.x] = sm;
+}
+
+// The walk of smith_waterman (:249-278) WITH its gap entries, one wave per problem on the register-resident decision
+// blocks (Walker<R, 2>): whole diagonal, horizontal and vertical runs per ballot, entries packed in LDS back to front, rows
+// to HBM coalesced (as dtw_walk).  LDS: (n + m) packed entries.
+template <int R>
+__global__ __launch_bounds__(kWave) void k_sw_trace_batch(const ExplicitProblem* __restrict__ probs, const int64_t* __restrict__ dirs_off,
+                                                         const uint32_t* __restrict__ dirs, const SeedMax* __restrict__ seeds,
+                                                         int32_t* __restrict__ aln, BatchTrace* __restrict__ out) {
+    extern __shared__ double lds[];
+    const ExplicitProblem pb = probs[blockIdx.x];
+    const SeedMax sm = seeds[blockIdx.x];
+    const int lane = threadIdx.x;
+    uint32_t* arow = reinterpret_cast<uint32_t*>(lds);
+    const int cap = pb.n + pb.m;
+    int idx = 0;
+    if (sm.i > 0) {
+        Walker<R, 2, 1> wk;
+        wk.init(dirs + dirs_off[blockIdx.x], tblocks(pb.m, 16), lane);
+        int i = __builtin_amdgcn_readfirstlane(sm.i), j = __builtin_amdgcn_readfirstlane(sm.j);
+        wk.set_row(i - 1);
+#pragma unroll 1
+        while (i > 0 && j > 0) {
+            const uint32_t code = wk.get(i - 1, j - 1);
+            if (code == 0) break;
+            if (code == 1) {
+                const int run = wk.diag_run(i - 1, j - 1, [](uint32_t f) { return f == 1u; });
+                if (lane < run) arow[cap - idx - 1 - lane] = pack_entry(i - 1 - lane, j - 1 - lane);
+                idx += run;
+                i -= run;
+                j -= run;
+                if (i > 0) wk.set_row(i - 1);
+            } else if (code == 2) {
+                bool more;
+                const int run = wk.run_left(i - 1, j - 1, [](uint32_t f) { return f == 2u; }, more);
+                if (lane < run) arow[cap - idx - 1 - lane] = pack_entry(-1, j - 1 - lane);
+                idx += run;
+                j -= run;
+            } else {
+                bool more;
+                const int run = wk.template run_up<0>(i - 1, j - 1, [](uint32_t f) { return f == 3u; }, more);
+                if (lane < run) arow[cap - idx - 1 - lane] = pack_entry(i - 1 - lane, -1);
+                idx += run;
+                i -= run;
+                if (i > 0) wk.set_row(i - 1);
+            }
+        }
+    }
+    wave_sync();
+    const int first = cap - idx;
+    int32_t* a1 = aln + pb.aln_off;
+    int32_t* a2 = a1 + cap;
+    for (int x = first + lane; x < cap; x += kWave) {
+        const uint32_t u = arow[x];
+        const uint32_t i = u & 0xffffu, j = u >> 16;
+        a1[x] = i == kGap16 ? -1 : (int)i;
+        a2[x] = j == kGap16 ? -1 : (int)j;
+    }
+    if (lane == 0) {
+        out[blockIdx.x].len = idx;
+        out[blockIdx.x].start = first;
+    }
+}
+
 }  // namespace cr
 
 struct cr_explicit_batch {
@@ -386,6 +486,10 @@ struct cr_explicit_batch {
     DevBuf<uint32_t> bits;
     DevBuf<cr::AlignEnd> ends;
     DevBuf<cr::BatchTrace> trace;
+    DevBuf<cr::SeedMax> seeds;          // cr_smith_waterman_batch: first maximum of every problem
+    DevBuf<uint32_t> sw_dirs;           // ... its 2-bit decisions
+    DevBuf<int64_t> sw_dirs_off;        // ... word offset of every problem (laid out for the rows per lane of the launch)
+    int sw_dirs_r = 0;                  // ... rows per lane the offsets were laid out for (0: not yet)
     int64_t s_elems = 0;
     float last_ms = 0.f;             // device time of the last batch kernel (HIP events on the context's stream)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -617,6 +721,87 @@ int cr_smith_waterman_score_batch(cr_explicit_batch* b, double gap, double* scor
     CR_DOWNLOAD(b->ctx, scores, b->scores.p, sizeof(double) * (size_t)b->count);
     CR_HIP(hipStreamSynchronize(st));
     CR_HIP(hipEventElapsedTime(&b->last_ms, b->ev0, b->ev1));
+    return CR_OK;
+}
+
+int cr_smith_waterman_batch(cr_explicit_batch* b, double gap, int64_t* aln, int64_t aln_stride, int64_t* aln_len, double* scores,
+                            int32_t* all_zero) {
+    CR_REQUIRE(b != nullptr && aln != nullptr && aln_len != nullptr, "null argument");
+    int rc = set_device(b->ctx);
+    if (rc) return rc;
+    CR_REQUIRE(std::isfinite(gap), "gap must be finite");
+    CR_REQUIRE(aln_stride >= b->cap_max, "aln needs a stride of at least the longest n + m");
+    CR_REQUIRE(!b->has_minus1, "seq2: index outside the score matrix (-1 only ends a row of smith_waterman_score)");
+    hipStream_t st = b->ctx->stream;
+    const bool stream = b->all_ident;                    // contiguous columns everywhere: the streaming sweep
+    const int R = stream ? b->r_stream : kExplicitR;
+    int64_t aln_total = 0;
+    if (b->sw_dirs_r != R) {                             // decision layout of this launch's rows per lane
+        std::vector<int64_t> off((size_t)b->count);
+        int64_t total = 0;
+        for (int64_t p = 0; p < b->count; p++) {
+            const auto& e = b->h_probs[(size_t)p];
+            off[(size_t)p] = total;
+            total += (int64_t)cr::strips_of(e.n, R) * cr::tblocks(e.m, 16) * R * cr::kWave;
+        }
+        if ((rc = upload(b->sw_dirs_off, off.data(), off.size(), b->ctx))) return rc;
+        CR_HIP(b->sw_dirs.ensure((size_t)std::max<int64_t>(total, 1)));
+        b->sw_dirs_r = R;
+    }
+    for (const auto& e : b->h_probs) aln_total = std::max(aln_total, e.aln_off + 2 * (int64_t)(e.n + e.m));
+    CR_HIP(b->seeds.ensure((size_t)b->count));
+    CR_HIP(b->aln.ensure((size_t)aln_total));
+    CR_HIP(b->trace.ensure((size_t)b->count));
+    cr::SweepParams prm{gap, 0.0, 0.0};
+    CR_HIP(hipEventRecord(b->ev0, st));
+    auto fill = [&](auto rt, auto stream_tag) -> int {
+        constexpr int RR = decltype(rt)::value;
+        constexpr bool STREAM = decltype(stream_tag)::value;
+        using Src = std::conditional_t<STREAM, cr::ExplicitStream<RR>, cr::Explicit<RR>>;
+        const size_t lds = cr::sweep_lds_doubles<RR, cr::kSwTrace, Src>(b->n_max, b->m_max) * sizeof(double);
+        int rc2 = allow_lds(cr::k_explicit_sw_batch<RR, STREAM>, lds);
+        if (rc2) return rc2;
+        CR_LAUNCH((cr::k_explicit_sw_batch<RR, STREAM>), dim3((unsigned)b->count), dim3(cr::kWave), lds, st, b->probs.p, b->sw_dirs_off.p,
+                  b->S.p + kSlackFront, b->seqs.p, prm, b->sw_dirs.p, b->hand.p, b->seeds.p);
+        CR_HIP(hipGetLastError());
+        const size_t tl = sizeof(double) * cr::trace_lds_doubles(RR, b->cap_max);
+        if ((rc2 = allow_lds(cr::k_sw_trace_batch<RR>, tl))) return rc2;
+        CR_LAUNCH((cr::k_sw_trace_batch<RR>), dim3((unsigned)b->count), dim3(cr::kWave), tl, st, b->probs.p, b->sw_dirs_off.p, b->sw_dirs.p,
+                  b->seeds.p, b->aln.p, b->trace.p);
+        CR_HIP(hipGetLastError());
+        return CR_OK;
+    };
+    if (!stream) rc = fill(std::integral_constant<int, kExplicitR>{}, std::false_type{});
+    else rc = R == 1 ? fill(std::integral_constant<int, 1>{}, std::true_type{}) : R == 2 ? fill(std::integral_constant<int, 2>{}, std::true_type{})
+            : R == 3 ? fill(std::integral_constant<int, 3>{}, std::true_type{}) : R == 4 ? fill(std::integral_constant<int, 4>{}, std::true_type{})
+            : fill(std::integral_constant<int, 5>{}, std::true_type{});
+    if (rc) return rc;
+    CR_HIP(hipEventRecord(b->ev1, st));
+    std::vector<cr::SeedMax> seeds((size_t)b->count);
+    std::vector<cr::BatchTrace> tr((size_t)b->count);
+    std::vector<int32_t> h_aln((size_t)aln_total);
+    CR_DOWNLOAD(b->ctx, seeds.data(), b->seeds.p, sizeof(cr::SeedMax) * seeds.size());
+    CR_DOWNLOAD(b->ctx, tr.data(), b->trace.p, sizeof(cr::BatchTrace) * tr.size());
+    CR_DOWNLOAD(b->ctx, h_aln.data(), b->aln.p, sizeof(int32_t) * h_aln.size());
+    CR_HIP(hipStreamSynchronize(st));
+    CR_HIP(hipEventElapsedTime(&b->last_ms, b->ev0, b->ev1));
+    for (int64_t p = 0; p < b->count; p++) {
+        if (scores) scores[p] = seeds[(size_t)p].score;
+        if (all_zero) all_zero[p] = seeds[(size_t)p].i == 0 ? 1 : 0;
+        const cr::ExplicitProblem& e = b->h_probs[(size_t)p];
+        const int cap = e.n + e.m;
+        const int32_t* a1 = h_aln.data() + e.aln_off + tr[(size_t)p].start;
+        const int32_t* a2 = a1 + cap;
+        int64_t* o1 = aln + (size_t)p * 2 * (size_t)aln_stride;
+        int64_t* o2 = o1 + aln_stride;
+        const int len = tr[(size_t)p].len;
+        for (int x = 0; x < len; x++) {
+            o1[x] = a1[x];
+            o2[x] = a2[x];
+        }
+        for (int64_t x = len; x < aln_stride; x++) o1[x] = o2[x] = -2;
+        aln_len[p] = len;
+    }
     return CR_OK;
 }
 

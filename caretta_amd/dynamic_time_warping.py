@@ -122,6 +122,20 @@ class ExplicitBatch:
                                            ptr(lens), ptr(scores)))
         return [(aln[k, 0, :lens[k]].copy(), aln[k, 1, :lens[k]].copy(), float(scores[k])) for k in range(len(self))]
 
+    def smith_waterman(self, gap: float = 0.0):
+        """smith_waterman (dynamic_time_warping.py:226-278) of every problem -> list of (aln_1, aln_2, score); a problem
+        without a positive cell raises the reference's TypeError (its ``max_pos`` stays None)."""
+        stride = max(n + m for n, m in self.shapes)
+        aln = np.empty((len(self), 2, stride), dtype=np.int64)
+        lens = np.zeros(len(self), dtype=np.int64)
+        scores = np.zeros(len(self))
+        zero = np.zeros(len(self), dtype=np.int32)
+        check(self._lib.cr_smith_waterman_batch(self._h, float(gap), ptr(aln), stride, ptr(lens), ptr(scores), ptr(zero)))
+        if zero.any():
+            raise TypeError(f"cannot unpack non-iterable NoneType object (score matrix of problem {int(np.nonzero(zero)[0][0])} "
+                            "has no positive local alignment)")
+        return [(aln[k, 0, :lens[k]].copy(), aln[k, 1, :lens[k]].copy(), float(scores[k])) for k in range(len(self))]
+
     def last_kernel_ms(self) -> float:
         ms = C.c_float(0.0)
         check(self._lib.cr_explicit_batch_last_ms(self._h, C.byref(ms)))
@@ -144,6 +158,15 @@ def smith_waterman_score_batch(problems, gap: float = 0.0) -> np.ndarray:
     batch = ExplicitBatch(problems)
     try:
         return batch.smith_waterman_scores(gap)
+    finally:
+        batch.close()
+
+
+def smith_waterman_batch(problems, gap: float = 0.0):
+    """[smith_waterman(seq1, seq2, matrix, gap) for (seq1, seq2, matrix) in problems] in one launch sequence."""
+    batch = ExplicitBatch(problems)
+    try:
+        return batch.smith_waterman(gap)
     finally:
         batch.close()
 

@@ -134,11 +134,16 @@ class PairBatch:
         check(self._lib.cr_batch_set_pairs(self._h, ptr(self.pairs), len(self.pairs)))
         return self
 
-    def run(self, params: Optional[Params] = None, sw_out_device_ptr: Optional[int] = None, scores_only: bool = False):
+    def run(self, params: Optional[Params] = None, sw_out_device_ptr: Optional[int] = None, scores_only: bool = False,
+            flexible: bool = False):
         """Enqueue the pipeline.  ``scores_only``: just the P x P matrix entries (make_pairwise_matrix): the seed kernel and
-        a smith_waterman_score kernel, no pairwise dtw_align -- afterwards only ``fetch_scores`` has results."""
+        a smith_waterman_score kernel, no pairwise dtw_align -- afterwards only ``fetch_scores`` has results.
+        ``flexible`` (with ``scores_only``): the entries of the flexible=True score function, smith_waterman_score of the
+        tensor score matrix alone (cr_batch_run_tensor_scores)."""
         params = params or make_params()
-        fn = self._lib.cr_batch_run_scores if scores_only else self._lib.cr_batch_run
+        if flexible and not scores_only:
+            raise ValueError("flexible=True has no pairwise alignment stage: use scores_only=True")
+        fn = self._lib.cr_batch_run_tensor_scores if flexible else self._lib.cr_batch_run_scores if scores_only else self._lib.cr_batch_run
         check(fn(self._h, C.byref(params), C.c_void_p(sw_out_device_ptr) if sw_out_device_ptr else None))
 
     def run_streamed(self, params: Optional[Params] = None, want_alignments: bool = True, sw_out_device_ptr: Optional[int] = None):

@@ -178,7 +178,10 @@ def pack_proteins(proteins: typing.Sequence[Protein], staging: bool = False):
         coords, tensors = have[0][:total], have[1][:total]
     else:
         coords, tensors = np.empty((total, 3)), np.empty((total, d))
-    np.concatenate([np.asarray(p.coordinates) for p in proteins], axis=0, out=coords)
+    if any(p.coordinates is None for p in proteins):      # flexible=True nodes carry tensors only (multiple_alignment.py:361-362)
+        coords[:] = 0.0
+    else:
+        np.concatenate([np.asarray(p.coordinates) for p in proteins], axis=0, out=coords)
     np.concatenate([np.asarray(p.tensors) for p in proteins], axis=0, out=tensors)
     return coords, tensors, offsets
 
@@ -266,8 +269,8 @@ class MultipleAlignment:
     final_alignments = _NodeAttribute("final_alignments")
 
     # -- batched GPU path ---------------------------------------------------------------------
-    def _all_proteins(self) -> bool:
-        return all(type(s) is Protein and s.coordinates is not None for s in self.sequences)
+    def _all_proteins(self, need_coordinates: bool = True) -> bool:
+        return all(type(s) is Protein and (s.coordinates is not None or not need_coordinates) for s in self.sequences)
 
     def pairwise(self, score_function_params=None, gap_open_penalty=1.0, gap_extend_penalty=0.01, pairs=None,
                  want_alignments=True, context: typing.Optional[Context] = None,
@@ -275,8 +278,11 @@ class MultipleAlignment:
         """Pipeline H over a pair list (default: all i<j): the P x P score entry, the pairwise
         dtw_align alignment and its RMSD / coverage / TM, in one batched launch sequence."""
         prm = dict(score_function_params or {})
-        if prm.pop("flexible", False):
-            raise ValueError("flexible=True bypasses the pairwise path; not supported by the batched engine")
+        flexible = bool(prm.pop("flexible", False))
+        if flexible and not scores_only:
+            # (the reference has no pairwise alignment of flexible score matrices either: its 2-sequence branch and its
+            # progressive alignment call dtw_align on them, which dynamic_time_warping.dtw_align_batch serves)
+            raise ValueError("flexible=True: only the matrix entries (scores_only=True) run on the batched engine")
         prm.pop("verbose", None)
         params = make_params(gamma_tensor=prm.pop("gamma_tensor", 0.03), gamma_coords=prm.pop("gamma_coords", 0.03),
                              gap_open=gap_open_penalty, gap_extend=gap_extend_penalty)
@@ -288,7 +294,7 @@ class MultipleAlignment:
         try:
             pairs = all_pairs(len(self.sequences)) if pairs is None else np.asarray(pairs, np.int32).reshape(-1, 2)
             batch.set_pairs(pairs)
-            batch.run(params, scores_only=scores_only)
+            batch.run(params, scores_only=scores_only, flexible=flexible)
             if scores_only:                       # the matrix entries only: 12 bytes per pair come back
                 sw, flags = batch.fetch_scores()
                 # (two columns, not a zeroed PAIR_RESULT record per pair: 21 MB of host memory at 512 structures that nobody
@@ -347,6 +353,12 @@ class MultipleAlignment:
                     import warnings
                     engine.multi_device_failed()
                     warnings.warn(f"multi-GPU pairwise matrix failed ({exc}); running on one device from now on", RuntimeWarning)
+            out = self.pairwise(score_function_params, want_alignments=False, scores_only=True)
+            return assemble_matrix(out.pairs, out.results["sw"], num)
+        if (score_function_params.get("flexible", False) and self._all_proteins(need_coordinates=False)
+                and len({np.shape(s.tensors)[1] for s in self.sequences}) == 1):
+            # flexible=True: smith_waterman_score of the tensor score matrix of every pair (multiple_alignment.py:323-326,
+            # :164), one launch over the pair list (cr_batch_run_tensor_scores)
             out = self.pairwise(score_function_params, want_alignments=False, scores_only=True)
             return assemble_matrix(out.pairs, out.results["sw"], num)
         # third-party SequenceBase plugins: the score matrices come from the plugin's own score_function (its Python),

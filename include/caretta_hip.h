@@ -124,6 +124,11 @@ int cr_batch_run_stream_i32(cr_batch *b, const cr_params *params, cr_pair_result
  * Afterwards only cr_batch_fetch_scores (and d_sw_out) have results; the flags carry the seed conditions
  * (CR_FLAG_SEED_SKIPPED, CR_FLAG_SEED_ALL_ZERO) only.  With sw_gap != 0 it runs the full pipeline. */
 int cr_batch_run_scores(cr_batch *b, const cr_params *params, double *d_sw_out);
+/* flexible=True: Protein.score_function short-circuits to the tensor score matrix (multiple_alignment.py:323-326), whose
+ * smith_waterman_score (gap 0, dynamic_time_warping.py:205-222) is the P x P matrix entry (:164).  One launch over the pair
+ * list; only gamma_tensor of `params` is read; afterwards cr_batch_fetch_scores has the entries (flags are 0: this path of
+ * the reference raises nothing).  d_sw_out as for cr_batch_run. */
+int cr_batch_run_tensor_scores(cr_batch *b, const cr_params *params, double *d_sw_out);
 /* Synchronise and copy results to host.  Any pointer may be NULL.  results[npairs];
  * aln i64[npairs, 2, aln_stride] (rows padded with -2 after aln_len; aln_stride >= max(n+m)). */
 int cr_batch_fetch(cr_batch *b, cr_pair_result *results, int64_t *aln, int64_t aln_stride);
@@ -245,6 +250,12 @@ int cr_explicit_batch_destroy(cr_explicit_batch *b);
 int cr_explicit_batch_last_ms(cr_explicit_batch *b, float *ms);
 /* scores[count] = smith_waterman_score(seq1_k, seq2_k, S_k, gap)      dynamic_time_warping.py:205-222 */
 int cr_smith_waterman_score_batch(cr_explicit_batch *b, double gap, double *scores);
+/* smith_waterman WITH its traceback (dynamic_time_warping.py:226-278) of every problem: aln i64[count][2][aln_stride] = the
+ * two index rows (-1 = gap; padded with -2 behind aln_len[p]), scores[p] = the maximum, all_zero[p] != 0 where the matrix has no
+ * positive cell (the reference then fails to unpack max_pos = None).  aln_stride >= the longest n + m.  scores, all_zero may
+ * be NULL.  A -1 in seq2 is rejected (only smith_waterman_score gives it a meaning). */
+int cr_smith_waterman_batch(cr_explicit_batch *b, double gap, int64_t *aln, int64_t aln_stride, int64_t *aln_len, double *scores,
+                            int32_t *all_zero);
 /* dtw_align(seq1_k, seq2_k, S_k, gap_open, gap_extend) for every k     dynamic_time_warping.py:148-184
  * aln: int64 [count][2][aln_stride] (aln_stride >= longest n + m), rows padded with -2; aln may be NULL (scores only). */
 int cr_dtw_align_batch(cr_explicit_batch *b, double gap_open, double gap_extend, int64_t *aln, int64_t aln_stride,

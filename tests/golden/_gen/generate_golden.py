@@ -192,6 +192,26 @@ def gen_kabsch(rng):
     save("f1_kabsch.npz", out)
 
 
+def gen_kabsch_degenerate():
+    """Rank-deficient correlation matrices through the reference's own paired_svd_superpose (LAPACK dgesdd): collinear
+    positions (rank 1), coincident positions (rank 0), planar (rank 2), the same inputs tests/test_oracle_golden.py builds
+    in degenerate_kabsch_cases().  LAPACK's choice of the null-space basis is not the Jacobi SVD's: R is stored so that the
+    tests can RECORD the distance, the superposed coordinates / RMSD so that they can compare what is determined."""
+    sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+    from test_oracle_golden import degenerate_kabsch_cases
+    out = {}
+    c = 0
+    for tag, x1, x2 in degenerate_kabsch_cases():
+        rot, tran = sup.paired_svd_superpose(x1, x2)
+        moved = sup.apply_rotran(x2, rot, tran)
+        out[f"c{c}_x1"], out[f"c{c}_x2"], out[f"c{c}_R"], out[f"c{c}_t"], out[f"c{c}_moved"] = x1, x2, rot, tran, moved
+        out[f"c{c}_rmsd"] = np.float64(score_functions.get_rmsd(x1, moved))
+        out[f"c{c}_tag"] = np.array(tag)
+        c += 1
+    out["ncases"] = np.int64(c)
+    save("f8_kabsch_degenerate.npz", out)
+
+
 def gen_misc(rng):
     out = {}
     # get_common_positions
@@ -304,6 +324,26 @@ def gen_pipeline():
         print(f"  family {tag}: {len(pairs)} pairs in {time.time() - t0:.1f}s")
     out["families"] = np.array(list(fams.keys()))
     save("f2_pipeline.npz", out)
+
+
+def gen_flexible():
+    """flexible=True (multiple_alignment.py:323-326): the reference's own make_pairwise_matrix on two small families -- the
+    P x P matrix of smith_waterman_score over the TENSOR score matrices alone -- and one score matrix / alignment of its
+    two-sequence branch (smith_waterman on the flexible score function's matrix, :226-278)."""
+    out = {}
+    for tag, fam in (("FA", synthetic.make_family(8, 60, seed=20241, ragged=True)), ("FB", synthetic.make_family(3, 340, seed=20242, clades=1))):
+        store_family(out, f"fam{tag}", fam)
+        msa = multiple_alignment.MultipleAlignment(to_proteins(fam))
+        out[f"fam{tag}_M"] = msa.make_pairwise_matrix(score_function_params=dict(flexible=True, gamma_tensor=SF_PARAMS["gamma_tensor"]))
+        prots = to_proteins(fam)
+        s = prots[0].score_function(prots[1], flexible=True, gamma_tensor=SF_PARAMS["gamma_tensor"])
+        a1, a2, score = dtw.smith_waterman(np.arange(s.shape[0]), np.arange(s.shape[1]), s, gap=0.0)
+        if tag == "FA":                      # (the 340 x 340 matrix of FB would be 0.9 MB: its alignment and score are kept)
+            out[f"fam{tag}_S01"] = s
+        out[f"fam{tag}_sw_aln1"], out[f"fam{tag}_sw_aln2"] = a1.astype(np.int64), a2.astype(np.int64)
+        out[f"fam{tag}_sw_score"] = np.float64(score)
+    out["families"] = np.array(["FA", "FB"])
+    save("f9_flexible.npz", out)
 
 
 def gen_pipeline_long():
@@ -525,9 +565,11 @@ def main():
     steps += [("dtw", lambda: gen_dtw(np.random.default_rng(20228), mats)),
               ("sw", lambda: gen_sw(np.random.default_rng(20227), mats)),
               ("kabsch", lambda: gen_kabsch(np.random.default_rng(20226))),
+              ("kabsch_degenerate", gen_kabsch_degenerate),
               ("misc", lambda: gen_misc(np.random.default_rng(20225))),
               ("pipeline", gen_pipeline),
               ("long", gen_pipeline_long),
+              ("flexible", gen_flexible),
               ("tree", lambda: gen_tree(np.random.default_rng(20224))),
               ("tree64", gen_tree64),
               ("formats", lambda: gen_formats(np.random.default_rng(20222))),

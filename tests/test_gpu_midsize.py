@@ -160,3 +160,69 @@ def test_tensor_width_limit_of_the_one_workgroup_layouts(ctx, oracle, dim):
     res, aln = batch.fetch()
     batch.close()
     assert_bit_identical(res, aln, *oracle.pairwise_batch(coords, tensors, offsets, pairs, nthreads=8))
+
+
+def test_kabsch_degenerate_against_lapack(golden):
+    """The device's paired_svd_superpose on the reference's own outputs for collinear / coincident / planar positions
+    (tests/golden/f8_kabsch_degenerate.npz, LAPACK dgesdd): same landing positions and RMSD; R itself is only determined
+    for the planar and coincident classes (tests/test_oracle_golden.py records the distances)."""
+    from caretta_amd import superposition_functions as sup
+    from test_oracle_golden import check_degenerate_kabsch_against_lapack
+    check_degenerate_kabsch_against_lapack(golden("f8_kabsch_degenerate.npz"), sup.paired_svd_superpose)
+
+
+# ------------------------------------------------------------------------------- the two paths that used to run pair by pair
+def test_flexible_pairwise_matrix_runs_batched(oracle, golden):
+    """flexible=True (multiple_alignment.py:323-326): the P x P matrix is smith_waterman_score of the TENSOR score matrices
+    alone -- one launch over the pair list (cr_batch_run_tensor_scores) -- against the reference's own matrices
+    (f9_flexible.npz), against the oracle bit for bit, for one and for several strips per pair and tensor widths that are
+    padded, and against the per-pair calls of the score function + smith_waterman_score."""
+    from caretta_amd import dynamic_time_warping as dtw, multiple_alignment as ma
+    from test_oracle_golden import flexible_reference
+    g = golden("f9_flexible.npz")
+    for tag in ("FA", "FB"):
+        offs, tens, xyz = g[f"fam{tag}_offsets"], g[f"fam{tag}_tensors"], g[f"fam{tag}_coords"]
+        prots = [ma.Protein(f"s{k}", tens[offs[k]:offs[k + 1]], xyz[offs[k]:offs[k + 1]]) for k in range(len(offs) - 1)]
+        m = ma.MultipleAlignment(prots).make_pairwise_matrix(dict(flexible=True, gamma_tensor=7.0))
+        np.testing.assert_allclose(m, g[f"fam{tag}_M"], rtol=1e-9, atol=1e-12)
+        assert np.array_equal(m, flexible_reference(oracle, g, tag))
+        # tensors only (what mean_function(flexible=True) leaves of a node): same matrix
+        bare = [ma.Protein(p.name, p.tensors) for p in prots]
+        assert np.array_equal(ma.MultipleAlignment(bare).make_pairwise_matrix(dict(flexible=True, gamma_tensor=7.0)), m)
+    for dim, lengths, seed in [(7, [700, 40, 333, 321, 64], 9301), (16, [150] * 7, 9302), (24, [90, 500, 257], 9303)]:
+        fam = synthetic.make_family(len(lengths), max(lengths), dim=dim, seed=seed, ragged=True, clades=2)
+        for s, cut in zip(fam, lengths):
+            s.coordinates, s.tensors = s.coordinates[:cut].copy(), s.tensors[:cut].copy()
+        prots = [ma.Protein(s.name, s.tensors, s.coordinates) for s in fam]
+        m = ma.MultipleAlignment(prots).make_pairwise_matrix(dict(flexible=True, gamma_tensor=1.3))
+        for i in range(len(prots) - 1):
+            for j in range(i + 1, len(prots)):
+                s_ij = oracle.make_score_matrix(prots[i].tensors, prots[j].tensors, 1.3)
+                assert m[i, j] == m[j, i] == oracle.smith_waterman_score(np.arange(len(prots[i])), np.arange(len(prots[j])), s_ij, 0.0)
+        s01 = prots[0].score_function(prots[1], flexible=True, gamma_tensor=1.3)        # the per-pair route of the product
+        assert m[0, 1] == dtw.smith_waterman_score(np.arange(s01.shape[0]), np.arange(s01.shape[1]), s01)
+
+
+def test_smith_waterman_batch_vs_oracle(oracle, golden):
+    """smith_waterman WITH its traceback over a list (cr_smith_waterman_batch; dynamic_time_warping.py:226-278): ragged
+    problems, alphabet mode, windows of larger matrices, negative scores, gap 0 and 0.25, the streaming kernels (contiguous
+    columns everywhere) and the tile kernels; the reference's own alignment on a flexible score matrix; an all-zero matrix
+    raises the reference's TypeError."""
+    from caretta_amd import dynamic_time_warping as dtw
+    from test_gpu_parity import _explicit_problems
+    rng = np.random.default_rng(9401)
+    mixed = [p for p in _explicit_problems(rng) if not np.any(np.asarray(p[1]) < 0)]
+    ident = [(np.arange(n), np.arange(m), rng.uniform(size=(n, m)) ** 2 - 0.15) for n, m in [(300, 300), (64, 65), (1, 9), (257, 130), (90, 400), (513, 77)]]
+    for problems in (mixed, ident, ident * 600):                 # (3 600 problems: one row per lane in the streaming kernels)
+        for gap in (0.0, 0.25):
+            got = dtw.smith_waterman_batch(problems, gap)
+            for (s1, s2, mat), (a1, a2, score) in zip(problems[:len(mixed) + len(ident)], got):
+                r1, r2, rs, none = oracle.smith_waterman(s1, s2, mat, gap)
+                assert not none and np.array_equal(a1, r1) and np.array_equal(a2, r2) and score == rs
+    g = golden("f9_flexible.npz")
+    s = g["famFA_S01"]
+    (a1, a2, score), = dtw.smith_waterman_batch([(np.arange(s.shape[0]), np.arange(s.shape[1]), s)], 0.0)
+    assert np.array_equal(a1, g["famFA_sw_aln1"]) and np.array_equal(a2, g["famFA_sw_aln2"])
+    assert abs(score - float(g["famFA_sw_score"])) <= 1e-12 * abs(score)
+    with pytest.raises(TypeError):
+        dtw.smith_waterman_batch([(np.arange(4), np.arange(5), np.ones((4, 5))), (np.arange(3), np.arange(3), -np.ones((3, 3)))], 0.0)

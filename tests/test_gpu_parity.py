@@ -1143,13 +1143,13 @@ def test_very_long_pairs_match_the_oracle():
 
 
 def test_randomised_parity_run():
-    """tests/fuzz_parity.py for a few seconds: random ragged batches, all parameter settings, the resident progressive
+    """tests/fuzz_parity.py for a minute: random ragged batches, all parameter settings, the resident progressive
     alignment and the explicit-matrix drop-ins, everything bit-identical to the oracle (longer runs: profiles/)."""
     import subprocess
     import sys
     from pathlib import Path
     script = Path(__file__).resolve().parent / "fuzz_parity.py"
-    out = subprocess.run([sys.executable, str(script), "8", "99"], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([sys.executable, str(script), "60", "99"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "all bit-identical to the oracle" in out.stdout
 

@@ -117,6 +117,33 @@ def degenerate_kabsch_cases():
     return cases
 
 
+def check_degenerate_kabsch_against_lapack(g, superpose):
+    """f8_kabsch_degenerate.npz: what the reference's LAPACK SVD returns for rank-deficient correlation matrices.  A rotation
+    about a line of collinear positions is not determined by the data, so R may differ (the distance is returned, per case,
+    for the record); what IS determined -- where the positions land, the RMSD, R a proper rotation -- must agree."""
+    dist = {}
+    for c in range(int(g["ncases"])):
+        tag, x1, x2 = str(g[f"c{c}_tag"]), g[f"c{c}_x1"], g[f"c{c}_x2"]
+        r, t = superpose(x1, x2)
+        np.testing.assert_allclose(r @ r.T, np.eye(3), atol=1e-12, err_msg=tag)
+        assert abs(np.linalg.det(r) - 1.0) < 1e-12 and abs(np.linalg.det(g[f"c{c}_R"]) - 1.0) < 1e-12, tag
+        moved = x2 @ r + t
+        np.testing.assert_allclose(moved, g[f"c{c}_moved"], atol=1e-9, err_msg=tag)
+        rmsd = float(np.sqrt(((x1 - moved) ** 2).sum() / len(x1)))
+        assert abs(rmsd - float(g[f"c{c}_rmsd"])) < 1e-5, tag
+        dist.setdefault(tag, []).append(float(np.linalg.norm(r - g[f"c{c}_R"])))
+        if tag in ("coincident", "planar"):               # rank 0: both return the identity; rank 2: R is determined
+            np.testing.assert_allclose(r, g[f"c{c}_R"], atol=1e-9, err_msg=tag)
+    return dist
+
+
+def test_kabsch_degenerate_against_lapack(oracle, golden):
+    dist = check_degenerate_kabsch_against_lapack(golden("f8_kabsch_degenerate.npz"), oracle.paired_svd_superpose)
+    # recorded: collinear positions leave the rotation about the line free -- LAPACK's R and the Jacobi SVD's are 1.5 .. 2.8
+    # apart (Frobenius) while the superposed positions agree to 1e-14
+    assert max(dist["collinear"]) > 1.0 and max(dist["coincident"]) == 0.0 and max(dist["planar"]) < 1e-12
+
+
 def test_kabsch_rank_deficient(oracle):
     """The reference's LAPACK SVD returns an orthonormal U for any input; so must the Jacobi SVD (collinear seeds)."""
     for tag, x1, x2 in degenerate_kabsch_cases():
@@ -307,3 +334,28 @@ def test_progressive_alignment(oracle, golden, tag):
         xn, tn, wn = nodes[p + k]
         np.testing.assert_allclose(xn, g[f"fam{tag}_n{k}_coords"], atol=1e-9)
         assert np.array_equal(tn, g[f"fam{tag}_n{k}_tensors"]) and np.array_equal(wn, g[f"fam{tag}_n{k}_weights"])
+
+
+def flexible_reference(oracle, g, tag, gamma_tensor=7.0):
+    """The oracle's restatement of the flexible=True matrix (multiple_alignment.py:323-326, :158-170) on a stored family."""
+    offs = g[f"fam{tag}_offsets"]
+    tens = g[f"fam{tag}_tensors"]
+    num = len(offs) - 1
+    m = np.zeros((num, num))
+    for i in range(num - 1):
+        for j in range(i + 1, num):
+            s = oracle.make_score_matrix(tens[offs[i]:offs[i + 1]], tens[offs[j]:offs[j + 1]], gamma_tensor)
+            m[i, j] = m[j, i] = oracle.smith_waterman_score(np.arange(s.shape[0]), np.arange(s.shape[1]), s, 0.0)
+    return m
+
+
+def test_flexible_matrix_golden(oracle, golden):
+    """f9_flexible.npz: the reference's own make_pairwise_matrix(flexible=True) and smith_waterman on a flexible score matrix."""
+    g = golden("f9_flexible.npz")
+    for tag in ("FA", "FB"):
+        np.testing.assert_allclose(flexible_reference(oracle, g, tag), g[f"fam{tag}_M"], rtol=1e-9, atol=1e-12)
+        offs, tens = g[f"fam{tag}_offsets"], g[f"fam{tag}_tensors"]
+        s = oracle.make_score_matrix(tens[offs[0]:offs[1]], tens[offs[1]:offs[2]], 7.0)
+        a1, a2, score, _none = oracle.smith_waterman(np.arange(s.shape[0]), np.arange(s.shape[1]), s, 0.0)
+        assert np.array_equal(a1, g[f"fam{tag}_sw_aln1"]) and np.array_equal(a2, g[f"fam{tag}_sw_aln2"])
+        assert abs(score - float(g[f"fam{tag}_sw_score"])) <= 1e-9 * abs(score)
