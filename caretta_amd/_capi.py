@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -138,10 +139,12 @@ def _share_torch_hip_runtime():
 
 def share_torch_rccl():
     """One RCCL per process, for the single-process multi-GPU path (cr_multi_*, which binds librccl at run time and
-    prefers a copy that is already loaded): when a torch installation is present its librccl.so is loaded now, so that a
-    later ``import torch.distributed`` in the same process finds the same object.  Without torch (or with
+    prefers a copy that is already loaded).  When a torch installation is present, torch itself is imported here: it then
+    loads its librccl.so and that library's dependencies in ITS order.  (Loading torch's librccl.so by path first and
+    importing torch later in the same process works until the process exits -- and then aborts in the libraries' teardown
+    with "double free or corruption": measured on ROCm 7.0 / torch 2.10, tools/exit_order_probe.py.)  Without torch (or with
     CARETTA_SYSTEM_HIP=1) the library falls back to the loader's search path and /opt/rocm/lib."""
-    if os.environ.get("CARETTA_SYSTEM_HIP") == "1":
+    if os.environ.get("CARETTA_SYSTEM_HIP") == "1" or "torch" in sys.modules:
         return
     try:
         import importlib.util
@@ -150,11 +153,10 @@ def share_torch_rccl():
         spec = None
     if spec is None or not spec.origin:
         return
-    cand = Path(spec.origin).parent / "lib" / "librccl.so"
-    if cand.exists():
+    if (Path(spec.origin).parent / "lib" / "librccl.so").exists():
         try:
-            C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
-        except OSError:
+            import torch  # noqa: F401
+        except Exception:  # noqa: BLE001 -- a broken torch installation must not break the one-device paths
             pass
 
 

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <limits>
 #include <mutex>
 #include <map>
@@ -1039,8 +1040,23 @@ int cr_context_set_profiling(cr_context* ctx, int slots) {
 // ---------------------------------------------------------------------------------------------
 // batch
 // ---------------------------------------------------------------------------------------------
+}  // extern "C"
+
+// (check_finite = false: the caller has validated the arrays -- cr_multi_pairwise_scores does it once for all devices)
+static int batch_create(cr_context* ctx, const double* coords, const double* tensors, const int64_t* offsets, int64_t num_structures,
+                        int64_t d, bool check_finite, cr_batch** out);
+
+extern "C" {
+
 int cr_batch_create(cr_context* ctx, const double* coords, const double* tensors, const int64_t* offsets,
                     int64_t num_structures, int64_t d, cr_batch** out) {
+    return batch_create(ctx, coords, tensors, offsets, num_structures, d, true, out);
+}
+
+}  // extern "C"
+
+static int batch_create(cr_context* ctx, const double* coords, const double* tensors, const int64_t* offsets, int64_t num_structures,
+                        int64_t d, bool check_finite, cr_batch** out) {
     CR_REQUIRE(out != nullptr, "null out");
     *out = nullptr;
     int rc = set_device(ctx);
@@ -1054,8 +1070,10 @@ int cr_batch_create(cr_context* ctx, const double* coords, const double* tensors
         CR_REQUIRE(offsets[s + 1] > offsets[s], "every structure needs at least one residue");
         CR_REQUIRE(offsets[s + 1] - offsets[s] <= cr::kMaxLength, "structure longer than 65534 residues");
     }
-    CR_REQUIRE(all_finite(coords, (size_t)offsets[num_structures] * 3), "coordinates contain NaN or infinity");
-    CR_REQUIRE(all_finite(tensors, (size_t)offsets[num_structures] * (size_t)d), "tensors contain NaN or infinity");
+    if (check_finite) {
+        CR_REQUIRE(all_finite(coords, (size_t)offsets[num_structures] * 3), "coordinates contain NaN or infinity");
+        CR_REQUIRE(all_finite(tensors, (size_t)offsets[num_structures] * (size_t)d), "tensors contain NaN or infinity");
+    }
     cr_batch* b = new (std::nothrow) cr_batch();
     if (!b) return fail(CR_ERR_MEMORY, "out of host memory");
     b->ctx = ctx;
@@ -1088,6 +1106,8 @@ int cr_batch_create(cr_context* ctx, const double* coords, const double* tensors
     *out = b;
     return CR_OK;
 }
+
+extern "C" {
 
 int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     CR_REQUIRE(b != nullptr, "null batch");

@@ -106,18 +106,89 @@ constexpr auto k_fill_f64 = k_fill_f64_t<>;
 struct cr_multi {
     std::vector<int> devices;
     std::vector<cr_context*> ctx;
-    std::vector<void*> comm;                 // ncclComm_t per device (empty until the first collective)
+    std::vector<void*> comm;                 // ncclComm_t per device, created by cr_multi_create (empty in loopback mode)
+    // Everything a device needs for its share is KEPT between calls: the batch (device copies of the structures, pair
+    // descriptors, scratch), the share's pair list, the gather buffers, the events, the host thread.  A call with the same
+    // layout (P, d, offsets) uploads coordinates and tensors into the kept batch -- 16 MB at 512 x 300, cheaper than any
+    // fingerprint of them -- and runs; another layout rebuilds the batch and the deal.
     struct PerDevice {
         DevBuf<double> local, gathered;
         DevBuf<uint32_t> local_flags, gathered_flags;
+        cr_batch* batch = nullptr;
+        std::vector<int64_t> owned;          // pair ids (row-major i < j) of this device's share, ascending
+        std::vector<int32_t> ij;             // ... as (i, j): the source of the batch's pair-list upload, alive with the batch
+        hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // on the device's stream: call start, share computed, gathered
+        int rc = CR_OK;
+        std::string err;
     };
     std::vector<PerDevice*> dev;
+    int64_t P = 0, d = 0;                    // layout the kept batches were made for
+    std::vector<int64_t> offsets;
     // The device list names a device twice (only accepted with CARETTA_MULTI_ALLOW_DUPLICATES=1; RCCL refuses such a
     // communicator): the shares are gathered with device copies instead.  This is how a one-GPU box runs the deal, the
     // host threads, the share layout and the scatter with MORE THAN ONE share (tests); it is not a product path.
     bool loopback = false;
-    float last_ms[3] = {0.f, 0.f, 0.f};      // wall ms of the last call: compute (all devices), all-gather, download + scatter
+    float last_ms[3] = {0.f, 0.f, 0.f};      // last call: slowest device's share (events), all-gather (events), download + scatter (wall)
+    // one host thread per device, parked between calls
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    std::function<void(int)> job;
+    uint64_t generation = 0;
+    int pending = 0;
+    bool stop = false;
 };
+
+namespace {
+
+// run fn(g) for every device on that device's host thread (the caller's thread when there is one device), wait for all
+void multi_run(cr_multi* m, const std::function<void(int)>& fn) {
+    const int G = (int)m->devices.size();
+    if (m->threads.empty()) {
+        for (int g = 0; g < G; g++) fn(g);
+        return;
+    }
+    std::unique_lock<std::mutex> lk(m->mu);
+    m->job = fn;
+    m->pending = G;
+    m->generation++;
+    m->cv_go.notify_all();
+    m->cv_done.wait(lk, [&] { return m->pending == 0; });
+    m->job = nullptr;
+}
+
+void multi_worker(cr_multi* m, int g) {
+    uint64_t seen = 0;
+    for (;;) {
+        std::function<void(int)> fn;
+        {
+            std::unique_lock<std::mutex> lk(m->mu);
+            m->cv_go.wait(lk, [&] { return m->stop || m->generation != seen; });
+            if (m->stop) return;
+            seen = m->generation;
+            fn = m->job;
+        }
+        fn(g);
+        {
+            std::lock_guard<std::mutex> lk(m->mu);
+            if (--m->pending == 0) m->cv_done.notify_all();
+        }
+    }
+}
+
+// the calling thread's current device, put back on every way out (the HIP runtime is shared with the caller: torch's
+// current device must not change behind its back)
+struct DeviceRestore {
+    int dev = -1;
+    DeviceRestore() {
+        if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    }
+    ~DeviceRestore() {
+        if (dev >= 0) (void)hipSetDevice(dev);
+    }
+};
+
+}  // namespace
 
 extern "C" {
 
@@ -133,6 +204,15 @@ int cr_partition_pairs(const int64_t* lengths, int64_t P, int world, int rank, i
 
 int cr_multi_destroy(cr_multi* m) {
     if (!m) return CR_OK;
+    DeviceRestore restore;
+    if (!m->threads.empty()) {
+        {
+            std::lock_guard<std::mutex> lk(m->mu);
+            m->stop = true;
+        }
+        m->cv_go.notify_all();
+        for (auto& t : m->threads) t.join();
+    }
     for (size_t g = 0; g < m->ctx.size(); g++) {
         if (m->ctx[g]) {
             (void)hipSetDevice(m->devices[g]);
@@ -146,6 +226,9 @@ int cr_multi_destroy(cr_multi* m) {
     }
     for (size_t g = 0; g < m->dev.size(); g++) {
         (void)hipSetDevice(m->devices[g]);
+        if (m->dev[g]->batch) (void)cr_batch_destroy(m->dev[g]->batch);
+        for (hipEvent_t e : m->dev[g]->ev)
+            if (e) (void)hipEventDestroy(e);
         delete m->dev[g];
     }
     for (cr_context* c : m->ctx) (void)cr_context_destroy(c);
@@ -156,6 +239,7 @@ int cr_multi_destroy(cr_multi* m) {
 int cr_multi_create(const int* devices, int ndev, cr_multi** out) {
     CR_REQUIRE(out != nullptr, "null out");
     *out = nullptr;
+    DeviceRestore restore;
     int visible = 0;
     CR_HIP(hipGetDeviceCount(&visible));
     if (visible <= 0) return fail(CR_ERR_HIP, "no HIP device visible: libcaretta_hip has no CPU fallback");
@@ -175,16 +259,41 @@ int cr_multi_create(const int* devices, int ndev, cr_multi** out) {
             m->devices.push_back(devices[g]);
         }
     }
+    const int G = (int)m->devices.size();
     for (int dv : m->devices) {
         cr_context* c = nullptr;
-        const int rc = cr_context_create(dv, nullptr, &c);
+        int rc = cr_context_create(dv, nullptr, &c);
         if (rc) {
             cr_multi_destroy(m);
             return rc;
         }
         m->ctx.push_back(c);
         m->dev.push_back(new cr_multi::PerDevice());
+        for (hipEvent_t& e : m->dev.back()->ev)
+            if (hipEventCreate(&e) != hipSuccess) {
+                cr_multi_destroy(m);
+                return fail(CR_ERR_HIP, "creating events");
+            }
     }
+    // The communicators are part of the object: a box without a usable RCCL fails HERE, before any share is computed (the
+    // caller then knows to stay on one device), and the first timed call does not pay for ncclCommInitAll.
+    if (!m->loopback) {
+        RcclApi* api = rccl_api();
+        if (!api->error.empty()) {
+            const std::string why = api->error;
+            cr_multi_destroy(m);
+            return fail(CR_ERR_HIP, why);
+        }
+        m->comm.assign((size_t)G, nullptr);
+        const int r = api->CommInitAll(m->comm.data(), G, m->devices.data());
+        if (r != 0) {
+            m->comm.clear();
+            cr_multi_destroy(m);
+            return fail(CR_ERR_HIP, std::string("ncclCommInitAll: ") + api->GetErrorString(r));
+        }
+    }
+    if (G > 1)
+        for (int g = 0; g < G; g++) m->threads.emplace_back(multi_worker, m, g);
     *out = m;
     return CR_OK;
 }
@@ -206,44 +315,48 @@ int cr_multi_pairwise_scores(cr_multi* m, const double* coords, const double* te
                              int64_t P, int64_t d, const cr_params* params, double* scores, uint32_t* flags) {
     CR_REQUIRE(m && coords && tensors && offsets && params && scores, "null argument");
     CR_REQUIRE(P >= 2, "need at least two structures");
+    CR_REQUIRE(d >= 1 && offsets[0] == 0, "bad layout");
+    DeviceRestore restore;
     const int G = (int)m->devices.size();
     const int64_t np = P * (P - 1) / 2;
     const int64_t shard = (np + G - 1) / G;
-    const auto t0 = std::chrono::steady_clock::now();
-    auto ms_since = [](std::chrono::steady_clock::time_point t) {
-        return (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
-    };
-    std::vector<int64_t> lengths((size_t)P);
-    for (int64_t s = 0; s < P; s++) lengths[(size_t)s] = offsets[s + 1] - offsets[s];
-    // pair id -> (i, j), row-major (multiple_alignment.py:162-163)
-    std::vector<int32_t> all_ij((size_t)np * 2);
-    {
+    const int64_t total = offsets[P];
+    // validated once, here, not once per device
+    CR_REQUIRE(all_finite(coords, (size_t)total * 3), "coordinates contain NaN or infinity");
+    CR_REQUIRE(all_finite(tensors, (size_t)total * (size_t)d), "tensors contain NaN or infinity");
+    bool same_layout = m->P == P && m->d == d && m->offsets.size() == (size_t)P + 1 && std::equal(offsets, offsets + P + 1, m->offsets.begin());
+    for (int g = 0; g < G && same_layout; g++) same_layout = m->dev[(size_t)g]->batch != nullptr;
+    if (!same_layout) {
+        std::vector<int64_t> lengths((size_t)P);
+        for (int64_t s = 0; s < P; s++) lengths[(size_t)s] = offsets[s + 1] - offsets[s];
+        // pair id -> (i, j), row-major (multiple_alignment.py:162-163)
+        std::vector<int32_t> all_ij((size_t)np * 2);
         int64_t p = 0;
         for (int64_t i = 0; i < P; i++)
             for (int64_t j = i + 1; j < P; j++, p++) {
                 all_ij[(size_t)(2 * p)] = (int32_t)i;
                 all_ij[(size_t)(2 * p + 1)] = (int32_t)j;
             }
+        for (int g = 0; g < G; g++) {
+            cr_multi::PerDevice& pd = *m->dev[(size_t)g];
+            partition_pairs_host(lengths.data(), P, G, g, pd.owned);
+            pd.ij.resize(pd.owned.size() * 2);
+            for (size_t k = 0; k < pd.owned.size(); k++) {
+                pd.ij[2 * k] = all_ij[(size_t)(2 * pd.owned[k])];
+                pd.ij[2 * k + 1] = all_ij[(size_t)(2 * pd.owned[k] + 1)];
+            }
+        }
+        m->P = 0;                                       // (valid again once every device has its batch)
     }
-    std::vector<std::vector<int64_t>> owned((size_t)G);
-    for (int g = 0; g < G; g++) partition_pairs_host(lengths.data(), P, G, g, owned[(size_t)g]);
 
     // ---- every device: its share of the pair set, driven by its own host thread -------------------------------
-    std::vector<int> rcs((size_t)G, CR_OK);
-    std::vector<std::string> errs((size_t)G);
-    std::vector<cr_batch*> batches((size_t)G, nullptr);
-    auto work = [&](int g) {
+    multi_run(m, [&](int g) {
+        cr_multi::PerDevice& pd = *m->dev[(size_t)g];
         auto run = [&]() -> int {
             cr_context* ctx = m->ctx[(size_t)g];
-            cr_multi::PerDevice& pd = *m->dev[(size_t)g];
             int rc = set_device(ctx);
             if (rc) return rc;
-            const std::vector<int64_t>& mine = owned[(size_t)g];
-            std::vector<int32_t> ij(mine.size() * 2);
-            for (size_t k = 0; k < mine.size(); k++) {
-                ij[2 * k] = all_ij[(size_t)(2 * mine[k])];
-                ij[2 * k + 1] = all_ij[(size_t)(2 * mine[k] + 1)];
-            }
+            CR_HIP(hipEventRecord(pd.ev[0], ctx->stream));
             CR_HIP(pd.local.ensure((size_t)shard));
             CR_HIP(pd.local_flags.ensure((size_t)shard));
             CR_HIP(pd.gathered.ensure((size_t)shard * G));
@@ -253,57 +366,56 @@ int cr_multi_pairwise_scores(cr_multi* m, const double* coords, const double* te
                       std::numeric_limits<double>::quiet_NaN(), shard);
             CR_HIP(hipGetLastError());
             CR_HIP(hipMemsetAsync(pd.local_flags.p, 0, sizeof(uint32_t) * (size_t)shard, ctx->stream));
-            rc = cr_batch_create(ctx, coords, tensors, offsets, P, d, &batches[(size_t)g]);
-            if (rc) return rc;
-            cr_batch* b = batches[(size_t)g];
-            rc = cr_batch_set_pairs(b, ij.data(), (int64_t)mine.size());
-            if (rc) return rc;
+            if (!same_layout) {
+                if (pd.batch) {
+                    (void)cr_batch_destroy(pd.batch);
+                    pd.batch = nullptr;
+                }
+                rc = batch_create(ctx, coords, tensors, offsets, P, d, /*check_finite=*/false, &pd.batch);
+                if (rc) return rc;
+                rc = cr_batch_set_pairs(pd.batch, pd.ij.data(), (int64_t)pd.owned.size());
+                if (rc) return rc;
+            } else {
+                // same layout: the structures into the kept batch, in stream order before the kernels
+                rc = upload_async(ctx, pd.batch->coords.p, coords, sizeof(double) * (size_t)total * 3);
+                if (!rc) rc = upload_async(ctx, pd.batch->tensors.p, tensors, sizeof(double) * (size_t)total * (size_t)d);
+                if (rc) return rc;
+            }
+            cr_batch* b = pd.batch;
             rc = cr_batch_run_scores(b, params, pd.local.p);
             if (rc) return rc;
-            if (!mine.empty()) {                      // the flags, in the caller's pair order like the scores
+            if (!pd.owned.empty()) {                  // the flags, in the caller's pair order like the scores
                 if (b->reordered) {
-                    CR_LAUNCH(cr::k_scatter_flags, dim3((unsigned)((mine.size() + 255) / 256)), dim3(256), 0, ctx->stream, b->res.p,
-                              b->d_order.p, pd.local_flags.p, (int)mine.size());
+                    CR_LAUNCH(cr::k_scatter_flags, dim3((unsigned)((pd.owned.size() + 255) / 256)), dim3(256), 0, ctx->stream, b->res.p,
+                              b->d_order.p, pd.local_flags.p, (int)pd.owned.size());
                     CR_HIP(hipGetLastError());
                 } else {
                     CR_HIP(hipMemcpy2DAsync(pd.local_flags.p, sizeof(uint32_t),
                                             reinterpret_cast<const char*>(b->res.p) + offsetof(cr_pair_result, flags), sizeof(cr::PairResult),
-                                            sizeof(uint32_t), mine.size(), hipMemcpyDeviceToDevice, ctx->stream));
+                                            sizeof(uint32_t), pd.owned.size(), hipMemcpyDeviceToDevice, ctx->stream));
                 }
             }
+            CR_HIP(hipEventRecord(pd.ev[1], ctx->stream));
             return CR_OK;
         };
-        rcs[(size_t)g] = run();
-        if (rcs[(size_t)g]) errs[(size_t)g] = g_err;
-    };
-    if (G == 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> threads;
-        for (int g = 0; g < G; g++) threads.emplace_back(work, g);
-        for (auto& t : threads) t.join();
-    }
-    auto cleanup = [&]() {
-        for (int g = 0; g < G; g++)
-            if (batches[(size_t)g]) {
-                (void)cr_batch_destroy(batches[(size_t)g]);        // (waits for the device's stream)
-                batches[(size_t)g] = nullptr;
-            }
-    };
-    for (int g = 0; g < G; g++)
-        if (rcs[(size_t)g]) {
-            cleanup();
-            return fail(rcs[(size_t)g], "device " + std::to_string(m->devices[(size_t)g]) + ": " + errs[(size_t)g]);
-        }
-    const bool timing = std::getenv("CARETTA_MULTI_TIMING") != nullptr;
-    if (timing) {                                      // (the phases are only separable with a wait in between)
+        pd.rc = run();
+        pd.err = pd.rc ? g_err : std::string();
+    });
+    auto drain = [&]() {                                // a failed call: nothing in flight, batches rebuilt next time
         for (int g = 0; g < G; g++) {
             (void)hipSetDevice(m->devices[(size_t)g]);
             (void)hipStreamSynchronize(m->ctx[(size_t)g]->stream);
         }
-        m->last_ms[0] = ms_since(t0);
-    }
-    const auto t1 = std::chrono::steady_clock::now();
+        m->P = 0;
+    };
+    for (int g = 0; g < G; g++)
+        if (m->dev[(size_t)g]->rc) {
+            drain();
+            return fail(m->dev[(size_t)g]->rc, "device " + std::to_string(m->devices[(size_t)g]) + ": " + m->dev[(size_t)g]->err);
+        }
+    m->P = P;
+    m->d = d;
+    m->offsets.assign(offsets, offsets + P + 1);
 
     // ---- one grouped all-gather: every device ends up with every share ------------------------------------------
     if (m->loopback) {
@@ -314,57 +426,56 @@ int cr_multi_pairwise_scores(cr_multi* m, const double* coords, const double* te
                 CR_HIP(hipSetDevice(m->devices[(size_t)g]));
                 CR_HIP(hipStreamSynchronize(m->ctx[(size_t)g]->stream));
             }
-            for (int g = 0; g < G; g++)
+            for (int g = 0; g < G; g++) {
+                CR_HIP(hipSetDevice(m->devices[(size_t)g]));
                 for (int r = 0; r < G; r++) {
                     CR_HIP(hipMemcpyAsync(m->dev[(size_t)g]->gathered.p + (size_t)r * shard, m->dev[(size_t)r]->local.p, sizeof(double) * (size_t)shard,
                                           hipMemcpyDeviceToDevice, m->ctx[(size_t)g]->stream));
                     CR_HIP(hipMemcpyAsync(m->dev[(size_t)g]->gathered_flags.p + (size_t)r * shard, m->dev[(size_t)r]->local_flags.p,
                                           sizeof(uint32_t) * (size_t)shard, hipMemcpyDeviceToDevice, m->ctx[(size_t)g]->stream));
                 }
+                CR_HIP(hipEventRecord(m->dev[(size_t)g]->ev[2], m->ctx[(size_t)g]->stream));
+            }
             return CR_OK;
         };
         const int rc_copy = copy_all();
         if (rc_copy) {
-            cleanup();
+            drain();
             return rc_copy;
         }
-    }
-    RcclApi* api = m->loopback ? nullptr : rccl_api();
-    if (api && !api->error.empty()) {
-        cleanup();
-        return fail(CR_ERR_HIP, api->error);
-    }
-    if (api && m->comm.empty()) {
-        m->comm.assign((size_t)G, nullptr);
-        const int r = api->CommInitAll(m->comm.data(), G, m->devices.data());
+    } else {
+        RcclApi* api = rccl_api();
+        // (a group that has been opened is always closed, whatever an ncclAllGather inside it returns: the librccl is the
+        // one the caller's torch uses)
+        int first_bad = 0;
+        const char* what = "";
+        int r = api->GroupStart();
         if (r != 0) {
-            m->comm.clear();
-            cleanup();
-            return fail(CR_ERR_HIP, std::string("ncclCommInitAll: ") + api->GetErrorString(r));
+            drain();
+            return fail(CR_ERR_HIP, std::string("ncclGroupStart: ") + api->GetErrorString(r));
         }
-    }
-    auto gather = [&]() -> int {
-        CR_RCCL(api, api->GroupStart());
-        for (int g = 0; g < G; g++) {
+        for (int g = 0; g < G && !first_bad; g++) {
             cr_multi::PerDevice& pd = *m->dev[(size_t)g];
-            CR_RCCL(api, api->AllGather(pd.local.p, pd.gathered.p, (size_t)shard, kNcclFloat64, m->comm[(size_t)g], m->ctx[(size_t)g]->stream));
-            CR_RCCL(api, api->AllGather(pd.local_flags.p, pd.gathered_flags.p, (size_t)shard, kNcclUint32, m->comm[(size_t)g],
-                                        m->ctx[(size_t)g]->stream));
+            r = api->AllGather(pd.local.p, pd.gathered.p, (size_t)shard, kNcclFloat64, m->comm[(size_t)g], m->ctx[(size_t)g]->stream);
+            if (r == 0) r = api->AllGather(pd.local_flags.p, pd.gathered_flags.p, (size_t)shard, kNcclUint32, m->comm[(size_t)g], m->ctx[(size_t)g]->stream);
+            if (r != 0) {
+                first_bad = r;
+                what = "ncclAllGather: ";
+            }
         }
-        CR_RCCL(api, api->GroupEnd());
-        return CR_OK;
-    };
-    int rc = api ? gather() : CR_OK;
-    if (rc) {
-        cleanup();
-        return rc;
-    }
-    if (timing) {
+        r = api->GroupEnd();
+        if (r != 0 && !first_bad) {
+            first_bad = r;
+            what = "ncclGroupEnd: ";
+        }
+        if (first_bad) {
+            drain();
+            return fail(CR_ERR_HIP, std::string(what) + api->GetErrorString(first_bad));
+        }
         for (int g = 0; g < G; g++) {
             (void)hipSetDevice(m->devices[(size_t)g]);
-            (void)hipStreamSynchronize(m->ctx[(size_t)g]->stream);
+            (void)hipEventRecord(m->dev[(size_t)g]->ev[2], m->ctx[(size_t)g]->stream);
         }
-        m->last_ms[1] = ms_since(t1);
     }
     const auto t2 = std::chrono::steady_clock::now();
 
@@ -383,7 +494,7 @@ int cr_multi_pairwise_scores(cr_multi* m, const double* coords, const double* te
         CR_HIP(hipMemcpyAsync(h_fl, m->dev[0]->gathered_flags.p, sizeof(uint32_t) * cnt, hipMemcpyDeviceToHost, ctx->stream));
         CR_HIP(hipStreamSynchronize(ctx->stream));
         for (int g = 0; g < G; g++) {
-            const std::vector<int64_t>& mine = owned[(size_t)g];
+            const std::vector<int64_t>& mine = m->dev[(size_t)g]->owned;
             for (size_t k = 0; k < mine.size(); k++) {
                 scores[mine[k]] = h_sw[(size_t)g * shard + k];
                 if (flags) flags[mine[k]] = h_fl[(size_t)g * shard + k];
@@ -391,18 +502,29 @@ int cr_multi_pairwise_scores(cr_multi* m, const double* coords, const double* te
         }
         return CR_OK;
     };
-    rc = collect();
-    // the other devices' streams: their part of the collective must be over before their buffers are reused
+    int rc = collect();
+    // the other devices' streams: their part of the collective is over before their buffers are reused by the next call
     for (int g = 1; g < G; g++) {
         (void)hipSetDevice(m->devices[(size_t)g]);
         (void)hipStreamSynchronize(m->ctx[(size_t)g]->stream);
     }
-    cleanup();
-    if (rc) return rc;
+    if (rc) {
+        drain();
+        return rc;
+    }
     for (int64_t p = 0; p < np; p++)
         if (std::isnan(scores[p])) return fail(CR_ERR_HIP, "all-gather left pair " + std::to_string(p) + " without a score");
-    m->last_ms[2] = ms_since(t2);
-    if (!timing) m->last_ms[0] = ms_since(t0);
+    // the phases of this call, from the events on every device's stream (no host wait separates them)
+    float compute = 0.f, gather = 0.f;
+    for (int g = 0; g < G; g++) {
+        (void)hipSetDevice(m->devices[(size_t)g]);
+        float a = 0.f, b = 0.f;
+        if (hipEventElapsedTime(&a, m->dev[(size_t)g]->ev[0], m->dev[(size_t)g]->ev[1]) == hipSuccess) compute = std::max(compute, a);
+        if (hipEventElapsedTime(&b, m->dev[(size_t)g]->ev[1], m->dev[(size_t)g]->ev[2]) == hipSuccess) gather = std::max(gather, b);
+    }
+    m->last_ms[0] = compute;
+    m->last_ms[1] = gather;
+    m->last_ms[2] = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count();
     return CR_OK;
 }
 
