@@ -298,6 +298,50 @@ struct ExplicitStream {
         issue<true>(0, pend);
         park<false>(0, first);
     }
+    // ---- the same streams with their per-window state kept in registers (sweep_stream below) ---------------------------
+    // Window w of an owner = its steps [8 w, 8 w + 8); what a window newly needs is the aligned block it ENDS in.  Per load y
+    // and row slot q this lane keeps: the address of its quarter of that block, the block's first column, and the ring
+    // word it will be parked in.  A window later everything moves on by one block: + 64 bytes, + 8 columns, the other slot.
+    // (Requesting BOTH 64-byte halves of a 128-byte line when a stream enters the first one, the second kept in registers
+    // for the next window, was measured: 1.46 / 1.54 ms against 1.42 / 1.45 ms -- the kernel is not bound by the re-fetched
+    // lines, and the sixteen more registers cost more than the traffic saved.)
+    const double* wptr_[R][kLoads];
+    int wcol_[R][kLoads];
+    int wpark_[R][kLoads];
+    CR_D void window_init(int m) {                       // behind load_rows(): state of window 0
+        m_ = m;
+        const int64_t* so = stream_offsets();
+        const int part = lane_ & 3;
+#pragma unroll
+        for (int y = 0; y < kLoads; y++) {
+            const int o = 16 * y + (lane_ >> 2);
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const int64_t off = so[o * R + q];
+                const int64_t blk = ((off - o + (kBlk - 1)) >> 3) << 3;
+                wptr_[q][y] = S + blk + 2 * part;
+                wcol_[q][y] = off >= 0 ? (int)(blk - off) : -(1 << 30);          // (no row: never inside [0, m))
+                wpark_[q][y] = ((q * 2 + ((int)(blk >> 3) & 1)) * kBlk + 2 * part) * kWave + o;
+            }
+        }
+    }
+    // at step t0 = 8 w: park the block window w ends in (requested a window ago: `pend`), request window w + 1's
+    CR_D void window_advance() {
+#pragma unroll
+        for (int y = 0; y < kLoads; y++) {
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                ring_[wpark_[q][y]] = pend[q][y].a;
+                ring_[wpark_[q][y] + kWave] = pend[q][y].b;
+                wpark_[q][y] ^= kBlk * kWave;                  // the other ring slot
+                wptr_[q][y] += kBlk;
+                wcol_[q][y] += kBlk;
+                Pair8 v{0.0, 0.0};
+                if (wcol_[q][y] + kBlk > 0 && wcol_[q][y] < m_) v = *reinterpret_cast<const Pair8*>(wptr_[q][y]);
+                pend[q][y] = v;
+            }
+        }
+    }
     CR_D void load_chunk(double*, int, int, int) {}
     CR_D void step_begin(double*, int t, int m) {
         m_ = m;
@@ -318,7 +362,182 @@ struct ExplicitStream {
     CR_D double score(int q, const ExpEntry*) const { return val[q]; }
 };
 
+// ---------------------------------------------------------------------------------------------
+// The time-skewed sweep over ExplicitStream, written for it (sweep() of cr_kernels.h serves every provider): the wave
+// is bound by instruction issue -- one row per lane leaves ~50 instructions per cell of which 13 are the recurrence -- so
+//   * eight steps per loop body: the positions inside a decision word and the window boundaries are compile-time;
+//   * the streams' window state lives in registers (ExplicitStream::window_advance: 4 instructions per load instead of 17);
+//   * the row above the strip is read by ALL lanes from one LDS address (a broadcast; only lane 0 uses it, as the fill of
+//     the DPP shift), the border of strip 0 sits in the same buffer; lane 63 hands its last row down with the store all
+//     lanes execute (the others into a dump word): no EXEC juggling in a step.  (Handing down with plain 8-byte stores
+//     to HBM instead -- no ring, 9 KB of LDS, sixteen waves per CU -- was measured: 1.52 / 1.61 ms against 1.42 / 1.45.)
+//   * windows whose 64 lanes are all inside the matrix run without the column mask;
+//   * STORE = false (dtw_align's score alone, dynamic_time_warping.py:188-201): no decision words are formed or written.
+// MODE: kSwScore (smith_waterman_score with a gap) or kDtw.  Same arithmetic as sweep(): dp_column on the same values.
+// LDS (doubles): ring R * 1088 | pad to 128 | hout NB x 128 | hin NB x 64 | dump NB.
+// ---------------------------------------------------------------------------------------------
 template <int R, int MODE>
+__host__ __device__ inline size_t stream_lds_doubles() {
+    constexpr int NB = ((MODE & kSwScore) ? 1 : 0) + ((MODE & kDtw) ? 2 : 0);
+    return (size_t)((ExplicitStream<R>::kRingDoubles + 127) / 128 * 128) + (size_t)NB * (kRing + kWave) + 8;
+}
+
+template <int R, int MODE, bool STORE>
+CR_D void sweep_stream(ExplicitStream<R>& src, const int n, const int m, const SweepParams prm, double* lds,
+                       uint32_t* __restrict__ dtw_bits, double* __restrict__ hand_g, AlignEnd& end_out) {
+    constexpr bool SW = (MODE & kSwScore) != 0;
+    constexpr bool DTW = (MODE & kDtw) != 0;
+    constexpr int NB = (SW ? 1 : 0) + (DTW ? 2 : 0);
+    constexpr int kRingPad = (ExplicitStream<R>::kRingDoubles + 127) / 128 * 128;
+    const int lane = threadIdx.x;
+    double* ring = lds;
+    double* hout = ring + kRingPad;                    // [NB][128], every plane 1 KB-aligned: last row of lane 63, recent columns
+    double* hin = hout + NB * kRing;                   // [NB][64]: row above lane 0 (strip 0: the DP border), current 64 columns
+    src.init_ring(ring, lane);
+    const int nstrips = strips_of(n, R);
+    const int TB_DTW = tblocks(m, 8);
+    const double col0_m2 = kMinF64 - prm.gap_open;
+    DpState<R> st;
+    st.sw_max = 0.0;
+    // byte offsets of this lane's hand-down stores: lane 63 the ring (plus the column's slot), the others the dump word
+    uint32_t out_base[NB];
+    const uint32_t out_mask = lane == kWave - 1 ? 0x3f8u : 0u;
+#pragma unroll
+    for (int k = 0; k < NB; k++)
+        out_base[k] = lane == kWave - 1 ? (uint32_t)((kRingPad + k * kRing) * 8) : (uint32_t)((kRingPad + NB * kRing + NB * kWave + k) * 8);
+
+    for (int s = 0; s < nstrips; s++) {
+        const int rowbase = (s * kWave + lane) * R;
+        const int rows_here = n - s * kWave * R;
+        const int lanes_here = rows_here >= kWave * R ? kWave : (rows_here + R - 1) / R;
+        const int T = m + lanes_here - 1;
+        const bool hand_out = s + 1 < nstrips;
+        src.load_rows(rowbase, n);
+        src.window_init(m);
+        st.reset_column0(col0_m2);
+#pragma unroll
+        for (int q = 0; q < R; q++) st.swbits[q] = st.dtbits[q] = 0;
+        if (s == 0) {                                   // the DP border above row 0 (dynamic_time_warping.py:45-49)
+            if constexpr (SW) hin[lane] = 0.0;
+            if constexpr (DTW) {
+                hin[(NB - 2) * kWave + lane] = col0_m2;
+                hin[(NB - 1) * kWave + lane] = 0.0;
+            }
+        }
+        wave_sync();
+
+        // one step; K = t & 7 is a compile-time constant, MASKED = some lane may be outside the matrix
+        auto step = [&](auto ktag, auto masked_tag, const int t) {
+            constexpr int K = decltype(ktag)::value;
+            constexpr bool MASKED = decltype(masked_tag)::value;
+            const int c = t - lane;
+            src.t_ = t;
+            double h_top0 = 0.0, m0_top0 = 0.0, m1_top0 = 0.0;       // wave-uniform addresses: LDS broadcasts
+            if constexpr (SW) h_top0 = hin[t & (kWave - 1)];
+            if constexpr (DTW) {
+                m0_top0 = hin[(NB - 2) * kWave + (t & (kWave - 1))];
+                m1_top0 = hin[(NB - 1) * kWave + (t & (kWave - 1))];
+            }
+            double h_top = 0.0, m0_top = 0.0, m1_top = 0.0;
+            if constexpr (SW) h_top = wave_shr1(st.h_left[R - 1], h_top0);
+            if constexpr (DTW) {
+                m0_top = wave_shr1(st.m0_left[R - 1], m0_top0);
+                m1_top = wave_shr1(st.m1_left[R - 1], m1_top0);
+            }
+            auto cell = [&]() {
+                src.fetch_col(ring, 0);
+                dp_column<R, MODE>(src, st, prm, nullptr, c, rowbase, n, 0, K * 4, h_top, m0_top, m1_top, src.val);
+            };
+            if constexpr (MASKED) {
+                if ((unsigned)c < (unsigned)m) cell();
+            } else {
+                cell();
+            }
+            if (hand_out && t >= kWave - 1 && t - (kWave - 1) < m) {          // (uniform) lane 63 is inside the matrix
+                const uint32_t slot = (uint32_t)((t - (kWave - 1)) & (kRing - 1)) * 8u;
+                char* const base = reinterpret_cast<char*>(lds);
+                if constexpr (SW) *reinterpret_cast<double*>(base + ((slot & out_mask) | out_base[0])) = st.h_left[R - 1];
+                if constexpr (DTW) {
+                    *reinterpret_cast<double*>(base + ((slot & out_mask) | out_base[NB - 2])) = st.m0_left[R - 1];
+                    *reinterpret_cast<double*>(base + ((slot & out_mask) | out_base[NB - 1])) = st.m1_left[R - 1];
+                }
+            }
+            // (decisions are packed where they are formed: left alone, the compiler sinks the compares of all eight steps to
+            // the store behind the last one and keeps their operands alive -- 198 VGPRs with one row per lane instead of ~110)
+            if constexpr (DTW && STORE) {
+#pragma unroll
+                for (int q = 0; q < R; q++) asm volatile("" : "+v"(st.dtbits[q]));
+            }
+        };
+        for (int t0 = 0; t0 < T; t0 += 8) {
+            if ((t0 & (kWave - 1)) == 0 && nstrips > 1) {
+                wave_sync();
+                if (hand_out && t0 >= 2 * kWave) {              // columns [t0 - 128, t0 - 65] are complete
+                    const int cc = t0 - 2 * kWave + lane;
+                    if (cc < m)
+                        for (int k = 0; k < NB; k++) hand_g[(int64_t)k * m + cc] = hout[k * kRing + (cc & (kRing - 1))];
+                }
+                if (s > 0 && t0 + lane < m)
+                    for (int k = 0; k < NB; k++) hin[k * kWave + lane] = __builtin_nontemporal_load(hand_g + (int64_t)k * m + t0 + lane);
+                wave_sync();
+            }
+            src.window_advance();
+            asm volatile("" ::: "memory");                    // (LDS executes the wave's own writes and reads in order)
+            if (t0 >= kWave - 1 && t0 + 7 < m && t0 + 7 < T) {            // all 64 lanes inside the matrix for all eight steps
+                static_for<0, 8>([&](auto k) { step(k, std::false_type{}, t0 + decltype(k)::value); });
+            } else {
+                static_for<0, 8>([&](auto k) {
+                    if (t0 + decltype(k)::value < T) step(k, std::true_type{}, t0 + decltype(k)::value);
+                });
+            }
+            if constexpr (DTW && STORE) {
+                const int64_t base = ((int64_t)(s * TB_DTW + (t0 >> 3)) * R) * kWave + lane;
+#pragma unroll
+                for (int q = 0; q < R; q++) {
+                    dtw_bits[base + q * kWave] = st.dtbits[q];
+                    st.dtbits[q] = 0;
+                }
+            }
+        }
+        if (hand_out) {
+            // flush the hand-off columns not yet written (at most 127) and make them visible to this wave's own loads in the
+            // next strip
+            wave_sync();
+            const int tl = (T - 1) & ~(kWave - 1);                        // last chunk boundary seen
+            for (int cc = (tl >= 2 * kWave ? tl - kWave : 0) + lane; cc < m; cc += kWave)
+                for (int k = 0; k < NB; k++) hand_g[(int64_t)k * m + cc] = hout[k * kRing + (cc & (kRing - 1))];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+            wave_sync();
+        }
+    }
+    double sw_max = st.sw_max;
+    if constexpr (SW) {
+        for (int off = 32; off > 0; off >>= 1) sw_max = __builtin_fmax(sw_max, __shfl_xor(sw_max, off));
+    }
+    const int owner = ((n - 1) / R) % kWave;           // lane and register slot that own row n - 1
+    const int qo = (n - 1) % R;
+    double fin0 = 0.0, fin1 = 0.0, fin2 = 0.0;         // M[n][m][0..2]
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+        fin0 = (q == qo) ? st.m0_left[q] : fin0;
+        fin1 = (q == qo) ? st.m1_left[q] : fin1;
+        fin2 = (q == qo) ? st.m2_left[q] : fin2;
+    }
+    fin0 = lane_value(fin0, owner);
+    fin1 = lane_value(fin1, owner);
+    fin2 = lane_value(fin2, owner);
+    end_out.sw = sw_max;
+    int idx = 0;                                       // np.argmax of the three layers at (n, m), :181-182
+    double best = fin0;
+    if (fin1 > best) { best = fin1; idx = 1; }
+    if (fin2 > best) { best = fin2; idx = 2; }
+    end_out.dtw_score = DTW ? best : 0.0;
+    end_out.start_layer = idx;
+    end_out.pad = 0;
+}
+
+template <int R, int MODE, bool STORE>
 __global__ __launch_bounds__(kWave) void k_explicit_stream(const ExplicitProblem* __restrict__ probs,
                                                           const double* __restrict__ S,
                                                           const int32_t* __restrict__ seqs, SweepParams prm,
@@ -339,7 +558,7 @@ __global__ __launch_bounds__(kWave) void k_explicit_stream(const ExplicitProblem
     AlignEnd ae;
     ae.sw = ae.dtw_score = 0.0;
     ae.start_layer = ae.pad = 0;
-    if (pb.m > 0) sweep<R, MODE>(src, pb.n, pb.m, prm, lds, nullptr, bits + pb.bits_off_s, hand + pb.hand_off, sm, ae);
+    if (pb.m > 0) sweep_stream<R, MODE, STORE>(src, pb.n, pb.m, prm, lds, STORE ? bits + pb.bits_off_s : nullptr, hand + pb.hand_off, ae);
     if (threadIdx.x == 0) ends[blockIdx.x] = ae;
 }
 
@@ -508,16 +727,23 @@ int launch_sw_rows(cr_explicit_batch* b) {
     return CR_OK;
 }
 
-// the streaming sweep (contiguous columns) with R rows per lane
+// the streaming sweep (contiguous columns) with R rows per lane; bits == nullptr: no decision words (scores alone)
 template <int R, int MODE>
 int launch_stream(cr_explicit_batch* b, const cr::ExplicitProblem* probs, const cr::SweepParams& prm, uint32_t* bits) {
-    const size_t lds = cr::sweep_lds_doubles<R, MODE, cr::ExplicitStream<R>>(b->n_max, b->m_max) * sizeof(double);
-    int rc = allow_lds(cr::k_explicit_stream<R, MODE>, lds);
-    if (rc) return rc;
-    CR_LAUNCH((cr::k_explicit_stream<R, MODE>), dim3((unsigned)b->count), dim3(cr::kWave), lds, b->ctx->stream, probs,
-              b->S.p + kSlackFront, b->seqs.p, prm, bits, b->hand.p, b->ends.p);
-    CR_HIP(hipGetLastError());
-    return CR_OK;
+    size_t lds = cr::stream_lds_doubles<R, MODE>() * sizeof(double);
+    if (const char* env = std::getenv("CARETTA_STREAM_LDS_KB")) lds = std::max(lds, (size_t)std::atoi(env) * 1024);   // calibration: waves per CU
+    auto go = [&](auto kernel) -> int {
+        int rc = allow_lds(kernel, lds);
+        if (rc) return rc;
+        CR_LAUNCH(kernel, dim3((unsigned)b->count), dim3(cr::kWave), lds, b->ctx->stream, probs, b->S.p + kSlackFront, b->seqs.p, prm, bits,
+                  b->hand.p, b->ends.p);
+        CR_HIP(hipGetLastError());
+        return CR_OK;
+    };
+    if constexpr ((MODE & cr::kDtw) != 0) {
+        if (bits) return go(cr::k_explicit_stream<R, MODE, true>);
+    }
+    return go(cr::k_explicit_stream<R, MODE, false>);
 }
 
 template <int MODE>
@@ -827,7 +1053,7 @@ int cr_dtw_align_batch(cr_explicit_batch* b, double gap_open, double gap_extend,
     cr::SweepParams prm{0.0, gap_open, gap_extend};
     CR_HIP(hipEventRecord(b->ev0, st));
     if (stream) {
-        if ((rc = launch_stream_r<MODE>(R, b, b->probs.p, prm, b->bits.p))) return rc;
+        if ((rc = launch_stream_r<MODE>(R, b, b->probs.p, prm, aln ? b->bits.p : nullptr))) return rc;
     } else {
         const size_t lds = cr::sweep_lds_doubles<kExplicitR, MODE, cr::Explicit<kExplicitR>>(b->n_max, b->m_max) * sizeof(double);
         if ((rc = allow_lds(cr::k_explicit_batch<kExplicitR, MODE>, lds))) return rc;
