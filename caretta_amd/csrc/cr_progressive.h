@@ -199,14 +199,24 @@ int run_tree_planned(cr_progressive* h, const std::vector<std::vector<int64_t>>&
     if (rc) return rc;
     const int64_t dirs_words = max_count * cr::strips_of(bound, R) * cr::tblocks(bound, 16) * R * cr::kWave;
     const int64_t bits_words = max_count * cr::strips_of(bound, R) * cr::tblocks(bound, 8) * R * cr::kWave;
-    DevBuf<cr::PlanNode> d_plan;
-    DevBuf<int64_t> d_len, d_off, d_used;
-    DevBuf<int32_t> d_overflow;
-    CR_HIP(d_plan.ensure(plan.size()));
-    CR_HIP(d_len.ensure((size_t)(2 * P - 1)));
-    CR_HIP(d_off.ensure((size_t)(2 * P - 1)));
-    CR_HIP(d_used.ensure(1));
-    CR_HIP(d_overflow.ensure(1));
+    // the tree's small tables in ONE device block and ONE upload: plan | len | off | used | overflow (every separate small
+    // copy from or to pageable memory costs the host ~25 us: seventeen of them were 0.5 ms of a 5 ms tree)
+    const size_t nids = (size_t)(2 * P - 1);
+    const size_t o_len = (sizeof(cr::PlanNode) * plan.size() + 15) / 16 * 16, o_off = o_len + sizeof(int64_t) * nids;
+    const size_t o_used = o_off + sizeof(int64_t) * nids, o_over = o_used + sizeof(int64_t), meta_bytes = o_over + sizeof(int64_t);
+    DevBuf<char> d_meta;
+    CR_HIP(d_meta.ensure(meta_bytes));
+    struct {
+        cr::PlanNode* p;
+    } const d_plan{reinterpret_cast<cr::PlanNode*>(d_meta.p)};
+    struct I64 {
+        int64_t* p;
+    };
+    const I64 d_len{reinterpret_cast<int64_t*>(d_meta.p + o_len)}, d_off{reinterpret_cast<int64_t*>(d_meta.p + o_off)},
+        d_used{reinterpret_cast<int64_t*>(d_meta.p + o_used)};
+    struct {
+        int32_t* p;
+    } const d_overflow{reinterpret_cast<int32_t*>(d_meta.p + o_over)};
     CR_HIP(b.pairs.ensure((size_t)num_nodes));
     CR_HIP(b.xf.ensure((size_t)num_nodes));
     CR_HIP(b.seed_score.ensure((size_t)num_nodes));
@@ -216,11 +226,25 @@ int run_tree_planned(cr_progressive* h, const std::vector<std::vector<int64_t>>&
     CR_HIP(b.bits.ensure((size_t)bits_words));
     CR_HIP(b.aln.ensure((size_t)aln_total));
     if (staged) CR_HIP(h->staged.ensure((size_t)(max_count * shape.pair_doubles())));
-    CR_UPLOAD(h->ctx, d_plan.p, plan.data(), sizeof(cr::PlanNode) * plan.size());
-    CR_UPLOAD(h->ctx, d_len.p, h->len.data(), sizeof(int64_t) * (size_t)(2 * P - 1));
-    CR_UPLOAD(h->ctx, d_off.p, h->off.data(), sizeof(int64_t) * (size_t)(2 * P - 1));
-    CR_UPLOAD(h->ctx, d_used.p, &total, sizeof(int64_t));
-    CR_HIP(hipMemsetAsync(d_overflow.p, 0, sizeof(int32_t), stream));
+    {
+        std::vector<char> meta(meta_bytes, 0);
+        std::memcpy(meta.data(), plan.data(), sizeof(cr::PlanNode) * plan.size());
+        std::memcpy(meta.data() + o_len, h->len.data(), sizeof(int64_t) * nids);
+        std::memcpy(meta.data() + o_off, h->off.data(), sizeof(int64_t) * nids);
+        std::memcpy(meta.data() + o_used, &total, sizeof(int64_t));
+        // (through the context's page-locked ring whatever its size: the vector dies at the end of this block)
+        char* stage = nullptr;
+        if (meta_bytes <= kRingSlot) {
+            if ((rc = ring_slot(h->ctx, 0, &stage))) return rc;
+            std::memcpy(stage, meta.data(), meta_bytes);
+            CR_HIP(hipMemcpyAsync(d_meta.p, stage, meta_bytes, hipMemcpyHostToDevice, stream));
+            CR_HIP(hipEventRecord(h->ctx->ring_ev[0], stream));
+            h->ctx->ring_busy[0] = true;
+        } else {
+            CR_UPLOAD(h->ctx, d_meta.p, meta.data(), meta_bytes);
+            CR_HIP(hipStreamSynchronize(stream));
+        }
+    }
     b.r_seed = b.r_align = R;
     for (int64_t lv = 1; lv <= h->levels + 1; lv++) {
         const int64_t first = start[(size_t)lv], count = lv <= h->levels ? start[(size_t)lv + 1] - first : 0;
@@ -250,21 +274,33 @@ int run_tree_planned(cr_progressive* h, const std::vector<std::vector<int64_t>>&
                                    b.hand.p, b.aln.p, b.coords.p, b.tensors.p, h->weights.p, h->d_outs.p + first)))
             return rc;
     }
-    // one read-back for the whole tree
+    // one read-back for the whole tree: four copies into the context's page-locked landing area, ONE wait
     std::vector<cr::NodeOut> outs((size_t)num_nodes);
     std::vector<cr::NodeDesc> descs((size_t)num_nodes);
-    std::vector<int64_t> len((size_t)(2 * P - 1)), off((size_t)(2 * P - 1));
+    std::vector<int64_t> len(nids), off(nids);
     std::vector<int32_t> rows_host((size_t)aln_total);
     int32_t overflow = 0;
     int64_t used = 0;
-    CR_DOWNLOAD(h->ctx, outs.data(), h->d_outs.p, sizeof(cr::NodeOut) * (size_t)num_nodes);
-    CR_DOWNLOAD(h->ctx, descs.data(), h->d_nodes.p, sizeof(cr::NodeDesc) * (size_t)num_nodes);
-    CR_DOWNLOAD(h->ctx, len.data(), d_len.p, sizeof(int64_t) * len.size());
-    CR_DOWNLOAD(h->ctx, off.data(), d_off.p, sizeof(int64_t) * off.size());
-    if ((rc = download(h->ctx, rows_host.data(), b.aln.p, sizeof(int32_t) * (size_t)aln_total, false))) return rc;
-    CR_DOWNLOAD(h->ctx, &overflow, d_overflow.p, sizeof(int32_t));
-    CR_DOWNLOAD(h->ctx, &used, d_used.p, sizeof(int64_t));
-    CR_HIP(hipStreamSynchronize(stream));
+    {
+        const size_t b_outs = sizeof(cr::NodeOut) * (size_t)num_nodes, b_descs = sizeof(cr::NodeDesc) * (size_t)num_nodes;
+        const size_t b_tail = meta_bytes - o_len, b_rows = sizeof(int32_t) * (size_t)aln_total;
+        const size_t a_descs = (b_outs + 15) / 16 * 16, a_tail = a_descs + (b_descs + 15) / 16 * 16, a_rows = a_tail + (b_tail + 15) / 16 * 16;
+        void* land_v = nullptr;
+        if ((rc = host_landing(h->ctx, a_rows + b_rows, &land_v))) return rc;
+        char* land = static_cast<char*>(land_v);
+        CR_HIP(hipMemcpyAsync(land, h->d_outs.p, b_outs, hipMemcpyDeviceToHost, stream));
+        CR_HIP(hipMemcpyAsync(land + a_descs, h->d_nodes.p, b_descs, hipMemcpyDeviceToHost, stream));
+        CR_HIP(hipMemcpyAsync(land + a_tail, d_meta.p + o_len, b_tail, hipMemcpyDeviceToHost, stream));
+        if (b_rows) CR_HIP(hipMemcpyAsync(land + a_rows, b.aln.p, b_rows, hipMemcpyDeviceToHost, stream));
+        CR_HIP(hipStreamSynchronize(stream));
+        std::memcpy(outs.data(), land, b_outs);
+        std::memcpy(descs.data(), land + a_descs, b_descs);
+        std::memcpy(len.data(), land + a_tail, sizeof(int64_t) * nids);
+        std::memcpy(off.data(), land + a_tail + (o_off - o_len), sizeof(int64_t) * nids);
+        std::memcpy(&used, land + a_tail + (o_used - o_len), sizeof(int64_t));
+        std::memcpy(&overflow, land + a_tail + (o_over - o_len), sizeof(int32_t));
+        if (b_rows) std::memcpy(rows_host.data(), land + a_rows, b_rows);
+    }
     if (overflow) return 1;
     h->len = len;
     h->off = off;
