@@ -566,7 +566,7 @@ def main():
                          "algorithmic_bytes_with_readback": sb[dom_name + "_readback"],
                          "note": "SURVEY 8(d) bytes: features in + packed decisions out.  The fused RBF+DP kernels are bound by "
                                  "FP64-rate VALU issue, not HBM (DESIGN.md section 5; valu_f64 below); the HBM-bound kernel of the "
-                                 "path is the batched explicit-matrix row sweep (profiles/r03/explicit_batch_rate.txt)"},
+                                 "path is the batched explicit-matrix row sweep (profiles/r04/explicit_batch_rate.txt)"},
             "valu_f64": {"est_flop_per_cell": {"seed_fill": 59, "align_fill": 49},
                          "achieved_tflops": (59 + 49) * cells_rank / ((stage_ms[0] + stage_ms[1]) * 1e-3) / 1e12,
                          "peak_tflops": FP64_VALU_PEAK_TFLOPS},
@@ -575,7 +575,7 @@ def main():
         # cycles in which a SIMD issues a VALU instruction = SQ_INSTS_VALU / 1024 SIMDs x 4 cycles / (GRBM_GUI_ACTIVE / 8 XCDs)
         try:
             if args.workload == "headline" and args.gpus == 1:
-                for rnd in ("r03", "r02", "r01"):
+                for rnd in ("r04", "r03", "r02", "r01"):
                     f = ROOT / "profiles" / rnd / "pmc_summary.json"
                     if f.exists():
                         pmc = json.load(open(f))

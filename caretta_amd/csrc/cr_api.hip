@@ -246,8 +246,6 @@ struct cr_context {
     std::vector<hipEvent_t> sync_ev;
     // copy stream of the pipelined run + fetch (cr_batch_run_fetch_i32): results of one part of the pair list travel to
     // the host while the kernels of the next part run (created on first use)
-    hipStream_t copy_stream = nullptr;
-    std::vector<hipEvent_t> copy_ev;
     // page-locked landing area for small results of single calls; grown on demand by host_landing()
     void* landing = nullptr;
     size_t landing_bytes = 0;
@@ -817,7 +815,7 @@ constexpr int64_t kStagedWaveLimit = 1024;
 // Mid-size lists (cr_duo.h): up to this many waves (two strips per pair / more; CARETTA_MID_PAIRS overrides the pair limit
 // they give), columns resident in LDS.
 constexpr int64_t kMidWaveLimit2 = 2600, kMidWaveLimit = 3072;
-constexpr int kMidMaxColumns = 1088;
+constexpr int kMidMaxColumns = 1280;
 constexpr int kGroupLanes = 4;             // streams that row-per-lane groups are spread over
 int launch_seed_team(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm);   // cr_dropins.h
 
@@ -994,7 +992,6 @@ int cr_context_destroy(cr_context* ctx) {
     // context's streams, and nothing below may touch a stream after it has been destroyed
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& st : ctx->side) (void)hipStreamSynchronize(st);
-    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     if (ctx->ring) (void)hipHostFree(ctx->ring);
     for (hipEvent_t e : ctx->ring_ev)
         if (e) (void)hipEventDestroy(e);
@@ -1002,9 +999,7 @@ int cr_context_destroy(cr_context* ctx) {
     for (auto& l : ctx->ev)
         for (auto& e : l) (void)hipEventDestroy(e);
     for (auto& e : ctx->sync_ev) (void)hipEventDestroy(e);
-    for (auto& e : ctx->copy_ev) (void)hipEventDestroy(e);
     for (auto& st : ctx->side) (void)hipStreamDestroy(st);
-    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return CR_OK;
@@ -1177,6 +1172,10 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     {
         const char* mid = std::getenv("CARETTA_MID");
         StripPlan p{3, 2, 1};
+        // up to 512 pairs of at most 320 rows: FOUR waves per pair (2 + 1 + 1 + 1 rows per lane: 2 048 waves still fit the chip
+        // at once) -- 508 pairs of 300: 0.50 / 0.33 ms against 0.54 / 0.40 with two waves; from 581 pairs on two waves win the
+        // full pipeline again (profiles/r04/c3_share.txt, c3_share_plans.txt)
+        if (npairs <= 512 && b->n_max <= 5 * cr::kWave) p = StripPlan{2, 1, 1};
         if (const char* env = std::getenv("CARETTA_MID_PLAN")) {                                  // calibration: "RA,RB,nA"
             int ra = 0, rb = 0, na = 0;
             if (std::sscanf(env, "%d,%d,%d", &ra, &rb, &na) == 3) p = StripPlan{ra, rb, ra == rb ? 0 : na};

@@ -117,7 +117,7 @@ struct cr_multi {
         cr_batch* batch = nullptr;
         std::vector<int64_t> owned;          // pair ids (row-major i < j) of this device's share, ascending
         std::vector<int32_t> ij;             // ... as (i, j): the source of the batch's pair-list upload, alive with the batch
-        hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // on the device's stream: call start, share computed, gathered
+        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // on the device's stream: call start, share computed, gathered, (device 0) copied to the host
         int rc = CR_OK;
         std::string err;
     };
@@ -128,7 +128,7 @@ struct cr_multi {
     // communicator): the shares are gathered with device copies instead.  This is how a one-GPU box runs the deal, the
     // host threads, the share layout and the scatter with MORE THAN ONE share (tests); it is not a product path.
     bool loopback = false;
-    float last_ms[3] = {0.f, 0.f, 0.f};      // last call: slowest device's share (events), all-gather (events), download + scatter (wall)
+    float last_ms[3] = {0.f, 0.f, 0.f};      // last call: slowest device's share (events), all-gather (events), download (events) + scatter on the host (wall)
     // one host thread per device, parked between calls
     std::vector<std::thread> threads;
     std::mutex mu;
@@ -477,7 +477,7 @@ int cr_multi_pairwise_scores(cr_multi* m, const double* coords, const double* te
             (void)hipEventRecord(m->dev[(size_t)g]->ev[2], m->ctx[(size_t)g]->stream);
         }
     }
-    const auto t2 = std::chrono::steady_clock::now();
+    auto t_scatter = std::chrono::steady_clock::now();
 
     // ---- device 0's copy -> host, share order -> pair order ------------------------------------------------------
     auto collect = [&]() -> int {
@@ -492,7 +492,9 @@ int cr_multi_pairwise_scores(cr_multi* m, const double* coords, const double* te
         uint32_t* h_fl = reinterpret_cast<uint32_t*>(h_sw + cnt);
         CR_HIP(hipMemcpyAsync(h_sw, m->dev[0]->gathered.p, sizeof(double) * cnt, hipMemcpyDeviceToHost, ctx->stream));
         CR_HIP(hipMemcpyAsync(h_fl, m->dev[0]->gathered_flags.p, sizeof(uint32_t) * cnt, hipMemcpyDeviceToHost, ctx->stream));
+        CR_HIP(hipEventRecord(m->dev[0]->ev[3], ctx->stream));
         CR_HIP(hipStreamSynchronize(ctx->stream));
+        t_scatter = std::chrono::steady_clock::now();
         for (int g = 0; g < G; g++) {
             const std::vector<int64_t>& mine = m->dev[(size_t)g]->owned;
             for (size_t k = 0; k < mine.size(); k++) {
@@ -522,9 +524,12 @@ int cr_multi_pairwise_scores(cr_multi* m, const double* coords, const double* te
         if (hipEventElapsedTime(&a, m->dev[(size_t)g]->ev[0], m->dev[(size_t)g]->ev[1]) == hipSuccess) compute = std::max(compute, a);
         if (hipEventElapsedTime(&b, m->dev[(size_t)g]->ev[1], m->dev[(size_t)g]->ev[2]) == hipSuccess) gather = std::max(gather, b);
     }
+    float copy = 0.f;
+    (void)hipSetDevice(m->devices[0]);
+    (void)hipEventElapsedTime(&copy, m->dev[0]->ev[2], m->dev[0]->ev[3]);
     m->last_ms[0] = compute;
     m->last_ms[1] = gather;
-    m->last_ms[2] = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count();
+    m->last_ms[2] = copy + (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_scatter).count();
     return CR_OK;
 }
 

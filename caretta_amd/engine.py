@@ -149,7 +149,9 @@ class PairBatch:
     def run_streamed(self, params: Optional[Params] = None, want_alignments: bool = True, sw_out_device_ptr: Optional[int] = None):
         """``run`` with the download folded in (cr_batch_run_stream_i32): the alignment kernel writes every pair's rows
         (int32) and record straight into page-locked arrays kept by this batch.  Asynchronous; -> (results, aln) that are
-        complete after ``ctx.synchronize()`` and are REUSED by the next call."""
+        complete after ``ctx.synchronize()`` and are REUSED by the next call.  Only the first ``results["aln_len"][p]`` entries
+        of each row of pair p are written: what lies behind them is whatever an earlier batch (or nothing) left there --
+        ``fetch`` pads the same cells with -2, this call does not touch them."""
         params = params or make_params()
         n = len(self.pairs)
         stride = 0
@@ -262,7 +264,8 @@ class MultiDevice:
         return sw, flags
 
     def last_ms(self):
-        """wall ms of the last call: (upload + kernels, all-gather, download + scatter)"""
+        """ms of the last call's phases: (slowest device's upload + kernels, all-gather, download + scatter to pair order) -- the
+        first two and the download from events on the devices' streams, the scatter as host time"""
         buf = (C.c_float * 3)()
         check(self._lib.cr_multi_last_ms(self._h, C.byref(buf)))
         return tuple(buf)

@@ -161,7 +161,9 @@ int cr_batch_destroy(cr_batch *b);
  * collective), and assembles the score vector with ONE grouped RCCL all-gather over xGMI (ncclCommInitAll +
  * ncclGroupStart / ncclAllGather per device / ncclGroupEnd; librccl is bound at run time).  The result does not
  * depend on the number of devices, bit for bit.
- * devices == NULL or ndev <= 0: every visible device. */
+ * devices == NULL or ndev <= 0: every visible device.  cr_multi_create opens the contexts, starts one host thread per device
+ * and creates the communicators (a box without a usable RCCL fails here); batches, pair lists and buffers of a call are
+ * kept for the next call with the same layout (num_structures, d, offsets), which only re-uploads coordinates and tensors. */
 typedef struct cr_multi cr_multi;
 int cr_multi_create(const int *devices, int ndev, cr_multi **out);
 int cr_multi_device_count(cr_multi *m, int *ndev);
@@ -169,8 +171,9 @@ int cr_multi_device_count(cr_multi *m, int *ndev);
  * both in the row-major i < j order of multiple_alignment.py:162-163 (what cr_assemble_matrix takes). */
 int cr_multi_pairwise_scores(cr_multi *m, const double *coords, const double *tensors, const int64_t *offsets,
                              int64_t num_structures, int64_t d, const cr_params *params, double *scores, uint32_t *flags);
-/* wall ms of the last call: [0] upload + kernels on all devices, [1] the all-gather, [2] download + scatter
- * ([0] and [1] are only separated when CARETTA_MULTI_TIMING is set: that costs a device wait in between) */
+/* ms of the last call's phases: [0] upload + kernels of the slowest device, [1] the all-gather, [2] device 0's copy to the
+ * host + the scatter to pair order.  [0], [1] and the copy are read from events on the devices' streams (no host wait
+ * separates the phases), the scatter is host time. */
 int cr_multi_last_ms(cr_multi *m, float ms[3]);
 int cr_multi_destroy(cr_multi *m);
 /* The deal of the pair set over `world` devices or ranks (host only): indices into the row-major i < j pair list owned

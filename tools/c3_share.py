@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """One GPU's share of the headline configuration on 8 GPUs: every 8th of the 8 128 pairs of 128 x 300 (1 016 pairs).
 
-    python tools/c3_share.py [stride ...]        default stride 8; e.g. "2 4 8" = the shares at 2, 4 and 8 GPUs
+    python tools/c3_share.py [--family=P,L,seed] [stride ...]     default 128,300,20242 and stride 8; "2 4 8" = the shares at 2, 4, 8 GPUs
+    C3_LIMIT=1 / C3_ONE=1 / C3_ALL=1 python tools/c3_share.py ...   other mode sets (see MODES)
 
-For every share: the library's own choice and a set of forced layouts (read by cr_batch_set_pairs from the environment),
-full pipeline and matrix entries only, all results compared with the single-wave path bit for bit.
+For every share: one wave per pair, the library's own choice, and strip plans of the mid-size layout (cr_duo.h) forced through
+the environment (CARETTA_MID_PLAN=RA,RB,nA is read by cr_batch_set_pairs); full pipeline and matrix entries only, all results
+compared with the single-wave path bit for bit.
 """
 import os
 import sys
@@ -16,21 +18,23 @@ import numpy as np  # noqa: E402
 
 from caretta_amd import engine, synthetic  # noqa: E402
 
-KEYS = ("CARETTA_MID_ANY", "CARETTA_MID_PLAN", "CARETTA_MID_LDS_KB", "CARETTA_MID_PAIRS", "CARETTA_WIDE", "CARETTA_TEAM_PAIRS", "CARETTA_STAGED", "CARETTA_STAGED_WAVES", "CARETTA_NO_TEAM", "CARETTA_NO_WIDE", "CARETTA_MID")
+KEYS = ("CARETTA_MID_ANY", "CARETTA_MID_PLAN", "CARETTA_MID_LDS_KB", "CARETTA_MID_PAIRS", "CARETTA_MID", "CARETTA_WIDE", "CARETTA_TEAM_PAIRS",
+        "CARETTA_STAGED", "CARETTA_STAGED_WAVES", "CARETTA_NO_TEAM", "CARETTA_NO_WIDE")
+FORCE = {"CARETTA_MID_PAIRS": "100000"}
 MODES = [("single wave", {"CARETTA_NO_TEAM": "1", "CARETTA_MID": "0"}),
          ("default", {}),
-         ("mid 3,2,1 (2 waves)", {"CARETTA_MID_PLAN": "3,2,1", "CARETTA_MID_PAIRS": "100000"}),
-         ("mid 3,3,0 (2 waves)", {"CARETTA_MID_PLAN": "3,3,0", "CARETTA_MID_PAIRS": "100000"}),
-         ("mid 2,2,0 (3 waves)", {"CARETTA_MID_PLAN": "2,2,0", "CARETTA_MID_PAIRS": "100000"}),
-         ("mid 2,1,1 (4 waves)", {"CARETTA_MID_PLAN": "2,1,1", "CARETTA_MID_PAIRS": "100000"}),
-         ("mid 2,1,2 (3 waves)", {"CARETTA_MID_PLAN": "2,1,2", "CARETTA_MID_PAIRS": "100000"}),
-         ("mid 1,1,0 (5 waves)", {"CARETTA_MID_PLAN": "1,1,0", "CARETTA_MID_PAIRS": "100000"}),
-         ("mid 1,1,0 36 KB", {"CARETTA_MID_PLAN": "1,1,0", "CARETTA_MID_PAIRS": "100000", "CARETTA_MID_LDS_KB": "36"})]
-if os.environ.get("C3_LIMIT"):
-    MODES = MODES[:1] + [("mid 3,2,1 (2 waves)", {"CARETTA_MID_PLAN": "3,2,1", "CARETTA_MID_PAIRS": "100000"})]
-if os.environ.get("C3_ONE"):
-    MODES = MODES[:2] + [("mid 3,3,0 one wave", {"CARETTA_MID_PLAN": "3,3,0", "CARETTA_MID_PAIRS": "100000", "CARETTA_MID_ANY": "1", "CARETTA_TEAM_PAIRS": "0", "CARETTA_STAGED": "0"})]
-if os.environ.get("C3_ALL"):
+         ("mid 3,2,1 (2 waves)", dict(FORCE, CARETTA_MID_PLAN="3,2,1")),
+         ("mid 3,3,0 (2 waves)", dict(FORCE, CARETTA_MID_PLAN="3,3,0")),
+         ("mid 2,1,2 (3 waves)", dict(FORCE, CARETTA_MID_PLAN="2,1,2")),
+         ("mid 2,2,0 (3 waves)", dict(FORCE, CARETTA_MID_PLAN="2,2,0")),
+         ("mid 2,1,1 (4 waves)", dict(FORCE, CARETTA_MID_PLAN="2,1,1")),
+         ("mid 1,1,0 (5 waves)", dict(FORCE, CARETTA_MID_PLAN="1,1,0")),
+         ("mid 3,2,1, 70 KB (2 pairs per CU)", dict(FORCE, CARETTA_MID_PLAN="3,2,1", CARETTA_MID_LDS_KB="70"))]
+if os.environ.get("C3_LIMIT"):          # where the layout stops paying: the library's plan against one wave per pair
+    MODES = MODES[:1] + [("mid 3,2,1", dict(FORCE, CARETTA_MID_PLAN="3,2,1"))]
+if os.environ.get("C3_ONE"):            # k_pair_duo with ONE strip against k_seed + k_align (the kernel itself, no pacing)
+    MODES = MODES[:2] + [("mid 3,3,0 one wave", dict(FORCE, CARETTA_MID_PLAN="3,3,0", CARETTA_MID_ANY="1", CARETTA_TEAM_PAIRS="0", CARETTA_STAGED="0"))]
+if os.environ.get("C3_ALL"):            # the one-pair-per-CU layouts forced onto the list
     MODES += [("wide 3,3 (2 waves)", {"CARETTA_WIDE": "3,3,0,8"}),
               ("wide 2,2 (3 waves)", {"CARETTA_WIDE": "2,2,0,8"}),
               ("staged (5 waves)", {"CARETTA_STAGED_WAVES": str(1 << 40)})]

@@ -49,7 +49,7 @@ def main():
     trees_identical = bool(np.array_equal(tree_one, tree_multi) and np.array_equal(bl_one, bl_multi))
     out = {"devices": multi.num_devices, "structures": num, "residues": length, "pairs": int(len(pairs)),
            "one_gpu_ms": t_one * 1e3, "multi_gpu_ms": t_multi * 1e3, "speedup": t_one / t_multi,
-           "last_call_ms": dict(zip(("slowest_share_events", "all_gather_events", "download_scatter_wall"), multi.last_ms())),
+           "last_call_ms": dict(zip(("slowest_share_events", "all_gather_events", "download_events_plus_host_scatter"), multi.last_ms())),
            "scores_identical": bool(np.array_equal(sw, sw_one) and np.array_equal(flags, flags_one)),
            "nj_trees_identical": trees_identical,
            "note": "one process, one context + host thread per GPU, cr_partition_pairs, one grouped ncclAllGather (RCCL bound at run "

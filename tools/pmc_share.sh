@@ -1,8 +1,10 @@
 #!/bin/bash
 # rocprofv3 PMC passes over one GPU's share of BASELINE config 5 (252 pairs of 1200 x 1200, the wide layout: k_pair_wide):
-#   gpurun -- 'bash tools/pmc_share.sh [tag]'      -> gpurun_out/<tag>/summary.json
+#   gpurun -- 'bash tools/pmc_share.sh [tag [script]]'      -> gpurun_out/<tag>/summary.json
+# (script: the workload, default tools/config5_share_time.py; tools/c3_share_time.py = the headline's one-of-8 share)
 # Separate passes, --kernel-trace only (MI355X_MICROARCH.md).
-TAG=${1:-r03_pmc_c5share}
+TAG=${1:-r04_pmc_c5share}
+SCRIPT=${2:-tools/config5_share_time.py}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -15,7 +17,7 @@ PASSES=(
 i=0
 for P in "${PASSES[@]}"; do
   i=$((i+1))
-  rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/pass$i -- python3 tools/config5_share_time.py > $OUT/pass$i.log 2>&1
+  rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/pass$i -- python3 $SCRIPT > $OUT/pass$i.log 2>&1
   tail -1 $OUT/pass$i.log | cut -c1-200
 done
 python3 tools/pmc_summary.py $OUT

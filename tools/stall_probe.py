@@ -10,7 +10,7 @@ started on the device ~20 ms after its launch with nothing executing in between 
 script); now it starts within 0.1 ms.  DESIGN.md section 8 has the story.
 """
 import sys, time, numpy as np
-sys.path.insert(0,'/root/repo')
+from pathlib import Path; sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from caretta_amd import engine, multiple_alignment as ma, synthetic
 mode = sys.argv[1]
 fam = synthetic.make_family(512, 300, seed=20242)

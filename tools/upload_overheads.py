@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0, "/root/repo")
+from pathlib import Path; sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import numpy as np
 from caretta_amd import engine, synthetic
 fam = synthetic.make_family(128, 300, dim=10, seed=20242)
