@@ -26,6 +26,7 @@
 #include "cr_kernels.h"
 #include "cr_ilp_instances.h"
 #include "cr_duo.h"
+#include "cr_trio.h"
 #include "cr_duo_instances.h"
 #include "cr_flexible.h"
 
@@ -52,6 +53,9 @@ CR_ILP_PAIR_WIDE_INSTANCES(CR_X)
 #undef CR_X
 #define CR_X(RA, RB, D, SC) extern template CR_PAIR_DUO_SIGNATURE(RA, RB, D, SC)
 CR_DUO_INSTANCES(CR_X)
+#undef CR_X
+#define CR_X(R, D, SC) extern template CR_PAIR_TRIO_SIGNATURE(R, D, SC)
+CR_TRIO_INSTANCES(CR_X)
 #undef CR_X
 #endif
 
@@ -269,6 +273,7 @@ struct cr_batch {
     int wide_sync = 0;                  // > 0: the wide kernels (one wave per strip, up to 16 waves per pair) with a barrier every wide_sync steps
     int r_b = 5, wide_na = 0;           // wide kernels: strips [0, wide_na) have r_seed rows per lane, the others r_b (r_b == r_seed: all alike)
     std::vector<int32_t> duo_ij;        // ... the caller's pair list (k_pair_duo is built for sw_gap == 0: another gap lays the list out again)
+    bool trio = false;                  // the single-wave LAYOUT (5 rows per lane, one strip) on k_pair_trio (cr_trio.h): one wave of recurrences + two of scores per pair
     bool duo = false;                   // the wide LAYOUT on k_pair_duo (cr_duo.h): 2 .. 4 waves per pair paced by LDS progress words, several pairs per CU
     bool staged = false;                // scores formed by their own launches, sweeps with one row per lane (cr_staged.h)
     DevBuf<double> staged_scores;       // ... one chunk's scores
@@ -746,6 +751,37 @@ int launch_pair_duo(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm
     }
 }
 
+// ---- k_pair_trio (cr_trio.h): gap 0, pairs of at most 320 rows, tensor widths padded to at most 10 ----------------------
+template <int D, bool SC>
+int launch_pair_trio_t(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
+    constexpr int R = 5;
+    const int seed_entries = std::min(ck.n_max, ck.m_max), align_entries = ck.max_aln;
+    size_t lds = sizeof(double) * std::max(cr::trio_lds_doubles<R>(ck.m_max),
+                                           (size_t)cr::kExpDoubles + cr::trace_lds_doubles(R, SC ? seed_entries : align_entries));
+    if (const char* env = std::getenv("CARETTA_MID_LDS_KB")) lds = std::max(lds, (size_t)std::atoi(env) * 1024);   // calibration: pairs per CU
+    int rc = allow_lds(cr::k_pair_trio<R, D, SC>, lds);
+    if (rc) return rc;
+    // one wave of recurrences + two of scores; THREE of scores while the chip then still holds fewer than ~2 800 waves
+    // (tools/c3_share.py: 508 pairs of 300 0.45 -> 0.41 ms, 678 pairs 0.56 -> 0.46; 1 016 pairs 0.55 either way)
+    int waves = ck.count <= 700 ? 4 : 3;
+    if (const char* env = std::getenv("CARETTA_TRIO_WAVES")) waves = std::min(std::max(std::atoi(env), 2), cr::kTrioMaxWaves);   // calibration
+    CR_LAUNCH((cr::k_pair_trio<R, D, SC>), dim3((unsigned)ck.count), dim3(waves * cr::kWave), lds,
+              b->launch_stream ? b->launch_stream : b->ctx->stream, b->pairs.p + ck.first, b->tensors.p, (int)b->d, b->coords.p, prm.gamma_tensor,
+              prm.gamma_coords, prm.gap_open, prm.gap_extend, seed_entries, align_entries, b->dirs.p, b->bits.p, b->xf.p + ck.first,
+              b->seed_score.p + ck.first, b->aln.p, b->res.p + ck.first, host_out_for(b, ck));
+    CR_HIP(hipGetLastError());
+    return CR_OK;
+}
+
+int launch_pair_trio(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, bool scores) {
+    switch (b->d_pad) {
+        case 4: return scores ? launch_pair_trio_t<4, true>(b, ck, prm) : launch_pair_trio_t<4, false>(b, ck, prm);
+        case 8: return scores ? launch_pair_trio_t<8, true>(b, ck, prm) : launch_pair_trio_t<8, false>(b, ck, prm);
+        case 10: return scores ? launch_pair_trio_t<10, true>(b, ck, prm) : launch_pair_trio_t<10, false>(b, ck, prm);
+        default: return fail(CR_ERR_STATE, "no k_pair_trio instance for this tensor width");
+    }
+}
+
 // Strip plans k_pair_duo is built for: (RA, RB) of cr_duo_instances.h, at most kDuoMaxWaves strips, columns resident in LDS
 bool duo_fits(const StripPlan& p, int n_max, int m_max, int d_pad) {
     const int key = p.ra * 10 + p.rb;
@@ -815,6 +851,7 @@ constexpr int64_t kStagedWaveLimit = 1024;
 // Mid-size lists (cr_duo.h): up to this many waves (two strips per pair / more; CARETTA_MID_PAIRS overrides the pair limit
 // they give), columns resident in LDS.
 constexpr int64_t kMidWaveLimit2 = 2600, kMidWaveLimit = 3072;
+constexpr int64_t kTrioPairLimit = 1300;       // k_pair_trio: three waves per pair (four up to 700 pairs); 1 355 pairs tie with one wave per pair
 constexpr int kMidMaxColumns = 1280;
 constexpr int kGroupLanes = 4;             // streams that row-per-lane groups are spread over
 int launch_seed_team(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm);   // cr_dropins.h
@@ -1168,6 +1205,19 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     // strips); three strips: 1 016 of 360 0.99 -> 0.89, of 450 1.51 -> 1.28, 508 of 450 1.50 -> 0.87; five strips: 508 of 600
     // 2.49 -> 1.37, 1 016 of 600 2.45 -> 3.49 (5 080 waves do not fit the chip at once); 220 rows (one wave of 4 rows per lane
     // suffices) 0.45 -> 0.47: from 257 rows on.
+    // ... and up to 320 rows (one strip of five rows per lane) the split is by FUNCTION instead (cr_trio.h): one wave runs the
+    // recurrences of all 320 rows, two waves form the scores.  Single-wave layout, three waves per pair, all resident at once.
+    b->trio = false;
+    {
+        const char* env = std::getenv("CARETTA_TRIO");
+        int64_t trio_limit = kTrioPairLimit;
+        if (const char* lim = std::getenv("CARETTA_TRIO_PAIRS")) trio_limit = std::atoll(lim);   // calibration
+        if (!b->wide_sync && !b->team && npairs > team_limit && npairs <= trio_limit && !(env && env[0] == '0') && !g_no_wide &&
+            !std::getenv("CARETTA_NO_TEAM") && b->n_max > 4 * cr::kWave && b->n_max <= 5 * cr::kWave && b->m_max <= kMidMaxColumns && b->d_pad <= 10) {
+            b->trio = true;
+            b->r_seed = b->r_align = 5;
+        }
+    }
     b->duo = false;
     {
         const char* mid = std::getenv("CARETTA_MID");
@@ -1185,7 +1235,7 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
         // strips, 3 for more: beyond that the single-wave kernels fill the SIMDs by themselves)
         int64_t mid_limit = std::min<int64_t>(256 * (16 / strips), (strips == 2 ? kMidWaveLimit2 : kMidWaveLimit) / strips);
         if (const char* env = std::getenv("CARETTA_MID_PAIRS")) mid_limit = std::atoll(env);      // calibration
-        if (!b->wide_sync && !b->team && npairs > team_limit && npairs <= mid_limit && !(mid && mid[0] == '0') && !g_no_wide && !g_no_duo &&
+        if (!b->trio && !b->wide_sync && !b->team && npairs > team_limit && npairs <= mid_limit && !(mid && mid[0] == '0') && !g_no_wide && !g_no_duo &&
             !std::getenv("CARETTA_NO_TEAM") && !std::getenv("CARETTA_NO_WIDE") && (b->n_max > 4 * cr::kWave || std::getenv("CARETTA_MID_ANY")) &&
             b->m_max <= kMidMaxColumns && duo_fits(p, b->n_max, b->m_max, b->d_pad)) {
             b->team = true;                                         // the wide layout: one group, one plan
@@ -1222,6 +1272,7 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
             sizeof(double) * ((size_t)cr::kExpDoubles + cr::trace_team_lds_doubles(b->n_max + b->m_max)) <= 159 * 1024) {
             b->staged = true;
             b->duo = false;
+            b->trio = false;
             b->team = true;                                         // one group, one plan: the team kernels' layout rules
             b->wide_sync = 0;
             b->wide_na = 0;
@@ -1302,7 +1353,7 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     auto cost = [&](int32_t p) { return cost_of[(size_t)p]; };
     // Pairs are also grouped by the rows per lane that suit their row count (one launch pair per group, long rows
     // first): a 90-residue structure in a 5-rows-per-lane kernel would use 18 of 64 lanes.
-    const bool team_batch = b->team;
+    const bool team_batch = b->team || b->trio;       // (trio: the single-wave layout, but ONE group of five rows per lane)
     const int team_r = b->r_seed;
     auto group = [&](int32_t p) { return team_batch ? team_r : (int)group_of[(size_t)p]; };
     const bool grouped = !std::getenv("CARETTA_KEEP_ORDER");
@@ -1484,6 +1535,17 @@ static int run_batch(cr_batch* b, const cr_params* params, double* d_sw_out, boo
             if (rc) return rc;
             continue;
         }
+        if (b->trio && prm.sw_gap == 0.0) {
+            // three waves per pair, both stages in ONE launch (k_pair_trio); with a gap the same layout runs k_seed / k_align
+            rc = launch_pair_trio(b, ck, prm, scores_only);
+            if (!rc && prof) {
+                (void)hipEventRecord((*evl)[evi++], st);
+                (void)hipEventRecord((*evl)[evi++], st);
+            }
+            b->launch_stream = nullptr;
+            if (rc) return rc;
+            continue;
+        }
         if (b->wide_sync) {
             // the wide layout: both stages of a pair in ONE launch (k_pair_wide) -- the stage split of the events is
             // (everything, 0)
@@ -1609,7 +1671,7 @@ int cr_batch_work(cr_batch* b, double* alg_bytes, double* cells) {
 
 int cr_batch_layout(cr_batch* b, int* family, int* rows_a, int* rows_b, int* strips_a) {
     CR_REQUIRE(b != nullptr, "null batch");
-    if (family) *family = b->staged ? CR_LAYOUT_STAGED : b->duo ? CR_LAYOUT_DUO : b->wide_sync ? CR_LAYOUT_WIDE : b->team ? CR_LAYOUT_TEAM : CR_LAYOUT_SINGLE;
+    if (family) *family = b->staged ? CR_LAYOUT_STAGED : b->trio ? CR_LAYOUT_TRIO : b->duo ? CR_LAYOUT_DUO : b->wide_sync ? CR_LAYOUT_WIDE : b->team ? CR_LAYOUT_TEAM : CR_LAYOUT_SINGLE;
     if (rows_a) *rows_a = b->r_seed;
     if (rows_b) *rows_b = b->wide_sync ? b->r_b : b->r_seed;
     if (strips_a) *strips_a = b->wide_sync ? b->wide_na : 0;

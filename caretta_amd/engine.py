@@ -218,10 +218,10 @@ class PairBatch:
 
     def layout(self):
         """(kernel family, rows per lane A, rows per lane B, strips with A) chosen by ``set_pairs`` -- "single" (one wave per
-        pair), "team", "wide" (one workgroup per pair), "staged" (scores by their own launches), "duo" (mid-size lists)."""
+        pair), "team", "wide" (one workgroup per pair), "staged" (scores by their own launches), "duo" / "trio" (mid-size lists: split by rows / by function)."""
         f, ra, rb, na = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
         check(self._lib.cr_batch_layout(self._h, C.byref(f), C.byref(ra), C.byref(rb), C.byref(na)))
-        return ("single", "team", "wide", "staged", "duo")[f.value], ra.value, rb.value, na.value
+        return ("single", "team", "wide", "staged", "duo", "trio")[f.value], ra.value, rb.value, na.value
 
     def close(self):
         if self._h:

@@ -149,7 +149,7 @@ int cr_batch_work(cr_batch *b, double *alg_bytes, double *cells);
 /* Which kernel family cr_batch_set_pairs chose for the current pair list (the results do not depend on it; the reference's
  * pair loop, multiple_alignment.py:158-170, knows nothing of it): family = CR_LAYOUT_*, rows per lane of the first `strips_a`
  * strips and of the others (equal when the layout has one kind of strip).  Any pointer may be NULL. */
-enum { CR_LAYOUT_SINGLE = 0, CR_LAYOUT_TEAM = 1, CR_LAYOUT_WIDE = 2, CR_LAYOUT_STAGED = 3, CR_LAYOUT_DUO = 4 };
+enum { CR_LAYOUT_SINGLE = 0, CR_LAYOUT_TEAM = 1, CR_LAYOUT_WIDE = 2, CR_LAYOUT_STAGED = 3, CR_LAYOUT_DUO = 4, CR_LAYOUT_TRIO = 5 };
 int cr_batch_layout(cr_batch *b, int *family, int *rows_a, int *rows_b, int *strips_a);
 int cr_batch_destroy(cr_batch *b);
 

@@ -59,15 +59,18 @@ def run_all_ways(ctx, oracle, coords, tensors, offsets, pairs, expect, sw_gaps=(
     batch.close()
 
 
-def test_one_of_eight_share_of_the_headline(ctx, oracle):
+def test_one_of_eight_share_of_the_headline(ctx, oracle, monkeypatch):
     """BASELINE config 3 sharded over 8 GPUs: every 8th of the 8 128 pairs of 128 x 300 (1 016 pairs) is what ONE GPU runs
-    (north star: ">= 6x further scaling at 8 GPUs").  That list runs two waves per pair (k_pair_duo); all 1 016 pairs, every
-    output, against the oracle."""
+    (north star: ">= 6x further scaling at 8 GPUs").  That list runs three waves per pair -- one of recurrences, two of
+    scores (k_pair_trio) --; all 1 016 pairs, every output, against the oracle; and the same list on the row-split layout
+    (k_pair_duo: CARETTA_TRIO=0)."""
     from caretta_amd import engine
     fam = synthetic.make_family(128, 300, seed=20242)
     coords, tensors, offsets = synthetic.pack(fam)
     pairs = engine.all_pairs(128)[::8]
     assert len(pairs) == 1016
+    run_all_ways(ctx, oracle, coords, tensors, offsets, pairs, "trio", sw_gaps=(0.0, 0.05))
+    monkeypatch.setenv("CARETTA_TRIO", "0")
     run_all_ways(ctx, oracle, coords, tensors, offsets, pairs, "duo")
 
 
@@ -77,7 +80,7 @@ def test_midsize_ragged_lists_vs_oracle(ctx, oracle, dim, seed):
     pairs of one launch end in strip 0 or strip 1, some have fewer rows than one strip; tensor widths that are padded (7)
     or not; with a Smith-Waterman gap the list is laid out again for the kernels that have a skewed seed sweep."""
     from caretta_amd import engine
-    fam = synthetic.make_family(15, 330, dim=dim, seed=seed, ragged=True, clades=3)
+    fam = synthetic.make_family(15, 330, dim=dim, seed=seed, clades=3)
     cuts = [330, 300, 257, 320, 321, 193, 192, 64, 65, 40, 288, 129, 310, 256, 191]
     for s, cut in zip(fam, cuts):
         s.coordinates, s.tensors = s.coordinates[:cut].copy(), s.tensors[:cut].copy()
@@ -87,10 +90,29 @@ def test_midsize_ragged_lists_vs_oracle(ctx, oracle, dim, seed):
     run_all_ways(ctx, oracle, coords, tensors, offsets, pairs, "duo", sw_gaps=(0.0, 0.05) if dim == 10 else (0.0,))
 
 
+@pytest.mark.parametrize("dim,seed,waves", [(10, 9111, None), (4, 9112, "5"), (8, 9113, "2"), (7, 9114, "4")])
+def test_midsize_lists_one_strip_by_function(ctx, oracle, monkeypatch, dim, seed, waves):
+    """k_pair_trio (cr_trio.h): lists of more than 256 pairs whose longest structure has 257 .. 320 rows -- one wave of
+    recurrences and one to four waves of scores per pair (the library's choice, or CARETTA_TRIO_WAVES).  Ragged lengths 1 .. 320
+    (fewer rows than lanes, fewer columns than a batch or than the ring), both orientations, widths that are padded or not;
+    with a Smith-Waterman gap the same layout runs the single-wave kernels."""
+    from caretta_amd import engine
+    fam = synthetic.make_family(15, 320, dim=dim, seed=seed, clades=3)
+    cuts = [320, 300, 257, 319, 1, 193, 192, 64, 65, 3, 288, 129, 7, 256, 9]
+    for s, cut in zip(fam, cuts):
+        s.coordinates, s.tensors = s.coordinates[:cut].copy(), s.tensors[:cut].copy()
+    coords, tensors, offsets = synthetic.pack(fam)
+    fwd = engine.all_pairs(15)
+    pairs = np.vstack([fwd, fwd[:, ::-1], fwd[::2]])             # 263 pairs
+    if waves:
+        monkeypatch.setenv("CARETTA_TRIO_WAVES", waves)
+    run_all_ways(ctx, oracle, coords, tensors, offsets, pairs, "trio", sw_gaps=(0.0, 0.05) if dim == 10 else (0.0,))
+
+
 def test_midsize_three_and_more_strips(ctx, oracle):
     """321 .. 600 rows: three to five waves per pair (3 rows per lane in strip 0, 2 in the others), ragged."""
     from caretta_amd import engine
-    fam = synthetic.make_family(18, 600, seed=9201, ragged=True, clades=2)
+    fam = synthetic.make_family(18, 600, seed=9201, clades=2)
     cuts = [600, 450, 321, 577, 448, 449, 320, 576, 300, 130, 512, 360, 333, 599, 64, 400, 585, 470]
     for s, cut in zip(fam, cuts):
         s.coordinates, s.tensors = s.coordinates[:cut].copy(), s.tensors[:cut].copy()
@@ -101,8 +123,9 @@ def test_midsize_three_and_more_strips(ctx, oracle):
 
 
 @pytest.mark.parametrize("npairs,rows,expect", [
-    (256, 193, ("wide", "staged")), (257, 193, ("single",)), (257, 256, ("single",)), (257, 257, ("duo",)), (256, 257, ("wide", "staged")),
-    (1300, 300, ("duo",)), (1301, 300, ("single",)), (1024, 360, ("duo",)), (1025, 360, ("single",)),
+    (256, 193, ("wide", "staged")), (257, 193, ("single",)), (257, 256, ("single",)), (257, 257, ("trio",)), (256, 257, ("wide", "staged")),
+    (700, 320, ("trio",)), (701, 320, ("trio",)), (257, 321, ("duo",)), (1300, 300, ("trio",)), (1301, 300, ("single",)), (1024, 360, ("duo",)),
+    (1025, 360, ("single",)),
     (256, 192, ("single", "staged")), (204, 300, ("staged",)), (205, 300, ("wide",))])
 def test_path_selection_boundaries(ctx, oracle, npairs, rows, expect):
     """The pair-count and row-count limits of cr_batch_set_pairs at their boundary values: which kernel family runs on either
@@ -155,7 +178,7 @@ def test_tensor_width_limit_of_the_one_workgroup_layouts(ctx, oracle, dim):
     coords, tensors, offsets = synthetic.pack(fam)
     pairs = np.vstack([engine.all_pairs(24), engine.all_pairs(24)[:40, ::-1]])       # 316 pairs
     batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
-    assert layout_of(batch)[0] == ("duo" if dim <= 16 else "single")
+    assert layout_of(batch)[0] == ("duo" if dim <= 16 else "single")            # (10 < d <= 16: no k_pair_trio instance)
     batch.run()
     res, aln = batch.fetch()
     batch.close()
@@ -213,7 +236,8 @@ def test_smith_waterman_batch_vs_oracle(oracle, golden):
     rng = np.random.default_rng(9401)
     mixed = [p for p in _explicit_problems(rng) if not np.any(np.asarray(p[1]) < 0)]
     ident = [(np.arange(n), np.arange(m), rng.uniform(size=(n, m)) ** 2 - 0.15) for n, m in [(300, 300), (64, 65), (1, 9), (257, 130), (90, 400), (513, 77)]]
-    for problems in (mixed, ident, ident * 600):                 # (3 600 problems: one row per lane in the streaming kernels)
+    small = [(np.arange(n), np.arange(m), rng.uniform(size=(n, m)) ** 2 - 0.15) for n, m in [(64, 65), (1, 9), (90, 40), (130, 77)]]
+    for problems in (mixed, ident, small * 800):                 # (3 200 problems: one row per lane in the streaming kernels)
         for gap in (0.0, 0.25):
             got = dtw.smith_waterman_batch(problems, gap)
             for (s1, s2, mat), (a1, a2, score) in zip(problems[:len(mixed) + len(ident)], got):

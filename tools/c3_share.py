@@ -18,11 +18,13 @@ import numpy as np  # noqa: E402
 
 from caretta_amd import engine, synthetic  # noqa: E402
 
-KEYS = ("CARETTA_MID_ANY", "CARETTA_MID_PLAN", "CARETTA_MID_LDS_KB", "CARETTA_MID_PAIRS", "CARETTA_MID", "CARETTA_WIDE", "CARETTA_TEAM_PAIRS",
+KEYS = ("CARETTA_TRIO", "CARETTA_TRIO_PAIRS", "CARETTA_TRIO_WAVES", "CARETTA_MID_ANY", "CARETTA_MID_PLAN", "CARETTA_MID_LDS_KB", "CARETTA_MID_PAIRS", "CARETTA_MID", "CARETTA_WIDE", "CARETTA_TEAM_PAIRS",
         "CARETTA_STAGED", "CARETTA_STAGED_WAVES", "CARETTA_NO_TEAM", "CARETTA_NO_WIDE")
-FORCE = {"CARETTA_MID_PAIRS": "100000"}
-MODES = [("single wave", {"CARETTA_NO_TEAM": "1", "CARETTA_MID": "0"}),
+FORCE = {"CARETTA_MID_PAIRS": "100000", "CARETTA_TRIO": "0"}
+MODES = [("single wave", {"CARETTA_NO_TEAM": "1", "CARETTA_MID": "0", "CARETTA_TRIO": "0"}),
          ("default", {}),
+         ("trio 1 + 2 waves", {"CARETTA_TRIO_PAIRS": "100000", "CARETTA_TRIO_WAVES": "3"}),
+         ("trio 1 + 3 waves", {"CARETTA_TRIO_PAIRS": "100000", "CARETTA_TRIO_WAVES": "4"}),
          ("mid 3,2,1 (2 waves)", dict(FORCE, CARETTA_MID_PLAN="3,2,1")),
          ("mid 3,3,0 (2 waves)", dict(FORCE, CARETTA_MID_PLAN="3,3,0")),
          ("mid 2,1,2 (3 waves)", dict(FORCE, CARETTA_MID_PLAN="2,1,2")),
@@ -31,7 +33,8 @@ MODES = [("single wave", {"CARETTA_NO_TEAM": "1", "CARETTA_MID": "0"}),
          ("mid 1,1,0 (5 waves)", dict(FORCE, CARETTA_MID_PLAN="1,1,0")),
          ("mid 3,2,1, 70 KB (2 pairs per CU)", dict(FORCE, CARETTA_MID_PLAN="3,2,1", CARETTA_MID_LDS_KB="70"))]
 if os.environ.get("C3_LIMIT"):          # where the layout stops paying: the library's plan against one wave per pair
-    MODES = MODES[:1] + [("mid 3,2,1", dict(FORCE, CARETTA_MID_PLAN="3,2,1"))]
+    MODES = MODES[:1] + [("mid 3,2,1", dict(FORCE, CARETTA_MID_PLAN="3,2,1")), ("trio 1 + 2 waves", {"CARETTA_TRIO_PAIRS": "100000", "CARETTA_TRIO_WAVES": "3"}),
+                         ("trio 1 + 3 waves", {"CARETTA_TRIO_PAIRS": "100000", "CARETTA_TRIO_WAVES": "4"})]
 if os.environ.get("C3_ONE"):            # k_pair_duo with ONE strip against k_seed + k_align (the kernel itself, no pacing)
     MODES = MODES[:2] + [("mid 3,3,0 one wave", dict(FORCE, CARETTA_MID_PLAN="3,3,0", CARETTA_MID_ANY="1", CARETTA_TEAM_PAIRS="0", CARETTA_STAGED="0"))]
 if os.environ.get("C3_ALL"):            # the one-pair-per-CU layouts forced onto the list

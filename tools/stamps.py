@@ -75,7 +75,7 @@ def run(names):
         print(f"{name} ({len(pairs)} pairs of {length}, CARETTA_WIDE={os.environ.get('CARETTA_WIDE', '-')}): shader-clock cycles (s_memtime; ~2.4 GHz)\n"
               f"  seed : fill {med(d[:, 0]):9.0f}  walk {med(d[:, 1]):9.0f}  kabsch/rest {med(d[:, 2]):9.0f}   launch span {span_seed}\n"
               f"  align: fill {med(d[:, 4]):9.0f}  walk {med(d[:, 5]):9.0f}  kabsch/metrics {med(d[:, 6]):9.0f}   launch span {span_align}", flush=True)
-        if getattr(lib, "cr_debug_duo_stamps", None) is not None and os.environ.get("CARETTA_MID") != "0":
+        if getattr(lib, "cr_debug_duo_stamps", None) is not None and (os.environ.get("CARETTA_MID") != "0" or os.environ.get("CARETTA_TRIO") != "0"):
             lib.cr_debug_duo_stamps.restype = C.c_int
             lib.cr_debug_duo_stamps.argtypes = [C.c_void_p, C.c_int]
             nb = min(len(pairs), 4096)
@@ -87,7 +87,7 @@ def run(names):
                 for wv in range(4):
                     if not ds[:, wv, 1].any():
                         continue
-                    print(f"  duo wave {wv}: seed loop {med(ds[:, wv, 1] - ds[:, wv, 0]):9.0f} (start +{med(ds[:, wv, 0] - t0):7.0f}, waited {med(ds[:, wv, 2]):8.0f})   "
+                    print(f"  wave {wv}: seed loop {med(ds[:, wv, 1] - ds[:, wv, 0]):9.0f} (start +{med(ds[:, wv, 0] - t0):7.0f}, waited {med(ds[:, wv, 2]):8.0f})   "
                           f"align loop {med(ds[:, wv, 5] - ds[:, wv, 4]):9.0f} (start +{med(ds[:, wv, 4] - st[:nb, 4]):7.0f}, waited {med(ds[:, wv, 6]):8.0f})", flush=True)
         if os.environ.get("STAMPS_DETAIL"):
             pc = lambda x: " ".join(f"{v:8.0f}" for v in np.percentile(x, [0, 10, 50, 90, 100]))
