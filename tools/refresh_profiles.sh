@@ -15,6 +15,7 @@ ls $O/ktrace
 bash tools/pmc_profile.sh ${R}_pmc --steps 3 --warmup 1 --no-cpu-baseline --no-extras
 bash tools/pmc_share.sh ${R}_pmc_c5share > $O/pmc_c5share.log 2>&1
 bash tools/pmc_share.sh ${R}_pmc_c3share tools/c3_share_time.py > $O/pmc_c3share.log 2>&1
+CARETTA_TRIO=0 bash tools/pmc_share.sh ${R}_pmc_c3duo tools/c3_share_time.py > $O/pmc_c3duo.log 2>&1
 python tools/bench_msa.py 128 300 > $O/msa_128.txt 2>&1
 python tools/bench_msa.py 512 300 > $O/msa_512.txt 2>&1
 python tools/config5_share_time.py > $O/config5_share.txt 2>&1
@@ -30,11 +31,12 @@ for t in valu_latency dpp_latency wave_placement; do /opt/rocm/bin/hipcc --offlo
 ./tools/dpp_latency.bin > $O/dpp_latency.txt 2>&1
 (./tools/wave_placement.bin 1016 128 17; ./tools/wave_placement.bin 1016 64 10; ./tools/wave_placement.bin 2032 64 10; ./tools/wave_placement.bin 1016 320 36) > $O/wave_placement.txt 2>&1
 python tools/c3_share.py 16 8 4 > $O/c3_share.txt 2>&1
-C3_LIMIT=1 python tools/c3_share.py 12 10 8 7 6 5 > $O/c3_share_limit.txt 2>&1
+C3_LIMIT=1 python tools/c3_share.py 14 12 10 9 8 7 6 5 > $O/c3_share_limit.txt 2>&1
 (C3_LIMIT=1 python tools/c3_share.py --family=128,360,14 8 16; C3_LIMIT=1 python tools/c3_share.py --family=128,450,11 8 16; C3_LIMIT=1 python tools/c3_share.py --family=128,600,12 8 16) > $O/c3_share_lengths.txt 2>&1
 python tools/c5_share_layouts.py > $O/c5_share_layouts.txt 2>&1
-python tools/stamps.py run c3share > $O/stamps_c3share.txt 2>&1
-CARETTA_MID=0 python tools/stamps.py run c3share c3quarter > $O/stamps_c3share_single.txt 2>&1
+STAMPS_DETAIL=1 python tools/stamps.py run c3share > $O/stamps_c3share.txt 2>&1
+STAMPS_DETAIL=1 CARETTA_TRIO=0 python tools/stamps.py run c3share > $O/stamps_c3share_duo.txt 2>&1
+CARETTA_TRIO=0 CARETTA_MID=0 python tools/stamps.py run c3share c3quarter > $O/stamps_c3share_single.txt 2>&1
 python tools/multi_gpu_check.py 512 300 2>/dev/null | grep '^{' > $O/multi_gpu_check_1device.json
 python tools/dropin_latency.py > $O/dropin_latency.txt 2>&1
 python tools/nj_device_time.py > $O/nj_device_time.txt 2>&1
