@@ -147,8 +147,10 @@ int cr_batch_stage_ms(cr_batch *b, float ms[CR_NUM_STAGES], int *runs_averaged);
 /* algorithmic HBM bytes of one run of the current pair list (SURVEY.md 8(d) B_alg) and DP cells */
 int cr_batch_work(cr_batch *b, double *alg_bytes, double *cells);
 /* Which kernel family cr_batch_set_pairs chose for the current pair list (the results do not depend on it; the reference's
- * pair loop, multiple_alignment.py:158-170, knows nothing of it): family = CR_LAYOUT_*, rows per lane of the first `strips_a`
- * strips and of the others (equal when the layout has one kind of strip).  Any pointer may be NULL. */
+ * pair loop, multiple_alignment.py:158-170, knows nothing of it): family = CR_LAYOUT_* -- one wave per pair; four-wave teams;
+ * one workgroup per pair with a wave per strip ("wide"); scores formed by their own launches ("staged"); mid-size lists with a
+ * pair's rows over 2 .. 8 waves ("duo") or one wave of recurrences + waves of scores ("trio") --, rows per lane of the first
+ * `strips_a` strips and of the others (equal when the layout has one kind of strip).  Any pointer may be NULL. */
 enum { CR_LAYOUT_SINGLE = 0, CR_LAYOUT_TEAM = 1, CR_LAYOUT_WIDE = 2, CR_LAYOUT_STAGED = 3, CR_LAYOUT_DUO = 4, CR_LAYOUT_TRIO = 5 };
 int cr_batch_layout(cr_batch *b, int *family, int *rows_a, int *rows_b, int *strips_a);
 int cr_batch_destroy(cr_batch *b);
