@@ -65,6 +65,7 @@ thread_local std::string g_err;
 // Work may be in flight on the device since the last device-wide wait of this thread (set by every API entry and every
 // kernel launch; DevBuf::release waits once and clears it, instead of once per buffer).
 thread_local bool g_dirty = true;
+thread_local bool g_no_trio = false;     // ... when a trio batch of at most kTeamPairLimit pairs meets sw_gap != 0 (the one-pair-per-CU layouts serve it better)
 thread_local bool g_no_duo = false;      // set around cr_batch_set_pairs when a duo batch meets sw_gap != 0 (run_batch)
 thread_local bool g_no_wide = false;     // set around cr_batch_set_pairs by callers whose second kernel has no wide version (cr_progressive_node)
 
@@ -273,6 +274,7 @@ struct cr_batch {
     int wide_sync = 0;                  // > 0: the wide kernels (one wave per strip, up to 16 waves per pair) with a barrier every wide_sync steps
     int r_b = 5, wide_na = 0;           // wide kernels: strips [0, wide_na) have r_seed rows per lane, the others r_b (r_b == r_seed: all alike)
     std::vector<int32_t> duo_ij;        // ... the caller's pair list (k_pair_duo is built for sw_gap == 0: another gap lays the list out again)
+    bool trio_few = false;              // ... chosen for a list the one-pair-per-CU layouts would take with a Smith-Waterman gap (laid out again then)
     bool trio = false;                  // the single-wave LAYOUT (5 rows per lane, one strip) on k_pair_trio (cr_trio.h): one wave of recurrences + two of scores per pair
     bool duo = false;                   // the wide LAYOUT on k_pair_duo (cr_duo.h): 2 .. 4 waves per pair paced by LDS progress words, several pairs per CU
     bool staged = false;                // scores formed by their own launches, sweeps with one row per lane (cr_staged.h)
@@ -752,9 +754,8 @@ int launch_pair_duo(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm
 }
 
 // ---- k_pair_trio (cr_trio.h): gap 0, pairs of at most 320 rows, tensor widths padded to at most 10 ----------------------
-template <int D, bool SC>
+template <int R, int D, bool SC>
 int launch_pair_trio_t(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
-    constexpr int R = 5;
     const int seed_entries = std::min(ck.n_max, ck.m_max), align_entries = ck.max_aln;
     size_t lds = sizeof(double) * std::max(cr::trio_lds_doubles<R>(ck.m_max),
                                            (size_t)cr::kExpDoubles + cr::trace_lds_doubles(R, SC ? seed_entries : align_entries));
@@ -773,12 +774,23 @@ int launch_pair_trio_t(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& 
     return CR_OK;
 }
 
-int launch_pair_trio(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, bool scores) {
+template <int R>
+int launch_pair_trio_r(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, bool scores) {
     switch (b->d_pad) {
-        case 4: return scores ? launch_pair_trio_t<4, true>(b, ck, prm) : launch_pair_trio_t<4, false>(b, ck, prm);
-        case 8: return scores ? launch_pair_trio_t<8, true>(b, ck, prm) : launch_pair_trio_t<8, false>(b, ck, prm);
-        case 10: return scores ? launch_pair_trio_t<10, true>(b, ck, prm) : launch_pair_trio_t<10, false>(b, ck, prm);
+        case 4: return scores ? launch_pair_trio_t<R, 4, true>(b, ck, prm) : launch_pair_trio_t<R, 4, false>(b, ck, prm);
+        case 8: return scores ? launch_pair_trio_t<R, 8, true>(b, ck, prm) : launch_pair_trio_t<R, 8, false>(b, ck, prm);
+        case 10: return scores ? launch_pair_trio_t<R, 10, true>(b, ck, prm) : launch_pair_trio_t<R, 10, false>(b, ck, prm);
         default: return fail(CR_ERR_STATE, "no k_pair_trio instance for this tensor width");
+    }
+}
+
+int launch_pair_trio(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, bool scores) {
+    switch (b->r_seed) {
+        case 2: return launch_pair_trio_r<2>(b, ck, prm, scores);
+        case 3: return launch_pair_trio_r<3>(b, ck, prm, scores);
+        case 4: return launch_pair_trio_r<4>(b, ck, prm, scores);
+        case 5: return launch_pair_trio_r<5>(b, ck, prm, scores);
+        default: return fail(CR_ERR_STATE, "no k_pair_trio instance for these rows per lane");
     }
 }
 
@@ -852,6 +864,7 @@ constexpr int64_t kStagedWaveLimit = 1024;
 // they give), columns resident in LDS.
 constexpr int64_t kMidWaveLimit2 = 2600, kMidWaveLimit = 3072;
 constexpr int64_t kTrioPairLimit = 1300;       // k_pair_trio: three waves per pair (four up to 700 pairs); 1 355 pairs tie with one wave per pair
+constexpr int kTrioMinRows = 64;               // ... from 65 rows on (one strip of two to five rows per lane)
 constexpr int kMidMaxColumns = 1280;
 constexpr int kGroupLanes = 4;             // streams that row-per-lane groups are spread over
 int launch_seed_team(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm);   // cr_dropins.h
@@ -1164,6 +1177,21 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     // single-wave kernels) they never win.  Hence: at most 256 pairs, more than 192 rows.
     int64_t team_limit = kTeamPairLimit;
     if (const char* env = std::getenv("CARETTA_TEAM_PAIRS")) team_limit = std::atoll(env);   // calibration
+    // Lists of at most 320 rows go to the split by FUNCTION (cr_trio.h, below) from fewer pairs on than that: its time does not
+    // depend on the pair count while the chip is not full (0.345 ms at 300 rows, 0.235 at 220, 0.157 at 150) where the
+    // one-pair-per-CU layouts grow with it -- 300 rows: 120 pairs 0.326 (staged) / 0.343, 190 pairs 0.366 / 0.348, 253 pairs
+    // 0.417 (wide) / 0.346; 220 rows: 120 pairs 0.229 / 0.233, 253 pairs 0.269 / 0.236; 150 rows: 66 pairs 0.161 / 0.156, 253
+    // pairs 0.193 / 0.158 (C3_FEW=1 tools/c3_share.py).
+    const int trio_r = std::max(2, (b->n_max + cr::kWave - 1) / cr::kWave);
+    int64_t trio_limit = kTrioPairLimit, trio_from = trio_r >= 5 ? 160 : trio_r == 4 ? 110 : 64;
+    int trio_min_rows = kTrioMinRows;
+    if (const char* lim = std::getenv("CARETTA_TRIO_PAIRS")) trio_limit = std::atoll(lim);        // calibration
+    if (const char* lim = std::getenv("CARETTA_TRIO_FROM")) trio_from = std::atoll(lim);          // calibration
+    if (const char* lim = std::getenv("CARETTA_TRIO_MIN_ROWS")) trio_min_rows = std::atoi(lim);   // calibration
+    const char* trio_env = std::getenv("CARETTA_TRIO");
+    const bool trio_shape = !(trio_env && trio_env[0] == '0') && !g_no_wide && !g_no_trio && !std::getenv("CARETTA_NO_TEAM") && b->n_max > trio_min_rows &&
+                            b->n_max <= 5 * cr::kWave && b->m_max <= kMidMaxColumns && b->d_pad <= 10 && npairs > trio_from && npairs <= trio_limit;
+    if (trio_shape) team_limit = std::min(team_limit, trio_from);
     const bool few = npairs > 0 && npairs <= team_limit && !std::getenv("CARETTA_NO_TEAM");
     b->team = few && b->n_max > 3 * cr::kWave && b->n_max <= 5 * cr::kTeamWaves * cr::kWave;
     if (b->team) b->r_seed = b->r_align = (b->n_max + cr::kTeamWaves * cr::kWave - 1) / (cr::kTeamWaves * cr::kWave);
@@ -1205,18 +1233,17 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     // strips); three strips: 1 016 of 360 0.99 -> 0.89, of 450 1.51 -> 1.28, 508 of 450 1.50 -> 0.87; five strips: 508 of 600
     // 2.49 -> 1.37, 1 016 of 600 2.45 -> 3.49 (5 080 waves do not fit the chip at once); 220 rows (one wave of 4 rows per lane
     // suffices) 0.45 -> 0.47: from 257 rows on.
-    // ... and up to 320 rows (one strip of five rows per lane) the split is by FUNCTION instead (cr_trio.h): one wave runs the
-    // recurrences of all 320 rows, two waves form the scores.  Single-wave layout, three waves per pair, all resident at once.
-    b->trio = false;
-    {
-        const char* env = std::getenv("CARETTA_TRIO");
-        int64_t trio_limit = kTrioPairLimit;
-        if (const char* lim = std::getenv("CARETTA_TRIO_PAIRS")) trio_limit = std::atoll(lim);   // calibration
-        if (!b->wide_sync && !b->team && npairs > team_limit && npairs <= trio_limit && !(env && env[0] == '0') && !g_no_wide &&
-            !std::getenv("CARETTA_NO_TEAM") && b->n_max > 4 * cr::kWave && b->n_max <= 5 * cr::kWave && b->m_max <= kMidMaxColumns && b->d_pad <= 10) {
-            b->trio = true;
-            b->r_seed = b->r_align = 5;
-        }
+    // ... and up to 320 rows (ONE strip of two to five rows per lane) the split is by FUNCTION instead (cr_trio.h): one wave runs
+    // the recurrences of all rows, two or three waves form the scores.  Single-wave layout, all workgroups resident at once.
+    // Single wave -> this layout (C3_TRIO=1 tools/c3_share.py, full pipeline, ms): 496 pairs of 150 (BASELINE config 2) 0.232 ->
+    // 0.165, 1 035 of 150 0.335 -> 0.255, 496 of 220 0.412 -> 0.255, 1 035 of 220 0.571 -> 0.500, 496 of 100 0.148 -> 0.115, 780 of
+    // 100 0.149 -> 0.122; 1 540 of 150 0.355 -> 0.355 (the limit stays 1 300 pairs).
+    b->trio = b->trio_few = false;
+    if (trio_shape && !b->wide_sync && !b->team) {
+        b->trio = true;
+        b->r_seed = b->r_align = trio_r;                             // one strip of 2 .. 5 rows per lane
+        b->trio_few = npairs <= kTeamPairLimit;
+        if (b->trio_few) b->duo_ij.assign(pairs, pairs + 2 * npairs);   // (sw_gap != 0 at run time: the list is laid out again)
     }
     b->duo = false;
     {
@@ -1265,7 +1292,9 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
         const int64_t strips1 = shape.waves;
         int row_limit = cr::kStagedMaxRows;                        // one row per lane up to 512 rows ... four up to 2048
         if (const char* lim = std::getenv("CARETTA_STAGED_ROWS")) row_limit = std::min(std::atoi(lim), cr::kStagedMaxRows);   // calibration
-        if (npairs > 0 && !g_no_wide && !(env && env[0] == '0') && !std::getenv("CARETTA_NO_TEAM") && !std::getenv("CARETTA_WIDE") &&
+        // (lists the split by function takes -- more than 256 pairs of at most 320 rows -- stay there: 496 pairs of 100 rows 0.190
+        // staged against 0.115 ms, 300 of 150 0.226 / 0.168, 300 of 190 0.266 / 0.206, 378 of 128 0.191 / 0.138; tools/c3_share.py)
+        if (npairs > 0 && !b->trio && !g_no_wide && !(env && env[0] == '0') && !std::getenv("CARETTA_NO_TEAM") && !std::getenv("CARETTA_WIDE") &&
             !std::getenv("CARETTA_NO_WIDE") && b->n_max <= row_limit && npairs * strips1 <= wave_limit &&
             (double)npairs * (double)shape.pair_doubles() * sizeof(double) <= 2.0 * 1024 * 1024 * 1024 &&
             // (the alignment columns of a pair and the term tile of the workgroup-wide sums share the LDS)
@@ -1482,11 +1511,11 @@ static int run_batch(cr_batch* b, const cr_params* params, double* d_sw_out, boo
                "gamma_tensor and gamma_coords must be finite and >= 1e-290 (below that every score is exactly 1.0)");
     CR_REQUIRE(std::isfinite(prm.gap_open) && std::isfinite(prm.gap_extend) && std::isfinite(prm.sw_gap),
                "gap penalties must be finite");
-    if (b->duo && prm.sw_gap != 0.0) {                            // k_pair_duo is the gap-0 pipeline: lay the list out without it
+    if ((b->duo || (b->trio && b->trio_few)) && prm.sw_gap != 0.0) {   // k_pair_duo / k_pair_trio are gap-0 pipelines: lay the list out without them
         const std::vector<int32_t> ij = std::move(b->duo_ij);
-        g_no_duo = true;
+        g_no_duo = g_no_trio = true;
         rc = cr_batch_set_pairs(b, ij.data(), (int64_t)(ij.size() / 2));
-        g_no_duo = false;
+        g_no_duo = g_no_trio = false;
         if (rc) return rc;
     }
     const bool prof = ctx->slots > 0;

@@ -26,7 +26,26 @@
 
 namespace cr {
 
-constexpr int kTrioRing = 8;            // columns (steps) of scores between the producers and the consumer
+// (calibration builds override these: tools/trio_variants.sh)
+#ifndef CR_TRIO_RING
+#define CR_TRIO_RING 8
+#endif
+#ifndef CR_TRIO_EARLY
+#define CR_TRIO_EARLY 1
+#endif
+#ifndef CR_TRIO_CONS_SLEEP
+#define CR_TRIO_CONS_SLEEP 2
+#endif
+#ifndef CR_TRIO_PROD_SLEEP
+#define CR_TRIO_PROD_SLEEP 2
+#endif
+#ifndef CR_TRIO_PRIO_CONS
+#define CR_TRIO_PRIO_CONS 3
+#endif
+#ifndef CR_TRIO_PRIO_PROD
+#define CR_TRIO_PRIO_PROD 0
+#endif
+constexpr int kTrioRing = CR_TRIO_RING; // columns (steps) of scores between the producers and the consumer
 constexpr int kTrioBatch = 4;           // columns (steps) per wait / publication of the consumer
 constexpr int kTrioMaxWaves = 5;        // 1 consumer + up to 4 producers (the launch decides: blockDim.x / 64)
 
@@ -36,12 +55,16 @@ __host__ __device__ inline size_t trio_lds_doubles(int m) {
     return (size_t)kExpDoubles + 4 + (size_t)kTrioRing * R * kWave + (size_t)3 * m;
 }
 
-// largest column (step) = par (mod np) below `end`, plus one: what prod[par] must have reached for [.., end) to be complete
-CR_D int trio_need(int end, int par, int np) {
-    const int last = end - 1;                            // last column of the batch
-    int back = (last - par) % np;                        // (last >= 0, par < np)
-    back = back < 0 ? back + np : back;
-    return last - back + 1;                              // (<= the batch's first column: the batch holds no such column)
+template <int SLEEP>
+CR_D void trio_wait(const int* word, int need, unsigned long long& waited) {
+#ifdef CR_STAMPS
+    const unsigned long long t0 = CR_DUO_NOW();
+#endif
+    while (__builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int*>(word)) < need) __builtin_amdgcn_s_sleep(SLEEP);
+    asm volatile("" ::: "memory");       // (compiler: the scores are read behind the word)
+#ifdef CR_STAMPS
+    waited += CR_DUO_NOW() - t0;
+#endif
 }
 
 // ---- seed stage -----------------------------------------------------------------------------------------------------
@@ -64,12 +87,12 @@ CR_D void trio_seed_producer(const int p, const int np, RbfTensor<R, D>& src, co
     CR_DUO_STAMP(p + 1, 0, CR_DUO_NOW());
 #pragma unroll 1
     for (int c = p; c < m; c += np) {
-        if (c >= kTrioRing) duo_wait(words + 4, c - kTrioRing + 1, waited);          // the slot's last column has been consumed
+        if (c >= kTrioRing) trio_wait<CR_TRIO_PROD_SLEEP>(words + 4, c - kTrioRing + 1, waited);          // the slot's last column has been consumed
         double acc[R];
 #pragma unroll
         for (int q = 0; q < R; q++) acc[q] = src.dist2_of(q, src.col);
         fetch(c + np < m ? c + np : c);                  // (the next own column while the exps run)
-        double* slot = ring + (size_t)(c & (kTrioRing - 1)) * (R * kWave) + lane;
+        double* slot = ring + (size_t)((unsigned)c % (unsigned)kTrioRing) * (R * kWave) + lane;
 #pragma unroll
         for (int q = 0; q < R; q++) slot[q * kWave] = exp_tab<true>(src.neg_gamma * acc[q], tab);
         if (lane == 0) duo_publish(words + p, c + 1);
@@ -131,22 +154,31 @@ struct TrioCols {
     }
 };
 
-// wait for the batch [j0, jend) of both producers, then take its scores into registers
-// wait for the batch [j0, jend) of all producers, then take its scores into registers
+// wait for the batch [j0, jend) of all producers (`r0` = j0 mod np, kept by the caller: no division here), take its scores
+// into registers and give the slots back at once: LDS executes this wave's reads before the word's write, and a producer
+// writes a slot only behind its own read of the word
 template <int R>
-CR_D void trio_take(const double* ring, const int* words, int j0, int jend, double (&sc)[kTrioBatch][R], unsigned long long& waited) {
+CR_D void trio_take(const double* ring, int* words, int j0, int jend, int& r0, double (&sc)[kTrioBatch][R], unsigned long long& waited) {
     const int lane = threadIdx.x & (kWave - 1);
     const int np = (int)(blockDim.x >> 6) - 1;
-    for (int p = 0; p < np; p++) {
-        const int need = trio_need(jend, p, np);
-        if (need > j0) duo_wait(words + p, need, waited);
+    const int len = jend - j0;
+    for (int k = len - 1; k >= 0 && k >= len - np; k--) {        // the last column of every producer in the batch
+        int p = r0 + k;
+        while (p >= np) p -= np;
+        trio_wait<CR_TRIO_CONS_SLEEP>(words + p, j0 + k + 1, waited);
     }
+    r0 += kTrioBatch;                                            // (the next batch starts kTrioBatch columns on)
+    while (r0 >= np) r0 -= np;
+    static_assert(kTrioRing % kTrioBatch == 0, "a batch's slots are contiguous");
+    const double* slot = ring + (size_t)((unsigned)j0 % (unsigned)kTrioRing) * (R * kWave) + lane;       // (j0 is a multiple of kTrioBatch)
 #pragma unroll
     for (int k = 0; k < kTrioBatch; k++) {
-        const double* slot = ring + (size_t)((j0 + k) & (kTrioRing - 1)) * (R * kWave) + lane;
 #pragma unroll
-        for (int q = 0; q < R; q++) sc[k][q] = slot[q * kWave];       // (columns past jend: stale slots, never used)
+        for (int q = 0; q < R; q++) sc[k][q] = slot[(k * R + q) * kWave];            // (columns past jend: stale slots, never used)
     }
+#if CR_TRIO_EARLY
+    if (lane == 0) duo_publish(words + 4, jend);
+#endif
 }
 
 template <int R>
@@ -156,12 +188,14 @@ CR_D void trio_seed_consumer(const int n, const int m, const double* ring, int* 
     TrioCols<R> st;
     st.reset();
     unsigned long long waited = 0;
+    const int nb = kTrioBatch;
+    int r0 = 0;
     CR_DUO_STAMP(0, 0, CR_DUO_NOW());
 #pragma unroll 1
-    for (int j0 = 0; j0 < m; j0 += kTrioBatch) {
-        const int jend = j0 + kTrioBatch < m ? j0 + kTrioBatch : m;
+    for (int j0 = 0; j0 < m; j0 += nb) {
+        const int jend = j0 + nb < m ? j0 + nb : m;
         double sc[kTrioBatch][R];
-        trio_take<R>(ring, words, j0, jend, sc, waited);
+        trio_take<R>(ring, words, j0, jend, r0, sc, waited);
 #pragma unroll
         for (int k = 0; k < kTrioBatch; k++) {
             const int j = j0 + k;
@@ -177,7 +211,9 @@ CR_D void trio_seed_consumer(const int n, const int m, const double* ring, int* 
                 }
             }
         }
+#if !CR_TRIO_EARLY
         if (lane == 0) duo_publish(words + 4, jend);
+#endif
     }
     (void)TB;
     CR_DUO_STAMP(0, 1, CR_DUO_NOW());
@@ -208,11 +244,11 @@ CR_D void trio_align_producer(const int p, const int np, RbfCoords<R>& src, cons
     CR_DUO_STAMP(p + 1, 4, CR_DUO_NOW());
 #pragma unroll 1
     for (int t = p; t < T; t += np) {
-        if (t >= kTrioRing) duo_wait(words + 4, t - kTrioRing + 1, waited);
+        if (t >= kTrioRing) trio_wait<CR_TRIO_PROD_SLEEP>(words + 4, t - kTrioRing + 1, waited);
         const int c = t - lane;
         if ((unsigned)c < (unsigned)m) {
             src.fetch_resident(cols, m, c);
-            double* slot = ring + (size_t)(t & (kTrioRing - 1)) * (R * kWave) + lane;
+            double* slot = ring + (size_t)((unsigned)t % (unsigned)kTrioRing) * (R * kWave) + lane;
 #pragma unroll
             for (int q = 0; q < R; q++) slot[q * kWave] = src.score(q, tab);
         }
@@ -237,12 +273,14 @@ CR_D void trio_align_consumer(const int n, const int m, const int T, const Sweep
 #pragma unroll
     for (int q = 0; q < R; q++) st.swbits[q] = st.dtbits[q] = 0;
     unsigned long long waited = 0;
+    const int nb = kTrioBatch;
+    int r0 = 0;
     CR_DUO_STAMP(0, 4, CR_DUO_NOW());
 #pragma unroll 1
-    for (int t0 = 0; t0 < T; t0 += kTrioBatch) {
-        const int tend = t0 + kTrioBatch < T ? t0 + kTrioBatch : T;
+    for (int t0 = 0; t0 < T; t0 += nb) {
+        const int tend = t0 + nb < T ? t0 + nb : T;
         double sc[kTrioBatch][R];
-        trio_take<R>(ring, words, t0, tend, sc, waited);
+        trio_take<R>(ring, words, t0, tend, r0, sc, waited);
 #pragma unroll
         for (int k = 0; k < kTrioBatch; k++) {
             const int t = t0 + k;
@@ -267,7 +305,9 @@ CR_D void trio_align_consumer(const int n, const int m, const int T, const Sweep
                 }
             }
         }
+#if !CR_TRIO_EARLY
         if (lane == 0) duo_publish(words + 4, tend);
+#endif
     }
     CR_DUO_STAMP(0, 5, CR_DUO_NOW());
     CR_DUO_STAMP(0, 6, waited);
@@ -306,9 +346,9 @@ CR_D void trio_score_producer(const int p, const int np, RbfCoords<R>& src, cons
     unsigned long long waited = 0;
 #pragma unroll 1
     for (int c = p; c < m; c += np) {
-        if (c >= kTrioRing) duo_wait(words + 4, c - kTrioRing + 1, waited);
+        if (c >= kTrioRing) trio_wait<CR_TRIO_PROD_SLEEP>(words + 4, c - kTrioRing + 1, waited);
         src.fetch_resident(cols, m, c);                  // wave-uniform address: an LDS broadcast
-        double* slot = ring + (size_t)(c & (kTrioRing - 1)) * (R * kWave) + lane;
+        double* slot = ring + (size_t)((unsigned)c % (unsigned)kTrioRing) * (R * kWave) + lane;
 #pragma unroll
         for (int q = 0; q < R; q++) slot[q * kWave] = src.score(q, tab);
         if (lane == 0) duo_publish(words + p, c + 1);
@@ -321,15 +361,19 @@ CR_D double trio_score_consumer(const int n, const int m, const double* ring, in
     TrioCols<R> st;
     st.reset();
     unsigned long long waited = 0;
+    const int nb = kTrioBatch;
+    int r0 = 0;
 #pragma unroll 1
-    for (int j0 = 0; j0 < m; j0 += kTrioBatch) {
-        const int jend = j0 + kTrioBatch < m ? j0 + kTrioBatch : m;
+    for (int j0 = 0; j0 < m; j0 += nb) {
+        const int jend = j0 + nb < m ? j0 + nb : m;
         double sc[kTrioBatch][R];
-        trio_take<R>(ring, words, j0, jend, sc, waited);
+        trio_take<R>(ring, words, j0, jend, r0, sc, waited);
 #pragma unroll
         for (int k = 0; k < kTrioBatch; k++)
             if (j0 + k < jend) st.advance_score(sc[k]);
+#if !CR_TRIO_EARLY
         if (lane == 0) duo_publish(words + 4, jend);
+#endif
     }
     // H[n][m]: row n - 1 lives in lane (n - 1) / R, slot (n - 1) % R (np.max of the matrix, by monotonicity)
     const int qo = (n - 1) % R;
@@ -368,7 +412,7 @@ __global__ __launch_bounds__(kTrioMaxWaves* kWave, 2) void k_pair_trio(const Pai
     sm.score = 0.0;
     sm.i = sm.j = 0;
     if (w == 0) {
-        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(CR_TRIO_PRIO_CONS);
         trio_seed_consumer<R>(pd.n, pd.m, ring, words, dirs + pd.dirs_off, sm);
         drain_stores();
         CR_STAMP(1);
@@ -381,7 +425,7 @@ __global__ __launch_bounds__(kTrioMaxWaves* kWave, 2) void k_pair_trio(const Pai
         }
         CR_STAMP(3);
     } else {
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(CR_TRIO_PRIO_PROD);
         RbfTensor<R, D> src;
         src.rows_g = tensors + pd.off_i * d;
         src.cols_g = tensors + pd.off_j * d;

@@ -90,15 +90,18 @@ def test_midsize_ragged_lists_vs_oracle(ctx, oracle, dim, seed):
     run_all_ways(ctx, oracle, coords, tensors, offsets, pairs, "duo", sw_gaps=(0.0, 0.05) if dim == 10 else (0.0,))
 
 
-@pytest.mark.parametrize("dim,seed,waves", [(10, 9111, None), (4, 9112, "5"), (8, 9113, "2"), (7, 9114, "4")])
-def test_midsize_lists_one_strip_by_function(ctx, oracle, monkeypatch, dim, seed, waves):
-    """k_pair_trio (cr_trio.h): lists of more than 256 pairs whose longest structure has 257 .. 320 rows -- one wave of
-    recurrences and one to four waves of scores per pair (the library's choice, or CARETTA_TRIO_WAVES).  Ragged lengths 1 .. 320
-    (fewer rows than lanes, fewer columns than a batch or than the ring), both orientations, widths that are padded or not;
-    with a Smith-Waterman gap the same layout runs the single-wave kernels."""
+@pytest.mark.parametrize("dim,seed,waves,longest", [(10, 9111, None, 320), (4, 9112, "5", 320), (8, 9113, "2", 320), (7, 9114, "4", 320),
+                                                    (10, 9115, None, 256), (8, 9116, "3", 255), (10, 9117, None, 192), (4, 9118, "5", 150),
+                                                    (10, 9119, None, 128), (7, 9120, "2", 100)])
+def test_midsize_lists_one_strip_by_function(ctx, oracle, monkeypatch, dim, seed, waves, longest):
+    """k_pair_trio (cr_trio.h): lists of more than 256 pairs whose longest structure has 65 .. 320 rows (one strip of two to
+    five rows per lane) -- one wave of recurrences and one to four waves of scores per pair (the library's choice, or
+    CARETTA_TRIO_WAVES).  Ragged lengths 1 .. 320 (fewer rows than lanes, fewer columns than a batch or than the ring), both
+    orientations, widths that are padded or not; with a Smith-Waterman gap the same layout runs the single-wave kernels."""
     from caretta_amd import engine
     fam = synthetic.make_family(15, 320, dim=dim, seed=seed, clades=3)
-    cuts = [320, 300, 257, 319, 1, 193, 192, 64, 65, 3, 288, 129, 7, 256, 9]
+    cuts = [min(c, longest) for c in [320, 300, 257, 319, 1, 193, 192, 64, 65, 3, 288, 129, 7, 256, 9]]
+    cuts[0] = longest
     for s, cut in zip(fam, cuts):
         s.coordinates, s.tensors = s.coordinates[:cut].copy(), s.tensors[:cut].copy()
     coords, tensors, offsets = synthetic.pack(fam)
@@ -123,10 +126,12 @@ def test_midsize_three_and_more_strips(ctx, oracle):
 
 
 @pytest.mark.parametrize("npairs,rows,expect", [
-    (256, 193, ("wide", "staged")), (257, 193, ("single",)), (257, 256, ("single",)), (257, 257, ("trio",)), (256, 257, ("wide", "staged")),
-    (700, 320, ("trio",)), (701, 320, ("trio",)), (257, 321, ("duo",)), (1300, 300, ("trio",)), (1301, 300, ("single",)), (1024, 360, ("duo",)),
+    (256, 193, ("trio",)), (257, 193, ("trio",)), (257, 256, ("trio",)), (257, 257, ("trio",)), (256, 257, ("trio",)),
+    (257, 64, ("single", "staged")), (257, 65, ("trio",)), (300, 128, ("trio",)), (300, 129, ("trio",)),
+    (160, 300, ("wide", "staged")), (161, 300, ("trio",)), (110, 250, ("wide", "staged")), (111, 250, ("trio",)), (64, 150, ("single", "staged")), (65, 150, ("trio",)),
+    (700, 320, ("trio",)), (701, 320, ("trio",)), (257, 321, ("duo",)), (256, 321, ("wide", "staged")), (1300, 300, ("trio",)), (1301, 300, ("single",)), (1024, 360, ("duo",)),
     (1025, 360, ("single",)),
-    (256, 192, ("single", "staged")), (204, 300, ("staged",)), (205, 300, ("wide",))])
+    (256, 64, ("single", "staged")), (170, 330, ("staged",)), (171, 330, ("wide",))])
 def test_path_selection_boundaries(ctx, oracle, npairs, rows, expect):
     """The pair-count and row-count limits of cr_batch_set_pairs at their boundary values: which kernel family runs on either
     side, and that both sides give the oracle's results (a sample of the pairs is compared: the lists differ by one pair)."""

@@ -18,7 +18,7 @@ import numpy as np  # noqa: E402
 
 from caretta_amd import engine, synthetic  # noqa: E402
 
-KEYS = ("CARETTA_TRIO", "CARETTA_TRIO_PAIRS", "CARETTA_TRIO_WAVES", "CARETTA_MID_ANY", "CARETTA_MID_PLAN", "CARETTA_MID_LDS_KB", "CARETTA_MID_PAIRS", "CARETTA_MID", "CARETTA_WIDE", "CARETTA_TEAM_PAIRS",
+KEYS = ("CARETTA_TRIO", "CARETTA_TRIO_PAIRS", "CARETTA_TRIO_FROM", "CARETTA_TRIO_WAVES", "CARETTA_MID_ANY", "CARETTA_MID_PLAN", "CARETTA_MID_LDS_KB", "CARETTA_MID_PAIRS", "CARETTA_MID", "CARETTA_WIDE", "CARETTA_TEAM_PAIRS",
         "CARETTA_STAGED", "CARETTA_STAGED_WAVES", "CARETTA_NO_TEAM", "CARETTA_NO_WIDE")
 FORCE = {"CARETTA_MID_PAIRS": "100000", "CARETTA_TRIO": "0"}
 MODES = [("single wave", {"CARETTA_NO_TEAM": "1", "CARETTA_MID": "0", "CARETTA_TRIO": "0"}),
@@ -32,6 +32,10 @@ MODES = [("single wave", {"CARETTA_NO_TEAM": "1", "CARETTA_MID": "0", "CARETTA_T
          ("mid 2,1,1 (4 waves)", dict(FORCE, CARETTA_MID_PLAN="2,1,1")),
          ("mid 1,1,0 (5 waves)", dict(FORCE, CARETTA_MID_PLAN="1,1,0")),
          ("mid 3,2,1, 70 KB (2 pairs per CU)", dict(FORCE, CARETTA_MID_PLAN="3,2,1", CARETTA_MID_LDS_KB="70"))]
+if os.environ.get("C3_TRIO"):           # only the split by function, one to four score waves, against one wave per pair and the library's choice
+    MODES = MODES[:2] + [(f"trio 1 + {w - 1} waves", {"CARETTA_TRIO_PAIRS": "100000", "CARETTA_TRIO_WAVES": str(w), "CARETTA_STAGED": "0"}) for w in (2, 3, 4, 5)]
+if os.environ.get("C3_FEW"):            # at most 256 pairs: the one-pair-per-CU layouts and staged scores against the split by function forced onto the list
+    MODES = MODES[:2] + [("no trio", {"CARETTA_TRIO": "0"})] + [(f"trio 1 + {w - 1} waves", {"CARETTA_TRIO_PAIRS": "100000", "CARETTA_TEAM_PAIRS": "0", "CARETTA_TRIO_FROM": "0", "CARETTA_TRIO_WAVES": str(w), "CARETTA_STAGED": "0"}) for w in (3, 4, 5)]
 if os.environ.get("C3_LIMIT"):          # where the layout stops paying: the library's plan against one wave per pair
     MODES = MODES[:1] + [("mid 3,2,1", dict(FORCE, CARETTA_MID_PLAN="3,2,1")), ("trio 1 + 2 waves", {"CARETTA_TRIO_PAIRS": "100000", "CARETTA_TRIO_WAVES": "3"}),
                          ("trio 1 + 3 waves", {"CARETTA_TRIO_PAIRS": "100000", "CARETTA_TRIO_WAVES": "4"})]
@@ -73,6 +77,7 @@ def main():
             os.environ.update(env)
             try:
                 b = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
+                lay = b.layout()
                 full = timed(b, ctx, prm, 20, False)
                 res, aln = b.fetch()
                 mat = timed(b, ctx, prm, 20, True)
@@ -87,7 +92,7 @@ def main():
             same = ""
             if ref is not None:
                 same = "identical" if (cur[0] == ref[0] and np.array_equal(cur[1], ref[1]) and np.array_equal(cur[2], ref[2])) else "DIFFERENT"
-            print(f"stride {stride} {len(pairs):5d} pairs  {name:22s}: full {full:7.3f} ms   matrix only {mat:7.3f} ms   {same}", flush=True)
+            print(f"stride {stride} {len(pairs):5d} pairs  {name:22s}: full {full:7.3f} ms   matrix only {mat:7.3f} ms   {same}  {lay[0]} {lay[1]}", flush=True)
     for k in KEYS:
         os.environ.pop(k, None)
 

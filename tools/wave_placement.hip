@@ -33,7 +33,7 @@ int main(int argc, char** argv) {
     hipDeviceSynchronize();
     std::vector<unsigned> h(2 * waves);
     hipMemcpy(h.data(), d, sizeof(unsigned) * 2 * waves, hipMemcpyDeviceToHost);
-    std::map<unsigned, int> per_simd, per_cu;
+    std::map<unsigned, int> per_simd, per_cu, first_per_simd;
     int same_simd = 0;
     for (int w = 0; w < waves; w++) {
         const unsigned hw = h[2 * w], xcc = h[2 * w + 1] & 0xf;
@@ -41,6 +41,7 @@ int main(int argc, char** argv) {
         const unsigned cukey = (xcc << 12) | (se << 8) | (sh << 4) | cu;
         per_simd[(cukey << 2) | simd]++;
         per_cu[cukey]++;
+        first_per_simd[(cukey << 2) | simd] += (w % wpb) == 0 ? 1 : 0;
         if (wpb > 1 && (w % wpb) == 1 && (((h[2 * (w - 1)] >> 4) & 3) == simd)) same_simd++;
     }
     std::map<int, int> hist_simd, hist_cu;
@@ -50,6 +51,12 @@ int main(int argc, char** argv) {
     for (auto& kv : hist_simd) printf("  %d waves: %d SIMDs;", kv.first, kv.second);
     printf("\n  waves per CU:");
     for (auto& kv : hist_cu) printf("  %d waves: %d CUs;", kv.first, kv.second);
+    if (wpb > 1) {                                       // kernels whose waves have different jobs (cr_trio.h): how many FIRST waves does a SIMD hold?
+        std::map<int, int> hist_first;
+        for (auto& kv : first_per_simd) hist_first[kv.second]++;
+        printf("\n  first waves of a workgroup per SIMD:");
+        for (auto& kv : hist_first) printf("  %d: %d SIMDs;", kv.first, kv.second);
+    }
     if (wpb > 1) printf("\n  workgroups whose waves 0 and 1 share a SIMD: %d of %d", same_simd, blocks);
     printf("\n  first waves (hw_id): ");
     for (int w = 0; w < 8 && w < waves; w++) printf("%08x/%x ", h[2 * w], h[2 * w + 1] & 0xf);
