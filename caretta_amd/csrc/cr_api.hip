@@ -27,7 +27,6 @@
 #include "cr_ilp_instances.h"
 #include "cr_duo.h"
 #include "cr_trio.h"
-#include "cr_fed.h"
 #include "cr_duo_instances.h"
 #include "cr_flexible.h"
 
@@ -57,9 +56,6 @@ CR_DUO_INSTANCES(CR_X)
 #undef CR_X
 #define CR_X(R, D, SC) extern template CR_PAIR_TRIO_SIGNATURE(R, D, SC)
 CR_TRIO_INSTANCES(CR_X)
-#undef CR_X
-#define CR_X(RA, RB, D) extern template CR_PAIR_FED_SIGNATURE(RA, RB, D)
-CR_FED_INSTANCES(CR_X)
 #undef CR_X
 #endif
 
@@ -754,66 +750,6 @@ int launch_pair_duo(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm
         case 32: return launch_pair_duo_r<3, 2>(b, ck, prm, scores);
         case 33: return launch_pair_duo_r<3, 3>(b, ck, prm, scores);
         default: return fail(CR_ERR_STATE, "no k_pair_duo instance for this strip plan");
-    }
-}
-
-// ---- k_pair_fed (cr_fed.h): the wide layout with a score wave per strip; gap 0, full pipeline, at most eight strips ----------
-template <int RA>
-size_t fed_lds_bytes(int waves, int ring, int m_max, int seed_entries, int align_entries) {
-    return sizeof(double) * std::max(std::max(cr::fed_seed_lds_doubles<RA>(waves, ring), cr::fed_align_lds_doubles<RA>(waves, ring, m_max)),
-                                     (size_t)cr::kExpDoubles + cr::trace_team_lds_doubles(std::max(seed_entries, align_entries)));
-}
-constexpr size_t kFedLdsLimit = 160 * 1024 - 512;      // (the kernel's static shared variables)
-
-// the score ring (columns / steps per strip) that fits the LDS: 8, else 4, else 0 (no k_pair_fed for this chunk)
-template <int RA>
-int fed_ring(int waves, const cr_batch::Chunk& ck) {
-    const int seed_entries = std::min(ck.n_max, ck.m_max), align_entries = ck.max_aln;
-    int first = 8;
-    if (const char* env = std::getenv("CARETTA_FED_RING")) first = std::atoi(env) >= 8 ? 8 : 4;   // calibration
-    for (int ring = first; ring >= 4; ring /= 2)
-        if (fed_lds_bytes<RA>(waves, ring, ck.m_max, seed_entries, align_entries) <= kFedLdsLimit) return ring;
-    return 0;
-}
-
-template <int RA, int RB, int D>
-int launch_pair_fed_t(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
-    const int seed_entries = std::min(ck.n_max, ck.m_max), align_entries = ck.max_aln;
-    const int waves = plan_of(b).strips(ck.n_max);
-    const int ring = fed_ring<RA>(waves, ck);
-    if (!ring) return fail(CR_ERR_STATE, "k_pair_fed: the score rings do not fit the LDS");
-    const size_t lds = fed_lds_bytes<RA>(waves, ring, ck.m_max, seed_entries, align_entries);
-    int rc = allow_lds(cr::k_pair_fed<RA, RB, D>, lds);
-    if (rc) return rc;
-    CR_LAUNCH((cr::k_pair_fed<RA, RB, D>), dim3((unsigned)ck.count), dim3(2 * waves * cr::kWave), lds,
-              b->launch_stream ? b->launch_stream : b->ctx->stream, b->pairs.p + ck.first, b->tensors.p, (int)b->d, b->coords.p, prm.gamma_tensor,
-              prm.gamma_coords, prm.gap_open, prm.gap_extend, seed_entries, align_entries, b->wide_na, ring, b->dirs.p, b->bits.p, b->xf.p + ck.first,
-              b->seed_score.p + ck.first, b->aln.p, b->res.p + ck.first, host_out_for(b, ck));
-    CR_HIP(hipGetLastError());
-    return CR_OK;
-}
-
-// does this chunk of a wide / mid-size batch run k_pair_fed?  (CARETTA_FED: "0" never, "1" wherever an instance exists)
-bool fed_applies(const cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, bool scores_only) {
-    const char* env = std::getenv("CARETTA_FED");
-    if (!b->wide_sync || prm.sw_gap != 0.0 || scores_only || b->d_pad != 10 || (env && env[0] == '0')) return false;
-    if (!(env && env[0] == '1')) return false;
-    const int key = b->r_seed * 10 + b->r_b;
-    const int waves = plan_of(b).strips(ck.n_max);
-    if (waves > cr::kFedMaxStrips) return false;
-    switch (key) {
-        case 22: return fed_ring<2>(waves, ck) != 0;
-        case 32: case 33: return fed_ring<3>(waves, ck) != 0;
-        default: return false;
-    }
-}
-
-int launch_pair_fed(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
-    switch (b->r_seed * 10 + b->r_b) {
-        case 22: return launch_pair_fed_t<2, 2, 10>(b, ck, prm);
-        case 32: return launch_pair_fed_t<3, 2, 10>(b, ck, prm);
-        case 33: return launch_pair_fed_t<3, 3, 10>(b, ck, prm);
-        default: return fail(CR_ERR_STATE, "no k_pair_fed instance for this strip plan");
     }
 }
 
@@ -1642,9 +1578,7 @@ static int run_batch(cr_batch* b, const cr_params* params, double* d_sw_out, boo
         if (b->wide_sync) {
             // the wide layout: both stages of a pair in ONE launch (k_pair_wide) -- the stage split of the events is
             // (everything, 0)
-            rc = fed_applies(b, ck, prm, scores_only) ? launch_pair_fed(b, ck, prm)
-                 : b->duo                                ? launch_pair_duo(b, ck, prm, scores_only)
-                                                         : launch_pair_wide(b, ck, prm, scores_only && prm.sw_gap == 0.0);
+            rc = b->duo ? launch_pair_duo(b, ck, prm, scores_only) : launch_pair_wide(b, ck, prm, scores_only && prm.sw_gap == 0.0);
             if (!rc && prof) {
                 (void)hipEventRecord((*evl)[evi++], st);
                 (void)hipEventRecord((*evl)[evi++], st);

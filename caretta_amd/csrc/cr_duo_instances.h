@@ -19,11 +19,3 @@
     __global__ void cr::k_pair_trio<R, D, SC>(const cr::PairDesc*, const double*, int, const double*, double, double, double, \
                                               double, int, int, uint32_t*, uint32_t*, cr::Transform*, double*, int32_t*,      \
                                               cr::PairResult*, const cr::HostOut);
-
-// k_pair_fed (cr_fed.h): the wide layout with a score wave per strip; (RA, RB) as above, tensor widths padded to 4, 8, 10
-#define CR_FED_D(X, RA, RB) X(RA, RB, 10)
-#define CR_FED_INSTANCES(X) CR_FED_D(X, 2, 2) CR_FED_D(X, 3, 2) CR_FED_D(X, 3, 3)
-#define CR_PAIR_FED_SIGNATURE(RA, RB, D)                                                                                      \
-    __global__ void cr::k_pair_fed<RA, RB, D>(const cr::PairDesc*, const double*, int, const double*, double, double, double,   \
-                                              double, int, int, int, int, uint32_t*, uint32_t*, cr::Transform*, double*, int32_t*, \
-                                              cr::PairResult*, const cr::HostOut);

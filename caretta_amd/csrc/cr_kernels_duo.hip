@@ -7,7 +7,6 @@
 #define CR_KERNELS_TEMPLATES_ONLY
 #include "cr_duo.h"
 #include "cr_trio.h"
-#include "cr_fed.h"
 #include "cr_duo_instances.h"
 
 #define CR_X(RA, RB, D, SC) template CR_PAIR_DUO_SIGNATURE(RA, RB, D, SC)
@@ -15,7 +14,4 @@ CR_DUO_INSTANCES(CR_X)
 #undef CR_X
 #define CR_X(R, D, SC) template CR_PAIR_TRIO_SIGNATURE(R, D, SC)
 CR_TRIO_INSTANCES(CR_X)
-#undef CR_X
-#define CR_X(RA, RB, D) template CR_PAIR_FED_SIGNATURE(RA, RB, D)
-CR_FED_INSTANCES(CR_X)
 #undef CR_X
