@@ -21,8 +21,9 @@ from oracle import pyoracle  # noqa: E402
 def random_family(rng):
     kind = rng.integers(0, 5)
     dim = int(rng.choice([1, 2, 3, 4, 5, 8, 10, 13, 16, 10, 10, 17, 24, 29, 32]))
-    if kind == 4:      # a MID-SIZE list: 257 .. 600 rows, more than 256 pairs with both orientations (cr_duo.h: two to five waves per pair)
-        num, length = int(rng.integers(12, 21)), int(rng.choice([257, 300, 320, 321, 384, 450, 600]))
+    if kind == 4:      # a MID-SIZE list: 70 .. 600 rows, 36 .. 380 pairs (cr_trio.h: one strip of two to five rows per lane split by
+        # function, from 65 / 111 / 161 pairs on; cr_duo.h: two to five waves per pair beyond 320 rows and 256 pairs)
+        num, length = int(rng.integers(9, 21)), int(rng.choice([70, 100, 128, 129, 150, 192, 193, 220, 256, 257, 300, 320, 321, 384, 450, 600]))
         fam = synthetic.make_family(num, length, dim=min(dim, 16), seed=int(rng.integers(1 << 30)), ragged=bool(rng.integers(0, 2)), clades=int(rng.integers(1, 4)))
         return fam, min(dim, 16)
     if kind == 0:      # related structures, ragged

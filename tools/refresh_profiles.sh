@@ -33,6 +33,8 @@ for t in valu_latency dpp_latency wave_placement; do /opt/rocm/bin/hipcc --offlo
 python tools/c3_share.py 16 8 4 > $O/c3_share.txt 2>&1
 C3_LIMIT=1 python tools/c3_share.py 14 12 10 9 8 7 6 5 > $O/c3_share_limit.txt 2>&1
 (C3_LIMIT=1 python tools/c3_share.py --family=128,360,14 8 16; C3_LIMIT=1 python tools/c3_share.py --family=128,450,11 8 16; C3_LIMIT=1 python tools/c3_share.py --family=128,600,12 8 16) > $O/c3_share_lengths.txt 2>&1
+(export C3_TRIO=1; for f in 32,150 46,150 32,220 46,220 32,100 40,100 28,128 56,150; do python tools/c3_share.py --family=$f,20241 1; done) > $O/trio_sizes.txt 2>&1
+(export C3_FEW=1; for f in 12,300 16,300 20,300 23,300 12,150 16,150 23,150 16,220 23,220; do python tools/c3_share.py --family=$f,20241 1; done) > $O/trio_few.txt 2>&1
 python tools/c5_share_layouts.py > $O/c5_share_layouts.txt 2>&1
 STAMPS_DETAIL=1 python tools/stamps.py run c3share > $O/stamps_c3share.txt 2>&1
 STAMPS_DETAIL=1 CARETTA_TRIO=0 python tools/stamps.py run c3share > $O/stamps_c3share_duo.txt 2>&1
