@@ -1,21 +1,24 @@
-// Mid-size pair lists of at most 320 rows: THREE waves per pair with different jobs -- one wave runs the recurrences, two form
-// the scores (k_pair_trio).
+// Pair lists whose longest structure has 65 .. 320 rows (ONE strip of R = 2 .. 5 rows per lane): three or four waves per pair
+// with different jobs -- one wave runs the recurrences, two or three form the scores (k_pair_trio<R, D, SCORES>).
 //
 // One GPU's share of the headline configuration on 8 GPUs is 1 016 pairs of 300 x 300 on 1 024 SIMDs.  Splitting a pair by
 // ROWS (cr_duo.h: two waves of 3 and 2 rows per lane) leaves every wave a chain of dependent instructions per step -- score,
 // then recurrence, then the cross-lane hand-off -- and a wave bound by the latency of its chain loses time to every issue
 // slot its neighbour on the SIMD takes (0.60 ms where the instruction count alone would allow 0.40).  Here
 // the split is by FUNCTION: 50 of the 66 instructions of a seed cell and 23 of the 50 of an alignment cell form the score
-// exp(-gamma |a - b|^2), which depends on nothing the recurrence produces.  Waves 1 and 2 (the producers) form the scores of
-// alternate columns (steps) for all 5 x 64 rows and park them in an LDS ring; they have no dependency from one column to
+// exp(-gamma |a - b|^2), which depends on nothing the recurrence produces.  Waves 1 .. (the producers) form the scores of
+// alternate columns (steps) for all R x 64 rows and park them in an LDS ring; they have no dependency from one column to
 // the next, so they fill whatever issue slots the SIMD has.  Wave 0 (the consumer) reads the scores and runs dp_column /
-// the column-sweep recurrence of the single-wave kernels with all five rows per lane -- a single strip: no hand-off between
+// the column-sweep recurrence of the single-wave kernels with all R rows per lane -- a single strip: no hand-off between
 // strips, no lag, the decision words of k_seed / k_align in their layout, the same walkers and ordered sums behind it.
-// The consumer asks the SIMD's arbiter for priority (s_setprio): the pair is as fast as its recurrence.
+// The consumer asks the SIMD's arbiter for priority (s_setprio): taking it away costs 10 %.
+// The layout's time does not depend on the pair count while the chip is not full, so cr_batch_set_pairs hands it lists from
+// 65 (R <= 3) / 111 (R = 4) / 161 (R = 5) pairs on, up to 1 300 (BASELINE config 2, 496 pairs of 150, 0.23 -> 0.17 ms).
 //
 // Ring: kTrioRing columns (steps) of R x 64 doubles, slot = column (step) mod kTrioRing.  Progress words in LDS (LDS executes
-// one wave's instructions in order): prod[p] = columns producer p has finished + ... (see trio_*), cons = columns the
-// consumer has finished; the consumer waits once per kTrioBatch columns, a producer before it reuses a slot.
+// one wave's instructions in order): prod[p] = columns (steps) producer p has finished, cons = columns (steps) the consumer
+// has TAKEN into registers -- it takes kTrioBatch at a time and gives their slots back at once --; a producer waits before it
+// reuses a slot.
 // Every value bit-identical to the single-wave kernels: the providers' own score code, dp_column and the column-sweep
 // recurrence on the same values in the same order.
 //
@@ -26,7 +29,7 @@
 
 namespace cr {
 
-// (calibration builds override these: tools/trio_variants.sh)
+// (calibration builds override these: tools/trio_variants.sh builds, tools/trio_compare.sh times them beside the tree's library)
 #ifndef CR_TRIO_RING
 #define CR_TRIO_RING 8
 #endif
