@@ -41,6 +41,7 @@ def main():
         coords, tensors, offsets = synthetic.pack(fam)
         pairs = engine.all_pairs(num)[::stride]
         out = {}
+        os.environ["CARETTA_TRIO"] = "0"             # (the split by function of cr_trio.h would take the lists of 65 .. 320 rows in both modes)
         for mode in ("fused", "staged"):
             os.environ.pop("CARETTA_STAGED", None)
             os.environ.pop("CARETTA_STAGED_WAVES", None)
