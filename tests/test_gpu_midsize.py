@@ -112,6 +112,28 @@ def test_midsize_lists_one_strip_by_function(ctx, oracle, monkeypatch, dim, seed
     run_all_ways(ctx, oracle, coords, tensors, offsets, pairs, "trio", sw_gaps=(0.0, 0.05) if dim == 10 else (0.0,))
 
 
+def test_few_pairs_by_function_and_again_with_a_gap(ctx, oracle):
+    """Lists the split by function takes from the one-pair-per-CU layouts (more than 160 / 110 / 64 pairs, at most 256): 182 pairs of
+    up to 300 rows run on k_pair_trio; with a Smith-Waterman gap the SAME batch object is laid out again for the layouts that
+    have a skewed seed sweep (cr_batch_run), and goes on giving the oracle's results -- also back at gap 0."""
+    from caretta_amd import engine
+    from oracle.pyoracle import default_params
+    fam = synthetic.make_family(14, 300, seed=9301, ragged=True, clades=2)
+    coords, tensors, offsets = synthetic.pack(fam)
+    fwd = engine.all_pairs(14)
+    pairs = np.vstack([fwd, fwd[:, ::-1]])                       # 182 pairs
+    batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
+    assert layout_of(batch)[0] == "trio", layout_of(batch)
+    for gap in (0.0, 0.05, 0.0):
+        ref, ref_aln = oracle.pairwise_batch(coords, tensors, offsets, pairs, params=default_params(sw_gap=gap), nthreads=8)
+        batch.run(engine.make_params(sw_gap=gap))
+        res, aln = batch.fetch()
+        assert_bit_identical(res, aln, ref, ref_aln)
+        if gap != 0.0:
+            assert layout_of(batch)[0] != "trio", layout_of(batch)
+    batch.close()
+
+
 def test_midsize_three_and_more_strips(ctx, oracle):
     """321 .. 600 rows: three to five waves per pair (3 rows per lane in strip 0, 2 in the others), ragged."""
     from caretta_amd import engine
