@@ -65,6 +65,8 @@ SIGNATURES = {
     "cr_batch_stage_ms": [_vp, C.POINTER(C.c_float * CR_NUM_STAGES), C.POINTER(C.c_int)],
     "cr_batch_work": [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "cr_batch_layout": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "cr_batch_part_layout": [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64)],
+    "cr_config_reload": [],
     "cr_batch_destroy": [_vp],
     "cr_multi_create": [_vp, _i32, _pp],
     "cr_multi_device_count": [_vp, C.POINTER(C.c_int)],

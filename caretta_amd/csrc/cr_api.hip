@@ -23,6 +23,7 @@
 #include <string>
 #include <vector>
 
+#include "cr_config.h"
 #include "cr_kernels.h"
 #include "cr_ilp_instances.h"
 #include "cr_duo.h"
@@ -54,6 +55,9 @@ CR_ILP_PAIR_WIDE_INSTANCES(CR_X)
 #define CR_X(RA, RB, D, SC) extern template CR_PAIR_DUO_SIGNATURE(RA, RB, D, SC)
 CR_DUO_INSTANCES(CR_X)
 #undef CR_X
+#define CR_X(RA, RB, D, SC) extern template CR_PAIR_DUO_TEAM_SIGNATURE(RA, RB, D, SC)
+CR_DUO_TEAM_INSTANCES(CR_X)
+#undef CR_X
 #define CR_X(R, D, SC) extern template CR_PAIR_TRIO_SIGNATURE(R, D, SC)
 CR_TRIO_INSTANCES(CR_X)
 #undef CR_X
@@ -62,6 +66,8 @@ CR_TRIO_INSTANCES(CR_X)
 namespace {
 
 thread_local std::string g_err;
+// calibration switches: read from the environment when the library is loaded, again only by cr_config_reload()
+crcfg::Calibration g_cfg = crcfg::Calibration::from_env();
 // Work may be in flight on the device since the last device-wide wait of this thread (set by every API entry and every
 // kernel launch; DevBuf::release waits once and clears it, instead of once per buffer).
 thread_local bool g_dirty = true;
@@ -104,8 +110,7 @@ struct BlockCache {
     size_t cap = 0;                                       // 0: not determined yet (first give() on the device)
     size_t limit() {                                      // called with `mu` held and the device current
         if (cap) return cap;
-        const char* env = std::getenv("CARETTA_CACHE_MB");
-        const long long mb = env ? std::atoll(env) : 0;
+        const long long mb = g_cfg.cache_mb;
         if (mb > 0) return cap = (size_t)mb << 20;
         size_t free_b = 0, total_b = 0;
         cap = (size_t)24 << 30;
@@ -120,10 +125,7 @@ struct BlockCache {
         const size_t q = c / 8;
         return c + (bytes - c + q - 1) / q * q;
     }
-    static bool enabled() {
-        static const bool on = std::getenv("CARETTA_NO_CACHE") == nullptr;
-        return on;
-    }
+    static bool enabled() { return !g_cfg.no_cache; }
     void* take(size_t cls) {
         std::lock_guard<std::mutex> lock(mu);
         auto it = bins.find(cls);
@@ -161,12 +163,19 @@ struct DevBuf {
     size_t n = 0;
     size_t cls = 0;      // bytes of the underlying block (0: not from the cache)
     int dev = 0;
+    bool borrowed = false;   // another DevBuf owns the block (the size classes of a ragged pair list share their parent's structures)
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { release(); }
+    void borrow(const DevBuf& o) {
+        release();
+        p = o.p;
+        n = o.n;
+        borrowed = true;
+    }
     void release() {
-        if (p) {
+        if (p && !borrowed) {
             bool kept = false;
             if (cls) {
                 int cur = 0;
@@ -184,6 +193,7 @@ struct DevBuf {
         p = nullptr;
         n = 0;
         cls = 0;
+        borrowed = false;
     }
     hipError_t ensure(size_t count) {
         if (count <= n && p) return hipSuccess;
@@ -274,6 +284,7 @@ struct cr_batch {
     int wide_sync = 0;                  // > 0: the wide kernels (one wave per strip, up to 16 waves per pair) with a barrier every wide_sync steps
     int r_b = 5, wide_na = 0;           // wide kernels: strips [0, wide_na) have r_seed rows per lane, the others r_b (r_b == r_seed: all alike)
     std::vector<int32_t> duo_ij;        // ... the caller's pair list (k_pair_duo is built for sw_gap == 0: another gap lays the list out again)
+    std::vector<int32_t> relaid_ij;     // ... the list a gap-driven re-layout was made from: its upload may still be in flight, so it lives with the batch
     bool trio_few = false;              // ... chosen for a list the one-pair-per-CU layouts would take with a Smith-Waterman gap (laid out again then)
     bool trio = false;                  // the single-wave LAYOUT (5 rows per lane, one strip) on k_pair_trio (cr_trio.h): one wave of recurrences + two of scores per pair
     bool duo = false;                   // the wide LAYOUT on k_pair_duo (cr_duo.h): 2 .. 4 waves per pair paced by LDS progress words, several pairs per CU
@@ -310,6 +321,17 @@ struct cr_batch {
         int lane = 0;                    // 0: the context's stream; k > 0: side stream k-1 (one lane per group)
     };
     std::vector<Chunk> chunks;
+    bool duo_team = false;              // k_pair_duo with the sums behind the walks taken by the whole workgroup (one pair per CU)
+    // A RAGGED list is split into at most three size classes (cr_batch_set_pairs): each class is a batch of its own on
+    // this batch's structures (coords / tensors / offsets borrowed), with its own kernel family, scratch and launch
+    // sequence; its order map leads straight to the caller's pair indices, so results land in the caller's order.
+    std::vector<cr_batch*> parts;
+    bool is_part = false;
+    std::vector<int32_t> part_global;   // (a part) the caller's index of every pair of this class, in list order
+    int base_lane = 0;                  // a part's launches go to stream (base_lane + chunk lane) mod kGroupLanes of the context
+    ~cr_batch() {
+        for (cr_batch* c : parts) delete c;
+    }
 };
 
 static_assert(sizeof(cr::PairResult) == sizeof(cr_pair_result), "device/host result layouts differ");
@@ -605,7 +627,7 @@ int launch_align_team_zg(cr_batch* b, const cr_batch::Chunk& ck, const cr_params
                                                  (size_t)cr::kExpDoubles + cr::trace_lds_doubles(R, entries));
     int rc = allow_lds(cr::k_align_team<R, ZG>, lds);
     if (rc) return rc;
-    CR_LAUNCH((cr::k_align_team<R, ZG>), dim3((unsigned)ck.count), dim3(cr::kTeamWaves * cr::kWave), lds, b->ctx->stream,
+    CR_LAUNCH((cr::k_align_team<R, ZG>), dim3((unsigned)ck.count), dim3(cr::kTeamWaves * cr::kWave), lds, b->launch_stream ? b->launch_stream : b->ctx->stream,
                        b->pairs.p + ck.first, b->coords.p, b->xf.p + ck.first, b->seed_score.p + ck.first, prm.gamma_coords,
                        prm.sw_gap, prm.gap_open, prm.gap_extend, entries, b->bits.p, b->aln.p, b->res.p + ck.first, host_out_for(b, ck));
     CR_HIP(hipGetLastError());
@@ -710,19 +732,21 @@ int launch_pair_wide(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& pr
 }
 
 // ---- mid-size pair lists: the wide layout on small workgroups paced by progress words (cr_duo.h); gap 0 only ----------
-template <int RA, int RB, int D, bool SC>
+template <int RA, int RB, int D, bool SC, bool TEAM>
 int launch_pair_duo_t(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
     const int seed_entries = std::min(ck.n_max, ck.m_max), align_entries = ck.max_aln;
     const int waves = plan_of(b).strips(ck.n_max);
-    const size_t seed = std::max(cr::duo_cols_lds_doubles(waves, ck.m_max), (size_t)cr::kExpDoubles + cr::trace_lds_doubles(RA, seed_entries));
+    // (TEAM: the sums behind the walks by the whole workgroup -- their term tile shares the LDS with the fills)
+    const size_t seed_trace = (size_t)cr::kExpDoubles + (TEAM ? cr::trace_team_lds_doubles(seed_entries) : cr::trace_lds_doubles(RA, seed_entries));
+    const size_t align_trace = (size_t)cr::kExpDoubles + (TEAM ? cr::trace_team_lds_doubles(align_entries) : cr::trace_lds_doubles(RA, align_entries));
+    const size_t seed = std::max(cr::duo_cols_lds_doubles(waves, ck.m_max), seed_trace);
     const size_t second = SC ? cr::duo_score_lds_doubles<cr::RbfCoords<RA>>(waves, ck.m_max)
-                             : std::max(cr::duo_sweep_lds_doubles<cr::kSwScore | cr::kDtw, cr::RbfCoords<RA>>(waves, ck.m_max),
-                                        (size_t)cr::kExpDoubles + cr::trace_lds_doubles(RA, align_entries));
+                             : std::max(cr::duo_sweep_lds_doubles<cr::kSwScore | cr::kDtw, cr::RbfCoords<RA>>(waves, ck.m_max), align_trace);
     size_t lds = sizeof(double) * std::max(seed, second);
-    if (const char* env = std::getenv("CARETTA_MID_LDS_KB")) lds = std::max(lds, (size_t)std::atoi(env) * 1024);   // calibration: pairs per CU
-    int rc = allow_lds(cr::k_pair_duo<RA, RB, D, SC>, lds);
+    if (!TEAM && g_cfg.mid_lds_kb > 0) lds = std::max(lds, (size_t)g_cfg.mid_lds_kb * 1024);   // calibration: pairs per CU
+    int rc = allow_lds(cr::k_pair_duo<RA, RB, D, SC, TEAM>, lds);
     if (rc) return rc;
-    CR_LAUNCH((cr::k_pair_duo<RA, RB, D, SC>), dim3((unsigned)ck.count), dim3(waves * cr::kWave), lds,
+    CR_LAUNCH((cr::k_pair_duo<RA, RB, D, SC, TEAM>), dim3((unsigned)ck.count), dim3(waves * cr::kWave), lds,
               b->launch_stream ? b->launch_stream : b->ctx->stream, b->pairs.p + ck.first, b->tensors.p, (int)b->d, b->coords.p,
               prm.gamma_tensor, prm.gamma_coords, prm.gap_open, prm.gap_extend, seed_entries, align_entries, b->wide_na, b->dirs.p,
               b->bits.p, b->xf.p + ck.first, b->seed_score.p + ck.first, b->aln.p, b->res.p + ck.first, host_out_for(b, ck));
@@ -730,25 +754,33 @@ int launch_pair_duo_t(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& p
     return CR_OK;
 }
 
-template <int RA, int RB>
+template <int RA, int RB, bool TEAM>
 int launch_pair_duo_r(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, bool scores) {
     switch (b->d_pad) {
-        case 4: return scores ? launch_pair_duo_t<RA, RB, 4, true>(b, ck, prm) : launch_pair_duo_t<RA, RB, 4, false>(b, ck, prm);
-        case 8: return scores ? launch_pair_duo_t<RA, RB, 8, true>(b, ck, prm) : launch_pair_duo_t<RA, RB, 8, false>(b, ck, prm);
-        case 10: return scores ? launch_pair_duo_t<RA, RB, 10, true>(b, ck, prm) : launch_pair_duo_t<RA, RB, 10, false>(b, ck, prm);
-        case 16: return scores ? launch_pair_duo_t<RA, RB, 16, true>(b, ck, prm) : launch_pair_duo_t<RA, RB, 16, false>(b, ck, prm);
+        case 4: return scores ? launch_pair_duo_t<RA, RB, 4, true, TEAM>(b, ck, prm) : launch_pair_duo_t<RA, RB, 4, false, TEAM>(b, ck, prm);
+        case 8: return scores ? launch_pair_duo_t<RA, RB, 8, true, TEAM>(b, ck, prm) : launch_pair_duo_t<RA, RB, 8, false, TEAM>(b, ck, prm);
+        case 10: return scores ? launch_pair_duo_t<RA, RB, 10, true, TEAM>(b, ck, prm) : launch_pair_duo_t<RA, RB, 10, false, TEAM>(b, ck, prm);
+        case 16: return scores ? launch_pair_duo_t<RA, RB, 16, true, TEAM>(b, ck, prm) : launch_pair_duo_t<RA, RB, 16, false, TEAM>(b, ck, prm);
         default: return fail(CR_ERR_ARGUMENT, "unsupported tensor width");
     }
 }
 
 int launch_pair_duo(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, bool scores) {
     const int key = b->r_seed * 10 + b->r_b;
+    if (b->duo_team) {
+        switch (key) {
+            case 22: return launch_pair_duo_r<2, 2, true>(b, ck, prm, scores);
+            case 32: return launch_pair_duo_r<3, 2, true>(b, ck, prm, scores);
+            case 33: return launch_pair_duo_r<3, 3, true>(b, ck, prm, scores);
+            default: return fail(CR_ERR_STATE, "no k_pair_duo instance with workgroup-wide sums for this strip plan");
+        }
+    }
     switch (key) {
-        case 11: return launch_pair_duo_r<1, 1>(b, ck, prm, scores);
-        case 21: return launch_pair_duo_r<2, 1>(b, ck, prm, scores);
-        case 22: return launch_pair_duo_r<2, 2>(b, ck, prm, scores);
-        case 32: return launch_pair_duo_r<3, 2>(b, ck, prm, scores);
-        case 33: return launch_pair_duo_r<3, 3>(b, ck, prm, scores);
+        case 11: return launch_pair_duo_r<1, 1, false>(b, ck, prm, scores);
+        case 21: return launch_pair_duo_r<2, 1, false>(b, ck, prm, scores);
+        case 22: return launch_pair_duo_r<2, 2, false>(b, ck, prm, scores);
+        case 32: return launch_pair_duo_r<3, 2, false>(b, ck, prm, scores);
+        case 33: return launch_pair_duo_r<3, 3, false>(b, ck, prm, scores);
         default: return fail(CR_ERR_STATE, "no k_pair_duo instance for this strip plan");
     }
 }
@@ -759,16 +791,18 @@ int launch_pair_trio_t(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& 
     const int seed_entries = std::min(ck.n_max, ck.m_max), align_entries = ck.max_aln;
     size_t lds = sizeof(double) * std::max(cr::trio_lds_doubles<R>(ck.m_max),
                                            (size_t)cr::kExpDoubles + cr::trace_lds_doubles(R, SC ? seed_entries : align_entries));
-    if (const char* env = std::getenv("CARETTA_MID_LDS_KB")) lds = std::max(lds, (size_t)std::atoi(env) * 1024);   // calibration: pairs per CU
+    if (g_cfg.mid_lds_kb > 0) lds = std::max(lds, (size_t)g_cfg.mid_lds_kb * 1024);   // calibration: pairs per CU
     int rc = allow_lds(cr::k_pair_trio<R, D, SC>, lds);
     if (rc) return rc;
     // one wave of recurrences + two of scores; THREE of scores while the chip then still holds fewer than ~2 800 waves
     // (tools/c3_share.py: 508 pairs of 300 0.45 -> 0.41 ms, 678 pairs 0.56 -> 0.46; 1 016 pairs 0.55 either way)
     int waves = ck.count <= 700 ? 4 : 3;
-    if (const char* env = std::getenv("CARETTA_TRIO_WAVES")) waves = std::min(std::max(std::atoi(env), 2), cr::kTrioMaxWaves);   // calibration
+    if (g_cfg.trio_waves) waves = std::min(std::max(g_cfg.trio_waves, 2), cr::kTrioMaxWaves);   // calibration
+    int waves2 = waves;                                            // waves of the second stage (1 + its score waves)
+    if (g_cfg.trio_waves2) waves2 = std::min(std::max(g_cfg.trio_waves2, 2), waves);            // calibration
     CR_LAUNCH((cr::k_pair_trio<R, D, SC>), dim3((unsigned)ck.count), dim3(waves * cr::kWave), lds,
               b->launch_stream ? b->launch_stream : b->ctx->stream, b->pairs.p + ck.first, b->tensors.p, (int)b->d, b->coords.p, prm.gamma_tensor,
-              prm.gamma_coords, prm.gap_open, prm.gap_extend, seed_entries, align_entries, b->dirs.p, b->bits.p, b->xf.p + ck.first,
+              prm.gamma_coords, prm.gap_open, prm.gap_extend, seed_entries, align_entries, waves2 - 1, b->dirs.p, b->bits.p, b->xf.p + ck.first,
               b->seed_score.p + ck.first, b->aln.p, b->res.p + ck.first, host_out_for(b, ck));
     CR_HIP(hipGetLastError());
     return CR_OK;
@@ -794,104 +828,7 @@ int launch_pair_trio(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& pr
     }
 }
 
-// Strip plans k_pair_duo is built for: (RA, RB) of cr_duo_instances.h, at most kDuoMaxWaves strips, columns resident in LDS
-bool duo_fits(const StripPlan& p, int n_max, int m_max, int d_pad) {
-    const int key = p.ra * 10 + p.rb;
-    if (!(key == 11 || key == 21 || key == 22 || key == 32 || key == 33) || d_pad > 16) return false;
-    if (p.ra != p.rb && (p.na < 1 || p.na >= cr::kDuoMaxWaves)) return false;
-    const int waves = p.strips(n_max);
-    if ((waves < 2 && !std::getenv("CARETTA_MID_ANY")) || waves > cr::kDuoMaxWaves) return false;   // (CARETTA_MID_ANY: measurements)
-    const size_t fill = cr::duo_sweep_lds_doubles<cr::kSwScore | cr::kDtw, cr::RbfCoords<1>>(waves, m_max);
-    const size_t trace = cr::kExpDoubles + cr::trace_lds_doubles(1, n_max + m_max);
-    return sizeof(double) * std::max(fill, trace) <= 64 * 1024;
-}
-
-// Can a pair list with these maxima run on the wide kernels with this strip plan?  (strips <= 16 waves, the columns
-// of the tensor sweep -- the larger of the two -- resident in LDS next to the edge rings)
-bool wide_fits(const StripPlan& p, int n_max, int m_max, int d_pad) {
-    if (p.ra < 2 || p.ra > 3 || p.rb < 2 || p.rb > p.ra || d_pad > 16) return false;   // (the wide kernels are built for 2 or 3 rows per lane, widths up to 16)
-    if (p.ra != p.rb && !(p.ra == 3 && p.rb == 2)) return false;                        // (the one mixed instance)
-    const int waves = p.strips(n_max);
-    if (waves > cr::kWideMaxWaves) return false;
-    // (sized for sw_gap != 0, where the tensor sweep needs its columns resident too; the parameters come with cr_batch_run)
-    const size_t seed = cr::kExpDoubles + (size_t)d_pad * m_max + (size_t)waves * (cr::kWideEdge + 8);
-    const size_t align = cr::kExpDoubles + (size_t)3 * m_max + (size_t)waves * (3 * cr::kWideEdge + 8);
-    const size_t trace = cr::kExpDoubles + cr::trace_team_lds_doubles(n_max + m_max);
-    // (1 KB less than the CU's 160 KB: k_pair_wide also has a few hundred bytes of static LDS)
-    return sizeof(double) * std::max(std::max(seed, align), trace) <= 159 * 1024;
-}
-
-// The strip plan of a wide launch.  A workgroup's waves are dealt round robin to the CU's four SIMDs; a SIMD issues one
-// FP64-rate instruction per 4 cycles when two or more waves share it and a lone wave gets one per ~6.5 (DESIGN.md 4.1c),
-// and all strips advance together (barriers), so a sweep step costs what the fullest SIMD needs for its row slots.  The
-// skewed DTW fill takes lag * (S - 1) + m + 63 steps, the column sweeps of the seed and the score m + 16 * (S - 1).
-// Candidates: 2 or 3 rows per lane everywhere, or 3 in the first nA strips and 2 in the others.
-// 1200 rows: (3,3,3,2,2,2,2,2) -- 5,5,5,4 row slots per SIMD where seven strips of 3 have 6,6,6,3.
-StripPlan choose_wide_plan(int n_max, int m_max, int d_pad, int sync_every) {
-    StripPlan best{0, 0, 0};
-    double best_cost = 1e300;
-    auto consider = [&](const StripPlan& p) {
-        if (!wide_fits(p, n_max, m_max, d_pad)) return;
-        const int S = p.strips(n_max);
-        int load[4] = {0, 0, 0, 0}, waves[4] = {0, 0, 0, 0};
-        for (int w = 0; w < S; w++) {
-            load[w & 3] += (p.ra == p.rb || w < p.na) ? p.ra : p.rb;
-            waves[w & 3]++;
-        }
-        double step = 0.0;
-        for (int k = 0; k < 4; k++) step = std::max(step, load[k] * (waves[k] >= 2 ? 4.0 : 6.5));
-        const double lag = cr::kWave - 1 + sync_every;
-        const double steps = (lag * (S - 1) + m_max + cr::kWave - 1) + 2.0 * (m_max + 16.0 * (S - 1));
-        const double cost = step * steps;
-        // (ties between mixed plans go to the one with more 3-row strips: 252 x 1200 x 1200 measured 2.207 / 2.162 / 2.175 ms
-        // with nA = 4 against 2.213 / 2.183 / 2.189 with nA = 3 in three calibration runs)
-        if (cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && p.ra != p.rb && best.ra != best.rb && p.na > best.na)) {
-            best_cost = cost;
-            best = p;
-        }
-    };
-    consider(StripPlan{2, 2, 0});
-    consider(StripPlan{3, 3, 0});
-    for (int na = 1; na < cr::kWideMaxWaves; na++)
-        if (na * cr::kWave * 3 < n_max) consider(StripPlan{3, 2, na});
-    return best;
-}
-
-constexpr int64_t kTeamPairLimit = 256;
-// Pair lists of at most this many 64-row strips run on staged scores (cr_batch_set_pairs): one wave per SIMD of the chip.
-constexpr int64_t kStagedWaveLimit = 1024;
-// Mid-size lists (cr_duo.h): up to this many waves (two strips per pair / more; CARETTA_MID_PAIRS overrides the pair limit
-// they give), columns resident in LDS.
-constexpr int64_t kMidWaveLimit2 = 2600, kMidWaveLimit = 3072;
-constexpr int64_t kTrioPairLimit = 1300;       // k_pair_trio: three waves per pair (four up to 700 pairs); 1 355 pairs tie with one wave per pair
-constexpr int kTrioMinRows = 64;               // ... from 65 rows on (one strip of two to five rows per lane)
-constexpr int kMidMaxColumns = 1280;
-constexpr int kGroupLanes = 4;             // streams that row-per-lane groups are spread over
-int launch_seed_team(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm);   // cr_dropins.h
-
-// Rows per lane for a structure of n rows: the R in {2, 3, 4, 5} with the cheapest strips.  A strip walks all m
-// columns; its measured cost per column (tools/calibrate_rows_per_lane.py, 4095 equal pairs per length, both
-// kernels) is 1 : 1.175 : 1.534 : 1.77 for R = 2 : 3 : 4 : 5 -- not proportional to R, because the narrower kernels
-// keep more waves per SIMD.  Ties go to the larger R.  300 rows -> 5 (one strip), 230 -> 4, 150 -> 3, 100 -> 2,
-// 350 -> 3 (two strips), 450 -> 4 (two strips).
-int rows_per_lane(int n) {
-    if (const char* env = std::getenv("CARETTA_FORCE_R")) {       // calibration runs
-        const int r = std::atoi(env);
-        if (r >= 2 && r <= 5) return r;
-    }
-    const int rs[4] = {5, 4, 3, 2};
-    const double weight[4] = {1.77, 1.534, 1.175, 1.0};
-    int best = 5;
-    double best_cost = 1e300;
-    for (int k = 0; k < 4; k++) {
-        const double c = cr::strips_of(n, rs[k]) * weight[k];
-        if (c < best_cost - 1e-9) {
-            best_cost = c;
-            best = rs[k];
-        }
-    }
-    return best;
-}
+int rows_per_lane(int n);                                    // (below, with the layout table)
 
 int launch_seed_r(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
     return R == 2 ? launch_seed_d<2>(b, ck, prm) : R == 3 ? launch_seed_d<3>(b, ck, prm)
@@ -934,6 +871,11 @@ int padded_width(int64_t d) {
 // Shared body of the two fetch entry points: pack on the device (caller's order and layout), then copies into the
 // caller's arrays -- straight DMA when those are page-locked (cr_host_alloc), through the context's page-locked ring
 // otherwise (download()).
+namespace {
+template <class F>
+int for_each_part(cr_batch* b, F&& f);      // (defined with the size classes, below)
+}
+
 template <class T>
 int fetch_packed(cr_batch* b, cr_pair_result* results, T* aln, int64_t aln_stride) {
     CR_REQUIRE(b != nullptr, "null batch");
@@ -953,15 +895,21 @@ int fetch_packed(cr_batch* b, cr_pair_result* results, T* aln, int64_t aln_strid
     }
     const size_t np = (size_t)b->npairs;
     const size_t aln_bytes = aln ? np * 2 * (size_t)aln_stride * sizeof(T) : 0;
-    const bool permute = b->reordered;
+    // (size classes: every class packs into the parent's arrays through its order map)
+    const bool permute = b->reordered || !b->parts.empty();
     if (results && permute) CR_HIP(b->res_packed.ensure(np));
     if (aln) CR_HIP(b->aln_packed.ensure((aln_bytes + 7) / 8));
     if (aln || (results && permute)) {
-        CR_LAUNCH(cr::k_pack_results<T>, dim3((unsigned)np), dim3(cr::kWave), 0, st, b->pairs.p, b->res.p,
-                  permute ? b->d_order.p : (const int32_t*)nullptr, b->aln.p, aln_stride,
-                  (results && permute) ? b->res_packed.p : (cr::PairResult*)nullptr,
-                  aln ? reinterpret_cast<T*>(b->aln_packed.p) : (T*)nullptr);
-        CR_HIP(hipGetLastError());
+        rc = for_each_part(b, [&](cr_batch* c) -> int {
+            if (!c->npairs) return CR_OK;
+            CR_LAUNCH(cr::k_pack_results<T>, dim3((unsigned)c->npairs), dim3(cr::kWave), 0, st, c->pairs.p, c->res.p,
+                      c->reordered ? c->d_order.p : (const int32_t*)nullptr, c->aln.p, aln_stride,
+                      (results && permute) ? b->res_packed.p : (cr::PairResult*)nullptr,
+                      aln ? reinterpret_cast<T*>(b->aln_packed.p) : (T*)nullptr);
+            CR_HIP(hipGetLastError());
+            return CR_OK;
+        });
+        if (rc) return rc;
     }
     if (results) {
         rc = download(b->ctx, results, permute ? (const void*)b->res_packed.p : (const void*)b->res.p, sizeof(cr_pair_result) * np, false);
@@ -1152,173 +1100,337 @@ static int batch_create(cr_context* ctx, const double* coords, const double* ten
     return CR_OK;
 }
 
-extern "C" {
+namespace {
 
-int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
-    CR_REQUIRE(b != nullptr, "null batch");
-    int rc = set_device(b->ctx);
-    if (rc) return rc;
-    CR_REQUIRE(npairs >= 0 && (npairs == 0 || pairs != nullptr), "bad pair list");
-    CR_REQUIRE(npairs < (int64_t)std::numeric_limits<int32_t>::max(), "too many pairs for one batch");
+// ---------------------------------------------------------------------------------------------
+// Which kernel family serves a pair list: ONE table, consulted by ONE function (choose_layout).
+//
+// A rule applies to a list whose longest structure has rows in [rows_lo, rows_hi] and columns <= cols_hi, whose pair
+// count lies in [pairs_lo, pairs_hi] and whose padded tensor width is at most d_pad_hi; the first rule that applies
+// AND whose family's `fits` check passes (LDS of the launch, waves resident at once, bytes of staged scores -- what a
+// range cannot say) wins.  Every limit was measured on equal-length synthetic families on an MI355X; `calibration`
+// names the committed record.  The environment switches of cr_config.h move single limits for measurements.
+// ---------------------------------------------------------------------------------------------
+enum Family : int { kFamSingle = 0, kFamTeam, kFamWide, kFamDuoTeam, kFamDuo, kFamTrio, kFamStaged };
+
+struct LayoutRule {
+    Family family;
+    int rows_lo, rows_hi;
+    int64_t pairs_lo, pairs_hi;
+    int cols_hi;
+    int d_pad_hi;
+    const char* calibration;
+};
+
+constexpr int64_t kAnyPairs = std::numeric_limits<int64_t>::max();
+constexpr int kAnyLength = cr::kMaxLength;
+constexpr int64_t kTeamPairLimit = 256;
+// Pair lists of at most this many 64-row strips run on staged scores: one wave per SIMD of the chip.
+constexpr int64_t kStagedWaveLimit = 1024;
+// Mid-size lists (cr_duo.h): up to this many waves (two strips per pair / more), columns resident in LDS.
+constexpr int64_t kMidWaveLimit2 = 2600, kMidWaveLimit = 3072;
+constexpr int64_t kTrioPairLimit = 1300;       // k_pair_trio: 1 355 pairs tie with one wave per pair
+constexpr int kMidMaxColumns = 1280;
+constexpr int kGroupLanes = 4;                 // streams that row-per-lane groups (and size classes) are spread over
+constexpr int64_t kClassSplitPairs = 4096;     // a ragged list of at most this many pairs is split into size classes
+
+constexpr LayoutRule kLayoutTable[] = {
+    // split by FUNCTION (cr_trio.h): one strip of 2 .. 5 rows per lane; its time does not depend on the pair count while the
+    // chip is not full, the one-pair-per-CU layouts and staged scores grow with it -- hence "from" 65 / 111 / 161 pairs
+    {kFamTrio, 65, 192, 65, kTrioPairLimit, kMidMaxColumns, 10, "profiles/r04/trio_few.txt, trio_sizes.txt"},
+    {kFamTrio, 193, 256, 111, kTrioPairLimit, kMidMaxColumns, 10, "profiles/r04/trio_few.txt, trio_sizes.txt"},
+    {kFamTrio, 257, 320, 161, kTrioPairLimit, kMidMaxColumns, 10, "profiles/r04/trio_few.txt, c3_share.txt, c3_share_limit.txt"},
+    // staged scores (cr_staged.h): at most one wave per SIMD of the chip (pairs x strips <= 1 024: checked by fits)
+    {kFamStaged, 1, cr::kStagedMaxRows, 1, kStagedWaveLimit, kAnyLength, 32, "profiles/r03/calibrate_staged.txt"},
+    // one pair per CU, strips paced by progress words + workgroup-wide sums (cr_duo.h, TEAM): up to 8 waves
+    {kFamDuoTeam, 513, 1472, 1, kTeamPairLimit, kMidMaxColumns, 16, "profiles/r05/c5_share_layouts.txt"},
+    // one pair per CU, up to 16 waves, barrier every 8 steps (k_pair_wide)
+    {kFamWide, 193, 3072, 1, kTeamPairLimit, kAnyLength, 16, "profiles/r03/calibrate_wide.txt"},
+    // four-wave teams: what the wide layout cannot take (tensor widths above 16)
+    {kFamTeam, 193, 5 * cr::kTeamWaves * cr::kWave, 1, kTeamPairLimit, kAnyLength, 32, "profiles/r01 (tools/calibrate_team_limit.py)"},
+    // split by ROWS (cr_duo.h): 2 .. 8 waves per pair, all workgroups resident at once (wave limits: checked by fits)
+    {kFamDuo, 257, 1088, kTeamPairLimit + 1, kMidWaveLimit / 2, kMidMaxColumns, 16, "profiles/r04/c3_share.txt, c3_share_lengths.txt"},
+    // one wave per pair, pairs grouped by rows per lane (2 .. 5)
+    {kFamSingle, 1, kAnyLength, 1, kAnyPairs, kAnyLength, 32, "profiles/r02 (tools/calibrate_rows_per_lane.py)"},
+};
+
+struct Layout {
+    Family family = kFamSingle;
+    int r_seed = 5, r_b = 5, wide_na = 0, wide_sync = 0;
+    bool trio_few = false;
+};
+
+// what the caller of cr_batch_set_pairs rules out (thread-local flags of the re-layouts)
+struct LayoutMask {
+    bool no_wide = false, no_trio = false, no_duo = false;
+};
+
+int launch_seed_team(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm);   // cr_dropins.h
+
+// Rows per lane for a structure of n rows: the R in {2, 3, 4, 5} with the cheapest strips.  A strip walks all m
+// columns; its measured cost per column (tools/calibrate_rows_per_lane.py, 4095 equal pairs per length, both
+// kernels) is 1 : 1.175 : 1.534 : 1.77 for R = 2 : 3 : 4 : 5 -- not proportional to R, because the narrower kernels
+// keep more waves per SIMD.  Ties go to the larger R.  300 rows -> 5 (one strip), 230 -> 4, 150 -> 3, 100 -> 2,
+// 350 -> 3 (two strips), 450 -> 4 (two strips).
+int rows_per_lane(int n) {
+    if (g_cfg.force_r >= 2 && g_cfg.force_r <= 5) return g_cfg.force_r;       // calibration runs
+    const int rs[4] = {5, 4, 3, 2};
+    const double weight[4] = {1.77, 1.534, 1.175, 1.0};
+    int best = 5;
+    double best_cost = 1e300;
+    for (int k = 0; k < 4; k++) {
+        const double c = cr::strips_of(n, rs[k]) * weight[k];
+        if (c < best_cost - 1e-9) {
+            best_cost = c;
+            best = rs[k];
+        }
+    }
+    return best;
+}
+
+// Strip plans k_pair_duo is built for: (RA, RB) of cr_duo_instances.h, at most kDuoMaxWaves strips, columns resident in LDS
+bool duo_fits(const StripPlan& p, int n_max, int m_max, int d_pad) {
+    const int key = p.ra * 10 + p.rb;
+    if (!(key == 11 || key == 21 || key == 22 || key == 32 || key == 33) || d_pad > 16) return false;
+    if (p.ra != p.rb && (p.na < 1 || p.na >= cr::kDuoMaxWaves)) return false;
+    const int waves = p.strips(n_max);
+    if ((waves < 2 && !g_cfg.mid_any) || waves > cr::kDuoMaxWaves) return false;   // (CARETTA_MID_ANY: measurements)
+    const size_t fill = cr::duo_sweep_lds_doubles<cr::kSwScore | cr::kDtw, cr::RbfCoords<1>>(waves, m_max);
+    const size_t trace = cr::kExpDoubles + cr::trace_lds_doubles(1, n_max + m_max);
+    return sizeof(double) * std::max(fill, trace) <= 64 * 1024;
+}
+
+// Can a pair list with these maxima run on the wide kernels with this strip plan?  (strips <= max_waves, the columns
+// of the tensor sweep -- the larger of the two -- resident in LDS next to the edge rings)
+bool wide_fits(const StripPlan& p, int n_max, int m_max, int d_pad, int max_waves = cr::kWideMaxWaves) {
+    if (p.ra < 2 || p.ra > 3 || p.rb < 2 || p.rb > p.ra || d_pad > 16) return false;   // (the wide kernels are built for 2 or 3 rows per lane, widths up to 16)
+    if (p.ra != p.rb && !(p.ra == 3 && p.rb == 2)) return false;                        // (the one mixed instance)
+    const int waves = p.strips(n_max);
+    if (waves > max_waves) return false;
+    // (sized for sw_gap != 0, where the tensor sweep needs its columns resident too; the parameters come with cr_batch_run)
+    const size_t seed = cr::kExpDoubles + (size_t)d_pad * m_max + (size_t)waves * (cr::kWideEdge + 8);
+    const size_t align = cr::kExpDoubles + (size_t)3 * m_max + (size_t)waves * (3 * cr::kWideEdge + 8);
+    const size_t trace = cr::kExpDoubles + cr::trace_team_lds_doubles(n_max + m_max);
+    // (1 KB less than the CU's 160 KB: k_pair_wide also has a few hundred bytes of static LDS)
+    return sizeof(double) * std::max(std::max(seed, align), trace) <= 159 * 1024;
+}
+
+// k_pair_duo with workgroup-wide sums: the wide layout's plans with at most kDuoMaxWaves strips, gap 0 (another gap lays the
+// list out again), the fill's resident columns and rings or the term tile of the sums in the LDS of one CU
+bool duo_team_fits(const StripPlan& p, int n_max, int m_max, int d_pad) {
+    const int key = p.ra * 10 + p.rb;
+    if (!(key == 22 || key == 32 || key == 33) || d_pad > 16) return false;
+    if (p.ra != p.rb && (p.na < 1 || p.na >= cr::kDuoMaxWaves)) return false;
+    const int waves = p.strips(n_max);
+    if (waves < 2 || waves > cr::kDuoMaxWaves) return false;
+    const size_t fill = cr::duo_sweep_lds_doubles<cr::kSwScore | cr::kDtw, cr::RbfCoords<1>>(waves, m_max);
+    const size_t trace = cr::kExpDoubles + cr::trace_team_lds_doubles(n_max + m_max);
+    return sizeof(double) * std::max(fill, trace) <= 159 * 1024;
+}
+
+// The strip plan of a wide launch.  A workgroup's waves are dealt round robin to the CU's four SIMDs; a SIMD issues one
+// FP64-rate instruction per 4 cycles when two or more waves share it and a lone wave gets one per ~6.5 (DESIGN.md 4.1c),
+// and all strips advance together (barriers), so a sweep step costs what the fullest SIMD needs for its row slots.  The
+// skewed DTW fill takes lag * (S - 1) + m + 63 steps, the column sweeps of the seed and the score m + 16 * (S - 1).
+// Candidates: 2 or 3 rows per lane everywhere, or 3 in the first nA strips and 2 in the others.
+// 1200 rows: (3,3,3,2,2,2,2,2) -- 5,5,5,4 row slots per SIMD where seven strips of 3 have 6,6,6,3.
+template <class Fits>
+StripPlan choose_wide_plan(int n_max, int m_max, int sync_every, Fits fits) {
+    StripPlan best{0, 0, 0};
+    double best_cost = 1e300;
+    auto consider = [&](const StripPlan& p) {
+        if (!fits(p)) return;
+        const int S = p.strips(n_max);
+        int load[4] = {0, 0, 0, 0}, waves[4] = {0, 0, 0, 0};
+        for (int w = 0; w < S; w++) {
+            load[w & 3] += (p.ra == p.rb || w < p.na) ? p.ra : p.rb;
+            waves[w & 3]++;
+        }
+        double step = 0.0;
+        for (int k = 0; k < 4; k++) step = std::max(step, load[k] * (waves[k] >= 2 ? 4.0 : 6.5));
+        const double lag = cr::kWave - 1 + sync_every;
+        const double steps = (lag * (S - 1) + m_max + cr::kWave - 1) + 2.0 * (m_max + 16.0 * (S - 1));
+        const double cost = step * steps;
+        // (ties between mixed plans go to the one with more 3-row strips: 252 x 1200 x 1200 measured 2.207 / 2.162 / 2.175 ms
+        // with nA = 4 against 2.213 / 2.183 / 2.189 with nA = 3 in three calibration runs)
+        if (cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && p.ra != p.rb && best.ra != best.rb && p.na > best.na)) {
+            best_cost = cost;
+            best = p;
+        }
+    };
+    consider(StripPlan{2, 2, 0});
+    consider(StripPlan{3, 3, 0});
+    for (int na = 1; na < cr::kWideMaxWaves; na++)
+        if (na * cr::kWave * 3 < n_max) consider(StripPlan{3, 2, na});
+    return best;
+}
+
+// the limits of a rule as the calibration switches move them
+LayoutRule effective_rule(LayoutRule r) {
+    const crcfg::Calibration& c = g_cfg;
+    switch (r.family) {
+        case kFamTrio:
+            if (c.trio_pairs >= 0) r.pairs_hi = c.trio_pairs;
+            if (c.trio_from >= 0) r.pairs_lo = c.trio_from + 1;
+            if (c.trio_min_rows >= 0 && r.rows_lo == cr::kWave + 1) r.rows_lo = (int)c.trio_min_rows + 1;
+            break;
+        case kFamStaged:
+            if (c.staged_waves >= 0) r.pairs_hi = kAnyPairs;
+            if (c.staged_rows >= 0) r.rows_hi = (int)std::min<long long>(c.staged_rows, cr::kStagedMaxRows);
+            break;
+        case kFamDuoTeam:
+        case kFamWide:
+        case kFamTeam:
+            if (c.team_pairs >= 0) r.pairs_hi = c.team_pairs;
+            break;
+        case kFamDuo:
+            if (c.team_pairs >= 0) r.pairs_lo = c.team_pairs + 1;
+            if (c.mid_pairs >= 0) r.pairs_hi = c.mid_pairs;
+            if (c.mid_any) r.rows_lo = 1;
+            break;
+        default: break;
+    }
+    return r;
+}
+
+// The kernel family (and its strip plan) for a list of `npairs` pairs whose longest structures have n_max rows / m_max columns.
+Layout choose_layout(int n_max, int m_max, int d_pad, int64_t npairs, const LayoutMask mask) {
+    const crcfg::Calibration& c = g_cfg;
+    Layout out;
+    out.r_seed = out.r_b = rows_per_lane(std::max(n_max, 1));
+    if (npairs <= 0) return out;
+    // calibration: CARETTA_WIDE="RA,RB,nA,B" forces the wide kernels with this plan
+    if (c.wide.set && !mask.no_wide && c.wide.sync >= 1 && c.wide.sync <= cr::kWideMaxSync && c.wide.na >= 0 && c.wide.na < cr::kWideMaxWaves &&
+        wide_fits(StripPlan{c.wide.ra, c.wide.rb, c.wide.ra == c.wide.rb ? 0 : c.wide.na}, n_max, m_max, d_pad)) {
+        out.family = kFamWide;
+        out.r_seed = c.wide.ra;
+        out.r_b = c.wide.rb;
+        out.wide_na = c.wide.ra == c.wide.rb ? 0 : c.wide.na;
+        out.wide_sync = c.wide.sync;
+        return out;
+    }
+    for (const LayoutRule& rule : kLayoutTable) {
+        const LayoutRule r = effective_rule(rule);
+        if (n_max < r.rows_lo || n_max > r.rows_hi || npairs < r.pairs_lo || npairs > r.pairs_hi || m_max > r.cols_hi || d_pad > r.d_pad_hi) continue;
+        switch (r.family) {
+            case kFamTrio: {
+                if (!c.trio || c.no_team || mask.no_wide || mask.no_trio) break;
+                out.family = kFamTrio;
+                out.r_seed = out.r_b = std::max(2, (n_max + cr::kWave - 1) / cr::kWave);       // one strip of 2 .. 5 rows per lane
+                out.trio_few = npairs <= kTeamPairLimit;
+                return out;
+            }
+            case kFamStaged: {
+                if (!c.staged || c.no_team || c.no_wide || c.wide.set || mask.no_wide) break;
+                const cr::StagedShape shape = staged_shape(std::max(n_max, 1), std::max(m_max, 1));
+                const int64_t wave_limit = c.staged_waves >= 0 ? c.staged_waves : kStagedWaveLimit;
+                if (npairs * shape.waves > wave_limit) break;
+                if ((double)npairs * (double)shape.pair_doubles() * sizeof(double) > 2.0 * 1024 * 1024 * 1024) break;
+                // (the alignment columns of a pair and the term tile of the workgroup-wide sums share the LDS)
+                if (sizeof(double) * ((size_t)cr::kExpDoubles + cr::trace_team_lds_doubles(n_max + m_max)) > 159 * 1024) break;
+                out.family = kFamStaged;
+                out.r_seed = out.r_b = shape.r;
+                return out;
+            }
+            case kFamDuoTeam: {
+                if (!c.duo_team || c.no_team || c.no_wide || mask.no_wide || mask.no_duo) break;
+                const StripPlan p = choose_wide_plan(n_max, m_max, cr::kDuoPublish, [&](const StripPlan& q) { return duo_team_fits(q, n_max, m_max, d_pad); });
+                if (!p.ra) break;
+                out.family = kFamDuoTeam;
+                out.r_seed = p.ra;
+                out.r_b = p.rb;
+                out.wide_na = p.na;
+                out.wide_sync = 8;
+                return out;
+            }
+            case kFamWide: {
+                if (c.no_team || c.no_wide || mask.no_wide) break;
+                const StripPlan p = choose_wide_plan(n_max, m_max, 8, [&](const StripPlan& q) { return wide_fits(q, n_max, m_max, d_pad); });
+                if (!p.ra) break;
+                out.family = kFamWide;
+                out.r_seed = p.ra;
+                out.r_b = p.rb;
+                out.wide_na = p.na;
+                out.wide_sync = 8;
+                return out;
+            }
+            case kFamTeam: {
+                if (c.no_team) break;
+                out.family = kFamTeam;
+                out.r_seed = out.r_b = (n_max + cr::kTeamWaves * cr::kWave - 1) / (cr::kTeamWaves * cr::kWave);
+                return out;
+            }
+            case kFamDuo: {
+                if (!c.mid || c.no_team || c.no_wide || mask.no_wide || mask.no_duo) break;
+                StripPlan p{3, 2, 1};
+                // up to 512 pairs of at most 320 rows: FOUR waves per pair (2 + 1 + 1 + 1 rows per lane: 2 048 waves still fit the
+                // chip at once) -- 508 pairs of 300: 0.50 / 0.33 ms against 0.54 / 0.40 with two waves
+                if (npairs <= 512 && n_max <= 5 * cr::kWave) p = StripPlan{2, 1, 1};
+                if (c.mid_plan.set) p = StripPlan{c.mid_plan.ra, c.mid_plan.rb, c.mid_plan.ra == c.mid_plan.rb ? 0 : c.mid_plan.na};
+                const int64_t strips = std::max(p.strips(std::max(n_max, 1)), 1);
+                // (every workgroup resident at once -- 16 waves per CU at <= 128 VGPRs --, and at most ~2.5 waves per SIMD for two
+                // strips, 3 for more: beyond that the single-wave kernels fill the SIMDs by themselves)
+                const int64_t mid_limit = c.mid_pairs >= 0 ? c.mid_pairs
+                                                           : std::min<int64_t>(256 * (16 / strips), (strips == 2 ? kMidWaveLimit2 : kMidWaveLimit) / strips);
+                if (npairs > mid_limit || !duo_fits(p, n_max, m_max, d_pad)) break;
+                out.family = kFamDuo;
+                out.r_seed = p.ra;
+                out.r_b = p.rb;
+                out.wide_na = p.na;
+                out.wide_sync = 8;
+                return out;
+            }
+            case kFamSingle: return out;
+        }
+    }
+    return out;
+}
+
+// the batch's layout flags from the chosen family (what the launch sequences of run_batch read)
+void apply_layout(cr_batch* b, const Layout& l) {
+    b->team = l.family == kFamTeam || l.family == kFamWide || l.family == kFamDuoTeam || l.family == kFamDuo || l.family == kFamStaged;
+    b->wide_sync = (l.family == kFamWide || l.family == kFamDuoTeam || l.family == kFamDuo) ? l.wide_sync : 0;
+    b->wide_na = b->wide_sync ? l.wide_na : 0;
+    b->duo = l.family == kFamDuo || l.family == kFamDuoTeam;
+    b->duo_team = l.family == kFamDuoTeam;
+    b->trio = l.family == kFamTrio;
+    b->trio_few = b->trio && l.trio_few;
+    b->staged = l.family == kFamStaged;
+    b->r_seed = b->r_align = l.r_seed;
+    b->r_b = b->wide_sync ? l.r_b : l.r_seed;
+}
+
+// Size class of a pair of n rows and m columns: A = one strip of the single-strip families (<= 320 rows), B = the row-split
+// families (<= 1 088 rows), C = everything else; the resident-column families need m <= 1 280.
+int size_class(int n, int m) {
+    if (m > kMidMaxColumns) return 2;
+    return n <= 5 * cr::kWave ? 0 : n <= 1088 ? 1 : 2;
+}
+
+// One pair list, one layout.  `global` (size classes): the caller's index of every pair of this list -- the order map then
+// leads from launch order straight to the caller's order.
+int set_pairs_one(cr_batch* b, const int32_t* pairs, int64_t npairs, const int32_t* global, const LayoutMask mask) {
+    int rc = CR_OK;
     b->npairs = npairs;
     b->ran = false;
     b->n_max = b->m_max = 0;
     for (int64_t p = 0; p < npairs; p++) {
-        int64_t i = pairs[2 * p], j = pairs[2 * p + 1];
-        CR_REQUIRE(i >= 0 && i < b->P && j >= 0 && j < b->P, "pair index out of range");
-        int n = (int)(b->offsets[i + 1] - b->offsets[i]), m = (int)(b->offsets[j + 1] - b->offsets[j]);
+        const int64_t i = pairs[2 * p], j = pairs[2 * p + 1];
+        const int n = (int)(b->offsets[i + 1] - b->offsets[i]), m = (int)(b->offsets[j + 1] - b->offsets[j]);
         b->n_max = std::max(b->n_max, n);
         b->m_max = std::max(b->m_max, m);
     }
-    b->r_seed = b->r_align = rows_per_lane(b->n_max);
-    // A pair list that cannot even give every CU one wave is latency bound: spread each pair over kTeamWaves waves.
-    // Measured (tools/calibrate_team_limit.py): with 300 rows the team kernels win up to ~250 pairs (0.66 vs 0.76 ms
-    // per pass) and lose from ~450 on; with 150 rows (three 64-row strips against one 192-row strip of the
-    // single-wave kernels) they never win.  Hence: at most 256 pairs, more than 192 rows.
-    int64_t team_limit = kTeamPairLimit;
-    if (const char* env = std::getenv("CARETTA_TEAM_PAIRS")) team_limit = std::atoll(env);   // calibration
-    // Lists of at most 320 rows go to the split by FUNCTION (cr_trio.h, below) from fewer pairs on than that: its time does not
-    // depend on the pair count while the chip is not full (0.345 ms at 300 rows, 0.235 at 220, 0.157 at 150) where the
-    // one-pair-per-CU layouts grow with it -- 300 rows: 120 pairs 0.326 (staged) / 0.343, 190 pairs 0.366 / 0.348, 253 pairs
-    // 0.417 (wide) / 0.346; 220 rows: 120 pairs 0.229 / 0.233, 253 pairs 0.269 / 0.236; 150 rows: 66 pairs 0.161 / 0.156, 253
-    // pairs 0.193 / 0.158 (C3_FEW=1 tools/c3_share.py).
-    const int trio_r = std::max(2, (b->n_max + cr::kWave - 1) / cr::kWave);
-    int64_t trio_limit = kTrioPairLimit, trio_from = trio_r >= 5 ? 160 : trio_r == 4 ? 110 : 64;
-    int trio_min_rows = kTrioMinRows;
-    if (const char* lim = std::getenv("CARETTA_TRIO_PAIRS")) trio_limit = std::atoll(lim);        // calibration
-    if (const char* lim = std::getenv("CARETTA_TRIO_FROM")) trio_from = std::atoll(lim);          // calibration
-    if (const char* lim = std::getenv("CARETTA_TRIO_MIN_ROWS")) trio_min_rows = std::atoi(lim);   // calibration
-    const char* trio_env = std::getenv("CARETTA_TRIO");
-    const bool trio_shape = !(trio_env && trio_env[0] == '0') && !g_no_wide && !g_no_trio && !std::getenv("CARETTA_NO_TEAM") && b->n_max > trio_min_rows &&
-                            b->n_max <= 5 * cr::kWave && b->m_max <= kMidMaxColumns && b->d_pad <= 10 && npairs > trio_from && npairs <= trio_limit;
-    if (trio_shape) team_limit = std::min(team_limit, trio_from);
-    const bool few = npairs > 0 && npairs <= team_limit && !std::getenv("CARETTA_NO_TEAM");
-    b->team = few && b->n_max > 3 * cr::kWave && b->n_max <= 5 * cr::kTeamWaves * cr::kWave;
-    if (b->team) b->r_seed = b->r_align = (b->n_max + cr::kTeamWaves * cr::kWave - 1) / (cr::kTeamWaves * cr::kWave);
-    // The wide layout (one workgroup per pair: one wave per strip of 2 or 3 rows per lane, up to 16 waves, a barrier every
-    // 8 steps, both stages in one launch, the sums behind the walks taken by the whole workgroup) beats the four-wave
-    // teams wherever those apply.  Measured (tools/calibrate_wide.py, round 3): 252 pairs of 1200 (one GPU's share of
-    // BASELINE config 5 on 8 GPUs) 2.74 -> 2.18 ms, 120 pairs of 600 0.96 -> 0.93, 66 pairs of 300 0.411 -> 0.391, one pair
-    // of 300 0.394 -> 0.379.
-    b->wide_sync = 0;
-    b->wide_na = 0;
-    // (also beyond the 1280 rows the four-wave teams reach: 105 pairs of 1500 take 13.5 ms one wave per pair, 3.3 ms wide)
-    if (few && b->n_max > 3 * cr::kWave && !g_no_wide && !std::getenv("CARETTA_NO_WIDE")) {
-        const StripPlan p = choose_wide_plan(b->n_max, b->m_max, b->d_pad, 8);
-        if (p.ra) {
-            b->team = true;                                         // same layout rules as the team kernels: one group, one plan
-            b->wide_sync = 8;
-            b->r_seed = b->r_align = p.ra;
-            b->r_b = p.rb;
-            b->wide_na = p.na;
-        }
-    }
-    if (const char* env = std::getenv("CARETTA_WIDE")) {           // calibration: "RA,RB,nA,B" forces the wide kernels with this plan
-        int ra = 0, rb = 0, na = 0, sync = 0;
-        if (std::sscanf(env, "%d,%d,%d,%d", &ra, &rb, &na, &sync) == 4 && npairs > 0 && sync >= 1 && sync <= cr::kWideMaxSync && !g_no_wide &&
-            na >= 0 && na < cr::kWideMaxWaves && wide_fits(StripPlan{ra, rb, ra == rb ? 0 : na}, b->n_max, b->m_max, b->d_pad)) {
-            b->team = true;                                         // same layout rules as the team kernels: one group, one plan
-            b->wide_sync = sync;
-            b->r_seed = b->r_align = ra;
-            b->r_b = rb;
-            b->wide_na = ra == rb ? 0 : na;
-        }
-    }
-    // Mid-size lists (one GPU's share of the headline configuration on 8 GPUs: 1 016 pairs of 300 x 300): too many pairs for
-    // one pair per CU, too few to give every SIMD two single-wave pairs -- a lone wave issues one FP64-rate instruction per
-    // ~7 cycles.  A pair becomes a small workgroup: 3 rows per lane in strip 0, 2 in the strips behind it (320 rows = two
-    // waves), paced by LDS progress words (cr_duo.h), several pairs per CU, all of them resident at once.  Measured
-    // (tools/c3_share.py, single wave -> this layout, full pipeline / matrix entries only, ms): 1 016 pairs of 300 0.69 -> 0.60 /
-    // 0.51 -> 0.43, 508 of 300 0.69 -> 0.55 / 0.51 -> 0.40, 1 162 of 300 0.92 -> 0.76, 1 355 of 300 0.94 -> 0.95 (the limit for two
-    // strips); three strips: 1 016 of 360 0.99 -> 0.89, of 450 1.51 -> 1.28, 508 of 450 1.50 -> 0.87; five strips: 508 of 600
-    // 2.49 -> 1.37, 1 016 of 600 2.45 -> 3.49 (5 080 waves do not fit the chip at once); 220 rows (one wave of 4 rows per lane
-    // suffices) 0.45 -> 0.47: from 257 rows on.
-    // ... and up to 320 rows (ONE strip of two to five rows per lane) the split is by FUNCTION instead (cr_trio.h): one wave runs
-    // the recurrences of all rows, two or three waves form the scores.  Single-wave layout, all workgroups resident at once.
-    // Single wave -> this layout (C3_TRIO=1 tools/c3_share.py, full pipeline, ms): 496 pairs of 150 (BASELINE config 2) 0.232 ->
-    // 0.165, 1 035 of 150 0.335 -> 0.255, 496 of 220 0.412 -> 0.255, 1 035 of 220 0.571 -> 0.500, 496 of 100 0.148 -> 0.115, 780 of
-    // 100 0.149 -> 0.122; 1 540 of 150 0.355 -> 0.355 (the limit stays 1 300 pairs).
-    b->trio = b->trio_few = false;
-    if (trio_shape && !b->wide_sync && !b->team) {
-        b->trio = true;
-        b->r_seed = b->r_align = trio_r;                             // one strip of 2 .. 5 rows per lane
-        b->trio_few = npairs <= kTeamPairLimit;
-        if (b->trio_few) b->duo_ij.assign(pairs, pairs + 2 * npairs);   // (sw_gap != 0 at run time: the list is laid out again)
-    }
-    b->duo = false;
-    {
-        const char* mid = std::getenv("CARETTA_MID");
-        StripPlan p{3, 2, 1};
-        // up to 512 pairs of at most 320 rows: FOUR waves per pair (2 + 1 + 1 + 1 rows per lane: 2 048 waves still fit the chip
-        // at once) -- 508 pairs of 300: 0.50 / 0.33 ms against 0.54 / 0.40 with two waves; from 581 pairs on two waves win the
-        // full pipeline again (profiles/r04/c3_share.txt, c3_share_plans.txt)
-        if (npairs <= 512 && b->n_max <= 5 * cr::kWave) p = StripPlan{2, 1, 1};
-        if (const char* env = std::getenv("CARETTA_MID_PLAN")) {                                  // calibration: "RA,RB,nA"
-            int ra = 0, rb = 0, na = 0;
-            if (std::sscanf(env, "%d,%d,%d", &ra, &rb, &na) == 3) p = StripPlan{ra, rb, ra == rb ? 0 : na};
-        }
-        const int64_t strips = std::max(p.strips(std::max(b->n_max, 1)), 1);
-        // (every workgroup resident at once -- 16 waves per CU at <= 128 VGPRs --, and at most ~2.5 waves per SIMD for two
-        // strips, 3 for more: beyond that the single-wave kernels fill the SIMDs by themselves)
-        int64_t mid_limit = std::min<int64_t>(256 * (16 / strips), (strips == 2 ? kMidWaveLimit2 : kMidWaveLimit) / strips);
-        if (const char* env = std::getenv("CARETTA_MID_PAIRS")) mid_limit = std::atoll(env);      // calibration
-        if (!b->trio && !b->wide_sync && !b->team && npairs > team_limit && npairs <= mid_limit && !(mid && mid[0] == '0') && !g_no_wide && !g_no_duo &&
-            !std::getenv("CARETTA_NO_TEAM") && !std::getenv("CARETTA_NO_WIDE") && (b->n_max > 4 * cr::kWave || std::getenv("CARETTA_MID_ANY")) &&
-            b->m_max <= kMidMaxColumns && duo_fits(p, b->n_max, b->m_max, b->d_pad)) {
-            b->team = true;                                         // the wide layout: one group, one plan
-            b->duo = true;
-            b->wide_sync = 8;
-            b->r_seed = b->r_align = p.ra;
-            b->r_b = p.rb;
-            b->wide_na = p.na;
-            b->duo_ij.assign(pairs, pairs + 2 * npairs);            // (sw_gap != 0 at run time: the list is laid out again)
-        }
-    }
-    // Lists so short that one wave per 64-row strip still leaves SIMDs idle (a single pair, 66 pairs of 300, 248 pairs of
-    // 150) are bound by the instruction issue of lone waves, most of it the RBF scores: those are formed by their own
-    // launches on every CU and the sweeps keep the recurrence, one row per lane (cr_staged.h).  Measured
-    // (tools/calibrate_staged.py, full pipeline, fused -> staged): one pair of 300 0.382 -> 0.253 ms, 66 pairs of 300
-    // 0.395 -> 0.299, 248 pairs of 150 0.218 -> 0.191, 120 pairs of 450 0.614 -> 0.529; with two rows per lane (513 .. 1024
-    // rows, against the wide layout): 28 pairs of 1000 1.62 -> 1.11, 28 of 750 1.18 -> 0.78, 120 of 750 1.22 -> 1.05, 120 of
-    // 900 1.52 -> 1.41; three / four rows per lane: 28 pairs of 1500 2.98 -> 2.20, 105 of 1500 3.01 -> 2.92, 6 of 2000 (no
-    // wide plan: one wave per pair) 21.5 -> 2.85; 496 pairs of 150 (1 488 strips for 1 024 SIMDs) 0.232 -> 0.275: hence at
-    // most kStagedWaveLimit strips.
-    b->staged = false;
-    {
-        const char* env = std::getenv("CARETTA_STAGED");
-        int64_t wave_limit = kStagedWaveLimit;
-        if (const char* lim = std::getenv("CARETTA_STAGED_WAVES")) wave_limit = std::atoll(lim);   // calibration
-        const cr::StagedShape shape = staged_shape(std::max(b->n_max, 1), std::max(b->m_max, 1));
-        const int64_t strips1 = shape.waves;
-        int row_limit = cr::kStagedMaxRows;                        // one row per lane up to 512 rows ... four up to 2048
-        if (const char* lim = std::getenv("CARETTA_STAGED_ROWS")) row_limit = std::min(std::atoi(lim), cr::kStagedMaxRows);   // calibration
-        // (lists the split by function takes -- more than 256 pairs of at most 320 rows -- stay there: 496 pairs of 100 rows 0.190
-        // staged against 0.115 ms, 300 of 150 0.226 / 0.168, 300 of 190 0.266 / 0.206, 378 of 128 0.191 / 0.138; tools/c3_share.py)
-        if (npairs > 0 && !b->trio && !g_no_wide && !(env && env[0] == '0') && !std::getenv("CARETTA_NO_TEAM") && !std::getenv("CARETTA_WIDE") &&
-            !std::getenv("CARETTA_NO_WIDE") && b->n_max <= row_limit && npairs * strips1 <= wave_limit &&
-            (double)npairs * (double)shape.pair_doubles() * sizeof(double) <= 2.0 * 1024 * 1024 * 1024 &&
-            // (the alignment columns of a pair and the term tile of the workgroup-wide sums share the LDS)
-            sizeof(double) * ((size_t)cr::kExpDoubles + cr::trace_team_lds_doubles(b->n_max + b->m_max)) <= 159 * 1024) {
-            b->staged = true;
-            b->duo = false;
-            b->trio = false;
-            b->team = true;                                         // one group, one plan: the team kernels' layout rules
-            b->wide_sync = 0;
-            b->wide_na = 0;
-            b->r_seed = b->r_align = shape.r;
-        }
-    }
-    if (!b->wide_sync) b->r_b = b->r_seed;
+    apply_layout(b, choose_layout(b->n_max, b->m_max, b->d_pad, npairs, mask));
+    // (a duo or few-pair trio list is laid out again when a run comes with a Smith-Waterman gap: keep the list)
+    b->duo_ij.clear();
+    if (b->duo || b->trio_few) b->duo_ij.assign(pairs, pairs + 2 * npairs);
     // scratch budget per chunk (decision words); CARETTA_SCRATCH_MB overrides the 8 GiB default
     int64_t budget_words = (int64_t)8192 * 1024 * 1024 / 4;
-    if (const char* env = std::getenv("CARETTA_SCRATCH_MB")) {
-        const long long mb = std::atoll(env);
-        if (mb > 0) budget_words = (int64_t)mb * 1024 * 1024 / 4;
-    }
+    if (g_cfg.scratch_mb > 0) budget_words = (int64_t)g_cfg.scratch_mb * 1024 * 1024 / 4;
     // Structures of equal length (every BASELINE configuration): nothing to sort, every pair has the same footprint, and the
     // descriptors are built on the device from the (i, j) list (k_make_pairs_uniform) -- at 130 816 pairs the host side of
     // this call drops from 3.2 to under 1 ms.
-    bool equal_lengths = npairs > 0;
+    bool equal_lengths = npairs > 0 && !global;
     for (int64_t s = 1; s < b->P && equal_lengths; s++)
         equal_lengths = b->offsets[(size_t)s + 1] - b->offsets[(size_t)s] == b->offsets[1] - b->offsets[0];
     if (equal_lengths) {
@@ -1369,7 +1481,7 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     std::vector<int64_t> cost_of((size_t)npairs);               // sort keys, computed once per pair
     std::vector<int8_t> group_of((size_t)npairs);
     {
-        std::vector<int8_t> r_of_len;                             // rows_per_lane by row count (it reads the environment)
+        std::vector<int8_t> r_of_len;                             // rows_per_lane by row count
         for (int64_t p = 0; p < npairs; p++) {
             const int64_t i = pairs[2 * p], j = pairs[2 * p + 1];
             const int64_t n = b->offsets[i + 1] - b->offsets[i], m = b->offsets[j + 1] - b->offsets[j];
@@ -1382,11 +1494,11 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     auto cost = [&](int32_t p) { return cost_of[(size_t)p]; };
     // Pairs are also grouped by the rows per lane that suit their row count (one launch pair per group, long rows
     // first): a 90-residue structure in a 5-rows-per-lane kernel would use 18 of 64 lanes.
-    const bool team_batch = b->team || b->trio;       // (trio: the single-wave layout, but ONE group of five rows per lane)
+    const bool team_batch = b->team || b->trio;       // (trio: the single-wave layout, but ONE group of R rows per lane)
     const int team_r = b->r_seed;
     auto group = [&](int32_t p) { return team_batch ? team_r : (int)group_of[(size_t)p]; };
-    const bool grouped = !std::getenv("CARETTA_KEEP_ORDER");
-    bool uniform = true;                             // equal keys everywhere (all BASELINE configs): nothing to sort
+    const bool grouped = !g_cfg.keep_order;
+    bool uniform = true;                             // equal keys everywhere: nothing to sort
     for (int64_t p = 1; p < npairs && uniform; p++)
         uniform = cost_of[(size_t)p] == cost_of[0] && group_of[(size_t)p] == group_of[0];
     if (grouped && !uniform)                         // (CARETTA_KEEP_ORDER, for measurements: one group, the caller's order)
@@ -1394,12 +1506,9 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
             const int ga = group(a), gc = group(c);
             return ga != gc ? ga > gc : cost(a) > cost(c);
         });
-    b->reordered = false;
-    for (int64_t k = 0; k < npairs; k++)
-        if (b->order[(size_t)k] != k) {
-            b->reordered = true;
-            break;
-        }
+    b->reordered = global != nullptr;
+    for (int64_t k = 0; k < npairs && !b->reordered; k++)
+        if (b->order[(size_t)k] != k) b->reordered = true;
     int64_t dirs_off = 0, bt_off = 0, aln_off = 0, max_aln = 0, dirs_max = 0, bits_max = 0, hand_off = 0, hand_max = 0;
     // Each group owns a region of the decision scratch (its chunks run in order on the group's stream and reuse the
     // region; different groups run side by side); the budget is shared equally between the groups.
@@ -1474,6 +1583,8 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     b->aln_elems = aln_off;
     b->alg_bytes = bytes;
     b->cells = cells;
+    if (global)                                                 // launch order -> the CALLER's pair index
+        for (int64_t k = 0; k < npairs; k++) b->order[(size_t)k] = global[b->order[(size_t)k]];
     hipError_t e = b->pairs.ensure((size_t)npairs);
     if (e == hipSuccess) e = b->dirs.ensure((size_t)dirs_max);
     if (e == hipSuccess) e = b->bits.ensure((size_t)bits_max);
@@ -1497,57 +1608,174 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     return CR_OK;
 }
 
-static int run_batch(cr_batch* b, const cr_params* params, double* d_sw_out, bool scores_only) {
-    CR_REQUIRE(b != nullptr && params != nullptr, "null argument");
-    int rc = set_device(b->ctx);
-    if (rc) return rc;
-    if (b->npairs == 0) {
-        b->ran = true;
-        return CR_OK;
-    }
-    cr_context* ctx = b->ctx;
-    const cr_params prm = *params;
-    CR_REQUIRE(gamma_ok(prm.gamma_tensor) && gamma_ok(prm.gamma_coords),
-               "gamma_tensor and gamma_coords must be finite and >= 1e-290 (below that every score is exactly 1.0)");
-    CR_REQUIRE(std::isfinite(prm.gap_open) && std::isfinite(prm.gap_extend) && std::isfinite(prm.sw_gap),
-               "gap penalties must be finite");
-    if ((b->duo || (b->trio && b->trio_few)) && prm.sw_gap != 0.0) {   // k_pair_duo / k_pair_trio are gap-0 pipelines: lay the list out without them
-        const std::vector<int32_t> ij = std::move(b->duo_ij);
-        g_no_duo = g_no_trio = true;
-        rc = cr_batch_set_pairs(b, ij.data(), (int64_t)(ij.size() / 2));
-        g_no_duo = g_no_trio = false;
+// a size class of `parent`'s list as a batch of its own on the parent's structures
+cr_batch* make_part(cr_batch* parent, int index) {
+    cr_batch* c = new (std::nothrow) cr_batch();
+    if (!c) return nullptr;
+    c->ctx = parent->ctx;
+    c->P = parent->P;
+    c->d = parent->d;
+    c->d_pad = parent->d_pad;
+    c->total = parent->total;
+    c->offsets = parent->offsets;
+    c->coords.borrow(parent->coords);
+    c->tensors.borrow(parent->tensors);
+    c->d_offsets.borrow(parent->d_offsets);
+    c->is_part = true;
+    c->base_lane = index;
+    return c;
+}
+
+void drop_parts(cr_batch* b) {
+    for (cr_batch* c : b->parts) delete c;
+    b->parts.clear();
+}
+
+// the batches that hold pair lists: the size classes of a split list, else the batch itself
+template <class F>
+int for_each_part(cr_batch* b, F&& f) {
+    if (b->parts.empty()) return f(b);
+    for (cr_batch* c : b->parts) {
+        const int rc = f(c);
         if (rc) return rc;
     }
-    const bool prof = ctx->slots > 0;
-    std::vector<hipEvent_t>* evl = nullptr;
-    if (prof) {                                                   // three events per chunk: start, seed done, align done
-        evl = &ctx->ev[(size_t)(ctx->runs_recorded % ctx->slots)];
-        const size_t need = 3 * b->chunks.size();
-        while (evl->size() < need) {
-            hipEvent_t e;
-            CR_HIP(hipEventCreate(&e));
-            evl->push_back(e);
-        }
+    return CR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cr_config_reload(void) {
+    g_cfg = crcfg::Calibration::from_env();
+    return CR_OK;
+}
+
+int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
+    CR_REQUIRE(b != nullptr, "null batch");
+    int rc = set_device(b->ctx);
+    if (rc) return rc;
+    CR_REQUIRE(npairs >= 0 && (npairs == 0 || pairs != nullptr), "bad pair list");
+    CR_REQUIRE(npairs < (int64_t)std::numeric_limits<int32_t>::max(), "too many pairs for one batch");
+    const LayoutMask mask{g_no_wide, g_no_trio, g_no_duo};
+    // (parts of an earlier list may still be running: the blocks they give back wait for the device, DevBuf::release)
+    drop_parts(b);
+    int n_max = 0, m_max = 0;
+    int64_t in_class[3] = {0, 0, 0};
+    int cn[3] = {0, 0, 0}, cm[3] = {0, 0, 0};
+    for (int64_t p = 0; p < npairs; p++) {
+        const int64_t i = pairs[2 * p], j = pairs[2 * p + 1];
+        CR_REQUIRE(i >= 0 && i < b->P && j >= 0 && j < b->P, "pair index out of range");
+        const int n = (int)(b->offsets[i + 1] - b->offsets[i]), m = (int)(b->offsets[j + 1] - b->offsets[j]);
+        n_max = std::max(n_max, n);
+        m_max = std::max(m_max, m);
+        const int c = size_class(n, m);
+        in_class[c]++;
+        cn[c] = std::max(cn[c], n);
+        cm[c] = std::max(cm[c], m);
     }
-    int lanes_used = 1;
-    for (const cr_batch::Chunk& ck : b->chunks) lanes_used = std::max(lanes_used, ck.lane + 1);
-    if (lanes_used > 1) {                                         // fork: the side streams start after the work queued so far
-        while ((int)ctx->side.size() < lanes_used - 1) {
-            hipStream_t st;
-            CR_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-            ctx->side.push_back(st);
+    // Size classes.  The layout of a list follows from its LONGEST structure, so one 600-residue member moves a family of
+    // 150-residue structures to another kernel family (or out of every family built for its size).  A ragged list of at
+    // most kClassSplitPairs pairs -- more fill the chip one wave per pair, which groups by rows per lane already -- is
+    // therefore split into at most three classes by rows (<= 320 / <= 1 088 / longer, or more than 1 280 columns), each
+    // laid out as a list of its own -- when that gives any class another family than one wave per pair.
+    const int nclasses = (in_class[0] > 0) + (in_class[1] > 0) + (in_class[2] > 0);
+    bool split = false;
+    if (g_cfg.classes && nclasses >= 2 && npairs <= kClassSplitPairs && !b->is_part) {
+        const Family whole = choose_layout(n_max, m_max, b->d_pad, npairs, mask).family;
+        bool all_same = true, any_special = false;
+        for (int c = 0; c < 3; c++) {
+            if (!in_class[c]) continue;
+            const Family f = choose_layout(cn[c], cm[c], b->d_pad, in_class[c], mask).family;
+            all_same = all_same && f == whole;
+            any_special = any_special || f != kFamSingle;
         }
-        while ((int)ctx->sync_ev.size() < lanes_used) {
-            hipEvent_t e;
-            CR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            ctx->sync_ev.push_back(e);
-        }
-        CR_HIP(hipEventRecord(ctx->sync_ev[0], ctx->stream));
-        for (int k = 1; k < lanes_used; k++) CR_HIP(hipStreamWaitEvent(ctx->side[(size_t)k - 1], ctx->sync_ev[0], 0));
+        split = any_special && !all_same;
     }
-    size_t evi = 0;
+    if (!split) return set_pairs_one(b, pairs, npairs, nullptr, mask);
+    // the parent keeps the totals; every class is a batch of its own
+    b->npairs = npairs;
+    b->ran = false;
+    b->n_max = n_max;
+    b->m_max = m_max;
+    b->chunks.clear();
+    b->h_pairs.clear();
+    b->order.clear();
+    b->reordered = false;
+    b->team = b->duo = b->duo_team = b->trio = b->trio_few = b->staged = false;
+    b->wide_sync = b->wide_na = 0;
+    b->max_aln = 0;
+    b->aln_elems = 0;
+    b->alg_bytes = b->cells = 0.0;
+    std::vector<int32_t> list, global;
+    for (int c = 0; c < 3; c++) {
+        if (!in_class[c]) continue;
+        list.clear();
+        global.clear();
+        for (int64_t p = 0; p < npairs; p++) {
+            const int64_t i = pairs[2 * p], j = pairs[2 * p + 1];
+            if (size_class((int)(b->offsets[i + 1] - b->offsets[i]), (int)(b->offsets[j + 1] - b->offsets[j])) != c) continue;
+            list.push_back((int32_t)i);
+            list.push_back((int32_t)j);
+            global.push_back((int32_t)p);
+        }
+        cr_batch* part = make_part(b, (int)b->parts.size());
+        if (!part) return fail(CR_ERR_MEMORY, "out of host memory");
+        b->parts.push_back(part);
+        part->part_global = global;
+        if ((rc = set_pairs_one(part, list.data(), (int64_t)global.size(), part->part_global.data(), mask))) return rc;
+        b->max_aln = std::max(b->max_aln, part->max_aln);
+        b->aln_elems += part->aln_elems;
+        b->alg_bytes += part->alg_bytes;
+        b->cells += part->cells;
+        // (the uploads of `list` are in flight at most until the stream's next wait; small lists are copied by the runtime
+        // before hipMemcpyAsync returns, large ones went through the context's ring)
+    }
+    return CR_OK;
+}
+
+// k_pair_duo / k_pair_trio are gap-0 pipelines: a Smith-Waterman gap lays a duo or few-pair trio list out again without them.
+// The re-layout may change the launch order (and so `reordered` / d_order): callers that hand the kernels an order map
+// (cr_batch_run_stream_i32) call this BEFORE they build it.  The list it is made from stays with the batch -- set_pairs
+// returns with its upload possibly still in flight.
+static int relayout_for_gap(cr_batch* b, const cr_params& prm) {
+    if (!((b->duo || (b->trio && b->trio_few)) && prm.sw_gap != 0.0)) return CR_OK;
+    b->relaid_ij = std::move(b->duo_ij);
+    b->duo_ij.clear();
+    LayoutMask mask{g_no_wide, true, true};
+    if (!b->is_part) {
+        g_no_duo = g_no_trio = true;
+        const int rc = cr_batch_set_pairs(b, b->relaid_ij.data(), (int64_t)(b->relaid_ij.size() / 2));
+        g_no_duo = g_no_trio = false;
+        return rc;
+    }
+    // a size class: the same pairs with the same caller indices, another family
+    return set_pairs_one(b, b->relaid_ij.data(), b->npairs, b->part_global.data(), mask);
+}
+
+// the context's stream number k: 0 = its own, k > 0 = side stream k - 1 (created on first use)
+static int lane_stream(cr_context* ctx, int k, hipStream_t* out) {
+    if (k == 0) {
+        *out = ctx->stream;
+        return CR_OK;
+    }
+    while ((int)ctx->side.size() < k) {
+        hipStream_t st;
+        CR_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        ctx->side.push_back(st);
+    }
+    *out = ctx->side[(size_t)k - 1];
+    return CR_OK;
+}
+
+// the launch sequence of ONE pair list (a batch without size classes, or one class); `evl` / `evi`: profiling events
+static int run_part(cr_batch* b, const cr_params& prm, bool scores_only, std::vector<hipEvent_t>* evl, size_t& evi) {
+    cr_context* ctx = b->ctx;
+    const bool prof = evl != nullptr;
+    int rc = CR_OK;
     for (const cr_batch::Chunk& ck : b->chunks) {
-        hipStream_t st = ck.lane == 0 ? ctx->stream : ctx->side[(size_t)ck.lane - 1];
+        hipStream_t st = nullptr;
+        if ((rc = lane_stream(ctx, (b->base_lane + ck.lane) % kGroupLanes, &st))) return rc;
         b->launch_stream = st;
         if (prof) (void)hipEventRecord((*evl)[evi++], st);
         if (b->staged) {
@@ -1576,8 +1804,8 @@ static int run_batch(cr_batch* b, const cr_params* params, double* d_sw_out, boo
             continue;
         }
         if (b->wide_sync) {
-            // the wide layout: both stages of a pair in ONE launch (k_pair_wide) -- the stage split of the events is
-            // (everything, 0)
+            // the wide layout: both stages of a pair in ONE launch (k_pair_wide / k_pair_duo) -- the stage split of the
+            // events is (everything, 0)
             rc = b->duo ? launch_pair_duo(b, ck, prm, scores_only) : launch_pair_wide(b, ck, prm, scores_only && prm.sw_gap == 0.0);
             if (!rc && prof) {
                 (void)hipEventRecord((*evl)[evi++], st);
@@ -1599,19 +1827,127 @@ static int run_batch(cr_batch* b, const cr_params* params, double* d_sw_out, boo
         b->launch_stream = nullptr;
         if (rc) return rc;
     }
-    for (int k = 1; k < lanes_used; k++) {                         // join
+    return CR_OK;
+}
+
+// the streams a run of `b` uses beside the context's own (row-per-lane groups and size classes run side by side)
+static int lanes_of(cr_batch* b) {
+    int lanes = 1;
+    (void)for_each_part(b, [&](cr_batch* c) {
+        for (const cr_batch::Chunk& ck : c->chunks) lanes = std::max(lanes, (c->base_lane + ck.lane) % kGroupLanes + 1);
+        return CR_OK;
+    });
+    return lanes;
+}
+
+static int fork_lanes(cr_context* ctx, int lanes_used) {
+    if (lanes_used <= 1) return CR_OK;                            // fork: the side streams start after the work queued so far
+    hipStream_t st;
+    int rc = lane_stream(ctx, lanes_used - 1, &st);
+    if (rc) return rc;
+    while ((int)ctx->sync_ev.size() < lanes_used) {
+        hipEvent_t e;
+        CR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->sync_ev.push_back(e);
+    }
+    CR_HIP(hipEventRecord(ctx->sync_ev[0], ctx->stream));
+    for (int k = 1; k < lanes_used; k++) CR_HIP(hipStreamWaitEvent(ctx->side[(size_t)k - 1], ctx->sync_ev[0], 0));
+    return CR_OK;
+}
+
+static int join_lanes(cr_context* ctx, int lanes_used) {
+    for (int k = 1; k < lanes_used; k++) {
         CR_HIP(hipEventRecord(ctx->sync_ev[(size_t)k], ctx->side[(size_t)k - 1]));
         CR_HIP(hipStreamWaitEvent(ctx->stream, ctx->sync_ev[(size_t)k], 0));
     }
-    if (d_sw_out && b->reordered) {
-        CR_LAUNCH(cr::k_scatter_sw, dim3((unsigned)((b->npairs + 255) / 256)), dim3(256), 0, ctx->stream, b->res.p,
-                           b->d_order.p, d_sw_out, (int)b->npairs);
-        CR_HIP(hipGetLastError());
-    } else if (d_sw_out) {
-        // strided device-to-device copy of the first field of every PairResult
-        CR_HIP(hipMemcpy2DAsync(d_sw_out, sizeof(double), b->res.p, sizeof(cr::PairResult), sizeof(double),
-                                (size_t)b->npairs, hipMemcpyDeviceToDevice, ctx->stream));
+    return CR_OK;
+}
+
+// res[k].sw of every pair list of `b` into d_sw_out in the caller's pair order (on the context's stream)
+static int scores_to_device(cr_batch* b, double* d_sw_out) {
+    cr_context* ctx = b->ctx;
+    return for_each_part(b, [&](cr_batch* c) -> int {
+        if (!c->npairs) return CR_OK;
+        if (c->reordered) {
+            CR_LAUNCH(cr::k_scatter_sw, dim3((unsigned)((c->npairs + 255) / 256)), dim3(256), 0, ctx->stream, c->res.p, c->d_order.p, d_sw_out,
+                      (int)c->npairs);
+            CR_HIP(hipGetLastError());
+        } else {
+            // strided device-to-device copy of the first field of every PairResult
+            CR_HIP(hipMemcpy2DAsync(d_sw_out, sizeof(double), c->res.p, sizeof(cr::PairResult), sizeof(double), (size_t)c->npairs,
+                                    hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        return CR_OK;
+    });
+}
+
+// ... and the flags (cr_multi.h gathers both)
+static int flags_to_device(cr_batch* b, uint32_t* d_flags_out) {
+    cr_context* ctx = b->ctx;
+    return for_each_part(b, [&](cr_batch* c) -> int {
+        if (!c->npairs) return CR_OK;
+        if (c->reordered) {
+            CR_LAUNCH(cr::k_scatter_flags, dim3((unsigned)((c->npairs + 255) / 256)), dim3(256), 0, ctx->stream, c->res.p, c->d_order.p, d_flags_out,
+                      (int)c->npairs);
+            CR_HIP(hipGetLastError());
+        } else {
+            CR_HIP(hipMemcpy2DAsync(d_flags_out, sizeof(uint32_t), reinterpret_cast<const char*>(c->res.p) + offsetof(cr_pair_result, flags),
+                                    sizeof(cr::PairResult), sizeof(uint32_t), (size_t)c->npairs, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        return CR_OK;
+    });
+}
+
+// `host` (cr_batch_run_stream_i32): page-locked arrays the alignment kernels write into; every list gets them with ITS order map
+static int run_batch(cr_batch* b, const cr_params* params, double* d_sw_out, bool scores_only, const cr::HostOut* host = nullptr) {
+    CR_REQUIRE(b != nullptr && params != nullptr, "null argument");
+    int rc = set_device(b->ctx);
+    if (rc) return rc;
+    if (b->npairs == 0) {
+        b->ran = true;
+        return CR_OK;
     }
+    cr_context* ctx = b->ctx;
+    const cr_params prm = *params;
+    CR_REQUIRE(gamma_ok(prm.gamma_tensor) && gamma_ok(prm.gamma_coords),
+               "gamma_tensor and gamma_coords must be finite and >= 1e-290 (below that every score is exactly 1.0)");
+    CR_REQUIRE(std::isfinite(prm.gap_open) && std::isfinite(prm.gap_extend) && std::isfinite(prm.sw_gap),
+               "gap penalties must be finite");
+    // (before any order map is handed to a kernel)
+    if ((rc = for_each_part(b, [&](cr_batch* c) { return relayout_for_gap(c, prm); }))) return rc;
+    const bool prof = ctx->slots > 0;
+    std::vector<hipEvent_t>* evl = nullptr;
+    if (prof) {                                                   // three events per chunk: start, seed done, align done
+        evl = &ctx->ev[(size_t)(ctx->runs_recorded % ctx->slots)];
+        size_t need = 0;
+        (void)for_each_part(b, [&](cr_batch* c) {
+            need += 3 * c->chunks.size();
+            return CR_OK;
+        });
+        while (evl->size() < need) {
+            hipEvent_t e;
+            CR_HIP(hipEventCreate(&e));
+            evl->push_back(e);
+        }
+    }
+    const int lanes_used = lanes_of(b);
+    if ((rc = fork_lanes(ctx, lanes_used))) return rc;
+    size_t evi = 0;
+    rc = for_each_part(b, [&](cr_batch* c) -> int {
+        if (host) {
+            cr::HostOut h = *host;
+            h.order = c->reordered ? c->d_order.p : nullptr;
+            c->host_out = h;
+        }
+        const int r = run_part(c, prm, scores_only, evl, evi);
+        c->host_out = cr::HostOut{};
+        c->ran = r == CR_OK;
+        c->scores_only = scores_only && prm.sw_gap == 0.0;
+        return r;
+    });
+    if (rc) return rc;
+    if ((rc = join_lanes(ctx, lanes_used))) return rc;
+    if (d_sw_out && (rc = scores_to_device(b, d_sw_out))) return rc;
     if (prof) ctx->runs_recorded++;
     b->ran = true;
     b->scores_only = scores_only && prm.sw_gap == 0.0;
@@ -1633,11 +1969,8 @@ int cr_batch_run_stream_i32(cr_batch* b, const cr_params* params, cr_pair_result
     if (results) CR_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h.res), results, 0));
     if (aln) CR_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h.aln), aln, 0));
     h.stride = aln_stride;
-    h.order = b->reordered ? b->d_order.p : nullptr;
-    b->host_out = h;
-    rc = run_batch(b, params, d_sw_out, false);
-    b->host_out = cr::HostOut{};
-    return rc;
+    // (the order map of every pair list is filled in by run_batch, behind a gap-driven re-layout)
+    return run_batch(b, params, d_sw_out, false, &h);
 }
 
 int cr_batch_run_scores(cr_batch* b, const cr_params* params, double* d_sw_out) { return run_batch(b, params, d_sw_out, true); }
@@ -1648,20 +1981,19 @@ int cr_batch_run_tensor_scores(cr_batch* b, const cr_params* params, double* d_s
     if (rc) return rc;
     CR_REQUIRE(gamma_ok(params->gamma_tensor), "gamma_tensor must be finite and >= 1e-290 (below that every score is exactly 1.0)");
     cr_context* ctx = b->ctx;
-    for (const cr_batch::Chunk& ck : b->chunks) {                  // (one stream: a single light launch per chunk)
-        b->launch_stream = ctx->stream;
-        rc = launch_tensor_score_r(ck.r, b, ck, *params);
-        b->launch_stream = nullptr;
-        if (rc) return rc;
-    }
-    if (b->npairs && d_sw_out && b->reordered) {
-        CR_LAUNCH(cr::k_scatter_sw, dim3((unsigned)((b->npairs + 255) / 256)), dim3(256), 0, ctx->stream, b->res.p, b->d_order.p, d_sw_out,
-                  (int)b->npairs);
-        CR_HIP(hipGetLastError());
-    } else if (b->npairs && d_sw_out) {
-        CR_HIP(hipMemcpy2DAsync(d_sw_out, sizeof(double), b->res.p, sizeof(cr::PairResult), sizeof(double), (size_t)b->npairs,
-                                hipMemcpyDeviceToDevice, ctx->stream));
-    }
+    rc = for_each_part(b, [&](cr_batch* c) -> int {
+        for (const cr_batch::Chunk& ck : c->chunks) {              // (one stream: a single light launch per chunk)
+            c->launch_stream = ctx->stream;
+            const int r = launch_tensor_score_r(ck.r, c, ck, *params);
+            c->launch_stream = nullptr;
+            if (r) return r;
+        }
+        c->ran = true;
+        c->scores_only = true;
+        return CR_OK;
+    });
+    if (rc) return rc;
+    if (b->npairs && d_sw_out && (rc = scores_to_device(b, d_sw_out))) return rc;
     b->ran = true;
     b->scores_only = true;
     return CR_OK;
@@ -1678,7 +2010,12 @@ int cr_batch_stage_ms(cr_batch* b, float ms[CR_NUM_STAGES], int* runs_averaged) 
     double acc[CR_NUM_STAGES] = {};
     for (int64_t r = 0; r < n; r++) {
         const std::vector<hipEvent_t>& ev = ctx->ev[(size_t)r];
-        for (size_t c = 0; c < b->chunks.size() && 3 * c + 2 < ev.size(); c++) {
+        size_t nchunks = 0;
+        (void)for_each_part(b, [&](cr_batch* part) {
+            nchunks += part->chunks.size();
+            return CR_OK;
+        });
+        for (size_t c = 0; c < nchunks && 3 * c + 2 < ev.size(); c++) {
             for (int s = 0; s < CR_NUM_STAGES; s++) {
                 float t = 0.f;
                 CR_HIP(hipEventElapsedTime(&t, ev[3 * c + s], ev[3 * c + s + 1]));
@@ -1700,11 +2037,27 @@ int cr_batch_work(cr_batch* b, double* alg_bytes, double* cells) {
 
 int cr_batch_layout(cr_batch* b, int* family, int* rows_a, int* rows_b, int* strips_a) {
     CR_REQUIRE(b != nullptr, "null batch");
-    if (family) *family = b->staged ? CR_LAYOUT_STAGED : b->trio ? CR_LAYOUT_TRIO : b->duo ? CR_LAYOUT_DUO : b->wide_sync ? CR_LAYOUT_WIDE : b->team ? CR_LAYOUT_TEAM : CR_LAYOUT_SINGLE;
+    if (!b->parts.empty()) {                         // a ragged list in size classes: cr_batch_part_layout has the families
+        if (family) *family = CR_LAYOUT_CLASSES;
+        if (rows_a) *rows_a = (int)b->parts.size();
+        if (rows_b) *rows_b = 0;
+        if (strips_a) *strips_a = 0;
+        return CR_OK;
+    }
+    if (family) *family = b->staged ? CR_LAYOUT_STAGED : b->trio ? CR_LAYOUT_TRIO : b->duo_team ? CR_LAYOUT_DUO_TEAM : b->duo ? CR_LAYOUT_DUO : b->wide_sync ? CR_LAYOUT_WIDE : b->team ? CR_LAYOUT_TEAM : CR_LAYOUT_SINGLE;
     if (rows_a) *rows_a = b->r_seed;
     if (rows_b) *rows_b = b->wide_sync ? b->r_b : b->r_seed;
     if (strips_a) *strips_a = b->wide_sync ? b->wide_na : 0;
     return CR_OK;
+}
+
+int cr_batch_part_layout(cr_batch* b, int part, int* family, int* rows_a, int* rows_b, int* strips_a, int64_t* npairs) {
+    CR_REQUIRE(b != nullptr, "null batch");
+    const int count = b->parts.empty() ? 1 : (int)b->parts.size();
+    CR_REQUIRE(part >= 0 && part < count, "part index out of range");
+    cr_batch* c = b->parts.empty() ? b : b->parts[(size_t)part];
+    if (npairs) *npairs = c->npairs;
+    return cr_batch_layout(c, family, rows_a, rows_b, strips_a);
 }
 
 int cr_batch_max_aln_len(cr_batch* b, int64_t* out) {
@@ -1739,10 +2092,10 @@ int cr_batch_fetch_scores(cr_batch* b, double* sw, uint32_t* flags) {
     int rc = set_device(b->ctx);
     if (rc) return rc;
     if (b->npairs == 0) return CR_OK;
-    // gather the field on the device, then one contiguous copy (8 or 4 bytes per pair instead of 160)
+    // gather the fields on the device in the caller's pair order (8 + 4 bytes per pair instead of 160), then both land in
+    // the context's page-locked area with one wait
     hipStream_t st = b->ctx->stream;
     const size_t np = (size_t)b->npairs;
-    // both fields land in the context's page-locked area with one wait, then go to the caller's arrays in its order
     void* land = nullptr;
     rc = host_landing(b->ctx, np * (sizeof(double) + sizeof(uint32_t)), &land);
     if (rc) return rc;
@@ -1751,26 +2104,17 @@ int cr_batch_fetch_scores(cr_batch* b, double* sw, uint32_t* flags) {
     DevBuf<uint32_t> stage;
     if (sw) {
         CR_HIP(b->sw_stage.ensure(np));
-        CR_HIP(hipMemcpy2DAsync(b->sw_stage.p, sizeof(double), reinterpret_cast<const char*>(b->res.p) + offsetof(cr_pair_result, sw),
-                                sizeof(cr::PairResult), sizeof(double), np, hipMemcpyDeviceToDevice, st));
+        if ((rc = scores_to_device(b, b->sw_stage.p))) return rc;
         CR_HIP(hipMemcpyAsync(h_sw, b->sw_stage.p, sizeof(double) * np, hipMemcpyDeviceToHost, st));
     }
     if (flags) {
         CR_HIP(stage.ensure(np));
-        CR_HIP(hipMemcpy2DAsync(stage.p, sizeof(uint32_t), reinterpret_cast<const char*>(b->res.p) + offsetof(cr_pair_result, flags),
-                                sizeof(cr::PairResult), sizeof(uint32_t), np, hipMemcpyDeviceToDevice, st));
+        if ((rc = flags_to_device(b, stage.p))) return rc;
         CR_HIP(hipMemcpyAsync(h_flags, stage.p, sizeof(uint32_t) * np, hipMemcpyDeviceToHost, st));
     }
     CR_HIP(hipStreamSynchronize(st));
-    // launch order -> the caller's order
-    if (sw) {
-        if (b->reordered) for (size_t k = 0; k < np; k++) sw[b->order[k]] = h_sw[k];
-        else std::memcpy(sw, h_sw, sizeof(double) * np);
-    }
-    if (flags) {
-        if (b->reordered) for (size_t k = 0; k < np; k++) flags[b->order[k]] = h_flags[k];
-        else std::memcpy(flags, h_flags, sizeof(uint32_t) * np);
-    }
+    if (sw) std::memcpy(sw, h_sw, sizeof(double) * np);
+    if (flags) std::memcpy(flags, h_flags, sizeof(uint32_t) * np);
     return CR_OK;
 }
 

@@ -364,9 +364,8 @@ int run_explicit(cr_context* ctx, const int64_t* seq1, int64_t n, const int64_t*
     r.r = R;
     r.walked = false;
     {
-        const char* env = std::getenv("CARETTA_STAGED");
         const cr::StagedShape shape = staged_shape((int)std::min<int64_t>(n, cr::kStagedMaxRows), (int)m);
-        if (n <= cr::kStagedMaxRows && !(env && env[0] == '0') &&
+        if (n <= cr::kStagedMaxRows && g_cfg.staged &&
             (double)shape.pair_doubles() * sizeof(double) <= 2.0 * 1024 * 1024 * 1024 &&
             (!walk || sizeof(double) * cr::trace_lds_doubles(shape.r, (int)(n + m)) <= 159 * 1024))
             return by_rows(shape.r, [&](auto rt) { return run_explicit_staged<decltype(rt)::value, MODE>(ctx, n, m, s_cols, prm, r, walk, shape); });
@@ -444,7 +443,7 @@ int launch_seed_team_zg(cr_batch* b, const cr_batch::Chunk& ck, const cr_params&
     int rc = allow_lds(cr::k_seed_team<R, D, ZG>, lds);
     if (rc) return rc;
     CR_LAUNCH((cr::k_seed_team<R, D, ZG>), dim3((unsigned)ck.count), dim3(cr::kTeamWaves * cr::kWave), lds,
-                       b->ctx->stream, b->pairs.p + ck.first, b->tensors.p, (int)b->d, b->coords.p, prm.gamma_tensor,
+                       b->launch_stream ? b->launch_stream : b->ctx->stream, b->pairs.p + ck.first, b->tensors.p, (int)b->d, b->coords.p, prm.gamma_tensor,
                        prm.sw_gap, entries, b->dirs.p, b->xf.p + ck.first, b->seed_score.p + ck.first);
     CR_HIP(hipGetLastError());
     return CR_OK;
@@ -703,8 +702,7 @@ int cr_smith_waterman(cr_context* ctx, const int64_t* seq1, int64_t n, const int
 // CR_HD code on the host (bit-identical: FP64 +, -, *, /, sqrt are correctly rounded on both sides, the library is
 // built without FMA contraction); CARETTA_HOST_SMALL_K=0 sends everything to the kernels (the parity test does).
 static bool small_on_host(int64_t k) {
-    const char* env = std::getenv("CARETTA_HOST_SMALL_K");
-    return k <= (env ? (int64_t)std::atoll(env) : (int64_t)4096);
+    return k <= (int64_t)g_cfg.host_small_k;
 }
 
 int cr_paired_svd_superpose(cr_context* ctx, const double* x1, const double* x2, int64_t k, double* R, double* t) {
@@ -1096,10 +1094,7 @@ struct NjTeam {
 // CPUs this process may really use: the cgroup quota (cpu.max) when there is one -- spinning helpers beyond the
 // quota get the whole process throttled --, else the affinity mask.  CARETTA_NJ_THREADS overrides.
 int nj_threads() {
-    if (const char* env = std::getenv("CARETTA_NJ_THREADS")) {
-        const int t = std::atoi(env);
-        if (t >= 1) return std::min(t, 64);
-    }
+    if (g_cfg.nj_threads >= 1) return std::min(g_cfg.nj_threads, 64);
     int cpus = (int)std::thread::hardware_concurrency();
     cpu_set_t set;
     if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = std::min(cpus, CPU_COUNT(&set));

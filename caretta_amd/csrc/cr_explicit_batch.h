@@ -731,7 +731,7 @@ int launch_sw_rows(cr_explicit_batch* b) {
 template <int R, int MODE>
 int launch_stream(cr_explicit_batch* b, const cr::ExplicitProblem* probs, const cr::SweepParams& prm, uint32_t* bits) {
     size_t lds = cr::stream_lds_doubles<R, MODE>() * sizeof(double);
-    if (const char* env = std::getenv("CARETTA_STREAM_LDS_KB")) lds = std::max(lds, (size_t)std::atoi(env) * 1024);   // calibration: waves per CU
+    if (g_cfg.stream_lds_kb > 0) lds = std::max(lds, (size_t)g_cfg.stream_lds_kb * 1024);   // calibration: waves per CU
     auto go = [&](auto kernel) -> int {
         int rc = allow_lds(kernel, lds);
         if (rc) return rc;
@@ -792,11 +792,8 @@ int cr_explicit_batch_create(cr_context* ctx, const double* S, int64_t s_elems, 
     // R = 1 / 2 / 3 -> 1.52 / 1.76 / 2.13 ms (SW, gap 0.1: 3.84 TB/s), 2.22 / 2.31 / 2.69 ms (DTW); CARETTA_STREAM_R overrides
     // (a list too short to give every CU its twelve waves is bound by the strips one wave walks one after the other: 2 rows
     // per lane halve them -- 600 x 1200 x 1200: 4.2 vs 5.8 ms)
-    int r_stream = std::getenv("CARETTA_FORCE_R") ? rows_per_lane(std::max(n_all, 1)) : (count >= 3072 ? 1 : 2);
-    if (const char* env = std::getenv("CARETTA_STREAM_R")) {        // calibration
-        const int r = std::atoi(env);
-        if (r >= 1 && r <= 5) r_stream = r;
-    }
+    int r_stream = g_cfg.force_r ? rows_per_lane(std::max(n_all, 1)) : (count >= 3072 ? 1 : 2);
+    if (g_cfg.stream_r >= 1 && g_cfg.stream_r <= 5) r_stream = g_cfg.stream_r;        // calibration
     int64_t bits_off_s = 0;
     int64_t hand_off = 0, bits_off = 0, aln_off = 0;
     int m_max = 0, n_max = 0, m_max_sw = 0;

@@ -36,7 +36,7 @@ RcclApi* rccl_api() {
         // caller's choice, then the loader's search path, then ROCm's default location
         std::vector<std::pair<std::string, int>> tries;
         tries.push_back({"librccl.so.1", RTLD_NOW | RTLD_NOLOAD});
-        if (const char* env = std::getenv("CARETTA_RCCL_LIB")) tries.push_back({env, RTLD_NOW | RTLD_GLOBAL});
+        if (!g_cfg.rccl_lib.empty()) tries.push_back({g_cfg.rccl_lib, RTLD_NOW | RTLD_GLOBAL});
         tries.push_back({"librccl.so.1", RTLD_NOW | RTLD_GLOBAL});
         tries.push_back({"/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL});
         for (auto& t : tries) {
@@ -248,7 +248,7 @@ int cr_multi_create(const int* devices, int ndev, cr_multi** out) {
     if (devices == nullptr || ndev <= 0) {
         for (int g = 0; g < visible; g++) m->devices.push_back(g);
     } else {
-        const bool allow_twice = std::getenv("CARETTA_MULTI_ALLOW_DUPLICATES") != nullptr;
+        const bool allow_twice = g_cfg.multi_allow_duplicates;
         for (int g = 0; g < ndev; g++) {
             const bool twice = std::count(devices, devices + g, devices[g]) != 0;
             if (devices[g] < 0 || devices[g] >= visible || (twice && !allow_twice)) {
@@ -385,15 +385,8 @@ int cr_multi_pairwise_scores(cr_multi* m, const double* coords, const double* te
             rc = cr_batch_run_scores(b, params, pd.local.p);
             if (rc) return rc;
             if (!pd.owned.empty()) {                  // the flags, in the caller's pair order like the scores
-                if (b->reordered) {
-                    CR_LAUNCH(cr::k_scatter_flags, dim3((unsigned)((pd.owned.size() + 255) / 256)), dim3(256), 0, ctx->stream, b->res.p,
-                              b->d_order.p, pd.local_flags.p, (int)pd.owned.size());
-                    CR_HIP(hipGetLastError());
-                } else {
-                    CR_HIP(hipMemcpy2DAsync(pd.local_flags.p, sizeof(uint32_t),
-                                            reinterpret_cast<const char*>(b->res.p) + offsetof(cr_pair_result, flags), sizeof(cr::PairResult),
-                                            sizeof(uint32_t), pd.owned.size(), hipMemcpyDeviceToDevice, ctx->stream));
-                }
+                rc = flags_to_device(b, pd.local_flags.p);
+                if (rc) return rc;
             }
             CR_HIP(hipEventRecord(pd.ev[1], ctx->stream));
             return CR_OK;

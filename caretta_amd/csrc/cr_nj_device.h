@@ -475,10 +475,7 @@ namespace {
 // calibration)
 int nj_groups(int64_t P) {
     int g = (int)std::min<int64_t>(cr::kNjMaxGroups, std::max<int64_t>(1, (P + 2 * cr::kNjGroupWaves - 1) / (2 * cr::kNjGroupWaves)));
-    if (const char* env = std::getenv("CARETTA_NJ_GROUPS")) {
-        const int e = std::atoi(env);
-        if (e >= 1 && e <= cr::kNjMaxGroups) g = e;
-    }
+    if (g_cfg.nj_groups >= 1 && g_cfg.nj_groups <= cr::kNjMaxGroups) g = g_cfg.nj_groups;
     while ((int64_t)g * cr::kNjGroupWaves * cr::kNjRowsPerWave < P) g++;
     return g;
 }
@@ -529,7 +526,7 @@ int cr_neighbor_joining_device(cr_context* ctx, const double* D0, int64_t P, uin
     DevBuf<unsigned long long> dwords;                     // published words: [3][P] row sums, [3][waves][kNjCandWords] minima
     DevBuf<unsigned long long> dout;                       // [tree 2 * rows | branch lengths rows | barrier state]
     DevBuf<long long> dprof;
-    const bool profile = std::getenv("CARETTA_NJ_PROFILE") != nullptr;     // diagnostic: cycles per phase to stderr
+    const bool profile = g_cfg.nj_profile;     // diagnostic: cycles per phase to stderr
     if (profile) {
         CR_HIP(dprof.ensure(8));
         CR_HIP(hipMemsetAsync(dprof.p, 0, 8 * sizeof(long long), ctx->stream));
@@ -581,7 +578,7 @@ int cr_neighbor_joining_device(cr_context* ctx, const double* D0, int64_t P, uin
         // A workgroup did not arrive (the device is shared or busy and the workgroups were not co-resident): a scheduling
         // accident, not an error of the input.  The host implementation gives the same tree bit for bit;
         // CARETTA_NJ_DEVICE_STRICT=1 keeps the error (tests of the device kernel itself).
-        if (std::getenv("CARETTA_NJ_DEVICE_STRICT")) return fail(CR_ERR_HIP, "neighbor joining: a workgroup of the persistent launch did not arrive");
+        if (g_cfg.nj_device_strict) return fail(CR_ERR_HIP, "neighbor joining: a workgroup of the persistent launch did not arrive");
         return cr_neighbor_joining(D0, P, tree, bl);
     }
     return CR_OK;

@@ -72,7 +72,7 @@ int run_level(cr_progressive* h, const std::vector<int64_t>& ids, const cr_param
     for (int64_t id : ids) n_max = std::max<int>(n_max, (int)h->len[(size_t)h->child1[(size_t)id]]);
     // few blocks per launch: the team kernels (kTeamWaves waves per node) whenever the rows fit their strips
     // (with at most 192 rows one strip of a single-wave kernel beats three 64-row strips of the team, cr_batch_set_pairs)
-    const bool team = n_max > 3 * cr::kWave && n_max <= 5 * cr::kTeamWaves * cr::kWave && !std::getenv("CARETTA_NO_TEAM");
+    const bool team = n_max > 3 * cr::kWave && n_max <= 5 * cr::kTeamWaves * cr::kWave && !g_cfg.no_team;
     const int R = team ? (n_max + cr::kTeamWaves * cr::kWave - 1) / (cr::kTeamWaves * cr::kWave) : rows_per_lane(n_max);
     int64_t dirs_off = 0, bt_off = 0, aln_off = 0, hand_off = 0, rows = h->used;
     for (size_t x = 0; x < count; x++) {
@@ -161,14 +161,13 @@ int run_tree_planned(cr_progressive* h, const std::vector<std::vector<int64_t>>&
     int64_t longest = 0;
     for (int64_t s = 0; s < P; s++) longest = std::max(longest, h->len[(size_t)s]);
     const int bound = (int)std::min<int64_t>(cr::kStagedMaxRows, (longest * 3 + 1) / 2 + 8);
-    if (longest > bound || std::getenv("CARETTA_NO_TEAM")) return 1;
+    if (longest > bound || g_cfg.no_team) return 1;
     int64_t widest_level = 0;
     for (int64_t lv = 1; lv <= h->levels; lv++) widest_level = std::max<int64_t>(widest_level, (int64_t)by_level[(size_t)lv].size());
     // Scores formed by their own launches (cr_staged.h) while up to four rows per lane fit the 8 waves of its workgroups
     // (2048 rows) and the widest level's scores fit a tenth of the device memory; CARETTA_STAGED=0: the fused kernels
     const cr::StagedShape shape = staged_shape(bound, bound);
-    const char* staged_env = std::getenv("CARETTA_STAGED");
-    bool staged = bound <= cr::kStagedMaxRows && widest_level <= 65535 && !(staged_env && staged_env[0] == '0');
+    bool staged = bound <= cr::kStagedMaxRows && widest_level <= 65535 && g_cfg.staged;
     if (staged) {
         size_t free_b = 0, total_b = 0;
         CR_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -422,7 +421,7 @@ int cr_progressive_align(cr_context* ctx, const double* coords, const double* te
     }
     std::vector<std::vector<int64_t>> by_level((size_t)h->levels + 1);
     for (int64_t id = P; id < num_ids; id++) by_level[(size_t)h->level[(size_t)id]].push_back(id);
-    rc = std::getenv("CARETTA_SYNC_LEVELS") ? 1 : run_tree_planned(h, by_level, prm, gamma_weight);
+    rc = g_cfg.sync_levels ? 1 : run_tree_planned(h, by_level, prm, gamma_weight);
     if (rc < 0) return rc;
     if (rc == 1) {                                  // not applicable, or a node outgrew the bound: level by level
         h->used = total;

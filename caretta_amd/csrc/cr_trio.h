@@ -161,9 +161,8 @@ struct TrioCols {
 // into registers and give the slots back at once: LDS executes this wave's reads before the word's write, and a producer
 // writes a slot only behind its own read of the word
 template <int R>
-CR_D void trio_take(const double* ring, int* words, int j0, int jend, int& r0, double (&sc)[kTrioBatch][R], unsigned long long& waited) {
+CR_D void trio_take(const double* ring, int* words, const int np, int j0, int jend, int& r0, double (&sc)[kTrioBatch][R], unsigned long long& waited) {
     const int lane = threadIdx.x & (kWave - 1);
-    const int np = (int)(blockDim.x >> 6) - 1;
     const int len = jend - j0;
     for (int k = len - 1; k >= 0 && k >= len - np; k--) {        // the last column of every producer in the batch
         int p = r0 + k;
@@ -185,7 +184,7 @@ CR_D void trio_take(const double* ring, int* words, int j0, int jend, int& r0, d
 }
 
 template <int R>
-CR_D void trio_seed_consumer(const int n, const int m, const double* ring, int* words, uint32_t* __restrict__ sw_dirs, SeedMax& seed_out) {
+CR_D void trio_seed_consumer(const int np, const int n, const int m, const double* ring, int* words, uint32_t* __restrict__ sw_dirs, SeedMax& seed_out) {
     const int lane = threadIdx.x & (kWave - 1);
     const int TB = (m + 15) >> 4;
     TrioCols<R> st;
@@ -198,7 +197,7 @@ CR_D void trio_seed_consumer(const int n, const int m, const double* ring, int* 
     for (int j0 = 0; j0 < m; j0 += nb) {
         const int jend = j0 + nb < m ? j0 + nb : m;
         double sc[kTrioBatch][R];
-        trio_take<R>(ring, words, j0, jend, r0, sc, waited);
+        trio_take<R>(ring, words, np, j0, jend, r0, sc, waited);
 #pragma unroll
         for (int k = 0; k < kTrioBatch; k++) {
             const int j = j0 + k;
@@ -262,7 +261,7 @@ CR_D void trio_align_producer(const int p, const int np, RbfCoords<R>& src, cons
 }
 
 template <int R, int MODE>
-CR_D void trio_align_consumer(const int n, const int m, const int T, const SweepParams prm, const double* ring, int* words,
+CR_D void trio_align_consumer(const int np, const int n, const int m, const int T, const SweepParams prm, const double* ring, int* words,
                               uint32_t* __restrict__ dtw_bits, AlignEnd& end_out) {
     constexpr bool SW = (MODE & kSwScore) != 0;
     constexpr bool DTW = (MODE & kDtw) != 0;
@@ -283,7 +282,7 @@ CR_D void trio_align_consumer(const int n, const int m, const int T, const Sweep
     for (int t0 = 0; t0 < T; t0 += nb) {
         const int tend = t0 + nb < T ? t0 + nb : T;
         double sc[kTrioBatch][R];
-        trio_take<R>(ring, words, t0, tend, r0, sc, waited);
+        trio_take<R>(ring, words, np, t0, tend, r0, sc, waited);
 #pragma unroll
         for (int k = 0; k < kTrioBatch; k++) {
             const int t = t0 + k;
@@ -359,7 +358,7 @@ CR_D void trio_score_producer(const int p, const int np, RbfCoords<R>& src, cons
 }
 
 template <int R>
-CR_D double trio_score_consumer(const int n, const int m, const double* ring, int* words) {
+CR_D double trio_score_consumer(const int np, const int n, const int m, const double* ring, int* words) {
     const int lane = threadIdx.x & (kWave - 1);
     TrioCols<R> st;
     st.reset();
@@ -370,7 +369,7 @@ CR_D double trio_score_consumer(const int n, const int m, const double* ring, in
     for (int j0 = 0; j0 < m; j0 += nb) {
         const int jend = j0 + nb < m ? j0 + nb : m;
         double sc[kTrioBatch][R];
-        trio_take<R>(ring, words, j0, jend, r0, sc, waited);
+        trio_take<R>(ring, words, np, j0, jend, r0, sc, waited);
 #pragma unroll
         for (int k = 0; k < kTrioBatch; k++)
             if (j0 + k < jend) st.advance_score(sc[k]);
@@ -395,7 +394,7 @@ template <int R, int D, bool SCORES>
 __global__ __launch_bounds__(kTrioMaxWaves* kWave, 2) void k_pair_trio(const PairDesc* __restrict__ pairs, const double* __restrict__ tensors, int d,
                                                                    const double* __restrict__ coords, double gamma_tensor,
                                                                    double gamma_coords, double gap_open, double gap_extend,
-                                                                   int seed_entries, int align_entries, uint32_t* __restrict__ dirs,
+                                                                   int seed_entries, int align_entries, int np2, uint32_t* __restrict__ dirs,
                                                                    uint32_t* __restrict__ bits, Transform* __restrict__ xf,
                                                                    double* __restrict__ seed_score, int32_t* __restrict__ aln,
                                                                    PairResult* __restrict__ res, const HostOut hout) {
@@ -416,7 +415,7 @@ __global__ __launch_bounds__(kTrioMaxWaves* kWave, 2) void k_pair_trio(const Pai
     sm.i = sm.j = 0;
     if (w == 0) {
         __builtin_amdgcn_s_setprio(CR_TRIO_PRIO_CONS);
-        trio_seed_consumer<R>(pd.n, pd.m, ring, words, dirs + pd.dirs_off, sm);
+        trio_seed_consumer<R>((int)(blockDim.x >> 6) - 1, pd.n, pd.m, ring, words, dirs + pd.dirs_off, sm);
         drain_stores();
         CR_STAMP(1);
         Transform tr;
@@ -447,17 +446,22 @@ __global__ __launch_bounds__(kTrioMaxWaves* kWave, 2) void k_pair_trio(const Pai
         src.load_resident(cols, pd.m, pd.m, (int)threadIdx.x, (int)blockDim.x);
         if (threadIdx.x < 8) words[threadIdx.x] = 0;
         __syncthreads();
+        // The two stages can run with different numbers of score waves (np2 <= blockDim.x / 64 - 1 in the second): the seed's
+        // tensor scores are 50 of a cell's 66 instructions, the coordinate scores 23 of 50.  The waves the second stage does not
+        // use have helped to load its resident columns and leave here (a finished wave no longer counts at a barrier -- there is
+        // none behind this point anyway).
+        if (w > np2) return;
         const int lanes_here = pd.n >= kWave * R ? kWave : (pd.n + R - 1) / R;
         const int T = pd.m + lanes_here - 1;
+        const int np = np2;
         if (w != 0) {
-            const int np = (int)(blockDim.x >> 6) - 1;
             if constexpr (SCORES) trio_score_producer<R>(w - 1, np, src, pd.n, pd.m, tab, cols, ring, words);
             else trio_align_producer<R>(w - 1, np, src, pd.n, pd.m, T, tab, cols, ring, words);
             return;                                        // wave 0 goes on alone (wave_sync, no s_barrier from here on)
         }
         PairResult r;
         if constexpr (SCORES) {
-            r.sw = trio_score_consumer<R>(pd.n, pd.m, ring, words);
+            r.sw = trio_score_consumer<R>(np, pd.n, pd.m, ring, words);
             r.dtw_score = 0.0;
 #pragma unroll
             for (int x = 0; x < 9; x++) r.R[x] = 0.0;
@@ -469,7 +473,7 @@ __global__ __launch_bounds__(kTrioMaxWaves* kWave, 2) void k_pair_trio(const Pai
         } else {
             AlignEnd e;
             SweepParams prm{0.0, gap_open, gap_extend};
-            trio_align_consumer<R, kSwScore | kDtw | kZeroGap>(pd.n, pd.m, T, prm, ring, words, bits + pd.bt_off, e);
+            trio_align_consumer<R, kSwScore | kDtw | kZeroGap>(np, pd.n, pd.m, T, prm, ring, words, bits + pd.bt_off, e);
             drain_stores();
             CR_STAMP(5);
             // (the producers may still be leaving their last loop iteration: they touch LDS no more -- their last writes were

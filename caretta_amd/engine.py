@@ -112,6 +112,15 @@ def all_pairs(num: int) -> np.ndarray:
     return np.ascontiguousarray(np.stack([i, j], axis=1), dtype=np.int32)
 
 
+LAYOUT_NAMES = ("single", "team", "wide", "staged", "duo", "trio", "classes", "duo_team")
+
+
+def reload_config():
+    """Have the library read its calibration switches (CARETTA_* environment variables, caretta_amd/csrc/cr_config.h) again:
+    they are read once when the library is loaded.  Measurement tools and tests that change os.environ call this."""
+    check(_capi.load().cr_config_reload())
+
+
 class PairBatch:
     def __init__(self, ctx: Context, coords, tensors, offsets):
         self.ctx = ctx
@@ -221,7 +230,18 @@ class PairBatch:
         pair), "team", "wide" (one workgroup per pair), "staged" (scores by their own launches), "duo" / "trio" (mid-size lists: split by rows / by function)."""
         f, ra, rb, na = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
         check(self._lib.cr_batch_layout(self._h, C.byref(f), C.byref(ra), C.byref(rb), C.byref(na)))
-        return ("single", "team", "wide", "staged", "duo", "trio")[f.value], ra.value, rb.value, na.value
+        return LAYOUT_NAMES[f.value], ra.value, rb.value, na.value
+
+    def part_layouts(self):
+        """[(kernel family, rows per lane A, rows per lane B, strips with A, pairs)] of the size classes a ragged list was split
+        into (``layout()[0] == "classes"``), or of the one list."""
+        count = self.layout()[1] if self.layout()[0] == "classes" else 1
+        out = []
+        for k in range(count):
+            f, ra, rb, na, n = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_int64(0)
+            check(self._lib.cr_batch_part_layout(self._h, k, C.byref(f), C.byref(ra), C.byref(rb), C.byref(na), C.byref(n)))
+            out.append((LAYOUT_NAMES[f.value], ra.value, rb.value, na.value, n.value))
+        return out
 
     def close(self):
         if self._h:

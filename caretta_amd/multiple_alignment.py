@@ -356,7 +356,8 @@ class MultipleAlignment:
             out = self.pairwise(score_function_params, want_alignments=False, scores_only=True)
             return assemble_matrix(out.pairs, out.results["sw"], num)
         if (score_function_params.get("flexible", False) and self._all_proteins(need_coordinates=False)
-                and len({np.shape(s.tensors)[1] for s in self.sequences}) == 1):
+                and len({np.shape(s.tensors)[1] for s in self.sequences}) == 1
+                and np.shape(self.sequences[0].tensors)[1] <= 32):      # (wider tensors: the plugin route below, as before)
             # flexible=True: smith_waterman_score of the tensor score matrix of every pair (multiple_alignment.py:323-326,
             # :164), one launch over the pair list (cr_batch_run_tensor_scores)
             out = self.pairwise(score_function_params, want_alignments=False, scores_only=True)

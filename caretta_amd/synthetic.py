@@ -97,6 +97,34 @@ def make_family(num: int, length: int, dim: int = 10, seed: int = 20240,
     return out
 
 
+def make_ragged_family(num: int, shortest: int, longest: int, dim: int = 10, seed: int = 20250, clades: int | None = None) -> List[Structure]:
+    """A family whose members keep a random contiguous window of ``shortest`` .. ``longest`` residues of a ``longest``-residue
+    family member each: ragged lengths as every real input has them (the reference's own example is 85 / 79 / 80 residues),
+    still one family (related structures, alignments with gaps)."""
+    fam = make_family(num, longest, dim=dim, seed=seed, clades=clades)
+    rng = np.random.default_rng(seed + 7)
+    for s in fam:
+        keep = int(rng.integers(shortest, longest + 1))
+        start = int(rng.integers(0, s.coordinates.shape[0] - keep + 1))
+        s.coordinates = np.ascontiguousarray(s.coordinates[start:start + keep])
+        s.tensors = np.ascontiguousarray(s.tensors[start:start + keep])
+        s.sequence = s.sequence[start:start + keep]
+    return fam
+
+
+def make_mixed_family(num_short: int, short_len: int, num_long: int, long_len: int, dim: int = 10, seed: int = 20251) -> List[Structure]:
+    """``num_short`` structures of ``short_len`` residues (windows of the long ones' family) followed by ``num_long`` members of
+    ``long_len`` residues: a family of domains with a few full-length chains in it."""
+    fam = make_family(num_short + num_long, long_len, dim=dim, seed=seed)
+    rng = np.random.default_rng(seed + 11)
+    for s in fam[:num_short]:
+        start = int(rng.integers(0, long_len - short_len + 1))
+        s.coordinates = np.ascontiguousarray(s.coordinates[start:start + short_len])
+        s.tensors = np.ascontiguousarray(s.tensors[start:start + short_len])
+        s.sequence = s.sequence[start:start + short_len]
+    return fam
+
+
 def pack(structures: List[Structure]):
     """Concatenate a family into the packed layout the C-ABI takes.
 

@@ -56,3 +56,37 @@ def golden():
         return cache[name]
 
     return load
+
+
+def _reload_library_config():
+    """The library reads its CARETTA_* calibration switches once, when it is loaded (caretta_amd/csrc/cr_config.h); a test
+    that changes one has the library read them again."""
+    from caretta_amd import _capi
+    if _capi._lib is not None:
+        _capi._lib.cr_config_reload()
+
+
+@pytest.fixture
+def monkeypatch(monkeypatch):
+    """pytest's monkeypatch, with setenv / delenv of a CARETTA_* variable followed by cr_config_reload(), and the library
+    told again once the environment has been restored."""
+    set_env, del_env = monkeypatch.setenv, monkeypatch.delenv
+    touched = []
+
+    def setenv(name, value, prepend=None):
+        set_env(name, value, prepend)
+        if name.startswith("CARETTA_"):
+            touched.append(name)
+            _reload_library_config()
+
+    def delenv(name, raising=True):
+        del_env(name, raising)
+        if name.startswith("CARETTA_"):
+            touched.append(name)
+            _reload_library_config()
+
+    monkeypatch.setenv, monkeypatch.delenv = setenv, delenv
+    yield monkeypatch
+    monkeypatch.undo()
+    if touched:
+        _reload_library_config()

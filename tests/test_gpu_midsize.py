@@ -134,6 +134,41 @@ def test_few_pairs_by_function_and_again_with_a_gap(ctx, oracle):
     batch.close()
 
 
+@pytest.mark.parametrize("family", ["trio_few", "duo"])
+def test_streamed_run_with_a_gap_first_on_a_fresh_batch(ctx, oracle, family):
+    """The gap-driven re-layout of a duo / few-pair trio list happens inside the FIRST run.  When that first run is the
+    streamed one (the alignment kernel writes into the caller's page-locked arrays through the batch's order map), the map
+    must be the one of the NEW layout: the list below is already sorted by cells (so the gap-0 layout keeps the caller's
+    order and has no map at all) but spans several rows-per-lane groups (so the layout for the gap reorders it)."""
+    from caretta_amd import engine
+    from oracle.pyoracle import default_params
+    rows = [300, 290, 260, 230, 200, 170, 150, 120, 100, 90, 80, 70] if family == "trio_few" else \
+           [500, 480, 450, 400, 360, 330, 300, 250, 200, 150, 100, 90, 80, 70, 66, 65, 50, 40]
+    fam = synthetic.make_family(len(rows), max(rows), seed=9501 + len(rows), clades=2)
+    for s, cut in zip(fam, rows):
+        s.coordinates, s.tensors = s.coordinates[:cut].copy(), s.tensors[:cut].copy()
+    coords, tensors, offsets = synthetic.pack(fam)
+    fwd = engine.all_pairs(len(rows))
+    pairs = np.vstack([fwd, fwd[:, ::-1]])
+    if family == "trio_few":
+        pairs = np.vstack([pairs, fwd[:60]])                     # 192 pairs: more than 160, at most 256
+    cells = np.diff(offsets)[pairs[:, 0]] * np.diff(offsets)[pairs[:, 1]]
+    pairs = np.ascontiguousarray(pairs[np.argsort(-cells, kind="stable")])
+    batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
+    assert layout_of(batch)[0] == ("trio" if family == "trio_few" else "duo"), layout_of(batch)
+    prm = engine.make_params(sw_gap=0.05)
+    ref, ref_aln = oracle.pairwise_batch(coords, tensors, offsets, pairs, params=default_params(sw_gap=0.05), nthreads=8)
+    res_s, aln_s = batch.run_streamed(prm)                       # the first run of the batch
+    ctx.synchronize()
+    assert layout_of(batch)[0] not in ("trio", "duo"), layout_of(batch)
+    for key in ("sw", "dtw_score", "seed_score", "rmsd", "coverage", "tm", "aln_len", "seed_len", "flags"):
+        assert np.array_equal(res_s[key], ref[key]), f"{key}: streamed results landed on the wrong pairs"
+    for p in range(len(pairs)):
+        ln = int(ref["aln_len"][p])
+        assert np.array_equal(aln_s[p, :, :ln], ref_aln[p, :, :ln]), f"pair {p}: alignment differs"
+    batch.close()
+
+
 def test_midsize_three_and_more_strips(ctx, oracle):
     """321 .. 600 rows: three to five waves per pair (3 rows per lane in strip 0, 2 in the others), ragged."""
     from caretta_amd import engine

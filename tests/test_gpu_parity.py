@@ -1204,6 +1204,7 @@ def test_single_process_multi_device_path_equals_the_batch(ctx):
     # to pair order -- is the product path.  3 and 4 shares, ragged and equal lengths, pair counts that do not divide.
     import os
     os.environ["CARETTA_MULTI_ALLOW_DUPLICATES"] = "1"
+    engine.reload_config()
     try:
         for shares in (3, 4):
             multi = engine.MultiDevice([0] * shares)
@@ -1220,6 +1221,7 @@ def test_single_process_multi_device_path_equals_the_batch(ctx):
             multi.close()
     finally:
         del os.environ["CARETTA_MULTI_ALLOW_DUPLICATES"]
+        engine.reload_config()
 
 
 def test_streamed_run_writes_what_fetch_copies(ctx):

@@ -18,7 +18,7 @@ import numpy as np  # noqa: E402
 
 from caretta_amd import engine, synthetic  # noqa: E402
 
-KEYS = ("CARETTA_TRIO", "CARETTA_TRIO_PAIRS", "CARETTA_TRIO_FROM", "CARETTA_TRIO_WAVES", "CARETTA_MID_ANY", "CARETTA_MID_PLAN", "CARETTA_MID_LDS_KB", "CARETTA_MID_PAIRS", "CARETTA_MID", "CARETTA_WIDE", "CARETTA_TEAM_PAIRS",
+KEYS = ("CARETTA_TRIO", "CARETTA_TRIO_PAIRS", "CARETTA_TRIO_FROM", "CARETTA_TRIO_WAVES", "CARETTA_TRIO_WAVES2", "CARETTA_MID_ANY", "CARETTA_MID_PLAN", "CARETTA_MID_LDS_KB", "CARETTA_MID_PAIRS", "CARETTA_MID", "CARETTA_WIDE", "CARETTA_TEAM_PAIRS",
         "CARETTA_STAGED", "CARETTA_STAGED_WAVES", "CARETTA_NO_TEAM", "CARETTA_NO_WIDE")
 FORCE = {"CARETTA_MID_PAIRS": "100000", "CARETTA_TRIO": "0"}
 MODES = [("single wave", {"CARETTA_NO_TEAM": "1", "CARETTA_MID": "0", "CARETTA_TRIO": "0"}),
@@ -34,6 +34,9 @@ MODES = [("single wave", {"CARETTA_NO_TEAM": "1", "CARETTA_MID": "0", "CARETTA_T
          ("mid 3,2,1, 70 KB (2 pairs per CU)", dict(FORCE, CARETTA_MID_PLAN="3,2,1", CARETTA_MID_LDS_KB="70"))]
 if os.environ.get("C3_TRIO"):           # only the split by function, one to four score waves, against one wave per pair and the library's choice
     MODES = MODES[:2] + [(f"trio 1 + {w - 1} waves", {"CARETTA_TRIO_PAIRS": "100000", "CARETTA_TRIO_WAVES": str(w), "CARETTA_STAGED": "0"}) for w in (2, 3, 4, 5)]
+if os.environ.get("C3_STAGES"):         # score waves per STAGE (seed + its waves, alignment + its waves), against one wave per pair and the library's choice
+    MODES = MODES[:2] + [(f"trio 1+{a - 1} / 1+{b - 1}", {"CARETTA_TRIO_PAIRS": "100000", "CARETTA_TRIO_WAVES": str(a), "CARETTA_TRIO_WAVES2": str(b), "CARETTA_STAGED": "0"})
+                         for a, b in ((2, 2), (3, 2), (3, 3), (4, 2), (4, 3), (4, 4), (5, 3), (5, 4))]
 if os.environ.get("C3_FEW"):            # at most 256 pairs: the one-pair-per-CU layouts and staged scores against the split by function forced onto the list
     MODES = MODES[:2] + [("no trio", {"CARETTA_TRIO": "0"})] + [(f"trio 1 + {w - 1} waves", {"CARETTA_TRIO_PAIRS": "100000", "CARETTA_TEAM_PAIRS": "0", "CARETTA_TRIO_FROM": "0", "CARETTA_TRIO_WAVES": str(w), "CARETTA_STAGED": "0"}) for w in (3, 4, 5)]
 if os.environ.get("C3_LIMIT"):          # where the layout stops paying: the library's plan against one wave per pair
@@ -76,6 +79,7 @@ def main():
                 os.environ.pop(k, None)
             os.environ.update(env)
             try:
+                engine.reload_config()        # (the library reads its calibration switches once: cr_config.h)
                 b = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
                 lay = b.layout()
                 full = timed(b, ctx, prm, 20, False)

@@ -7,9 +7,11 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import numpy as np
 from caretta_amd import engine, synthetic
-fam = synthetic.make_family(64, 1200, seed=20244)
+shape = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [64, 1200, 20244, 8]     # structures, residues, seed, stride
+fam = synthetic.make_family(shape[0], shape[1], seed=shape[2])
 coords, tensors, offsets = synthetic.pack(fam)
-pairs = engine.all_pairs(64)[::8]
+pairs = engine.all_pairs(shape[0])[::shape[3]]
+print(f"{len(pairs)} pairs of {shape[1]}", flush=True)
 ctx = engine.Context(0)
 prm = engine.make_params()
 def timed(b, so):
@@ -18,13 +20,14 @@ def timed(b, so):
     for _ in range(5): b.run(prm, scores_only=so)
     ctx.synchronize(); return (time.perf_counter() - t0) / 5 * 1e3
 ref = None
-for name, env in [("default (wide)", {}), ("duo 3,2,3", {"CARETTA_TEAM_PAIRS": "0", "CARETTA_STAGED": "0", "CARETTA_MID_PLAN": "3,2,3", "CARETTA_MID_PAIRS": "100000"}),
+for name, env in [("default", {}), ("wide (CARETTA_DUO_TEAM=0)", {"CARETTA_DUO_TEAM": "0"}), ("duo 3,2,3", {"CARETTA_TEAM_PAIRS": "0", "CARETTA_STAGED": "0", "CARETTA_MID_PLAN": "3,2,3", "CARETTA_MID_PAIRS": "100000"}),
                   ("duo 3,2,4", {"CARETTA_TEAM_PAIRS": "0", "CARETTA_STAGED": "0", "CARETTA_MID_PLAN": "3,2,4", "CARETTA_MID_PAIRS": "100000"}),
                   ("duo 3,3,0", {"CARETTA_TEAM_PAIRS": "0", "CARETTA_STAGED": "0", "CARETTA_MID_PLAN": "3,3,0", "CARETTA_MID_PAIRS": "100000"}),
                   ("duo 2,2,0", {"CARETTA_TEAM_PAIRS": "0", "CARETTA_STAGED": "0", "CARETTA_MID_PLAN": "2,2,0", "CARETTA_MID_PAIRS": "100000"})]:
-    for k in ("CARETTA_TEAM_PAIRS", "CARETTA_STAGED", "CARETTA_MID_PLAN", "CARETTA_MID_PAIRS"): os.environ.pop(k, None)
+    for k in ("CARETTA_TEAM_PAIRS", "CARETTA_STAGED", "CARETTA_MID_PLAN", "CARETTA_MID_PAIRS", "CARETTA_DUO_TEAM"): os.environ.pop(k, None)
     os.environ.update(env)
     try:
+        engine.reload_config()        # (the library reads its calibration switches once: cr_config.h)
         b = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
         lay = b.layout()
         full = timed(b, False); res, aln = b.fetch(); mat = timed(b, True); b.close()

@@ -18,6 +18,7 @@ out = []
 for L in (48, 64, 80, 100, 128, 150, 192, 220, 256, 300, 320, 350, 384, 420, 450, 512, 560, 600, 640, 700, 800, 960):
     fam = synthetic.make_family(91, L, seed=L, clades=4)          # 4095 pairs
     coords, tensors, offsets = synthetic.pack(fam)
+    engine.reload_config()        # (the library reads its calibration switches once: cr_config.h)
     b = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(engine.all_pairs(len(fam)))
     prm = engine.make_params()
     for _ in range(2):

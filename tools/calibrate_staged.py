@@ -49,6 +49,7 @@ def main():
                 os.environ["CARETTA_STAGED"] = "0"
             else:
                 os.environ["CARETTA_STAGED_WAVES"] = str(1 << 40)
+            engine.reload_config()        # (the library reads its calibration switches once: cr_config.h)
             b = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
             reps = 20 if len(pairs) < 3000 else 5
             full = timed(b, ctx, prm, reps, False)

@@ -15,6 +15,7 @@ for L in (150, 300):
     for num in (12, 17, 23, 32, 40, 46, 56, 64):
         fam = synthetic.make_family(num, L, seed=L + num, clades=4)
         coords, tensors, offsets = synthetic.pack(fam)
+        engine.reload_config()        # (the library reads its calibration switches once: cr_config.h)
         b = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(engine.all_pairs(num))
         prm = engine.make_params()
         for _ in range(3):

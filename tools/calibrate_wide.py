@@ -96,12 +96,14 @@ def main():
         pairs = engine.all_pairs(num)[::stride]
         reps = 5 if length >= 600 else 20
         os.environ.pop("CARETTA_WIDE", None)
+        engine.reload_config()        # (the library reads its calibration switches once: cr_config.h)
         b = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
         print(f"{name}: {len(pairs)} pairs of {length}: default {timed(b, ctx, prm, reps):.3f} ms, scores only {timed_scores(b, ctx, prm, reps):.3f} ms", flush=True)
         dflt = b.fetch() if False else None
         b.run(prm)
         dflt = b.fetch()
         os.environ["CARETTA_NO_WIDE"] = "1"
+        engine.reload_config()        # (the library reads its calibration switches once: cr_config.h)
         b.set_pairs(pairs)
         base_ms = timed(b, ctx, prm, reps)
         base = b.fetch()
@@ -110,6 +112,7 @@ def main():
         print(f"  without wide kernels: {base_ms:.3f} ms; default path {'bit-identical' if verdict is None else 'MISMATCH: ' + verdict}", flush=True)
         for ra, rb, na, sync in grid(length):
             os.environ["CARETTA_WIDE"] = f"{ra},{rb},{na},{sync}"
+            engine.reload_config()        # (the library reads its calibration switches once: cr_config.h)
             b.set_pairs(pairs)
             ms = timed(b, ctx, prm, reps)
             ctx.set_profiling(reps)
