@@ -13,13 +13,22 @@ Workloads (BASELINE.json configs; d=10, seeds 20240+k):
              (N=1 is BASELINE config 3: 128 x 300 = 8128 pairs; per-GPU work is fixed -> weak scaling)
   c2       : 32 x 150      c4 : 512 x 300      c5 : 64 x 1200
 
-Besides `value` (device-resident rate, SURVEY.md 8(d) and the driver's contract) the line carries
+Besides `value` (device-resident rate, SURVEY.md 8(d) and the driver's contract; the timed region of K steps is REPEATED
+`--repeats` times and `ms_per_step` / `value` are the MEDIAN run's, min / median / max in `repeats`) the line carries
+  value_strong         : (N > 1) BASELINE config 3's own 128 x 300 with the pair set FIXED and sharded over the N ranks, pairs/s --
+                         `value` itself is the WEAK headline (P grows with sqrt(N)); `config.workload` says so;
   value_incl_transfers : the same pair set INCLUDING the upload of the structures and the download of every result
-                         (alignment rows, transforms, metrics) -- the metric as SURVEY.md 8(d) words it;
+                         (alignment rows, transforms, metrics), one batch with a wait behind it -- the metric as SURVEY.md 8(d)
+                         words it; value_incl_transfers_pipelined: the steady state of a two-stream pipeline of such batches;
+  ragged, mixed        : what every real input is -- 160 structures of 80 .. 520 residues, all 12 720 pairs (ms, Mcells/s beside the
+                         headline's, >= 1 % of the pairs gated against the oracle), and a 150-residue family with two 600-residue
+                         members as one list against the sum of its homogeneous parts (tools/ragged_time.py);
+  explicit_batch       : the reference's functions on EXPLICIT score matrices over the 8 128 x 300 x 300 list, with and without
+                         their tracebacks: ms, GB/s of SURVEY 8(d)'s explicit-mode bytes (tools/explicit_batch_rate.py);
   c3_sharded, c4_sharded, c5_sharded : BASELINE configs 3, 4 and 5 timed in the same run with the pair set FIXED and sharded
                          over the N ranks + one all-gather, with the speed-up against ONE GPU running the whole config
                          (measured on rank 0) -- c3_sharded at N > 1 is the strong-scaling record of the headline's own 128 x 300;
-                         at N=1 also `share_of_8`: one GPU's share of the 8-GPU split run on this GPU;
+                         at N=1 also `share_of_2`, `share_of_4`, `share_of_8`: one GPU's share of the 2-, 4-, 8-GPU split run on this GPU;
   matrix_only          : the P x P matrix entries alone (cr_batch_run_scores), what make_pairwise_matrix -> NJ consumes;
   nj_gate              : neighbor-joining bipartitions of the GPU matrix = those of the all-core oracle matrix (N=1);
   msa                  : the consumers behind the matrix at N=1: neighbor joining and the progressive alignment of the guide
@@ -215,6 +224,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="headline", choices=["headline", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--repeats", type=int, default=10, help="how often the timed region of --steps steps is repeated (the line reports the median run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip value_incl_transfers and the c4/c5 sharded timings")
     args = ap.parse_args()
@@ -313,13 +323,18 @@ def main():
     for _ in range(args.warmup):
         head.step()
     fence()
-    ctx.set_profiling(min(args.steps, 4096))
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        head.step()
-    fence()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
+    repeats = max(1, args.repeats)
+    ctx.set_profiling(min(args.steps * repeats, 4096))
+    run_s = []
+    for _ in range(repeats):
+        # one timed region as the contract words it: EXACTLY `steps` steps between barrier + synchronize, max over ranks
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            head.step()
+        fence()
+        run_s.append(max_over_ranks(time.perf_counter() - t0))
+    elapsed = float(np.median(run_s))                  # the median run's time is the line's ms_per_step / value
     stage_ms, runs = head.batch.stage_ms()
     ctx.set_profiling(0)
     gathered = head.gathered_flat.view(world, -1) if head.gather else head.local.unsqueeze(0)
@@ -404,19 +419,21 @@ def main():
         pending[0].close()
         for c in ctx_pair:
             c.close()
-        t_incl = t_pipe
         if rank == 0:
-            extras["value_incl_transfers"] = len(pairs) / t_incl
+            # (value_incl_transfers is ONE batch with a wait behind it, as in rounds 1-3 and as SURVEY 8(d) words the metric;
+            # round 4's line carried the pipelined figure under this key)
+            extras["value_incl_transfers"] = len(pairs) / t_serial
+            extras["value_incl_transfers_pipelined"] = len(pairs) / t_pipe
             extras["incl_transfers"] = {
-                "ms_per_step": t_incl * 1e3, "ratio_to_resident": t_incl / (elapsed / args.steps),
-                "one_batch_alone": {"ms_per_step": t_serial * 1e3, "upload_ms": t_parts[0] * 1e3, "run_and_download_ms": t_parts[1] * 1e3,
-                                    "ratio_to_resident": t_serial / (elapsed / args.steps)},
+                "ms_per_step": t_serial * 1e3, "upload_ms": t_parts[0] * 1e3, "run_and_download_ms": t_parts[1] * 1e3,
+                "ratio_to_resident": t_serial / (elapsed / args.steps),
+                "pipelined": {"ms_per_step": t_pipe * 1e3, "ratio_to_resident": t_pipe / (elapsed / args.steps)},
                 "streamed_results_equal_fetched": bool(streamed_ok and pipelined_ok),
                 "downloaded_bytes_per_rank": int(r2.nbytes + a2.nbytes), "uploaded_bytes_per_rank": int(coords.nbytes + tensors.nbytes + my_pairs.nbytes),
-                "note": "per batch, steady state of a two-stream pipeline driven by one host thread: cr_batch_create + cr_batch_set_pairs "
-                        "(H2D of structures and pair list from page-locked arrays) and cr_batch_run_stream_i32 (the alignment kernel stores "
-                        "all int32 alignment rows + PairResult records into page-locked host arrays) of batch k + 1 are issued while batch "
-                        "k computes; every batch uploads and downloads everything.  one_batch_alone: the same calls with a wait after each batch"}
+                "note": "per batch: cr_batch_create + cr_batch_set_pairs (H2D of structures and pair list from page-locked arrays) and "
+                        "cr_batch_run_stream_i32 (the alignment kernel stores all int32 alignment rows + PairResult records into page-locked "
+                        "host arrays), a wait after the batch.  pipelined: the same calls as a two-stream pipeline driven by one host thread -- "
+                        "batch k + 1 is uploaded and queued while batch k computes; every batch uploads and downloads everything"}
         # ---------------------------------------------------------- BASELINE configs 4 and 5, sharded over the ranks
         gated = world == 1 and not args.no_cpu_baseline
         orc = None
@@ -463,22 +480,24 @@ def main():
                    "matrix_only": {"ms": t_sh_mat * 1e3, "ms_1gpu": (t_one_mat if t_one_mat is not None else t_sh_mat) * 1e3,
                                    "speedup_vs_1gpu": (t_one_mat / t_sh_mat) if t_one_mat is not None else 1.0}}
             if world == 1:
-                # one GPU's share of the 8-GPU split (every 8th pair), run here: what 8 GPUs would each do, before the
-                # (latency-bound, ~1 MB) all-gather
-                part = Sharded(n_c, l_c, s_c, ranks=1, me=0, stride=8)
-                t_part_mat = part.time(20 if key == "c3" else 10, 3, collective=False, scores_only=True)
-                t_part = part.time(20 if key == "c3" else 10, 3, collective=False)
-                rec["share_of_8"] = {"pairs": int(len(part.mine)), "ms": t_part * 1e3, "projected_speedup_8gpu": t_sh / t_part,
-                                     "matrix_only_ms": t_part_mat * 1e3, "matrix_only_projected_speedup_8gpu": t_sh_mat / t_part_mat}
-                if gated:
-                    # the whole config's matrix (the one-GPU run above) against the oracle's, and every output of the
-                    # share's pairs (>= 1 % of the config's pairs) against the oracle's
-                    r_p, a_p = part.batch.fetch(want_alignments=True, pinned=True)
-                    # (c3: EVERY pair of the share against the oracle, not a sample)
-                    rec.update(config_gate(orc, part.coords, part.tensors, part.offsets, part.pairs, full_scores, r_p, a_p, part.mine,
-                                           min_frac=len(part.mine) / len(part.pairs) if key == "c3" else 0.01))
-                    rec["share_of_8"]["layout"] = part.batch.layout()[0]
-                part.close()
+                # one GPU's share of the 2-, 4- and 8-GPU split (every 2nd / 4th / 8th pair), run here: what G GPUs would each do,
+                # before the (latency-bound, ~1 MB) all-gather.  The north star asks throughput at 1, 2, 4 and 8 GPUs.
+                for g in (2, 4, 8):
+                    part = Sharded(n_c, l_c, s_c, ranks=1, me=0, stride=g)
+                    reps_p = (20 if key == "c3" else 10) if g == 8 else (10 if key == "c3" else 5)
+                    t_part_mat = part.time(reps_p, 3, collective=False, scores_only=True)
+                    t_part = part.time(reps_p, 3, collective=False)
+                    rec[f"share_of_{g}"] = {"pairs": int(len(part.mine)), "ms": t_part * 1e3, f"projected_speedup_{g}gpu": t_sh / t_part,
+                                            "matrix_only_ms": t_part_mat * 1e3, f"matrix_only_projected_speedup_{g}gpu": t_sh_mat / t_part_mat,
+                                            "layout": part.batch.layout()[0]}
+                    if gated and g == 8:
+                        # the whole config's matrix (the one-GPU run above) against the oracle's, and every output of the
+                        # share's pairs (>= 1 % of the config's pairs) against the oracle's
+                        r_p, a_p = part.batch.fetch(want_alignments=True, pinned=True)
+                        # (c3: EVERY pair of the share against the oracle, not a sample)
+                        rec.update(config_gate(orc, part.coords, part.tensors, part.offsets, part.pairs, full_scores, r_p, a_p, part.mine,
+                                               min_frac=len(part.mine) / len(part.pairs) if key == "c3" else 0.01))
+                    part.close()
             extras[f"{key}_sharded"] = rec
 
     if rank == 0 and world == 1 and not args.no_extras and args.workload == "headline":
@@ -519,15 +538,42 @@ def main():
                                 "own children: node coordinates, tensors and consensus weights bit-identical"}
         extras["msa"] = rec
 
+    if rank == 0 and world == 1 and not args.no_extras and args.workload == "headline":
+        # ---------------------------------------------------------- what the reference actually runs: ragged families, and its
+        # functions on explicit score matrices WITH their tracebacks (dynamic_time_warping.py:148-184, :226-278)
+        sys.path.insert(0, str(ROOT / "tools"))
+        try:
+            import ragged_time
+            rec = ragged_time.ragged_record(ctx, params, orc)
+            rec["headline_mcells_per_s"] = float((lengths[pairs[:, 0]] * lengths[pairs[:, 1]]).sum()) / (elapsed / args.steps) / 1e6
+            rec["mcells_per_s_over_headline"] = rec["mcells_per_s"] / rec["headline_mcells_per_s"]
+            extras["ragged"] = rec
+            extras["mixed"] = ragged_time.mixed_record(ctx, params)
+        except Exception as exc:                          # noqa: BLE001 -- the headline line must survive
+            extras["ragged"] = {"error": repr(exc)}
+        try:
+            import explicit_batch_rate
+            extras["explicit_batch"] = explicit_batch_rate.explicit_record(8128, 300)
+            tfile = ROOT / "profiles" / "r05" / "explicit_batch_pmc.json"
+            if tfile.exists():
+                extras["explicit_batch"]["traffic_over_algorithmic"] = json.loads(tfile.read_text()).get("traffic_over_algorithmic")
+                extras["explicit_batch"]["traffic_source"] = "profiles/r05/explicit_batch_pmc.json"
+        except Exception as exc:                          # noqa: BLE001
+            extras["explicit_batch"] = {"error": repr(exc)}
+
     if rank == 0 and world == 1 and not args.no_extras and engine.device_count() > 1:
         # several GPUs visible to this ONE process: the single-process multi-GPU path behind make_pairwise_matrix
         # (cr_multi_*) on BASELINE config 4, in a child process with a time limit (tools/multi_gpu_check.py)
         import subprocess
         try:
-            p = subprocess.run([sys.executable, str(ROOT / "tools" / "multi_gpu_check.py")], capture_output=True, text=True, timeout=600)
+            # (the tool is a watchdog: a fresh child per measurement under its own time limit, non-zero exit on timeout or difference)
+            p = subprocess.run([sys.executable, str(ROOT / "tools" / "multi_gpu_check.py"), "--timeout", "240"], capture_output=True, text=True, timeout=600)
             line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-            extras["single_process_multi_gpu"] = json.loads(line[-1]) if p.returncode == 0 and line else {
-                "error": f"exit code {p.returncode}", "stderr_tail": p.stderr[-500:]}
+            rec_m = json.loads(line[-1]) if line else {}
+            if p.returncode != 0:
+                rec_m.setdefault("error", f"exit code {p.returncode}")
+                rec_m["stderr_tail"] = p.stderr[-500:]
+            extras["single_process_multi_gpu"] = rec_m
         except Exception as exc:                          # noqa: BLE001 -- the headline line must survive
             extras["single_process_multi_gpu"] = {"error": repr(exc)}
     if rank == 0:
@@ -552,9 +598,15 @@ def main():
             "metric": "pairwise alignments/sec", "value": total_pairs / (elapsed / args.steps), "unit": "pairs/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak" if args.workload == "headline" else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "repeats": {"runs": repeats, "steps_per_run": args.steps, "ms_per_step_min": min(run_s) / args.steps * 1e3,
+                        "ms_per_step_median": elapsed / args.steps * 1e3, "ms_per_step_max": max(run_s) / args.steps * 1e3,
+                        "note": "the timed region (K steps between barrier + synchronize) repeated; ms_per_step / value are the median run's"},
             "config": {"workload": f"{args.workload}: {num} structures x {length} residues, d={dim}, all {total_pairs} "
                                    f"pairs i<j sharded over {args.gpus} GPU(s), pipeline H (tensor-RBF SW seed -> Kabsch -> "
-                                   f"coord-RBF SW score + affine DTW(1.0,0.01) -> Kabsch/RMSD/TM)",
+                                   f"coord-RBF SW score + affine DTW(1.0,0.01) -> Kabsch/RMSD/TM)"
+                                   + (f"; `value` is the WEAK-scaling headline (P = round(128 sqrt(N)) = {num}: per-GPU work fixed); the "
+                                      f"STRONG-scaling figure of BASELINE config 3 (128 x 300 fixed) is `value_strong`"
+                                      if args.workload == "headline" and args.gpus > 1 else ""),
                        "structures": num, "residues": length, "tensor_width": dim, "pairs": total_pairs,
                        "pairs_per_gpu": int(len(mine)), "seed": seed},
             "dtw_mcells_per_s": cells_rank * world / (stage_ms[1] * 1e-3) / 1e6,
@@ -588,6 +640,9 @@ def main():
         except (OSError, ValueError, KeyError):
             pass
         out.update(extras)
+        if args.gpus > 1 and "c3_sharded" in extras:
+            out["value_strong"] = extras["c3_sharded"]["pairs_per_s"]
+            out["value_strong_note"] = "BASELINE config 3 (128 x 300, 8 128 pairs) FIXED and sharded over the ranks + one all-gather: pairs/s; speed-up vs one GPU in c3_sharded.speedup_vs_1gpu"
         out["build"] = ge.build_provenance()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], out["nj_gate"] = cpu_baseline(coords, tensors, offsets, pairs, res, aln, matrix)

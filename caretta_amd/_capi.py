@@ -72,6 +72,7 @@ SIGNATURES = {
     "cr_multi_device_count": [_vp, C.POINTER(C.c_int)],
     "cr_multi_pairwise_scores": [_vp, _vp, _vp, _vp, _i64, _i64, C.POINTER(Params), _vp, _vp],
     "cr_multi_last_ms": [_vp, C.POINTER(C.c_float * 3)],
+    "cr_multi_numa_nodes": [_vp, _vp],
     "cr_multi_destroy": [_vp],
     "cr_partition_pairs": [_vp, _i64, _i32, _i32, _vp, C.POINTER(C.c_int64)],
     "cr_make_score_matrix": [_vp, _vp, _i64, _vp, _i64, _i64, _f64, _vp],

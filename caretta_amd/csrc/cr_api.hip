@@ -55,9 +55,6 @@ CR_ILP_PAIR_WIDE_INSTANCES(CR_X)
 #define CR_X(RA, RB, D, SC) extern template CR_PAIR_DUO_SIGNATURE(RA, RB, D, SC)
 CR_DUO_INSTANCES(CR_X)
 #undef CR_X
-#define CR_X(RA, RB, D, SC) extern template CR_PAIR_DUO_TEAM_SIGNATURE(RA, RB, D, SC)
-CR_DUO_TEAM_INSTANCES(CR_X)
-#undef CR_X
 #define CR_X(R, D, SC) extern template CR_PAIR_TRIO_SIGNATURE(R, D, SC)
 CR_TRIO_INSTANCES(CR_X)
 #undef CR_X
@@ -321,7 +318,6 @@ struct cr_batch {
         int lane = 0;                    // 0: the context's stream; k > 0: side stream k-1 (one lane per group)
     };
     std::vector<Chunk> chunks;
-    bool duo_team = false;              // k_pair_duo with the sums behind the walks taken by the whole workgroup (one pair per CU)
     // A RAGGED list is split into at most three size classes (cr_batch_set_pairs): each class is a batch of its own on
     // this batch's structures (coords / tensors / offsets borrowed), with its own kernel family, scratch and launch
     // sequence; its order map leads straight to the caller's pair indices, so results land in the caller's order.
@@ -732,21 +728,19 @@ int launch_pair_wide(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& pr
 }
 
 // ---- mid-size pair lists: the wide layout on small workgroups paced by progress words (cr_duo.h); gap 0 only ----------
-template <int RA, int RB, int D, bool SC, bool TEAM>
+template <int RA, int RB, int D, bool SC>
 int launch_pair_duo_t(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
     const int seed_entries = std::min(ck.n_max, ck.m_max), align_entries = ck.max_aln;
     const int waves = plan_of(b).strips(ck.n_max);
-    // (TEAM: the sums behind the walks by the whole workgroup -- their term tile shares the LDS with the fills)
-    const size_t seed_trace = (size_t)cr::kExpDoubles + (TEAM ? cr::trace_team_lds_doubles(seed_entries) : cr::trace_lds_doubles(RA, seed_entries));
-    const size_t align_trace = (size_t)cr::kExpDoubles + (TEAM ? cr::trace_team_lds_doubles(align_entries) : cr::trace_lds_doubles(RA, align_entries));
-    const size_t seed = std::max(cr::duo_cols_lds_doubles(waves, ck.m_max), seed_trace);
+    const size_t seed = std::max(cr::duo_cols_lds_doubles(waves, ck.m_max), (size_t)cr::kExpDoubles + cr::trace_lds_doubles(RA, seed_entries));
     const size_t second = SC ? cr::duo_score_lds_doubles<cr::RbfCoords<RA>>(waves, ck.m_max)
-                             : std::max(cr::duo_sweep_lds_doubles<cr::kSwScore | cr::kDtw, cr::RbfCoords<RA>>(waves, ck.m_max), align_trace);
+                             : std::max(cr::duo_sweep_lds_doubles<cr::kSwScore | cr::kDtw, cr::RbfCoords<RA>>(waves, ck.m_max),
+                                        (size_t)cr::kExpDoubles + cr::trace_lds_doubles(RA, align_entries));
     size_t lds = sizeof(double) * std::max(seed, second);
-    if (!TEAM && g_cfg.mid_lds_kb > 0) lds = std::max(lds, (size_t)g_cfg.mid_lds_kb * 1024);   // calibration: pairs per CU
-    int rc = allow_lds(cr::k_pair_duo<RA, RB, D, SC, TEAM>, lds);
+    if (g_cfg.mid_lds_kb > 0) lds = std::max(lds, (size_t)g_cfg.mid_lds_kb * 1024);   // calibration: pairs per CU
+    int rc = allow_lds(cr::k_pair_duo<RA, RB, D, SC>, lds);
     if (rc) return rc;
-    CR_LAUNCH((cr::k_pair_duo<RA, RB, D, SC, TEAM>), dim3((unsigned)ck.count), dim3(waves * cr::kWave), lds,
+    CR_LAUNCH((cr::k_pair_duo<RA, RB, D, SC>), dim3((unsigned)ck.count), dim3(waves * cr::kWave), lds,
               b->launch_stream ? b->launch_stream : b->ctx->stream, b->pairs.p + ck.first, b->tensors.p, (int)b->d, b->coords.p,
               prm.gamma_tensor, prm.gamma_coords, prm.gap_open, prm.gap_extend, seed_entries, align_entries, b->wide_na, b->dirs.p,
               b->bits.p, b->xf.p + ck.first, b->seed_score.p + ck.first, b->aln.p, b->res.p + ck.first, host_out_for(b, ck));
@@ -754,33 +748,25 @@ int launch_pair_duo_t(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& p
     return CR_OK;
 }
 
-template <int RA, int RB, bool TEAM>
+template <int RA, int RB>
 int launch_pair_duo_r(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, bool scores) {
     switch (b->d_pad) {
-        case 4: return scores ? launch_pair_duo_t<RA, RB, 4, true, TEAM>(b, ck, prm) : launch_pair_duo_t<RA, RB, 4, false, TEAM>(b, ck, prm);
-        case 8: return scores ? launch_pair_duo_t<RA, RB, 8, true, TEAM>(b, ck, prm) : launch_pair_duo_t<RA, RB, 8, false, TEAM>(b, ck, prm);
-        case 10: return scores ? launch_pair_duo_t<RA, RB, 10, true, TEAM>(b, ck, prm) : launch_pair_duo_t<RA, RB, 10, false, TEAM>(b, ck, prm);
-        case 16: return scores ? launch_pair_duo_t<RA, RB, 16, true, TEAM>(b, ck, prm) : launch_pair_duo_t<RA, RB, 16, false, TEAM>(b, ck, prm);
+        case 4: return scores ? launch_pair_duo_t<RA, RB, 4, true>(b, ck, prm) : launch_pair_duo_t<RA, RB, 4, false>(b, ck, prm);
+        case 8: return scores ? launch_pair_duo_t<RA, RB, 8, true>(b, ck, prm) : launch_pair_duo_t<RA, RB, 8, false>(b, ck, prm);
+        case 10: return scores ? launch_pair_duo_t<RA, RB, 10, true>(b, ck, prm) : launch_pair_duo_t<RA, RB, 10, false>(b, ck, prm);
+        case 16: return scores ? launch_pair_duo_t<RA, RB, 16, true>(b, ck, prm) : launch_pair_duo_t<RA, RB, 16, false>(b, ck, prm);
         default: return fail(CR_ERR_ARGUMENT, "unsupported tensor width");
     }
 }
 
 int launch_pair_duo(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, bool scores) {
     const int key = b->r_seed * 10 + b->r_b;
-    if (b->duo_team) {
-        switch (key) {
-            case 22: return launch_pair_duo_r<2, 2, true>(b, ck, prm, scores);
-            case 32: return launch_pair_duo_r<3, 2, true>(b, ck, prm, scores);
-            case 33: return launch_pair_duo_r<3, 3, true>(b, ck, prm, scores);
-            default: return fail(CR_ERR_STATE, "no k_pair_duo instance with workgroup-wide sums for this strip plan");
-        }
-    }
     switch (key) {
-        case 11: return launch_pair_duo_r<1, 1, false>(b, ck, prm, scores);
-        case 21: return launch_pair_duo_r<2, 1, false>(b, ck, prm, scores);
-        case 22: return launch_pair_duo_r<2, 2, false>(b, ck, prm, scores);
-        case 32: return launch_pair_duo_r<3, 2, false>(b, ck, prm, scores);
-        case 33: return launch_pair_duo_r<3, 3, false>(b, ck, prm, scores);
+        case 11: return launch_pair_duo_r<1, 1>(b, ck, prm, scores);
+        case 21: return launch_pair_duo_r<2, 1>(b, ck, prm, scores);
+        case 22: return launch_pair_duo_r<2, 2>(b, ck, prm, scores);
+        case 32: return launch_pair_duo_r<3, 2>(b, ck, prm, scores);
+        case 33: return launch_pair_duo_r<3, 3>(b, ck, prm, scores);
         default: return fail(CR_ERR_STATE, "no k_pair_duo instance for this strip plan");
     }
 }
@@ -1111,7 +1097,7 @@ namespace {
 // range cannot say) wins.  Every limit was measured on equal-length synthetic families on an MI355X; `calibration`
 // names the committed record.  The environment switches of cr_config.h move single limits for measurements.
 // ---------------------------------------------------------------------------------------------
-enum Family : int { kFamSingle = 0, kFamTeam, kFamWide, kFamDuoTeam, kFamDuo, kFamTrio, kFamStaged };
+enum Family : int { kFamSingle = 0, kFamTeam, kFamWide, kFamDuo, kFamTrio, kFamStaged };
 
 struct LayoutRule {
     Family family;
@@ -1142,8 +1128,6 @@ constexpr LayoutRule kLayoutTable[] = {
     {kFamTrio, 257, 320, 161, kTrioPairLimit, kMidMaxColumns, 10, "profiles/r04/trio_few.txt, c3_share.txt, c3_share_limit.txt"},
     // staged scores (cr_staged.h): at most one wave per SIMD of the chip (pairs x strips <= 1 024: checked by fits)
     {kFamStaged, 1, cr::kStagedMaxRows, 1, kStagedWaveLimit, kAnyLength, 32, "profiles/r03/calibrate_staged.txt"},
-    // one pair per CU, strips paced by progress words + workgroup-wide sums (cr_duo.h, TEAM): up to 8 waves
-    {kFamDuoTeam, 513, 1472, 1, kTeamPairLimit, kMidMaxColumns, 16, "profiles/r05/c5_share_layouts.txt"},
     // one pair per CU, up to 16 waves, barrier every 8 steps (k_pair_wide)
     {kFamWide, 193, 3072, 1, kTeamPairLimit, kAnyLength, 16, "profiles/r03/calibrate_wide.txt"},
     // four-wave teams: what the wide layout cannot take (tensor widths above 16)
@@ -1215,19 +1199,6 @@ bool wide_fits(const StripPlan& p, int n_max, int m_max, int d_pad, int max_wave
     return sizeof(double) * std::max(std::max(seed, align), trace) <= 159 * 1024;
 }
 
-// k_pair_duo with workgroup-wide sums: the wide layout's plans with at most kDuoMaxWaves strips, gap 0 (another gap lays the
-// list out again), the fill's resident columns and rings or the term tile of the sums in the LDS of one CU
-bool duo_team_fits(const StripPlan& p, int n_max, int m_max, int d_pad) {
-    const int key = p.ra * 10 + p.rb;
-    if (!(key == 22 || key == 32 || key == 33) || d_pad > 16) return false;
-    if (p.ra != p.rb && (p.na < 1 || p.na >= cr::kDuoMaxWaves)) return false;
-    const int waves = p.strips(n_max);
-    if (waves < 2 || waves > cr::kDuoMaxWaves) return false;
-    const size_t fill = cr::duo_sweep_lds_doubles<cr::kSwScore | cr::kDtw, cr::RbfCoords<1>>(waves, m_max);
-    const size_t trace = cr::kExpDoubles + cr::trace_team_lds_doubles(n_max + m_max);
-    return sizeof(double) * std::max(fill, trace) <= 159 * 1024;
-}
-
 // The strip plan of a wide launch.  A workgroup's waves are dealt round robin to the CU's four SIMDs; a SIMD issues one
 // FP64-rate instruction per 4 cycles when two or more waves share it and a lone wave gets one per ~6.5,
 // and all strips advance together (barriers), so a sweep step costs what the fullest SIMD needs for its row slots.  The
@@ -1278,7 +1249,6 @@ LayoutRule effective_rule(LayoutRule r) {
             if (c.staged_waves >= 0) r.pairs_hi = kAnyPairs;
             if (c.staged_rows >= 0) r.rows_hi = (int)std::min<long long>(c.staged_rows, cr::kStagedMaxRows);
             break;
-        case kFamDuoTeam:
         case kFamWide:
         case kFamTeam:
             if (c.team_pairs >= 0) r.pairs_hi = c.team_pairs;
@@ -1332,17 +1302,6 @@ Layout choose_layout(int n_max, int m_max, int d_pad, int64_t npairs, const Layo
                 out.r_seed = out.r_b = shape.r;
                 return out;
             }
-            case kFamDuoTeam: {
-                if (!c.duo_team || c.no_team || c.no_wide || mask.no_wide || mask.no_duo) break;
-                const StripPlan p = choose_wide_plan(n_max, m_max, cr::kDuoPublish, [&](const StripPlan& q) { return duo_team_fits(q, n_max, m_max, d_pad); });
-                if (!p.ra) break;
-                out.family = kFamDuoTeam;
-                out.r_seed = p.ra;
-                out.r_b = p.rb;
-                out.wide_na = p.na;
-                out.wide_sync = 8;
-                return out;
-            }
             case kFamWide: {
                 if (c.no_team || c.no_wide || mask.no_wide) break;
                 const StripPlan p = choose_wide_plan(n_max, m_max, 8, [&](const StripPlan& q) { return wide_fits(q, n_max, m_max, d_pad); });
@@ -1388,11 +1347,10 @@ Layout choose_layout(int n_max, int m_max, int d_pad, int64_t npairs, const Layo
 
 // the batch's layout flags from the chosen family (what the launch sequences of run_batch read)
 void apply_layout(cr_batch* b, const Layout& l) {
-    b->team = l.family == kFamTeam || l.family == kFamWide || l.family == kFamDuoTeam || l.family == kFamDuo || l.family == kFamStaged;
-    b->wide_sync = (l.family == kFamWide || l.family == kFamDuoTeam || l.family == kFamDuo) ? l.wide_sync : 0;
+    b->team = l.family == kFamTeam || l.family == kFamWide || l.family == kFamDuo || l.family == kFamStaged;
+    b->wide_sync = (l.family == kFamWide || l.family == kFamDuo) ? l.wide_sync : 0;
     b->wide_na = b->wide_sync ? l.wide_na : 0;
-    b->duo = l.family == kFamDuo || l.family == kFamDuoTeam;
-    b->duo_team = l.family == kFamDuoTeam;
+    b->duo = l.family == kFamDuo;
     b->trio = l.family == kFamTrio;
     b->trio_few = b->trio && l.trio_few;
     b->staged = l.family == kFamStaged;
@@ -1702,7 +1660,7 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     b->h_pairs.clear();
     b->order.clear();
     b->reordered = false;
-    b->team = b->duo = b->duo_team = b->trio = b->trio_few = b->staged = false;
+    b->team = b->duo = b->trio = b->trio_few = b->staged = false;
     b->wide_sync = b->wide_na = 0;
     b->max_aln = 0;
     b->aln_elems = 0;
@@ -2044,7 +2002,7 @@ int cr_batch_layout(cr_batch* b, int* family, int* rows_a, int* rows_b, int* str
         if (strips_a) *strips_a = 0;
         return CR_OK;
     }
-    if (family) *family = b->staged ? CR_LAYOUT_STAGED : b->trio ? CR_LAYOUT_TRIO : b->duo_team ? CR_LAYOUT_DUO_TEAM : b->duo ? CR_LAYOUT_DUO : b->wide_sync ? CR_LAYOUT_WIDE : b->team ? CR_LAYOUT_TEAM : CR_LAYOUT_SINGLE;
+    if (family) *family = b->staged ? CR_LAYOUT_STAGED : b->trio ? CR_LAYOUT_TRIO : b->duo ? CR_LAYOUT_DUO : b->wide_sync ? CR_LAYOUT_WIDE : b->team ? CR_LAYOUT_TEAM : CR_LAYOUT_SINGLE;
     if (rows_a) *rows_a = b->r_seed;
     if (rows_b) *rows_b = b->wide_sync ? b->r_b : b->r_seed;
     if (strips_a) *strips_a = b->wide_sync ? b->wide_na : 0;

@@ -39,7 +39,6 @@ struct Calibration {
     bool mid = true;                 // CARETTA_MID=0 switches the mid-size row split off
     bool mid_any = false;            // CARETTA_MID_ANY: k_pair_duo also with a single strip (measurements)
     bool staged = true;              // CARETTA_STAGED=0: the fused kernels instead of staged scores
-    bool duo_team = true;            // CARETTA_DUO_TEAM=0: k_pair_wide instead of k_pair_duo with workgroup-wide sums
     bool classes = true;             // CARETTA_CLASSES=0: a ragged list stays ONE list (no size classes)
     long long team_pairs = -1;       // CARETTA_TEAM_PAIRS   (-1: the table's limit)
     long long trio_pairs = -1;       // CARETTA_TRIO_PAIRS
@@ -92,7 +91,6 @@ struct Calibration {
         c.mid = env_on("CARETTA_MID");
         c.mid_any = env_set("CARETTA_MID_ANY");
         c.staged = env_on("CARETTA_STAGED");
-        c.duo_team = env_on("CARETTA_DUO_TEAM");
         c.classes = env_on("CARETTA_CLASSES");
         c.team_pairs = env_ll("CARETTA_TEAM_PAIRS", -1);
         c.trio_pairs = env_ll("CARETTA_TRIO_PAIRS", -1);

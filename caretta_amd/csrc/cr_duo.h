@@ -401,11 +401,8 @@ CR_D double sweep_cols_score_duo(Src& src, const int n, const int m, double* lds
 // Both stages of a pair in one launch.  Dynamic LDS (doubles): the largest of the three fills and of
 // kExpDoubles + trace_lds_doubles (the walks and ordered sums are wave 0's, as in k_seed / k_align).
 // ---------------------------------------------------------------------------------------------
-// TEAM (lists of one pair per CU -- one GPU's share of a sharded long-chain family: 252 pairs of 1200 x 1200): the
-// position-ordered sums behind the two walks are taken by the WHOLE workgroup (kabsch_team / rmsd_tm_team, as k_pair_wide
-// does), the fills stay paced by progress words.  Dynamic LDS then also covers kExpDoubles + trace_team_lds_doubles.
-template <int RA, int RB, int D, bool SCORES, bool TEAM = false>
-__global__ __launch_bounds__(kDuoMaxWaves* kWave, TEAM ? 1 : 2) void k_pair_duo(const PairDesc* __restrict__ pairs,
+template <int RA, int RB, int D, bool SCORES>
+__global__ __launch_bounds__(kDuoMaxWaves* kWave, 2) void k_pair_duo(const PairDesc* __restrict__ pairs,
                                                                     const double* __restrict__ tensors, int d,
                                                                     const double* __restrict__ coords, double gamma_tensor,
                                                                     double gamma_coords, double gap_open, double gap_extend,
@@ -435,47 +432,7 @@ __global__ __launch_bounds__(kDuoMaxWaves* kWave, TEAM ? 1 : 2) void k_pair_duo(
         if (plan.wave_in_a(w)) fill(std::integral_constant<int, RA>{});
         else if constexpr (RA != RB) fill(std::integral_constant<int, RB>{});
     }
-    __shared__ int s_walk[4];
-    if constexpr (TEAM) {
-        // wave 0 walks (the others wait at the barrier); the sums behind the walk are everybody's
-        uint32_t* const seed_list = reinterpret_cast<uint32_t*>(lds + kExpDoubles);
-        double* const seed_terms = lds + kExpDoubles + ((size_t)seed_entries + 3) / 4 * 2;
-        if (threadIdx.x < kWave) {
-            CR_STAMP(1);
-            int k, len;
-            uint32_t fl;
-            seed_walk<RA, 0, RB>(pd, dirs, sm, seed_list, nA, k, len, fl);
-            if (threadIdx.x == 0) {
-                s_walk[0] = k;
-                s_walk[1] = len;
-                s_walk[2] = (int)fl;
-            }
-            CR_STAMP(2);
-        }
-        __syncthreads();
-        const int k = s_walk[0];
-        Transform tr;
-#pragma unroll
-        for (int x = 0; x < 3; x++) tr.c1[x] = tr.c2[x] = 0.0;
-#pragma unroll
-        for (int x = 0; x < 9; x++) tr.R[x] = (x % 4 == 0) ? 1.0 : 0.0;
-        tr.flags = (uint32_t)s_walk[2];
-        tr.seed_len = s_walk[1];
-        if (k <= 3) {
-            tr.flags |= kFlagSeedSkipped;
-        } else {
-            double t[3];
-            const int cap = pd.n < pd.m ? pd.n : pd.m;
-            kabsch_team(coords + pd.off_i * 3, coords + pd.off_j * 3, seed_list + (cap - k), k, k, seed_terms, seed_terms + kSumTile * kMaxAcc + kSumSlack,
-                        tr.c1, tr.c2, tr.R, t);
-        }
-        if (threadIdx.x == 0) {
-            xf[blockIdx.x] = tr;
-            seed_score[blockIdx.x] = sm.score;
-            s_tr = tr;
-        }
-        CR_STAMP(3);
-    } else if (threadIdx.x < kWave) {                      // wave 0 walks and superposes; the others wait at the barrier
+    if (threadIdx.x < kWave) {                             // wave 0 walks and superposes; the others wait at the barrier
         CR_STAMP(1);
         Transform tr;
         seed_trace<RA, 0, RB>(pd, seed_entries, coords, dirs, sm, lds + kExpDoubles, tr, nA);
@@ -508,54 +465,6 @@ __global__ __launch_bounds__(kDuoMaxWaves* kWave, TEAM ? 1 : 2) void k_pair_duo(
         };
         if (plan.wave_in_a(w)) fill(std::integral_constant<int, RA>{});
         else if constexpr (RA != RB) fill(std::integral_constant<int, RB>{});
-    }
-    if constexpr (TEAM && !SCORES) {
-        CR_STAMP(5);
-        PairResult r;
-        r.sw = e.sw;
-        r.dtw_score = e.dtw_score;
-#pragma unroll
-        for (int x = 0; x < 9; x++) r.R[x] = 0.0;
-#pragma unroll
-        for (int x = 0; x < 3; x++) r.t[x] = 0.0;
-        r.rmsd = r.coverage = r.tm = 0.0;
-        r.flags = 0;
-        uint32_t* const arow = reinterpret_cast<uint32_t*>(lds + kExpDoubles);
-        double* const terms = lds + kExpDoubles + ((size_t)align_entries + 3) / 4 * 2;
-        const int cap = pd.n + pd.m;
-        if (threadIdx.x < kWave) {                         // wave 0 walks, the others wait at the barrier
-            int idx, k;
-            dtw_walk<RA, RB>(pd.n, pd.m, align_entries, bits + pd.bt_off, e.start_layer, lds + kExpDoubles, aln + pd.aln_off, idx, k, nA);
-            stream_rows(hout, arow + (cap - idx), idx, (int)threadIdx.x);
-            if (threadIdx.x == 0) {
-                s_walk[0] = idx;
-                s_walk[1] = k;
-            }
-            CR_STAMP(6);
-        }
-        __syncthreads();
-        const int idx = s_walk[0], k = s_walk[1], first = cap - idx;
-        r.aln_len = idx;
-        r.aln_start = first;
-        if (k < 3) {
-            r.flags |= kFlagMetricsSkipped;
-        } else {
-            const double* Xi = coords + pd.off_i * 3;
-            const double* Xj = coords + pd.off_j * 3;
-            double c1[3], c2[3];
-            kabsch_team(Xi, Xj, arow + first, idx, k, terms, terms + kSumTile * kMaxAcc + kSumSlack, c1, c2, r.R, r.t);
-            rmsd_tm_team<true>(Xi, Xj, arow + first, idx, k, pd.n, pd.m, r.R, r.t, terms, terms + kSumTile * kMaxAcc + kSumSlack, r.rmsd, r.tm);
-            r.coverage = (double)k / (double)idx;
-        }
-        r.seed_score = sm.score;
-        r.seed_len = s_tr.seed_len;
-        r.flags |= s_tr.flags;
-        if (threadIdx.x == 0) {
-            res[blockIdx.x] = r;
-            if (hout.res) hout.res[hout.dst(blockIdx.x)] = r;
-        }
-        CR_STAMP(7);
-        return;
     }
     if (threadIdx.x >= kWave) return;                      // wave 0 goes on alone (wave_sync, no s_barrier from here on)
     CR_STAMP(5);

@@ -10,12 +10,6 @@
     __global__ void cr::k_pair_duo<RA, RB, D, SC>(const cr::PairDesc*, const double*, int, const double*, double, double,     \
                                                   double, double, int, int, int, uint32_t*, uint32_t*, cr::Transform*, double*, \
                                                   int32_t*, cr::PairResult*, const cr::HostOut);
-// ... with the sums behind the walks taken by the whole workgroup (one pair per CU: the strip plans of the wide layout)
-#define CR_DUO_TEAM_INSTANCES(X) CR_DUO_D(X, 2, 2) CR_DUO_D(X, 3, 2) CR_DUO_D(X, 3, 3)
-#define CR_PAIR_DUO_TEAM_SIGNATURE(RA, RB, D, SC)                                                                             \
-    __global__ void cr::k_pair_duo<RA, RB, D, SC, true>(const cr::PairDesc*, const double*, int, const double*, double, double, \
-                                                  double, double, int, int, int, uint32_t*, uint32_t*, cr::Transform*, double*, \
-                                                  int32_t*, cr::PairResult*, const cr::HostOut);
 
 // k_pair_trio (cr_trio.h): one wave of recurrences + two waves of scores per pair, pairs of at most 64 R rows
 // (two to five rows per lane: 65 .. 320 rows; tensor widths padded to 4, 8, 10)

@@ -12,9 +12,6 @@
 #define CR_X(RA, RB, D, SC) template CR_PAIR_DUO_SIGNATURE(RA, RB, D, SC)
 CR_DUO_INSTANCES(CR_X)
 #undef CR_X
-#define CR_X(RA, RB, D, SC) template CR_PAIR_DUO_TEAM_SIGNATURE(RA, RB, D, SC)
-CR_DUO_TEAM_INSTANCES(CR_X)
-#undef CR_X
 #define CR_X(R, D, SC) template CR_PAIR_TRIO_SIGNATURE(R, D, SC)
 CR_TRIO_INSTANCES(CR_X)
 #undef CR_X

@@ -131,6 +131,7 @@ struct cr_multi {
     float last_ms[3] = {0.f, 0.f, 0.f};      // last call: slowest device's share (events), all-gather (events), download (events) + scatter on the host (wall)
     // one host thread per device, parked between calls
     std::vector<std::thread> threads;
+    std::vector<int> numa_node;         // per device: the NUMA node its host thread was pinned to (CARETTA_MULTI_NUMA=1), else -1
     std::mutex mu;
     std::condition_variable cv_go, cv_done;
     std::function<void(int)> job;
@@ -157,7 +158,62 @@ void multi_run(cr_multi* m, const std::function<void(int)>& fn) {
     m->job = nullptr;
 }
 
+// CARETTA_MULTI_NUMA=1 (default off; for the first run on an 8-GPU node to A/B): the host thread that drives device `device`
+// runs on the CPUs of the NUMA node the device hangs off (sysfs: numa_node of its PCI function, cpulist of that node), so
+// that its staging copies and launch calls do not cross the socket interconnect.  Best effort: anything unreadable leaves
+// the thread where it is.  Returns the node, or -1.
+int pin_thread_to_device_numa(int device) {
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    for (char* c = bus; *c; c++) *c = (char)std::tolower((unsigned char)*c);
+    int node = -1;
+    {
+        const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/numa_node";
+        FILE* f = std::fopen(path.c_str(), "r");
+        if (!f) return -1;
+        if (std::fscanf(f, "%d", &node) != 1) node = -1;
+        std::fclose(f);
+    }
+    if (node < 0) return -1;
+    char list[4096] = {0};
+    {
+        const std::string path = "/sys/devices/system/node/node" + std::to_string(node) + "/cpulist";
+        FILE* f = std::fopen(path.c_str(), "r");
+        if (!f) return -1;
+        const bool ok = std::fgets(list, (int)sizeof(list), f) != nullptr;
+        std::fclose(f);
+        if (!ok) return -1;
+    }
+    cpu_set_t allowed, want;
+    CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return -1;
+    int any = 0;
+    for (const char* c = list; *c;) {                      // "0-63,128-191"
+        char* end = nullptr;
+        const long lo = std::strtol(c, &end, 10);
+        if (end == c) break;
+        long hi = lo;
+        c = end;
+        if (*c == '-') {
+            hi = std::strtol(c + 1, &end, 10);
+            c = end;
+        }
+        for (long k = lo; k <= hi && k < CPU_SETSIZE; k++)
+            if (CPU_ISSET((int)k, &allowed)) {             // (never outside what the cgroup / the caller's mask allows)
+                CPU_SET((int)k, &want);
+                any++;
+            }
+        while (*c == ',' || *c == ' ' || *c == '\n') c++;
+    }
+    if (!any) return -1;
+    return pthread_setaffinity_np(pthread_self(), sizeof(want), &want) == 0 ? node : -1;
+}
+
 void multi_worker(cr_multi* m, int g) {
+    if (g_cfg.multi_numa) m->numa_node[(size_t)g] = pin_thread_to_device_numa(m->devices[(size_t)g]);
     uint64_t seen = 0;
     for (;;) {
         std::function<void(int)> fn;
@@ -292,6 +348,7 @@ int cr_multi_create(const int* devices, int ndev, cr_multi** out) {
             return fail(CR_ERR_HIP, std::string("ncclCommInitAll: ") + api->GetErrorString(r));
         }
     }
+    m->numa_node.assign((size_t)G, -1);
     if (G > 1)
         for (int g = 0; g < G; g++) m->threads.emplace_back(multi_worker, m, g);
     *out = m;
@@ -301,6 +358,12 @@ int cr_multi_create(const int* devices, int ndev, cr_multi** out) {
 int cr_multi_device_count(cr_multi* m, int* ndev) {
     CR_REQUIRE(m && ndev, "null argument");
     *ndev = (int)m->devices.size();
+    return CR_OK;
+}
+
+int cr_multi_numa_nodes(cr_multi* m, int* nodes) {
+    CR_REQUIRE(m && nodes, "null argument");
+    for (size_t g = 0; g < m->devices.size(); g++) nodes[g] = g < m->numa_node.size() ? m->numa_node[g] : -1;
     return CR_OK;
 }
 

@@ -112,7 +112,7 @@ def all_pairs(num: int) -> np.ndarray:
     return np.ascontiguousarray(np.stack([i, j], axis=1), dtype=np.int32)
 
 
-LAYOUT_NAMES = ("single", "team", "wide", "staged", "duo", "trio", "classes", "duo_team")
+LAYOUT_NAMES = ("single", "team", "wide", "staged", "duo", "trio", "classes")
 
 
 def reload_config():
@@ -289,6 +289,12 @@ class MultiDevice:
         buf = (C.c_float * 3)()
         check(self._lib.cr_multi_last_ms(self._h, C.byref(buf)))
         return tuple(buf)
+
+    def numa_nodes(self):
+        """Per device: the NUMA node its host thread was pinned to (CARETTA_MULTI_NUMA=1), else -1."""
+        nodes = np.full(self.num_devices, -1, dtype=np.int32)
+        check(self._lib.cr_multi_numa_nodes(self._h, ptr(nodes)))
+        return [int(x) for x in nodes]
 
     def close(self):
         if self._h:

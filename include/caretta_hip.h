@@ -151,12 +151,11 @@ int cr_batch_work(cr_batch *b, double *alg_bytes, double *cells);
  * one workgroup per pair with a wave per strip ("wide"); scores formed by their own launches ("staged"); mid-size lists with a
  * pair's rows over 2 .. 8 waves ("duo") or one wave of recurrences + waves of scores ("trio") --, rows per lane of the first
  * `strips_a` strips and of the others (equal when the layout has one kind of strip).  Any pointer may be NULL.
- * CR_LAYOUT_DUO_TEAM: the row split with one pair per CU and the sums behind the walks taken by the whole workgroup.
  * CR_LAYOUT_CLASSES: a ragged list that cr_batch_set_pairs split into size classes (at most three: longest structure of a
  * pair <= 320 rows / <= 1 088 rows / longer), each laid out as a list of its own; rows_a then holds their number and
  * cr_batch_part_layout reports every class (part 0 .. count - 1; a list that was not split has the one part 0). */
 enum { CR_LAYOUT_SINGLE = 0, CR_LAYOUT_TEAM = 1, CR_LAYOUT_WIDE = 2, CR_LAYOUT_STAGED = 3, CR_LAYOUT_DUO = 4, CR_LAYOUT_TRIO = 5,
-       CR_LAYOUT_CLASSES = 6, CR_LAYOUT_DUO_TEAM = 7 };
+       CR_LAYOUT_CLASSES = 6 };
 int cr_batch_layout(cr_batch *b, int *family, int *rows_a, int *rows_b, int *strips_a);
 int cr_batch_part_layout(cr_batch *b, int part, int *family, int *rows_a, int *rows_b, int *strips_a, int64_t *npairs);
 /* The calibration switches (CARETTA_* environment variables: caretta_amd/csrc/cr_config.h) are read ONCE, when the library is
@@ -187,6 +186,9 @@ int cr_multi_pairwise_scores(cr_multi *m, const double *coords, const double *te
  * host + the scatter to pair order.  [0], [1] and the copy are read from events on the devices' streams (no host wait
  * separates the phases), the scatter is host time. */
 int cr_multi_last_ms(cr_multi *m, float ms[3]);
+/* nodes[device_count]: the NUMA node each device's host thread was pinned to (CARETTA_MULTI_NUMA=1; default off: all -1).
+ * No reference counterpart (the reference is single-device). */
+int cr_multi_numa_nodes(cr_multi *m, int *nodes);
 int cr_multi_destroy(cr_multi *m);
 /* The deal of the pair set over `world` devices or ranks (host only): indices into the row-major i < j pair list owned
  * by `rank`, ascending -- pairs sorted by DP cell count (descending, stable on the index) and dealt round robin; equal

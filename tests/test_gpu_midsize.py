@@ -34,13 +34,17 @@ def layout_of(batch):
     return batch.layout()
 
 
-def run_all_ways(ctx, oracle, coords, tensors, offsets, pairs, expect, sw_gaps=(0.0,), threads=8):
+def run_all_ways(ctx, oracle, coords, tensors, offsets, pairs, expect, sw_gaps=(0.0,), threads=8, parts=None):
     """Full pipeline, matrix entries only and the streamed run of one pair list against the oracle; `expect`: the kernel
     family cr_batch_set_pairs must have chosen."""
     from caretta_amd import engine
     from oracle.pyoracle import default_params
     batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
-    assert layout_of(batch)[0] == expect, f"layout {layout_of(batch)}, expected {expect}"
+    expect = (expect,) if isinstance(expect, str) else tuple(expect)
+    assert layout_of(batch)[0] in expect, f"layout {layout_of(batch)}, expected one of {expect}"
+    if parts is not None:                                         # the families of the size classes of a split list
+        assert [x[0] for x in batch.part_layouts()] == list(parts), batch.part_layouts()
+        assert sum(x[4] for x in batch.part_layouts()) == len(pairs)
     for gap in sw_gaps:
         ref, ref_aln = oracle.pairwise_batch(coords, tensors, offsets, pairs, params=default_params(sw_gap=gap), nthreads=threads)
         prm = engine.make_params(sw_gap=gap)
@@ -75,7 +79,7 @@ def test_one_of_eight_share_of_the_headline(ctx, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("dim,seed", [(10, 9101), (4, 9102), (16, 9103), (7, 9104)])
-def test_midsize_ragged_lists_vs_oracle(ctx, oracle, dim, seed):
+def test_midsize_ragged_lists_vs_oracle(ctx, oracle, monkeypatch, dim, seed):
     """Ragged lengths 40 .. 330 rows, both orientations of every pair (290 .. 400 pairs: beyond the one-pair-per-CU layouts):
     pairs of one launch end in strip 0 or strip 1, some have fewer rows than one strip; tensor widths that are padded (7)
     or not; with a Smith-Waterman gap the list is laid out again for the kernels that have a skewed seed sweep."""
@@ -87,7 +91,14 @@ def test_midsize_ragged_lists_vs_oracle(ctx, oracle, dim, seed):
     coords, tensors, offsets = synthetic.pack(fam)
     fwd = engine.all_pairs(15)
     pairs = np.vstack([fwd, fwd[:, ::-1], fwd[::2]])             # 105 + 105 + 53 = 263 > 256
+    # as ONE list (the row split: the longest structure has 330 rows) ...
+    monkeypatch.setenv("CARETTA_CLASSES", "0")
     run_all_ways(ctx, oracle, coords, tensors, offsets, pairs, "duo", sw_gaps=(0.0, 0.05) if dim == 10 else (0.0,))
+    # ... and as the library lays it out: two size classes (rows <= 320: one strip, by function -- no instance for widths
+    # above 10: staged scores or one wave per pair --; the 321- and 330-row structures' pairs: staged scores)
+    monkeypatch.delenv("CARETTA_CLASSES")
+    run_all_ways(ctx, oracle, coords, tensors, offsets, pairs, "classes", sw_gaps=(0.0, 0.05) if dim == 10 else (0.0,),
+                 parts=("trio", "staged") if dim <= 10 else None)
 
 
 @pytest.mark.parametrize("dim,seed,waves,longest", [(10, 9111, None, 320), (4, 9112, "5", 320), (8, 9113, "2", 320), (7, 9114, "4", 320),
@@ -135,7 +146,7 @@ def test_few_pairs_by_function_and_again_with_a_gap(ctx, oracle):
 
 
 @pytest.mark.parametrize("family", ["trio_few", "duo"])
-def test_streamed_run_with_a_gap_first_on_a_fresh_batch(ctx, oracle, family):
+def test_streamed_run_with_a_gap_first_on_a_fresh_batch(ctx, oracle, monkeypatch, family):
     """The gap-driven re-layout of a duo / few-pair trio list happens inside the FIRST run.  When that first run is the
     streamed one (the alignment kernel writes into the caller's page-locked arrays through the batch's order map), the map
     must be the one of the NEW layout: the list below is already sorted by cells (so the gap-0 layout keeps the caller's
@@ -154,6 +165,7 @@ def test_streamed_run_with_a_gap_first_on_a_fresh_batch(ctx, oracle, family):
         pairs = np.vstack([pairs, fwd[:60]])                     # 192 pairs: more than 160, at most 256
     cells = np.diff(offsets)[pairs[:, 0]] * np.diff(offsets)[pairs[:, 1]]
     pairs = np.ascontiguousarray(pairs[np.argsort(-cells, kind="stable")])
+    monkeypatch.setenv("CARETTA_CLASSES", "0")                   # (ONE list: the re-layout of the whole list is what is tested)
     batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
     assert layout_of(batch)[0] == ("trio" if family == "trio_few" else "duo"), layout_of(batch)
     prm = engine.make_params(sw_gap=0.05)
@@ -169,7 +181,7 @@ def test_streamed_run_with_a_gap_first_on_a_fresh_batch(ctx, oracle, family):
     batch.close()
 
 
-def test_midsize_three_and_more_strips(ctx, oracle):
+def test_midsize_three_and_more_strips(ctx, oracle, monkeypatch):
     """321 .. 600 rows: three to five waves per pair (3 rows per lane in strip 0, 2 in the others), ragged."""
     from caretta_amd import engine
     fam = synthetic.make_family(18, 600, seed=9201, clades=2)
@@ -179,7 +191,34 @@ def test_midsize_three_and_more_strips(ctx, oracle):
     coords, tensors, offsets = synthetic.pack(fam)
     fwd = engine.all_pairs(18)
     pairs = np.vstack([fwd, fwd[:, ::-1]])                      # 306 pairs
+    monkeypatch.setenv("CARETTA_CLASSES", "0")                  # one list: the row split with three to five waves per pair
     run_all_ways(ctx, oracle, coords, tensors, offsets, pairs, "duo")
+    monkeypatch.delenv("CARETTA_CLASSES")                       # size classes: up to 320 rows / 321 .. 600 rows
+    run_all_ways(ctx, oracle, coords, tensors, offsets, pairs, "classes")
+
+
+def test_size_classes_of_a_mixed_list(ctx, oracle):
+    """A family of 150-residue domains with two 600-residue chains in it (and one of 1 300): the list is split into size
+    classes by rows, each laid out as a list of its own (cr_batch_set_pairs) -- full pipeline, matrix entries, the streamed
+    run and a Smith-Waterman gap (which lays the few-pair classes out again, each keeping its place in the caller's order)
+    against the oracle; the flexible=True matrix entries through the same classes."""
+    from caretta_amd import engine
+    from oracle.pyoracle import default_params
+    fam = synthetic.make_mixed_family(20, 150, 3, 1300, seed=9601)
+    for s, cut in zip(fam[20:], (600, 600, 1300)):
+        s.coordinates, s.tensors = s.coordinates[:cut].copy(), s.tensors[:cut].copy()
+    coords, tensors, offsets = synthetic.pack(fam)
+    fwd = engine.all_pairs(len(fam))
+    pairs = np.vstack([fwd, fwd[:, ::-1]])                       # 506 pairs: rows 150 (440), 600 (44), 1 300 (22)
+    run_all_ways(ctx, oracle, coords, tensors, offsets, pairs, "classes", sw_gaps=(0.0, 0.05), parts=("trio", "staged", "staged"))
+    batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
+    batch.run(engine.make_params(gamma_tensor=1.3), scores_only=True, flexible=True)
+    sw, _ = batch.fetch_scores()
+    batch.close()
+    for p in (0, 19, 21, 250, 505):
+        i, j = pairs[p]
+        s_ij = oracle.make_score_matrix(fam[i].tensors, fam[j].tensors, 1.3)
+        assert sw[p] == oracle.smith_waterman_score(np.arange(len(fam[i].tensors)), np.arange(len(fam[j].tensors)), s_ij, 0.0)
 
 
 @pytest.mark.parametrize("npairs,rows,expect", [

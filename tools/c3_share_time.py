@@ -14,7 +14,9 @@ prm = engine.make_params()
 for _ in range(3): b.run(prm)
 ctx.synchronize()
 t0 = time.perf_counter()
-for _ in range(10): b.run(prm)
+for _ in range(50): b.run(prm)
 ctx.synchronize()
+dt = (time.perf_counter() - t0) / 50
+b.run(prm, scores_only=True)
 sw, _ = b.fetch_scores()
-print(f"{len(pairs)} pairs of 300 x 300, layout {b.layout()}: {(time.perf_counter()-t0)/10*1e3:.3f} ms per pass, checksum {sw.sum():.6f}")
+print(f"{len(pairs)} pairs of 300 x 300, layout {b.layout()}: {dt*1e3:.3f} ms per pass, checksum {sw.sum():.6f}")

@@ -20,11 +20,11 @@ def timed(b, so):
     for _ in range(5): b.run(prm, scores_only=so)
     ctx.synchronize(); return (time.perf_counter() - t0) / 5 * 1e3
 ref = None
-for name, env in [("default", {}), ("wide (CARETTA_DUO_TEAM=0)", {"CARETTA_DUO_TEAM": "0"}), ("duo 3,2,3", {"CARETTA_TEAM_PAIRS": "0", "CARETTA_STAGED": "0", "CARETTA_MID_PLAN": "3,2,3", "CARETTA_MID_PAIRS": "100000"}),
+for name, env in [("default (wide)", {}), ("duo 3,2,3", {"CARETTA_TEAM_PAIRS": "0", "CARETTA_STAGED": "0", "CARETTA_MID_PLAN": "3,2,3", "CARETTA_MID_PAIRS": "100000"}),
                   ("duo 3,2,4", {"CARETTA_TEAM_PAIRS": "0", "CARETTA_STAGED": "0", "CARETTA_MID_PLAN": "3,2,4", "CARETTA_MID_PAIRS": "100000"}),
                   ("duo 3,3,0", {"CARETTA_TEAM_PAIRS": "0", "CARETTA_STAGED": "0", "CARETTA_MID_PLAN": "3,3,0", "CARETTA_MID_PAIRS": "100000"}),
                   ("duo 2,2,0", {"CARETTA_TEAM_PAIRS": "0", "CARETTA_STAGED": "0", "CARETTA_MID_PLAN": "2,2,0", "CARETTA_MID_PAIRS": "100000"})]:
-    for k in ("CARETTA_TEAM_PAIRS", "CARETTA_STAGED", "CARETTA_MID_PLAN", "CARETTA_MID_PAIRS", "CARETTA_DUO_TEAM"): os.environ.pop(k, None)
+    for k in ("CARETTA_TEAM_PAIRS", "CARETTA_STAGED", "CARETTA_MID_PLAN", "CARETTA_MID_PAIRS"): os.environ.pop(k, None)
     os.environ.update(env)
     try:
         engine.reload_config()        # (the library reads its calibration switches once: cr_config.h)

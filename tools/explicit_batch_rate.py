@@ -1,10 +1,14 @@
 #!/usr/bin/env python3
-"""Read rate of the batched explicit-score-matrix kernels: COUNT matrices of N x N doubles resident in HBM.
+"""Rates of the batched explicit-score-matrix kernels: COUNT matrices of N x N doubles resident in HBM.
 
     python tools/explicit_batch_rate.py [COUNT [N]]        default 8128 x 300 x 300 = 5.85 GB (BASELINE config 3's pair count)
 
-Prints the device time of one smith_waterman_score_batch launch (HIP events on the launch stream), the algorithmic
-read rate (8 bytes per cell / that time) against the 8 TB/s HBM peak, and the same for dtw_align_batch (scores only).
+For every function of the reference that takes an explicit score matrix (dynamic_time_warping.py:148-184 dtw_align -- which
+ALWAYS traces back --, :188-201 dtw_align_score, :205-222 smith_waterman_score, :226-278 smith_waterman): the device time of
+the launch sequence (HIP events on the launch stream: fill kernel + traceback kernel where there is one), the algorithmic
+bytes of SURVEY.md 8(d)'s explicit mode -- 8 n m (the matrix, read once) + n m / 2 (4-bit DTW decisions; n m / 4 for the 2-bit
+SW ones; none for a score alone) + 24 (n + m) + 8 -- and their rate against the 8 TB/s HBM peak.
+bench.py imports `explicit_record`.
 """
 import sys
 import time
@@ -15,25 +19,48 @@ import numpy as np  # noqa: E402
 
 from caretta_amd import dynamic_time_warping as dtw  # noqa: E402
 
-count = int(sys.argv[1]) if len(sys.argv) > 1 else 8128
-n = int(sys.argv[2]) if len(sys.argv) > 2 else 300
-rng = np.random.default_rng(1)
-base = rng.uniform(size=(64, n, n)) ** 3                 # 64 distinct matrices, tiled: the kernels still read every byte
-idx = np.arange(n)
-t0 = time.perf_counter()
-batch = dtw.ExplicitBatch([(idx, idx, base[k % 64]) for k in range(count)])
-t_up = time.perf_counter() - t0
-nbytes = 8.0 * batch.cells
-for name, fn in (("smith_waterman_score_batch (gap 0, row sweep)", lambda: batch.smith_waterman_scores(0.0)),
-                 ("smith_waterman_score_batch (gap 0.1, skewed sweep)", lambda: batch.smith_waterman_scores(0.1)),
-                 ("dtw_align_batch (scores only)", lambda: batch.dtw_align(1.0, 0.01, want_alignments=False))):
-    out = fn()
-    ms = []
-    for _ in range(5):
-        out = fn()
-        ms.append(batch.last_kernel_ms())
-    best = min(ms)
-    print(f"{name}: {count} x {n} x {n}: {best:.3f} ms (median {sorted(ms)[2]:.3f}) -> {nbytes / best / 1e6:.0f} GB/s "
-          f"= {nbytes / best / 1e6 / 8000:.3f} of the 8 TB/s peak; checksum {float(np.sum(out)):.6f}")
-print(f"packing + upload of {nbytes / 1e9:.2f} GB: {t_up:.2f} s")
-batch.close()
+HBM_PEAK_GBS = 8000.0
+
+
+def explicit_record(count=8128, n=300, reps=5, with_tracebacks=True):
+    rng = np.random.default_rng(1)
+    base = rng.uniform(size=(64, n, n)) ** 3                 # 64 distinct matrices, tiled: the kernels still read every byte
+    idx = np.arange(n)
+    t0 = time.perf_counter()
+    batch = dtw.ExplicitBatch([(idx, idx, base[k % 64]) for k in range(count)])
+    t_up = time.perf_counter() - t0
+    cells = float(batch.cells)
+    rows = float(count) * 2 * n                              # sum of n + m
+    small = 24.0 * rows + 8.0 * count
+    modes = [("smith_waterman_score gap 0 (row sweep)", lambda: batch.smith_waterman_scores(0.0), 8.0 * cells + small),
+             ("smith_waterman_score gap 0.1 (skewed sweep)", lambda: batch.smith_waterman_scores(0.1), 8.0 * cells + small),
+             ("dtw_align_score (skewed sweep, no decisions)", lambda: batch.dtw_align(1.0, 0.01, want_alignments=False), 8.0 * cells + small)]
+    if with_tracebacks:
+        modes += [("dtw_align WITH traceback (4-bit decisions + walk)", lambda: batch.dtw_align(1.0, 0.01, want_alignments=True), 8.5 * cells + small),
+                  ("smith_waterman WITH traceback gap 0 (2-bit decisions + walk)", lambda: batch.smith_waterman(0.0), 8.25 * cells + small),
+                  ("smith_waterman WITH traceback gap 0.1", lambda: batch.smith_waterman(0.1), 8.25 * cells + small)]
+    out = {"matrices": count, "rows": n, "matrix_bytes": 8.0 * cells, "upload_s": t_up, "functions": {}}
+    for name, fn, nbytes in modes:
+        heavy = "WITH" in name
+        fn()
+        ms = []
+        for _ in range(2 if heavy else reps):
+            res = fn()
+            ms.append(batch.last_kernel_ms())
+        best = min(ms)
+        check = float(np.sum(res)) if not heavy else float(sum(r[2] for r in res))
+        out["functions"][name] = {"ms": best, "ms_median": sorted(ms)[len(ms) // 2], "algorithmic_bytes": nbytes,
+                                  "gb_per_s": nbytes / best / 1e6, "frac_of_hbm_peak": nbytes / best / 1e6 / HBM_PEAK_GBS, "checksum": check}
+        del res
+    batch.close()
+    return out
+
+
+if __name__ == "__main__":
+    count = int(sys.argv[1]) if len(sys.argv) > 1 else 8128
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+    rec = explicit_record(count, n)
+    for name, r in rec["functions"].items():
+        print(f"{name}: {count} x {n} x {n}: {r['ms']:.3f} ms (median {r['ms_median']:.3f}) -> {r['gb_per_s']:.0f} GB/s "
+              f"= {r['frac_of_hbm_peak']:.3f} of the 8 TB/s peak; checksum {r['checksum']:.6f}")
+    print(f"packing + upload of {rec['matrix_bytes'] / 1e9:.2f} GB: {rec['upload_s']:.2f} s")

@@ -89,6 +89,8 @@ def run(names):
                         continue
                     print(f"  wave {wv}: seed loop {med(ds[:, wv, 1] - ds[:, wv, 0]):9.0f} (start +{med(ds[:, wv, 0] - t0):7.0f}, waited {med(ds[:, wv, 2]):8.0f})   "
                           f"align loop {med(ds[:, wv, 5] - ds[:, wv, 4]):9.0f} (start +{med(ds[:, wv, 4] - st[:nb, 4]):7.0f}, waited {med(ds[:, wv, 6]):8.0f})", flush=True)
+        tot = st[:, 7] - st[:, 0]                   # (one block's stamps share a clock: the XCDs' counters are not synchronised)
+        print("  pair total (launch -> results), min p10 p50 p90 max: " + " ".join(f"{v:8.0f}" for v in np.percentile(tot, [0, 10, 50, 90, 100])), flush=True)
         if os.environ.get("STAMPS_DETAIL"):
             pc = lambda x: " ".join(f"{v:8.0f}" for v in np.percentile(x, [0, 10, 50, 90, 100]))
             t00 = st[:, 0].min()
