@@ -1116,7 +1116,8 @@ constexpr int64_t kStagedWaveLimit = 1024;
 // Mid-size lists (cr_duo.h): up to this many waves (two strips per pair / more), columns resident in LDS.
 constexpr int64_t kMidWaveLimit2 = 2600, kMidWaveLimit = 3072;
 constexpr int64_t kTrioPairLimit = 1300;       // k_pair_trio: 1 355 pairs tie with one wave per pair
-constexpr int kMidMaxColumns = 1280;
+constexpr int kMidMaxColumns = 1280;            // split by function: columns resident in LDS next to the score ring (four pairs per CU)
+constexpr int kDuoMaxRows = 3 * cr::kWave * (cr::kDuoMaxWaves - 1) + 2 * cr::kWave;      // 1 472: seven strips of 3 rows per lane and one of 2
 constexpr int kGroupLanes = 4;                 // streams that row-per-lane groups (and size classes) are spread over
 constexpr int64_t kClassSplitPairs = 4096;     // a ragged list of at most this many pairs is split into size classes
 
@@ -1133,7 +1134,7 @@ constexpr LayoutRule kLayoutTable[] = {
     // four-wave teams: what the wide layout cannot take (tensor widths above 16)
     {kFamTeam, 193, 5 * cr::kTeamWaves * cr::kWave, 1, kTeamPairLimit, kAnyLength, 32, "profiles/r01 (tools/calibrate_team_limit.py)"},
     // split by ROWS (cr_duo.h): 2 .. 8 waves per pair, all workgroups resident at once (wave limits: checked by fits)
-    {kFamDuo, 257, 1088, kTeamPairLimit + 1, kMidWaveLimit / 2, kMidMaxColumns, 16, "profiles/r04/c3_share.txt, c3_share_lengths.txt"},
+    {kFamDuo, 257, kDuoMaxRows, kTeamPairLimit + 1, kMidWaveLimit / 2, kDuoMaxRows, 16, "profiles/r04/c3_share.txt, c3_share_lengths.txt"},
     // one wave per pair, pairs grouped by rows per lane (2 .. 5)
     {kFamSingle, 1, kAnyLength, 1, kAnyPairs, kAnyLength, 32, "profiles/r02 (tools/calibrate_rows_per_lane.py)"},
 };
@@ -1325,12 +1326,21 @@ Layout choose_layout(int n_max, int m_max, int d_pad, int64_t npairs, const Layo
                 // up to 512 pairs of at most 320 rows: FOUR waves per pair (2 + 1 + 1 + 1 rows per lane: 2 048 waves still fit the
                 // chip at once) -- 508 pairs of 300: 0.50 / 0.33 ms against 0.54 / 0.40 with two waves
                 if (npairs <= 512 && n_max <= 5 * cr::kWave) p = StripPlan{2, 1, 1};
+                // beyond the 1 088 rows that one strip of 3 and seven of 2 rows per lane cover: more strips of 3 (eight waves: up to 1 472 rows)
+                if (n_max > 3 * cr::kWave + (cr::kDuoMaxWaves - 1) * 2 * cr::kWave)
+                    p = StripPlan{3, 2, (n_max - cr::kDuoMaxWaves * 2 * cr::kWave + cr::kWave - 1) / cr::kWave};
                 if (c.mid_plan.set) p = StripPlan{c.mid_plan.ra, c.mid_plan.rb, c.mid_plan.ra == c.mid_plan.rb ? 0 : c.mid_plan.na};
                 const int64_t strips = std::max(p.strips(std::max(n_max, 1)), 1);
                 // (every workgroup resident at once -- 16 waves per CU at <= 128 VGPRs --, and at most ~2.5 waves per SIMD for two
                 // strips, 3 for more: beyond that the single-wave kernels fill the SIMDs by themselves)
-                const int64_t mid_limit = c.mid_pairs >= 0 ? c.mid_pairs
-                                                           : std::min<int64_t>(256 * (16 / strips), (strips == 2 ? kMidWaveLimit2 : kMidWaveLimit) / strips);
+                int64_t mid_limit = std::min<int64_t>(256 * (16 / strips), (strips == 2 ? kMidWaveLimit2 : kMidWaveLimit) / strips);
+                // Long chains (seven or eight strips: 833 .. 1 472 rows) run in up to TWO rounds of 512 resident pairs: one wave per pair
+                // is bound there by the latency of a wave that takes four or more strips in turn (9.4 ms for 1 200 rows whatever the
+                // pair count), e.g. one GPU's share of BASELINE config 5 at 4 / 2 GPUs: 504 pairs of 1 200 9.6 -> 3.5 ms, 1 008 pairs
+                // 9.4 -> 6.8; 900 rows 5.4 -> 2.4 / 5.4 -> 4.8; 600 rows (five strips) 1 008 pairs 2.4 -> 3.5: not those
+                // (profiles/r05/long_share_layouts.txt)
+                if (strips >= 7) mid_limit = 2 * 256 * 2;
+                if (c.mid_pairs >= 0) mid_limit = c.mid_pairs;
                 if (npairs > mid_limit || !duo_fits(p, n_max, m_max, d_pad)) break;
                 out.family = kFamDuo;
                 out.r_seed = p.ra;
@@ -1358,11 +1368,11 @@ void apply_layout(cr_batch* b, const Layout& l) {
     b->r_b = b->wide_sync ? l.r_b : l.r_seed;
 }
 
-// Size class of a pair of n rows and m columns: A = one strip of the single-strip families (<= 320 rows), B = the row-split
-// families (<= 1 088 rows), C = everything else; the resident-column families need m <= 1 280.
+// Size class of a pair of n rows and m columns: A = one strip of the single-strip families (<= 320 rows; the split by function
+// keeps up to 1 280 columns resident), B = the row-split families (<= 1 472 rows and columns), C = everything else.
 int size_class(int n, int m) {
-    if (m > kMidMaxColumns) return 2;
-    return n <= 5 * cr::kWave ? 0 : n <= 1088 ? 1 : 2;
+    if (n <= 5 * cr::kWave && m <= kMidMaxColumns) return 0;
+    return (n <= kDuoMaxRows && m <= kDuoMaxRows) ? 1 : 2;
 }
 
 // One pair list, one layout.  `global` (size classes): the caller's index of every pair of this list -- the order map then
@@ -1635,7 +1645,7 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     // Size classes.  The layout of a list follows from its LONGEST structure, so one 600-residue member moves a family of
     // 150-residue structures to another kernel family (or out of every family built for its size).  A ragged list of at
     // most kClassSplitPairs pairs -- more fill the chip one wave per pair, which groups by rows per lane already -- is
-    // therefore split into at most three classes by rows (<= 320 / <= 1 088 / longer, or more than 1 280 columns), each
+    // therefore split into at most three classes by rows (<= 320 / <= 1 472 / longer; size_class()), each
     // laid out as a list of its own -- when that gives any class another family than one wave per pair.
     const int nclasses = (in_class[0] > 0) + (in_class[1] > 0) + (in_class[2] > 0);
     bool split = false;

@@ -152,7 +152,7 @@ int cr_batch_work(cr_batch *b, double *alg_bytes, double *cells);
  * pair's rows over 2 .. 8 waves ("duo") or one wave of recurrences + waves of scores ("trio") --, rows per lane of the first
  * `strips_a` strips and of the others (equal when the layout has one kind of strip).  Any pointer may be NULL.
  * CR_LAYOUT_CLASSES: a ragged list that cr_batch_set_pairs split into size classes (at most three: longest structure of a
- * pair <= 320 rows / <= 1 088 rows / longer), each laid out as a list of its own; rows_a then holds their number and
+ * pair <= 320 rows / <= 1 472 rows / longer), each laid out as a list of its own; rows_a then holds their number and
  * cr_batch_part_layout reports every class (part 0 .. count - 1; a list that was not split has the one part 0). */
 enum { CR_LAYOUT_SINGLE = 0, CR_LAYOUT_TEAM = 1, CR_LAYOUT_WIDE = 2, CR_LAYOUT_STAGED = 3, CR_LAYOUT_DUO = 4, CR_LAYOUT_TRIO = 5,
        CR_LAYOUT_CLASSES = 6 };

@@ -209,8 +209,8 @@ def test_size_classes_of_a_mixed_list(ctx, oracle):
         s.coordinates, s.tensors = s.coordinates[:cut].copy(), s.tensors[:cut].copy()
     coords, tensors, offsets = synthetic.pack(fam)
     fwd = engine.all_pairs(len(fam))
-    pairs = np.vstack([fwd, fwd[:, ::-1]])                       # 506 pairs: rows 150 (440), 600 (44), 1 300 (22)
-    run_all_ways(ctx, oracle, coords, tensors, offsets, pairs, "classes", sw_gaps=(0.0, 0.05), parts=("trio", "staged", "staged"))
+    pairs = np.vstack([fwd, fwd[:, ::-1]])                       # 506 pairs: rows 150 (440, 20 of them with 1 300 columns), 600 (44), 1 300 (22)
+    run_all_ways(ctx, oracle, coords, tensors, offsets, pairs, "classes", sw_gaps=(0.0, 0.05), parts=("trio", "staged"))
     batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
     batch.run(engine.make_params(gamma_tensor=1.3), scores_only=True, flexible=True)
     sw, _ = batch.fetch_scores()
@@ -227,7 +227,9 @@ def test_size_classes_of_a_mixed_list(ctx, oracle):
     (160, 300, ("wide", "staged")), (161, 300, ("trio",)), (110, 250, ("wide", "staged")), (111, 250, ("trio",)), (64, 150, ("single", "staged")), (65, 150, ("trio",)),
     (700, 320, ("trio",)), (701, 320, ("trio",)), (257, 321, ("duo",)), (256, 321, ("wide", "staged")), (1300, 300, ("trio",)), (1301, 300, ("single",)), (1024, 360, ("duo",)),
     (1025, 360, ("single",)),
-    (256, 64, ("single", "staged")), (170, 330, ("staged",)), (171, 330, ("wide",))])
+    (256, 64, ("single", "staged")), (170, 330, ("staged",)), (171, 330, ("wide",)),
+    # long chains (seven or eight strips): the row split in up to two rounds of 512 resident pairs
+    (300, 1200, ("duo",)), (1024, 900, ("duo",)), (1025, 900, ("single",))])
 def test_path_selection_boundaries(ctx, oracle, npairs, rows, expect):
     """The pair-count and row-count limits of cr_batch_set_pairs at their boundary values: which kernel family runs on either
     side, and that both sides give the oracle's results (a sample of the pairs is compared: the lists differ by one pair)."""
