@@ -18,8 +18,11 @@ CR_NUM_STAGES = 2
 FLAG_SEED_SKIPPED, FLAG_METRICS_SKIPPED, FLAG_SEED_ALL_ZERO, FLAG_MEAN_UNSUPERPOSED = 1, 2, 4, 8
 
 
+CR_ERR_ARGUMENT, CR_ERR_HIP, CR_ERR_MEMORY, CR_ERR_STATE = -1, -2, -3, -4      # include/caretta_hip.h
+
+
 class CarettaHipError(RuntimeError):
-    pass
+    code = CR_ERR_HIP
 
 
 class Params(C.Structure):
@@ -80,6 +83,7 @@ SIGNATURES = {
     "cr_progressive_node": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _f64, _f64, C.POINTER(Params), _f64,
                             _vp, _vp, C.POINTER(C.c_int64), _vp, _vp, _vp, C.POINTER(C.c_uint32)],
     "cr_progressive_align": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, C.POINTER(Params), _f64, _f64, C.POINTER(_vp)],
+    "cr_progressive_align_flexible": [_vp, _vp, _vp, _i64, _i64, _vp, _i64, C.POINTER(Params), _f64, _f64, C.POINTER(_vp)],
     "cr_progressive_sizes": [_vp, _vp],
     "cr_progressive_fetch_msa": [_vp, _vp],
     "cr_progressive_node_table": [_vp, _vp],
@@ -195,7 +199,9 @@ def check(rc: int):
         raise ValueError(msg)
     if rc == -3:
         raise MemoryError(msg)
-    raise CarettaHipError(msg)
+    err = CarettaHipError(msg)
+    err.code = rc
+    raise err
 
 
 def ptr(a: np.ndarray):

@@ -782,7 +782,9 @@ int launch_pair_trio_t(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& 
     if (rc) return rc;
     // one wave of recurrences + two of scores; THREE of scores while the chip then still holds fewer than ~2 800 waves
     // (tools/c3_share.py: 508 pairs of 300 0.45 -> 0.41 ms, 678 pairs 0.56 -> 0.46; 1 016 pairs 0.55 either way)
-    int waves = ck.count <= 700 ? 4 : 3;
+    // (the matrix entries alone -- both stages are column sweeps -- also at 1 016 pairs: 0.407 -> 0.388 ms, profiles/r05/c3_stages.txt;
+    // 1 024 pairs x 4 waves = every wave slot of the chip at four per SIMD)
+    int waves = ck.count <= (SC ? 1024 : 700) ? 4 : 3;
     if (g_cfg.trio_waves) waves = std::min(std::max(g_cfg.trio_waves, 2), cr::kTrioMaxWaves);   // calibration
     int waves2 = waves;                                            // waves of the second stage (1 + its score waves)
     if (g_cfg.trio_waves2) waves2 = std::min(std::max(g_cfg.trio_waves2, 2), waves);            // calibration

@@ -368,6 +368,42 @@ struct RbfNode {
     }
 };
 
+// The node score of the progressive alignment with flexible=True: Protein.score_function(flexible=True) is the TENSOR score
+// matrix alone (multiple_alignment.py:323-326), make_intermediate_node adds the consensus-weight term (:207-210).  Used by
+// the score staging kernel of cr_staged.h (columns resident, one plane per feature + one for the weights).
+template <int R, int D>
+struct RbfFlexNode {
+    static constexpr bool kNonNegative = true;
+    static constexpr bool kMaskRows = false;
+    RbfTensor<R, D> ten;
+    const double* __restrict__ w_rows;   // (n) consensus weights of node 1
+    const double* __restrict__ w_cols;   // (m) consensus weights of node 2
+    double mult1, mult2, neg_gamma_w;
+    double wrow[R], wcol;
+    static constexpr int kColDoubles = D + 1;
+
+    CR_D void load_rows(int rowbase, int n) {
+        ten.load_rows(rowbase, n);
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const int r = rowbase + q;
+            wrow[q] = r < n ? w_rows[r] * mult1 : kFarAway;
+        }
+    }
+    CR_D void load_resident_range(double* res, int stride, int c0, int c1, int tid, int nth) {
+        ten.load_resident_range(res, stride, c0, c1, tid, nth);
+        for (int c = c0 + tid; c < c1; c += nth) res[D * stride + c - c0] = w_cols[c] * mult2;
+    }
+    CR_D void fetch_resident(const double* res, int stride, int c) {
+        ten.fetch_resident(res, stride, c);
+        wcol = res[D * stride + c];
+    }
+    CR_D double score(int q, const ExpEntry* tab) const {
+        const double dw = wrow[q] - wcol;
+        return ten.score(q, tab) + exp_tab<true>(neg_gamma_w * (dw * dw), tab);
+    }
+};
+
 // Explicit score matrix with index sequences: S[seq1[i], seq2[j]] (dynamic_time_warping.py:24-26,79).
 // The strip's 64*R rows x the 128 most recent columns are staged in LDS: every 64 steps all lanes copy the next
 // 64 columns of every row of the strip with row-contiguous (coalesced when seq2 is a range) loads, so the sweep

@@ -30,6 +30,7 @@ struct cr_progressive {
     std::vector<std::vector<int32_t>> aln;   // per internal node k: row 1 then row 2, `len` entries each
     int64_t levels = 0;
     uint32_t any_flags = 0;
+    bool flexible = false;                   // flexible=True in score and mean function: tensors and consensus weights only
 };
 
 namespace {
@@ -173,6 +174,7 @@ int run_tree_planned(cr_progressive* h, const std::vector<std::vector<int64_t>>&
         CR_HIP(hipMemGetInfo(&free_b, &total_b));
         staged = (double)widest_level * (double)shape.pair_doubles() * sizeof(double) <= (double)total_b / 10.0;
     }
+    if (h->flexible && !staged) return 1;                    // (flexible=True runs on staged scores only)
     if (!staged && (bound <= 3 * cr::kWave || bound > 5 * cr::kTeamWaves * cr::kWave)) return 1;     // (the four-wave team kernels: 193 .. 1280 rows)
     const int R = staged ? shape.r : (bound + cr::kTeamWaves * cr::kWave - 1) / (cr::kTeamWaves * cr::kWave);
 
@@ -254,6 +256,18 @@ int run_tree_planned(cr_progressive* h, const std::vector<std::vector<int64_t>>&
         CR_HIP(hipGetLastError());
         if (count == 0) break;
         const cr_batch::Chunk ck{first, count, bound, bound, 2 * bound};
+        if (h->flexible) {
+            // flexible=True (multiple_alignment.py:323-326, :351-362): no seed stage -- node scores = tensor RBF + weight RBF
+            // (every CU) -> DTW sweep + node (mean tensors and weights)
+            if ((rc = launch_stage_flex(stream, (int)count, bound, b.d_pad, b.pairs.p + first, b.tensors.p, (int)h->d, h->weights.p,
+                                        h->d_nodes.p + first, prm, gamma_weight, h->staged.p, shape)))
+                return rc;
+            if ((rc = launch_node_staged(stream, (int)count, 2 * bound, b.pairs.p + first, b.coords.p, b.tensors.p, (int)h->d,
+                                         h->weights.p, h->d_nodes.p + first, b.xf.p + first, prm, h->staged.p, shape, b.bits.p,
+                                         b.aln.p, b.coords.p, b.tensors.p, h->weights.p, h->d_outs.p + first, /*flexible=*/true)))
+                return rc;
+            continue;
+        }
         if (staged) {
             // scores (every CU) -> SW sweep + seed superposition -> node scores in that frame (every CU) -> DTW sweep + node
             if ((rc = launch_stage_tensor(&b, ck, prm, h->staged.p, shape))) return rc;
@@ -327,14 +341,31 @@ int run_tree_planned(cr_progressive* h, const std::vector<std::vector<int64_t>>&
 
 extern "C" {
 
+static int progressive_align_impl(cr_context* ctx, const double* coords, const double* tensors, const int64_t* offsets, int64_t P,
+                                  int64_t d, const uint64_t* tree, int64_t tree_rows, const cr_params* params,
+                                  double consensus_weight, double gamma_weight, bool flexible, cr_progressive** out);
+
 int cr_progressive_align(cr_context* ctx, const double* coords, const double* tensors, const int64_t* offsets,
                          int64_t P, int64_t d, const uint64_t* tree, int64_t tree_rows, const cr_params* params,
                          double consensus_weight, double gamma_weight, cr_progressive** out) {
+    CR_REQUIRE(coords != nullptr, "null input");
+    return progressive_align_impl(ctx, coords, tensors, offsets, P, d, tree, tree_rows, params, consensus_weight, gamma_weight, false, out);
+}
+
+int cr_progressive_align_flexible(cr_context* ctx, const double* tensors, const int64_t* offsets, int64_t P, int64_t d,
+                                  const uint64_t* tree, int64_t tree_rows, const cr_params* params, double consensus_weight,
+                                  double gamma_weight, cr_progressive** out) {
+    return progressive_align_impl(ctx, nullptr, tensors, offsets, P, d, tree, tree_rows, params, consensus_weight, gamma_weight, true, out);
+}
+
+static int progressive_align_impl(cr_context* ctx, const double* coords, const double* tensors, const int64_t* offsets, int64_t P,
+                                  int64_t d, const uint64_t* tree, int64_t tree_rows, const cr_params* params,
+                                  double consensus_weight, double gamma_weight, bool flexible, cr_progressive** out) {
     CR_REQUIRE(out != nullptr, "null out");
     *out = nullptr;
     int rc = set_device(ctx);
     if (rc) return rc;
-    CR_REQUIRE(coords && tensors && offsets && tree && params, "null input");
+    CR_REQUIRE((coords || flexible) && tensors && offsets && tree && params, "null input");
     CR_REQUIRE(P >= 2 && tree_rows == 2 * P - 3, "tree must have 2P-3 rows");
     CR_REQUIRE(d >= 1 && padded_width(d) != 0, "tensor width > 32 is not supported by this build");
     CR_REQUIRE(offsets[0] == 0, "offsets[0] must be 0");
@@ -348,7 +379,7 @@ int cr_progressive_align(cr_context* ctx, const double* coords, const double* te
     CR_REQUIRE(std::isfinite(gamma_weight) && gamma_weight >= 0.0 && std::isfinite(consensus_weight),
                "gamma_weight must be finite and >= 0, consensus_weight finite");
     const int64_t total = offsets[P];
-    CR_REQUIRE(all_finite(coords, (size_t)total * 3), "coordinates contain NaN or infinity");
+    if (!flexible) CR_REQUIRE(all_finite(coords, (size_t)total * 3), "coordinates contain NaN or infinity");
     CR_REQUIRE(all_finite(tensors, (size_t)total * (size_t)d), "tensors contain NaN or infinity");
 
     // tree -> children of every internal node (ids P .. 2P-2), validated
@@ -362,6 +393,7 @@ int cr_progressive_align(cr_context* ctx, const double* coords, const double* te
     h->ctx = ctx;
     h->P = P;
     h->d = d;
+    h->flexible = flexible;
     h->scratch.ctx = ctx;
     h->scratch.P = P;
     h->scratch.d = d;
@@ -411,8 +443,10 @@ int cr_progressive_align(cr_context* ctx, const double* coords, const double* te
     {
         std::vector<double> w((size_t)total, consensus_weight);
         hipStream_t st = ctx->stream;
-        rc = upload_async(ctx, h->scratch.coords.p, coords, sizeof(double) * (size_t)total * 3);
-        if (rc) return rc;
+        if (!flexible) {
+            rc = upload_async(ctx, h->scratch.coords.p, coords, sizeof(double) * (size_t)total * 3);
+            if (rc) return rc;
+        }
         rc = upload_async(ctx, h->scratch.tensors.p, tensors, sizeof(double) * (size_t)(total * d));
         if (rc) return rc;
         rc = upload_async(ctx, h->weights.p, w.data(), sizeof(double) * (size_t)total);
@@ -423,6 +457,9 @@ int cr_progressive_align(cr_context* ctx, const double* coords, const double* te
     for (int64_t id = P; id < num_ids; id++) by_level[(size_t)h->level[(size_t)id]].push_back(id);
     rc = g_cfg.sync_levels ? 1 : run_tree_planned(h, by_level, prm, gamma_weight);
     if (rc < 0) return rc;
+    if (rc == 1 && flexible)
+        return fail(CR_ERR_STATE, "flexible progressive alignment: a tree node outgrew what the device path is sized for (1.5 x the "
+                                  "longest structure, at most 2048 columns)");       // (the host module then walks the tree itself)
     if (rc == 1) {                                  // not applicable, or a node outgrew the bound: level by level
         h->used = total;
         h->any_flags = 0;
@@ -512,6 +549,7 @@ int cr_progressive_fetch_nodes(cr_progressive* h, int64_t* aln, double* coords, 
         return CR_OK;
     };
     CR_HIP(hipStreamSynchronize(h->ctx->stream));
+    CR_REQUIRE(!(coords && h->flexible), "a flexible progressive alignment has no node coordinates");
     if (coords && (rc = slice(h->scratch.coords.p, 3, coords))) return rc;
     if (tensors && (rc = slice(h->scratch.tensors.p, h->d, tensors))) return rc;
     if (weights && (rc = slice(h->weights.p, 1, weights))) return rc;

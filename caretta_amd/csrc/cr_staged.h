@@ -108,6 +108,30 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_stage_node(const Pai
     stage_block<true, R>(src, pd.n, pd.m, tc, staged + (int64_t)blockIdx.y * shape.pair_doubles(), shape, lds);
 }
 
+// node score of the progressive alignment with flexible=True (multiple_alignment.py:323-326 + :207-210): tensor RBF + weight RBF
+template <int D, int R>
+__global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_stage_flex(const PairDesc* __restrict__ pairs,
+                                                                      const double* __restrict__ tensors, int d,
+                                                                      const double* __restrict__ weights,
+                                                                      const NodeDesc* __restrict__ nodes, double gamma_tensor,
+                                                                      double gamma_weight, int tc, double* __restrict__ staged,
+                                                                      const StagedShape shape) {
+    extern __shared__ double lds[];
+    const PairDesc pd = pairs[blockIdx.y];
+    const NodeDesc nd = nodes[blockIdx.y];
+    RbfFlexNode<R, D> src;
+    src.ten.rows_g = tensors + pd.off_i * d;
+    src.ten.cols_g = tensors + pd.off_j * d;
+    src.ten.d = d;
+    src.ten.neg_gamma = -gamma_tensor;
+    src.w_rows = weights + pd.off_i;
+    src.w_cols = weights + pd.off_j;
+    src.mult1 = nd.mult1;
+    src.mult2 = nd.mult2;
+    src.neg_gamma_w = -gamma_weight;
+    stage_block<true, R>(src, pd.n, pd.m, tc, staged + (int64_t)blockIdx.y * shape.pair_doubles(), shape, lds);
+}
+
 // coordinate RBF of a pair in the frame of its seed superposition (multiple_alignment.py:158-170, Protein.score_function)
 template <int R>
 __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_stage_coords(const PairDesc* __restrict__ pairs,
@@ -190,7 +214,9 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_seed_staged(const Pa
 
 // Node stage on staged scores: affine DTW fill with one wave per strip, then the traceback (wave 0) and, by the whole
 // workgroup, what node_finish does behind it: the superposition on the aligned positions and the merged node.
-template <int R>
+// FLEX: flexible=True in score and mean function -- no seed, no superposition, no coordinates: the node is its mean tensors and
+// consensus weights (multiple_alignment.py:351-362); `coords`, `xfs` and `Xn_base` are not touched.
+template <int R, bool FLEX = false>
 __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_node_staged(const PairDesc* __restrict__ pairs, const double* coords,
                                                                      const double* tensors, int d, const double* weights,
                                                                      const NodeDesc* __restrict__ nodes,
@@ -241,29 +267,33 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_node_staged(const Pa
     double* Xn = Xn_base + nd.out_off * 3;
     double* Tn = Tn_base + nd.out_off * d;
     double* Wn = Wn_base + nd.out_off;
-    uint32_t flags = xfs[blockIdx.x].flags;
+    uint32_t flags = FLEX ? 0u : xfs[blockIdx.x].flags;
     double c1[3] = {0, 0, 0}, c2[3] = {0, 0, 0}, Rm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3];
-    const bool superpose = k > 3;                        // multiple_alignment.py:364
-    if (superpose) kabsch_team(X1, X2, ent, idx, k, terms, terms + kSumTile * kMaxAcc + kSumSlack, c1, c2, Rm, t);
-    else flags |= 8u;
+    const bool superpose = !FLEX && k > 3;               // multiple_alignment.py:364
+    if constexpr (!FLEX) {
+        if (superpose) kabsch_team(X1, X2, ent, idx, k, terms, terms + kSumTile * kMaxAcc + kSumSlack, c1, c2, Rm, t);
+        else flags |= 8u;
+    }
     // Protein.mean_function (:351-381) and get_mean_weights (:73-82), one alignment column per thread
     for (int x = threadIdx.x; x < idx; x += blockDim.x) {
         const uint32_t u = ent[x];
         const uint32_t i = u & 0xffffu, j = u >> 16;
         const bool has1 = i != kGap16, has2 = j != kGap16;
-        double a[3] = {0, 0, 0}, b[3] = {0, 0, 0};
-        if (has1)
-            for (int c = 0; c < 3; c++) a[c] = superpose ? X1[(int64_t)i * 3 + c] - c1[c] : X1[(int64_t)i * 3 + c];
-        if (has2) {
-            if (superpose) {
-                const double v[3] = {X2[(int64_t)j * 3] - c2[0], X2[(int64_t)j * 3 + 1] - c2[1], X2[(int64_t)j * 3 + 2] - c2[2]};
-                rot3(v, Rm, b);
-            } else {
-                for (int c = 0; c < 3; c++) b[c] = X2[(int64_t)j * 3 + c];
-            }
-        }
         const int64_t o = first + x;
-        for (int c = 0; c < 3; c++) Xn[o * 3 + c] = !has1 ? b[c] : (!has2 ? a[c] : (a[c] + b[c]) / 2);
+        if constexpr (!FLEX) {
+            double a[3] = {0, 0, 0}, b[3] = {0, 0, 0};
+            if (has1)
+                for (int c = 0; c < 3; c++) a[c] = superpose ? X1[(int64_t)i * 3 + c] - c1[c] : X1[(int64_t)i * 3 + c];
+            if (has2) {
+                if (superpose) {
+                    const double v[3] = {X2[(int64_t)j * 3] - c2[0], X2[(int64_t)j * 3 + 1] - c2[1], X2[(int64_t)j * 3 + 2] - c2[2]};
+                    rot3(v, Rm, b);
+                } else {
+                    for (int c = 0; c < 3; c++) b[c] = X2[(int64_t)j * 3 + c];
+                }
+            }
+            for (int c = 0; c < 3; c++) Xn[o * 3 + c] = !has1 ? b[c] : (!has2 ? a[c] : (a[c] + b[c]) / 2);
+        }
         for (int c = 0; c < d; c++) {
             const double ta = has1 ? T1[(int64_t)i * d + c] : 0.0, tb = has2 ? T2[(int64_t)j * d + c] : 0.0;
             Tn[o * d + c] = !has1 ? tb : (!has2 ? ta : (ta + tb) / 2);
@@ -561,10 +591,43 @@ int launch_stage_node(hipStream_t stream, int count, int m_max, const cr::PairDe
     return by_rows(shape.r, [&](auto rt) { return go(cr::k_stage_node<decltype(rt)::value>); });
 }
 
+// flexible=True: the node scores (tensor RBF + consensus-weight RBF) of a level in the skewed step order
+template <int D>
+int launch_stage_flex_d(hipStream_t stream, int count, int m_max, const cr::PairDesc* pairs, const double* tensors, int d,
+                        const double* weights, const cr::NodeDesc* nodes, const cr_params& prm, double gamma_weight, double* staged,
+                        const cr::StagedShape shape) {
+    const int steps = m_max + cr::kWave - 1, tc = stage_steps(count, steps);
+    const size_t lds = sizeof(double) * cr::stage_lds_doubles(D + 1, tc);
+    const unsigned chunks = (unsigned)((steps + tc - 1) / tc);
+    auto go = [&](auto kernel) -> int {
+        int rc = allow_lds(kernel, lds);
+        if (rc) return rc;
+        CR_LAUNCH(kernel, dim3(chunks, (unsigned)count), dim3(shape.waves * cr::kWave), lds, stream, pairs, tensors, d, weights, nodes,
+                  prm.gamma_tensor, gamma_weight, tc, staged, shape);
+        CR_HIP(hipGetLastError());
+        return CR_OK;
+    };
+    return by_rows(shape.r, [&](auto rt) { return go(cr::k_stage_flex<D, decltype(rt)::value>); });
+}
+
+int launch_stage_flex(hipStream_t stream, int count, int m_max, int d_pad, const cr::PairDesc* pairs, const double* tensors, int d,
+                      const double* weights, const cr::NodeDesc* nodes, const cr_params& prm, double gamma_weight, double* staged,
+                      const cr::StagedShape shape) {
+    switch (d_pad) {
+        case 4: return launch_stage_flex_d<4>(stream, count, m_max, pairs, tensors, d, weights, nodes, prm, gamma_weight, staged, shape);
+        case 8: return launch_stage_flex_d<8>(stream, count, m_max, pairs, tensors, d, weights, nodes, prm, gamma_weight, staged, shape);
+        case 10: return launch_stage_flex_d<10>(stream, count, m_max, pairs, tensors, d, weights, nodes, prm, gamma_weight, staged, shape);
+        case 16: return launch_stage_flex_d<16>(stream, count, m_max, pairs, tensors, d, weights, nodes, prm, gamma_weight, staged, shape);
+        case 24: return launch_stage_flex_d<24>(stream, count, m_max, pairs, tensors, d, weights, nodes, prm, gamma_weight, staged, shape);
+        case 32: return launch_stage_flex_d<32>(stream, count, m_max, pairs, tensors, d, weights, nodes, prm, gamma_weight, staged, shape);
+        default: return fail(CR_ERR_ARGUMENT, "unsupported tensor width");
+    }
+}
+
 int launch_node_staged(hipStream_t stream, int count, int entries, const cr::PairDesc* pairs, const double* coords,
                        const double* tensors, int d, const double* weights, const cr::NodeDesc* nodes, const cr::Transform* xf,
                        const cr_params& prm, const double* staged, const cr::StagedShape shape, uint32_t* bits, int32_t* aln,
-                       double* xn, double* tn, double* wn, cr::NodeOut* out) {
+                       double* xn, double* tn, double* wn, cr::NodeOut* out, bool flexible = false) {
     const size_t lds = sizeof(double) * std::max(cr::sweep_staged_lds_doubles<cr::kDtw>(shape.waves),
                                                  (size_t)cr::kExpDoubles + cr::trace_team_lds_doubles(entries));
     auto go = [&](auto kernel) -> int {
@@ -575,7 +638,10 @@ int launch_node_staged(hipStream_t stream, int count, int entries, const cr::Pai
         CR_HIP(hipGetLastError());
         return CR_OK;
     };
-    return by_rows(shape.r, [&](auto rt) { return go(cr::k_node_staged<decltype(rt)::value>); });
+    return by_rows(shape.r, [&](auto rt) {
+        constexpr int R = decltype(rt)::value;
+        return flexible ? go(cr::k_node_staged<R, true>) : go(cr::k_node_staged<R, false>);
+    });
 }
 
 }  // namespace

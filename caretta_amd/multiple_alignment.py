@@ -394,13 +394,25 @@ class MultipleAlignment:
         mean_function_params = mean_function_params or {}
         score_function_params = score_function_params or {}
         tree = np.asarray(tree)
+        flex_score, flex_mean = bool(score_function_params.get("flexible", False)), bool(mean_function_params.get("flexible", False))
         if (len(self.sequences) >= 2 and tree.shape == (2 * len(self.sequences) - 3, 2)
                 and all(type(s) is Protein and s.coordinates is not None for s in self.sequences)
-                and not score_function_params.get("flexible", False)
-                and not mean_function_params.get("flexible", False)):
+                and not flex_score and not flex_mean):
             # every node of the tree on the device, one launch pair per tree level (cr_progressive_align)
             return self._progressive_align_resident(tree, gap_open_penalty, gap_extend_penalty, consensus_weight,
                                                     gamma_weight, score_function_params, mean_function_params)
+        if (len(self.sequences) >= 2 and tree.shape == (2 * len(self.sequences) - 3, 2) and flex_score and flex_mean
+                and self._all_proteins(need_coordinates=False) and len({np.shape(s.tensors)[1] for s in self.sequences}) == 1
+                and np.shape(self.sequences[0].tensors)[1] <= 32):
+            # flexible=True in score AND mean function (multiple_alignment.py:323-326, :351-362): nodes are tensors and consensus
+            # weights only -- the same resident tree without the seed stage (cr_progressive_align_flexible).  A node that outgrows
+            # the launch bound sends the tree to the host walk below.
+            try:
+                return self._progressive_align_resident(tree, gap_open_penalty, gap_extend_penalty, consensus_weight,
+                                                        gamma_weight, score_function_params, mean_function_params, flexible=True)
+            except _capi.CarettaHipError as exc:
+                if exc.code != _capi.CR_ERR_STATE:
+                    raise
         self._drop_pending_nodes()
         walk = _GuideTreeWalk(self.sequences, consensus_weight)
         fusable = not score_function_params.get("flexible", False) and not mean_function_params.get("flexible", False)
@@ -431,7 +443,7 @@ class MultipleAlignment:
         return top
 
     def _progressive_align_resident(self, tree, gap_open_penalty, gap_extend_penalty, consensus_weight, gamma_weight,
-                                    score_function_params, mean_function_params):
+                                    score_function_params, mean_function_params, flexible=False):
         """progressive_align (multiple_alignment.py:172-253) for Proteins through cr_progressive_align: the same
         nodes, alignments and attributes, computed level by level of the guide tree with everything resident in HBM."""
         lib = _capi.load()
@@ -447,9 +459,13 @@ class MultipleAlignment:
         # the nodes of an earlier call go first: their device blocks (arena, staged scores: hundreds of MB for long
         # structures) return to the library's cache and are handed to this call instead of being allocated beside them
         self._drop_pending_nodes()
-        check(lib.cr_progressive_align(default_context()._h, ptr(coords), ptr(tensors), ptr(offsets), P, d, ptr(tree_u),
-                                       tree_u.shape[0], C.byref(prm), float(consensus_weight), float(gamma_weight),
-                                       C.byref(h)))
+        if flexible:
+            check(lib.cr_progressive_align_flexible(default_context()._h, ptr(tensors), ptr(offsets), P, d, ptr(tree_u), tree_u.shape[0],
+                                                    C.byref(prm), float(consensus_weight), float(gamma_weight), C.byref(h)))
+        else:
+            check(lib.cr_progressive_align(default_context()._h, ptr(coords), ptr(tensors), ptr(offsets), P, d, ptr(tree_u),
+                                           tree_u.shape[0], C.byref(prm), float(consensus_weight), float(gamma_weight),
+                                           C.byref(h)))
         try:
             sizes = np.zeros(5, np.int64)
             check(lib.cr_progressive_sizes(h, ptr(sizes)))
@@ -486,7 +502,7 @@ class MultipleAlignment:
         alignment = {names[s]: msa[s] for s in order}
         # the intermediate nodes (:248-251) stay on the device until final_* is read
         self._pending_nodes = dict(handle=h, lib=lib, d=d, total=total, table=table, names=names, node_names=node_names,
-                                   consensus_weight=consensus_weight, msa=msa)
+                                   consensus_weight=consensus_weight, msa=msa, flexible=flexible)
         self.node_table = table
         return alignment
 
@@ -508,8 +524,9 @@ class MultipleAlignment:
         lib, h, d, total, table = pending["lib"], pending["handle"], pending["d"], pending["total"], pending["table"]
         try:
             aln = np.zeros(2 * total, np.int64)
-            xn, tn, wn = np.zeros((total, 3)), np.zeros((total, d)), np.zeros(total)
-            check(lib.cr_progressive_fetch_nodes(h, ptr(aln), ptr(xn), ptr(tn), ptr(wn)))
+            flexible = pending.get("flexible", False)
+            xn, tn, wn = (None if flexible else np.zeros((total, 3))), np.zeros((total, d)), np.zeros(total)
+            check(lib.cr_progressive_fetch_nodes(h, ptr(aln), None if flexible else ptr(xn), ptr(tn), ptr(wn)))
         finally:
             lib.cr_progressive_destroy(h)
         names, node_names, msa = pending["names"], pending["node_names"], pending["msa"]
@@ -523,7 +540,8 @@ class MultipleAlignment:
         for k in range(num_nodes):
             c1, c2, ln = int(table[k, 0]), int(table[k, 1]), int(table[k, 2])
             a1, a2 = aln[2 * o:2 * o + ln], aln[2 * o + ln:2 * o + 2 * ln]
-            final_sequences.append(Protein(node_names[k], tn[o:o + ln].copy(), xn[o:o + ln].copy()))
+            # (flexible=True: a node is its mean tensors, multiple_alignment.py:361-362)
+            final_sequences.append(Protein(node_names[k], tn[o:o + ln].copy(), None if xn is None else xn[o:o + ln].copy()))
             final_consensus_weights.append(wn[o:o + ln].reshape(-1, 1).copy())
             rows[c1] = np.where(a1 != -1, rows[c1][:, a1], -1)          # :218-229, all member rows at once
             rows[c2] = np.where(a2 != -1, rows[c2][:, a2], -1)

@@ -227,6 +227,13 @@ int cr_progressive_align(cr_context *ctx, const double *coords, const double *te
                          int64_t num_structures, int64_t d, const uint64_t *tree, int64_t tree_rows,
                          const cr_params *params, double consensus_weight, double gamma_weight,
                          cr_progressive **out);
+/* The same with flexible=True in the score function AND the mean function (multiple_alignment.py:323-326: the score matrix of
+ * two nodes is the tensor RBF alone; :351-362: a node is its mean tensors, no coordinates): tensors f64[total][d] only.
+ * cr_progressive_fetch_nodes then takes coords == NULL.  CR_ERR_STATE when a node outgrows the launch bound (1.5 x the
+ * longest structure, at most 2048 columns): the caller walks the tree itself (cr_dtw_align per node). */
+int cr_progressive_align_flexible(cr_context *ctx, const double *tensors, const int64_t *offsets, int64_t num_structures, int64_t d,
+                                  const uint64_t *tree, int64_t tree_rows, const cr_params *params, double consensus_weight,
+                                  double gamma_weight, cr_progressive **out);
 /* sizes[0] = columns of the final alignment, [1] = internal nodes (P-1), [2] = sum of their lengths,
  * [3] = levels (= launch pairs), [4] = OR of all node flags (CR_FLAG_*) */
 int cr_progressive_sizes(cr_progressive *h, int64_t sizes[5]);

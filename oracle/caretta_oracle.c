@@ -672,6 +672,41 @@ uint32_t cro_progressive_node(const double *X1, const double *T1, const double *
     return flags;
 }
 
+/* The same node with flexible=True in the score function AND the mean function (multiple_alignment.py:323-326: the tensor
+ * score matrix alone; :193-217: plus the consensus-weight term, dtw_align; :351-362: the mean tensors, no coordinates;
+ * :73-82: get_mean_weights). */
+void cro_progressive_node_flexible(const double *T1, const double *W1, int64_t n, const double *T2, const double *W2, int64_t m,
+                                   int64_t d, double mult1, double mult2, double gamma_tensor, double gamma_weight,
+                                   double gap_open, double gap_extend, int64_t *aln1, int64_t *aln2, int64_t *aln_len,
+                                   double *Tn, double *Wn) {
+    double *S = (double *)malloc(sizeof(double) * (size_t)n * (size_t)m);
+    cro_make_score_matrix(T1, n, T2, m, d, gamma_tensor, S);                                  /* :323-326 */
+    double *a = (double *)malloc(sizeof(double) * (size_t)n), *b = (double *)malloc(sizeof(double) * (size_t)m);
+    for (int64_t i = 0; i < n; i++) a[i] = W1[i] * mult1;                                     /* :207 */
+    for (int64_t j = 0; j < m; j++) b[j] = W2[j] * mult2;                                     /* :208 */
+    double *Sw = (double *)malloc(sizeof(double) * (size_t)n * (size_t)m);
+    cro_make_score_matrix(a, n, b, m, 1, gamma_weight, Sw);                                   /* :207-210 */
+    for (int64_t x = 0; x < n * m; x++) S[x] += Sw[x];
+    int64_t *s1 = arange64(n), *s2 = arange64(m);
+    double score;
+    int64_t len = 0;
+    cro_dtw_align(s1, n, s2, m, S, m, gap_open, gap_extend, aln1, aln2, &len, &score, NULL, NULL); /* :211-214 */
+    *aln_len = len;
+    for (int64_t e = 0; e < len; e++) {                                                       /* :351-362 */
+        int64_t x = aln1[e], y = aln2[e];
+        for (int64_t c = 0; c < d; c++) {
+            if (x == -1) Tn[e * d + c] = T2[y * d + c];
+            else if (y == -1) Tn[e * d + c] = T1[x * d + c];
+            else Tn[e * d + c] = (T1[x * d + c] + T2[y * d + c]) / 2;
+        }
+        double w = 0.0;                                                                       /* :73-82 */
+        if (x != -1) w += W1[x];
+        if (y != -1) w += W2[y];
+        Wn[e] = w;
+    }
+    free(S); free(Sw); free(a); free(b); free(s1); free(s2);
+}
+
 int cro_pairwise_batch(const double *coords, const double *tensors, const int64_t *offsets,
                        int64_t d, const int32_t *pairs, int64_t npairs, const cro_params *prm,
                        cro_pair_out *outs, int64_t *aln, int64_t aln_stride, int nthreads) {

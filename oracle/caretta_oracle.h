@@ -113,6 +113,11 @@ uint32_t cro_progressive_node(const double *X1, const double *T1, const double *
                               double mult1, double mult2, const cro_params *prm, double gamma_weight,
                               int64_t *aln1, int64_t *aln2, int64_t *aln_len,
                               double *Xn, double *Tn, double *Wn);
+/* ... with flexible=True in score and mean function: tensors and consensus weights only (multiple_alignment.py:323-326, :351-362) */
+void cro_progressive_node_flexible(const double *T1, const double *W1, int64_t n, const double *T2, const double *W2, int64_t m,
+                                   int64_t d, double mult1, double mult2, double gamma_tensor, double gamma_weight,
+                                   double gap_open, double gap_extend, int64_t *aln1, int64_t *aln2, int64_t *aln_len,
+                                   double *Tn, double *Wn);
 
 /* neighbor_joining.py:19-157.  tree: (2P-3, 2) uint64, branch_lengths: (2P-3).
  * hoist=0 recomputes the row sums inside the double loop exactly as written (O(P^4));

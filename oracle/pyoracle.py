@@ -81,6 +81,10 @@ class Oracle:
         lib.cro_svd3.argtypes = [_f64p, _f64p, _f64p, _f64p]
         lib.cro_pairwise_batch.argtypes = [_f64p, _f64p, _i64p, C.c_int64, _i32p, C.c_int64, C.POINTER(Params),
                                            C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
+        lib.cro_progressive_node_flexible.restype = None
+        lib.cro_progressive_node_flexible.argtypes = [_f64p, _f64p, C.c_int64, _f64p, _f64p, C.c_int64, C.c_int64, C.c_double, C.c_double,
+                                                      C.c_double, C.c_double, C.c_double, C.c_double, _i64p, _i64p, C.POINTER(C.c_int64),
+                                                      _f64p, _f64p]
         lib.cro_progressive_node.restype = C.c_uint32
         lib.cro_progressive_node.argtypes = [_f64p, _f64p, _f64p, C.c_int64, _f64p, _f64p, _f64p, C.c_int64, C.c_int64,
                                              C.c_double, C.c_double, C.POINTER(Params), C.c_double, _i64p, _i64p,
@@ -212,6 +216,18 @@ class Oracle:
                                               xn, tn, wn)
         k = ln.value
         return a1[:k].copy(), a2[:k].copy(), xn[:k].copy(), tn[:k].copy(), wn[:k].reshape(-1, 1).copy(), flags
+
+    def progressive_node_flexible(self, t1, w1, t2, w2, mult1, mult2, gamma_tensor=0.03, gamma_weight=1.0, gap_open=1.0, gap_extend=0.01):
+        """make_intermediate_node with flexible=True in score and mean function -> (aln1, aln2, tensors, weights (len,1))."""
+        t1, w1, t2, w2 = (self._f(v) for v in (t1, w1, t2, w2))
+        n, m, d = t1.shape[0], t2.shape[0], t1.shape[1]
+        a1, a2 = np.empty(n + m + 1, np.int64), np.empty(n + m + 1, np.int64)
+        ln = C.c_int64(0)
+        tn, wn = np.empty((n + m, d)), np.empty(n + m)
+        self.lib.cro_progressive_node_flexible(t1, w1.reshape(-1), n, t2, w2.reshape(-1), m, d, float(mult1), float(mult2), float(gamma_tensor),
+                                               float(gamma_weight), float(gap_open), float(gap_extend), a1, a2, C.byref(ln), tn, wn)
+        k = ln.value
+        return a1[:k].copy(), a2[:k].copy(), tn[:k].copy(), wn[:k].reshape(-1, 1).copy()
 
     def neighbor_joining(self, d, hoist=True):
         d = self._f(d)

@@ -478,6 +478,34 @@ def gen_progressive():
     save("f4_progressive.npz", out)
 
 
+def gen_flexible_progressive():
+    """flexible=True all the way (multiple_alignment.py:323-326 score function, :351-362 mean function): the reference's own
+    make_pairwise_matrix -> neighbor_joining -> progressive_align on two small families; every intermediate node carries
+    mean tensors and consensus weights only (no coordinates)."""
+    out = {}
+    sf = dict(flexible=True, gamma_tensor=SF_PARAMS["gamma_tensor"])
+    for tag, fam in (("G8", synthetic.make_family(8, 60, seed=20251, ragged=True)),
+                     ("G5", synthetic.make_family(5, 90, seed=20252, ragged=True, clades=2))):
+        store_family(out, f"fam{tag}", fam)
+        msa = multiple_alignment.MultipleAlignment(to_proteins(fam))
+        m = msa.make_pairwise_matrix(score_function_params=sf)
+        d = m.max() - m
+        aln = msa.multiple_align(d, gap_open_penalty=1.0, gap_extend_penalty=0.01, consensus_weight=1.0, gamma_weight=1.0,
+                                 score_function_params=sf, mean_function_params=dict(flexible=True))
+        out[f"fam{tag}_D"] = d
+        out[f"fam{tag}_tree"] = msa.tree
+        out[f"fam{tag}_msa"] = np.array([aln[s.name] for s in fam], dtype=np.int64)
+        nleaf = len(fam)
+        out[f"fam{tag}_nnodes"] = np.int64(len(msa.final_sequences) - nleaf)
+        for k, node in enumerate(msa.final_sequences[nleaf:]):
+            assert node.coordinates is None
+            out[f"fam{tag}_n{k}_tensors"] = node.tensors
+            out[f"fam{tag}_n{k}_weights"] = msa.final_consensus_weights[nleaf + k]
+            out[f"fam{tag}_n{k}_name"] = np.array(node.name)
+    out["families"] = np.array(["G8", "G5"])
+    save("f10_flexible_progressive.npz", out)
+
+
 def gen_post_msa():
     """Post-alignment products on the 8-structure family's MSA: superpose() (multiple_alignment.py:896-997),
     make_coverage_gap_distance_matrix (:45-56), get_reference_structures (:741-783),
@@ -574,6 +602,7 @@ def main():
               ("tree64", gen_tree64),
               ("formats", lambda: gen_formats(np.random.default_rng(20222))),
               ("progressive", gen_progressive),
+              ("flexprog", gen_flexible_progressive),
               ("c1", gen_c1_inputs),
               ("postmsa", gen_post_msa),
               ("extras", lambda: gen_extras(np.random.default_rng(20223)))]

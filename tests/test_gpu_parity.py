@@ -756,6 +756,79 @@ def test_progressive_nodes_golden_and_oracle(oracle, golden, tag):
         sizes.append(tot)
 
 
+def _replay_flexible_tree(oracle, msa, p, gamma_tensor, gamma_weight, gap_open, gap_extend):
+    """Every join of a flexible progressive alignment replayed by the oracle on the device's own child nodes: bit-identical."""
+    sizes = [1] * p
+    for k, (n1, n2) in enumerate(_replay_tree(msa, msa.tree, p)):
+        tot = sizes[n1] + sizes[n2]
+        s1, s2 = msa.final_sequences[n1], msa.final_sequences[n2]
+        a1, a2, tn, wn = oracle.progressive_node_flexible(s1.tensors, msa.final_consensus_weights[n1], s2.tensors, msa.final_consensus_weights[n2],
+                                                          sizes[n2] / (2 * tot), sizes[n1] / (2 * tot), gamma_tensor, gamma_weight, gap_open, gap_extend)
+        node = msa.final_sequences[p + k]
+        assert node.coordinates is None
+        assert np.array_equal(tn, node.tensors) and np.array_equal(wn, msa.final_consensus_weights[p + k]), f"node {k}"
+        sizes.append(tot)
+
+
+@pytest.mark.parametrize("tag", ["G8", "G5"])
+def test_flexible_progressive_golden_and_oracle(oracle, golden, tag):
+    """flexible=True in score AND mean function (multiple_alignment.py:323-326, :351-362) with every tree node on the device
+    (cr_progressive_align_flexible: node scores = tensor RBF + consensus-weight RBF by their own launches, DTW sweep, mean
+    tensors and weights): the reference's own multiple_align (f10_flexible_progressive.npz) -- pairwise matrix, tree, MSA exact,
+    node tensors and weights exact -- and the oracle replaying every join on the device's own children."""
+    from caretta_amd import multiple_alignment as ma
+    g = golden("f10_flexible_progressive.npz")
+    tensors, offsets = g[f"fam{tag}_tensors"], g[f"fam{tag}_offsets"]
+    p = len(offsets) - 1
+    prots = [ma.Protein(f"s{i:04d}", tensors[offsets[i]:offsets[i + 1]]) for i in range(p)]       # tensors only
+    msa = ma.MultipleAlignment(prots)
+    sf = dict(flexible=True, gamma_tensor=7.0)
+    m = msa.make_pairwise_matrix(sf)
+    np.testing.assert_allclose(m.max() - m, g[f"fam{tag}_D"], rtol=1e-9, atol=1e-12)
+    aln = msa.multiple_align(g[f"fam{tag}_D"], gap_open_penalty=1.0, gap_extend_penalty=0.01, consensus_weight=1.0, gamma_weight=1.0,
+                             score_function_params=sf, mean_function_params=dict(flexible=True))
+    assert getattr(msa, "node_table", None) is not None                  # (the resident path ran, not the host walk)
+    assert np.array_equal(np.array([aln[q.name] for q in prots]), g[f"fam{tag}_msa"])
+    assert np.array_equal(msa.tree, g[f"fam{tag}_tree"])
+    nn = int(g[f"fam{tag}_nnodes"])
+    assert len(msa.final_sequences) == p + nn
+    for k in range(nn):
+        node, w = msa.final_sequences[p + k], msa.final_consensus_weights[p + k]
+        assert node.coordinates is None
+        assert np.array_equal(node.tensors, g[f"fam{tag}_n{k}_tensors"]) and np.array_equal(w, g[f"fam{tag}_n{k}_weights"])
+    _replay_flexible_tree(oracle, msa, p, 7.0, 1.0, 1.0, 0.01)
+
+
+@pytest.mark.parametrize("num,length,dim,seed", [(24, 300, 10, 21), (7, 700, 7, 22), (40, 90, 16, 23)])
+def test_flexible_progressive_resident_vs_oracle_and_host_walk(oracle, monkeypatch, num, length, dim, seed):
+    """The resident flexible tree on larger families (several strips per node, two rows per lane, padded tensor widths, ragged
+    lengths): every join against the oracle, and the same MSA as the generic host walk (score_function / dtw_align /
+    mean_function per node)."""
+    from caretta_amd import multiple_alignment as ma
+    fam = synthetic.make_family(num, length, dim=dim, seed=seed, ragged=True, clades=3)
+    prots = [ma.Protein(s.name, s.tensors) for s in fam]
+    msa = ma.MultipleAlignment(prots)
+    sf = dict(flexible=True, gamma_tensor=2.5)
+    m = msa.make_pairwise_matrix(sf)
+    aln = msa.multiple_align(m.max() - m, gap_open_penalty=0.8, gap_extend_penalty=0.02, consensus_weight=1.0, gamma_weight=0.7,
+                             score_function_params=sf, mean_function_params=dict(flexible=True))
+    assert getattr(msa, "node_table", None) is not None
+    _replay_flexible_tree(oracle, msa, num, 2.5, 0.7, 0.8, 0.02)
+    walk = ma.MultipleAlignment([ma.Protein(s.name, s.tensors) for s in fam])
+
+    def refuse(*args, **kwargs):                  # what cr_progressive_align_flexible answers when a node outgrows its launch bound
+        err = ma._capi.CarettaHipError("a tree node outgrew the launch bound")
+        err.code = ma._capi.CR_ERR_STATE
+        raise err
+
+    monkeypatch.setattr(ma.MultipleAlignment, "_progressive_align_resident", refuse)
+    walk.multiple_align(m.max() - m, gap_open_penalty=0.8, gap_extend_penalty=0.02, consensus_weight=1.0, gamma_weight=0.7,
+                        score_function_params=sf, mean_function_params=dict(flexible=True))
+    assert getattr(walk, "node_table", None) is None
+    for q in prots:
+        assert np.array_equal(walk.alignment[q.name], aln[q.name])
+
+
 def _replay_tree(msa, tree, p):
     tree = np.asarray(tree).astype(np.int64)
     joins = [(int(tree[x, 0]), int(tree[x + 1, 0])) for x in range(0, tree.shape[0] - 1, 2)]

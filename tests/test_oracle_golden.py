@@ -336,6 +336,35 @@ def test_progressive_alignment(oracle, golden, tag):
         assert np.array_equal(tn, g[f"fam{tag}_n{k}_tensors"]) and np.array_equal(wn, g[f"fam{tag}_n{k}_weights"])
 
 
+def tree_joins(tree):
+    tree = np.asarray(tree).astype(np.int64)
+    return [(int(tree[x, 0]), int(tree[x + 1, 0])) for x in range(0, tree.shape[0] - 1, 2)] + [(int(tree[-1, 0]), int(tree[-1, 1]))]
+
+
+@pytest.mark.parametrize("tag", ["G8", "G5"])
+def test_flexible_progressive_alignment(oracle, golden, tag):
+    """f10_flexible_progressive.npz -- the reference's own multiple_align with flexible=True in score AND mean function -- replayed
+    by the oracle's flexible node (multiple_alignment.py:323-326, :193-217, :351-362, :73-82) over the golden guide tree:
+    identical MSA, node tensors and consensus weights exact (the mean of two tensors rounds the same way everywhere)."""
+    g = golden("f10_flexible_progressive.npz")
+    tensors, off = g[f"fam{tag}_tensors"], g[f"fam{tag}_offsets"]
+    p = len(off) - 1
+    nodes = [(tensors[off[i]:off[i + 1]], np.full((off[i + 1] - off[i], 1), 1.0)) for i in range(p)]
+    alns = [{i: np.arange(off[i + 1] - off[i])} for i in range(p)]
+    for n1, n2 in tree_joins(g[f"fam{tag}_tree"]):
+        tot = len(alns[n1]) + len(alns[n2])            # multiple_alignment.py:199-202
+        a1, a2, tn, wn = oracle.progressive_node_flexible(*nodes[n1], *nodes[n2], len(alns[n2]) / (2 * tot), len(alns[n1]) / (2 * tot),
+                                                          gamma_tensor=7.0, gamma_weight=1.0, gap_open=1.0, gap_extend=0.01)
+        merged = {k: np.array([v[i] if i != -1 else -1 for i in a1]) for k, v in alns[n1].items()}
+        merged.update({k: np.array([v[i] if i != -1 else -1 for i in a2]) for k, v in alns[n2].items()})
+        nodes.append((tn, wn))
+        alns.append(merged)
+    assert np.array_equal(np.array([alns[-1][i] for i in range(p)]), g[f"fam{tag}_msa"])
+    for k in range(int(g[f"fam{tag}_nnodes"])):
+        tn, wn = nodes[p + k]
+        assert np.array_equal(tn, g[f"fam{tag}_n{k}_tensors"]) and np.array_equal(wn, g[f"fam{tag}_n{k}_weights"])
+
+
 def flexible_reference(oracle, g, tag, gamma_tensor=7.0):
     """The oracle's restatement of the flexible=True matrix (multiple_alignment.py:323-326, :158-170) on a stored family."""
     offs = g[f"fam{tag}_offsets"]
