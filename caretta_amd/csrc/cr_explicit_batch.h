@@ -537,12 +537,21 @@ CR_D void sweep_stream(ExplicitStream<R>& src, const int n, const int m, const S
     end_out.pad = 0;
 }
 
+struct BatchTrace {
+    int32_t len, start;
+};
+
+// STORE with `aln`: dtw_align's traceback (dynamic_time_warping.py:90-144) follows the fill IN THE SAME WAVE, as in k_align: one
+// launch instead of two.  Measured neutral (8 128 x 300 x 300: 1.82-1.89 ms as two launches, 1.90 as one;
+// profiles/r05/explicit_batch_rate.txt): this kernel is bound by how many row streams are open, and a wave that walks has
+// none open -- the walk's 19 us per problem are not hidden under its neighbours' fills as they are in the issue-bound k_align.
 template <int R, int MODE, bool STORE>
 __global__ __launch_bounds__(kWave) void k_explicit_stream(const ExplicitProblem* __restrict__ probs,
                                                           const double* __restrict__ S,
                                                           const int32_t* __restrict__ seqs, SweepParams prm,
                                                           uint32_t* __restrict__ bits, double* __restrict__ hand,
-                                                          AlignEnd* __restrict__ ends) {
+                                                          AlignEnd* __restrict__ ends, int max_entries = 0,
+                                                          int32_t* __restrict__ aln = nullptr, BatchTrace* __restrict__ trace = nullptr) {
     extern __shared__ double lds[];
     const ExplicitProblem pb = probs[blockIdx.x];
     ExplicitStream<R> src;
@@ -560,11 +569,18 @@ __global__ __launch_bounds__(kWave) void k_explicit_stream(const ExplicitProblem
     ae.start_layer = ae.pad = 0;
     if (pb.m > 0) sweep_stream<R, MODE, STORE>(src, pb.n, pb.m, prm, lds, STORE ? bits + pb.bits_off_s : nullptr, hand + pb.hand_off, ae);
     if (threadIdx.x == 0) ends[blockIdx.x] = ae;
+    if constexpr (STORE && (MODE & kDtw) != 0) {
+        if (aln) {                                        // (uniform) the walk on this wave's own decision words
+            drain_stores();
+            int len, pairs;
+            dtw_walk<R>(pb.n, pb.m, max_entries, bits + pb.bits_off_s, ae.start_layer, lds, aln + pb.aln_off, len, pairs);
+            if (threadIdx.x == 0) {
+                trace[blockIdx.x].len = len;
+                trace[blockIdx.x].start = pb.n + pb.m - len;
+            }
+        }
+    }
 }
-
-struct BatchTrace {
-    int32_t len, start;
-};
 
 // dtw_align's traceback (dynamic_time_warping.py:90-144) for every problem of the batch: one wave per problem on the
 // register-resident decision blocks of the pairwise kernels (dtw_walk).  LDS: (n + m) packed entries.
@@ -728,15 +744,18 @@ int launch_sw_rows(cr_explicit_batch* b) {
 }
 
 // the streaming sweep (contiguous columns) with R rows per lane; bits == nullptr: no decision words (scores alone)
+// (walk_entries > 0: dtw_align's traceback in the same launch -- rows into b->aln, lengths into b->trace)
 template <int R, int MODE>
-int launch_stream(cr_explicit_batch* b, const cr::ExplicitProblem* probs, const cr::SweepParams& prm, uint32_t* bits) {
+int launch_stream(cr_explicit_batch* b, const cr::ExplicitProblem* probs, const cr::SweepParams& prm, uint32_t* bits, int walk_entries = 0) {
     size_t lds = cr::stream_lds_doubles<R, MODE>() * sizeof(double);
+    if (walk_entries > 0) lds = std::max(lds, sizeof(double) * cr::trace_lds_doubles(R, walk_entries));
     if (g_cfg.stream_lds_kb > 0) lds = std::max(lds, (size_t)g_cfg.stream_lds_kb * 1024);   // calibration: waves per CU
     auto go = [&](auto kernel) -> int {
         int rc = allow_lds(kernel, lds);
         if (rc) return rc;
         CR_LAUNCH(kernel, dim3((unsigned)b->count), dim3(cr::kWave), lds, b->ctx->stream, probs, b->S.p + kSlackFront, b->seqs.p, prm, bits,
-                  b->hand.p, b->ends.p);
+                  b->hand.p, b->ends.p, walk_entries, walk_entries > 0 ? b->aln.p : (int32_t*)nullptr,
+                  walk_entries > 0 ? b->trace.p : (cr::BatchTrace*)nullptr);
         CR_HIP(hipGetLastError());
         return CR_OK;
     };
@@ -747,9 +766,10 @@ int launch_stream(cr_explicit_batch* b, const cr::ExplicitProblem* probs, const 
 }
 
 template <int MODE>
-int launch_stream_r(int R, cr_explicit_batch* b, const cr::ExplicitProblem* probs, const cr::SweepParams& prm, uint32_t* bits) {
-    return R == 1 ? launch_stream<1, MODE>(b, probs, prm, bits) : R == 2 ? launch_stream<2, MODE>(b, probs, prm, bits) : R == 3 ? launch_stream<3, MODE>(b, probs, prm, bits)
-         : R == 4 ? launch_stream<4, MODE>(b, probs, prm, bits) : launch_stream<5, MODE>(b, probs, prm, bits);
+int launch_stream_r(int R, cr_explicit_batch* b, const cr::ExplicitProblem* probs, const cr::SweepParams& prm, uint32_t* bits, int walk_entries = 0) {
+    return R == 1 ? launch_stream<1, MODE>(b, probs, prm, bits, walk_entries) : R == 2 ? launch_stream<2, MODE>(b, probs, prm, bits, walk_entries)
+         : R == 3 ? launch_stream<3, MODE>(b, probs, prm, bits, walk_entries) : R == 4 ? launch_stream<4, MODE>(b, probs, prm, bits, walk_entries)
+         : launch_stream<5, MODE>(b, probs, prm, bits, walk_entries);
 }
 
 template <int R, bool STREAM>
@@ -1048,9 +1068,14 @@ int cr_dtw_align_batch(cr_explicit_batch* b, double gap_open, double gap_extend,
     CR_HIP(b->bits.ensure((size_t)bits_total));
     CR_HIP(b->ends.ensure((size_t)b->count));
     cr::SweepParams prm{0.0, gap_open, gap_extend};
+    if (aln) {
+        CR_HIP(b->aln.ensure((size_t)aln_total));
+        CR_HIP(b->trace.ensure((size_t)b->count));
+    }
     CR_HIP(hipEventRecord(b->ev0, st));
     if (stream) {
-        if ((rc = launch_stream_r<MODE>(R, b, b->probs.p, prm, aln ? b->bits.p : nullptr))) return rc;
+        // (with alignments: fill, decisions and the walk of every problem in ONE launch)
+        if ((rc = launch_stream_r<MODE>(R, b, b->probs.p, prm, aln ? b->bits.p : nullptr, aln ? b->cap_max : 0))) return rc;
     } else {
         const size_t lds = cr::sweep_lds_doubles<kExplicitR, MODE, cr::Explicit<kExplicitR>>(b->n_max, b->m_max) * sizeof(double);
         if ((rc = allow_lds(cr::k_explicit_batch<kExplicitR, MODE>, lds))) return rc;
@@ -1059,14 +1084,8 @@ int cr_dtw_align_batch(cr_explicit_batch* b, double gap_open, double gap_extend,
         CR_HIP(hipGetLastError());
     }
     std::vector<cr::BatchTrace> tr;
-    if (aln) {
-        const int entries = b->cap_max;
-        CR_HIP(b->aln.ensure((size_t)aln_total));
-        CR_HIP(b->trace.ensure((size_t)b->count));
-        if (!stream) rc = launch_trace<kExplicitR, false>(b, entries);
-        else rc = R == 1 ? launch_trace<1, true>(b, entries) : R == 2 ? launch_trace<2, true>(b, entries) : R == 3 ? launch_trace<3, true>(b, entries)
-                : R == 4 ? launch_trace<4, true>(b, entries) : launch_trace<5, true>(b, entries);
-        if (rc) return rc;
+    if (aln && !stream) {                                // (the tile kernels: the walks as a launch of their own)
+        if ((rc = launch_trace<kExplicitR, false>(b, b->cap_max))) return rc;
     }
     CR_HIP(hipEventRecord(b->ev1, st));
     std::vector<cr::AlignEnd> ends((size_t)b->count);
