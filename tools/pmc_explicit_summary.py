@@ -35,16 +35,30 @@ def main():
     n = int(sys.argv[3]) if len(sys.argv) > 3 else 300
     alg = 8.0 * count * n * n
     fetch, write = per_kernel(root, "FETCH_SIZE"), per_kernel(root, "WRITE_SIZE")
-    out = {}
+    kernels = {}
     for k in sorted(fetch):
-        if not (k.startswith("k_sw_score_rows") or k.startswith("k_explicit")):
+        if not k.startswith("k_"):
             continue
         f = sum(fetch[k]) / len(fetch[k])
         w = sum(write[k]) / len(write[k]) if write.get(k) else 0.0
         hbm = f * 1024 * 2 + w * 1024
-        out[k] = {"FETCH_SIZE_KiB_mean": f, "WRITE_SIZE_KiB_mean": w, "dispatches": len(fetch[k]), "hbm_bytes_per_launch": hbm,
-                  "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": hbm / alg}
-    print(json.dumps(out, indent=1))
+        kernels[k] = {"FETCH_SIZE_KiB_mean": f, "WRITE_SIZE_KiB_mean": w, "dispatches": len(fetch[k]), "hbm_bytes_per_launch": hbm,
+                      "matrix_bytes": alg, "traffic_over_matrix_bytes": hbm / alg}
+    # per FUNCTION of the reference (tools/explicit_batch_rate.py): the kernels of its launch sequence against SURVEY 8(d)'s
+    # explicit-mode bytes -- 8 n m + decisions (n m / 2 dtw_align, n m / 4 smith_waterman, none for a score) + 24 (n + m) + 8
+    cells, small = float(count) * n * n, 24.0 * count * 2 * n + 8.0 * count
+    functions = {"smith_waterman_score gap 0 (row sweep)": (["k_sw_score_rows<"], 8.0 * cells + small),
+                 "smith_waterman_score gap 0.1 (skewed sweep)": (["k_explicit_stream<1, 2, false>"], 8.0 * cells + small),
+                 "dtw_align_score (skewed sweep, no decisions)": (["k_explicit_stream<1, 4, false>"], 8.0 * cells + small),
+                 "dtw_align WITH traceback (4-bit decisions + walk)": (["k_explicit_stream<1, 4, true>", "k_dtw_trace_batch<"], 8.5 * cells + small),
+                 "smith_waterman WITH traceback (2-bit decisions + walk)": (["k_explicit_sw_batch<", "k_sw_trace_batch<"], 8.25 * cells + small)}
+    ratios = {}
+    for name, (prefixes, nbytes) in functions.items():
+        hbm = sum(v["hbm_bytes_per_launch"] for k, v in kernels.items() if any(k.startswith(p) for p in prefixes))
+        if hbm:
+            ratios[name] = {"hbm_bytes": hbm, "algorithmic_bytes": nbytes, "traffic_over_algorithmic": hbm / nbytes}
+    print(json.dumps({"kernels": kernels, "traffic_over_algorithmic": ratios,
+                      "note": "FETCH_SIZE x 2 + WRITE_SIZE (KiB counters, separate --pmc passes; gfx950 counts a 128-byte read request as 64 bytes)"}, indent=1))
 
 
 if __name__ == "__main__":
