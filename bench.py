@@ -63,13 +63,13 @@ def workload(name: str, n_gpus: int):
 
 def stage_bytes(lengths, pairs, d):
     """Algorithmic HBM bytes per launch of the two fill kernels, SURVEY.md 8(d) / DESIGN.md section 5:
-    k_seed reads the two structures' tensors and writes 2 bits per cell; k_align reads the coordinates and writes 4 bits
-    per cell plus the alignment rows.  `*_readback` adds the traceback's re-read of the decision words and the small
+    k_seed reads the two structures' tensors and writes 2 bits per cell (70 500 B per 300 x 300 pair, d = 10); k_align reads the
+    coordinates and writes 4 bits per cell, the two alignment rows and the pair's record (69 136 B).  `*_readback` adds the traceback's re-read of the decision words and the small
     per-pair records (the round-1 figure)."""
     n = lengths[pairs[:, 0]].astype(np.float64)
     m = lengths[pairs[:, 1]].astype(np.float64)
     seed = 8.0 * d * (n + m) + n * m / 4
-    align = 24.0 * (n + m) + n * m / 2 + 8.0 * (n + m)
+    align = 24.0 * (n + m) + n * m / 2 + 16.0 * (n + m) + 136.0       # (SURVEY 8(d): coordinates in; 4-bit decisions, two int64 rows, the 136-byte record out)
     seed_rb = seed + n * m / 4 + 24.0 * (n + m) + 144
     align_rb = align + n * m / 2 + 144 + 160
     return {"k_seed": float(seed.sum()), "k_align": float(align.sum()),

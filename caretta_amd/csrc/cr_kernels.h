@@ -712,12 +712,17 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
                     }
                 }
             }
+            // Decision words go out in the order the sweep forms them (one 256-byte row of words per store instruction), but
+            // only the words a walk can ever read: a lane whose rows lie past n, or whose steps of this word all lie outside
+            // the columns [0, m) -- the pipeline's ramps --, keeps out of the store (round 5: k_align wrote 503 MB where the
+            // cells' decisions are 366 MB; the padding words of the ramps and of the last lanes were a fifth of it).
             if constexpr (TRACE) {
                 if ((t & 15) == 15 || t == T - 1) {
                     const int64_t base = ((int64_t)(s * TB_SW + (t >> 4)) * R) * kWave + lane;
+                    const bool used = rowbase < n && t >= lane && (t & ~15) - lane < m;
 #pragma unroll
                     for (int q = 0; q < R; q++) {
-                        sw_dirs[base + q * kWave] = st.swbits[q];
+                        if (used) sw_dirs[base + q * kWave] = st.swbits[q];
                         st.swbits[q] = 0;
                     }
                 }
@@ -725,9 +730,10 @@ CR_D void sweep(Src& src, const int n, const int m, const SweepParams prm, doubl
             if constexpr (DTW) {
                 if ((t & 7) == 7 || t == T - 1) {
                     const int64_t base = ((int64_t)(s * TB_DTW + (t >> 3)) * R) * kWave + lane;
+                    const bool used = rowbase < n && t >= lane && (t & ~7) - lane < m;
 #pragma unroll
                     for (int q = 0; q < R; q++) {
-                        dtw_bits[base + q * kWave] = st.dtbits[q];
+                        if (used) dtw_bits[base + q * kWave] = st.dtbits[q];
                         st.dtbits[q] = 0;
                     }
                 }

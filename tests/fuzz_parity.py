@@ -19,8 +19,22 @@ from oracle import pyoracle  # noqa: E402
 
 
 def random_family(rng):
-    kind = rng.integers(0, 5)
+    kind = rng.integers(0, 7)
     dim = int(rng.choice([1, 2, 3, 4, 5, 8, 10, 13, 16, 10, 10, 17, 24, 29, 32]))
+    if kind == 5:      # a MIXED list (round 5: size classes of cr_batch_set_pairs): a family of short domains with a few long
+        # chains in it -- the list is split by rows (<= 320 / <= 1 472 / longer), every class laid out as a list of its own
+        short, long_len = int(rng.choice([70, 120, 150, 200, 300])), int(rng.choice([400, 600, 900, 1300, 1500]))
+        fam = synthetic.make_mixed_family(int(rng.integers(6, 22)), short, int(rng.integers(1, 4)), long_len, dim=min(dim, 16),
+                                          seed=int(rng.integers(1 << 30)))
+        if rng.integers(0, 2):                                    # ... ragged on top
+            for st in fam:
+                cut = int(rng.integers(max(1, int(0.7 * len(st.coordinates))), len(st.coordinates) + 1))
+                st.coordinates, st.tensors = st.coordinates[:cut].copy(), st.tensors[:cut].copy()
+        return fam, min(dim, 16)
+    if kind == 6:      # LONG chains, few structures with both orientations: the row split beyond 1 088 rows (round 5), the wide layout
+        num, length = int(rng.integers(3, 7)), int(rng.choice([850, 900, 1100, 1200, 1400, 1472]))
+        fam = synthetic.make_family(num, length, dim=min(dim, 16), seed=int(rng.integers(1 << 30)), ragged=bool(rng.integers(0, 2)), clades=2)
+        return fam, min(dim, 16)
     if kind == 4:      # a MID-SIZE list: 70 .. 600 rows, 36 .. 380 pairs (cr_trio.h: one strip of two to five rows per lane split by
         # function, from 65 / 111 / 161 pairs on; cr_duo.h: two to five waves per pair beyond 320 rows and 256 pairs)
         num, length = int(rng.integers(9, 21)), int(rng.choice([70, 100, 128, 129, 150, 192, 193, 220, 256, 257, 300, 320, 321, 384, 450, 600]))
@@ -63,9 +77,16 @@ def check_batch(ctx, oracle, fam, rng):
     prm = dict(gamma_tensor=float(rng.choice([7.0, 1.0, 0.3])), gamma_coords=float(rng.choice([0.03, 0.1, 1e-4])),
                gap_open=float(rng.choice([1.0, 0.0, 0.5, 3.0])), gap_extend=float(rng.choice([0.01, 0.0, 0.5])),
                sw_gap=float(rng.choice([0.0, 0.0, 0.0, 0.1])))
+    if len(pairs) < 300 and max(len(st.coordinates) for st in fam) > 832 and rng.integers(0, 2):
+        pairs = np.vstack([pairs] * int(np.ceil(300 / len(pairs))))    # (more than 256 pairs of long chains: k_pair_duo in rounds)
     batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
-    batch.run(engine.make_params(**prm))
-    res, aln = batch.fetch()
+    if rng.integers(0, 4) == 0:                                    # the streamed run FIRST (the order maps of a fresh batch)
+        res, aln32 = batch.run_streamed(engine.make_params(**prm))
+        ctx.synchronize()
+        res, aln = res.copy(), aln32.astype(np.int64)
+    else:
+        batch.run(engine.make_params(**prm))
+        res, aln = batch.fetch()
     if rng.integers(0, 3) == 0:                                    # the matrix entries alone (cr_batch_run_scores)
         batch.run(engine.make_params(**prm), scores_only=True)
         sw_only, flags_only = batch.fetch_scores()
@@ -82,6 +103,35 @@ def check_batch(ctx, oracle, fam, rng):
         if not np.array_equal(aln[p, :, :ln], ref_aln[p, :, :ln]):
             raise AssertionError(f"alignment of pair {pairs[p]} differs: params {prm}, lengths {np.diff(offsets)}")
     return len(pairs), res
+
+
+def check_flexible_progressive(oracle, fam, rng):
+    """flexible=True in score and mean function with every node on the device (cr_progressive_align_flexible) against the oracle's
+    flexible node replayed on the device's own children."""
+    num = len(fam)
+    if num < 3 or min(len(s.coordinates) for s in fam) < 5 or fam[0].tensors.shape[1] > 32:
+        return 0
+    prots = [ma.Protein(s.name, s.tensors) for s in fam]
+    msa = ma.MultipleAlignment(prots)
+    gt = float(rng.choice([7.0, 1.0]))
+    sf = dict(flexible=True, gamma_tensor=gt)
+    m = msa.make_pairwise_matrix(sf)
+    tree, _ = nj.neighbor_joining(m.max() - m)
+    go, ge, cw, gw = float(rng.choice([1.0, 0.5])), float(rng.choice([0.01, 0.1])), float(rng.choice([1.0, 0.5])), float(rng.choice([1.0, 0.2]))
+    msa.progressive_align(tree, go, ge, cw, gw, sf, dict(flexible=True))
+    tree = np.asarray(tree).astype(np.int64)
+    joins = [(int(tree[x, 0]), int(tree[x + 1, 0])) for x in range(0, tree.shape[0] - 1, 2)] + [(int(tree[-1, 0]), int(tree[-1, 1]))]
+    sizes = [1] * num
+    for k, (n1, n2) in enumerate(joins):
+        tot = sizes[n1] + sizes[n2]
+        s1, s2 = msa.final_sequences[n1], msa.final_sequences[n2]
+        _, _, tn, wn = oracle.progressive_node_flexible(s1.tensors, msa.final_consensus_weights[n1], s2.tensors, msa.final_consensus_weights[n2],
+                                                        sizes[n2] / (2 * tot), sizes[n1] / (2 * tot), gt, gw, go, ge)
+        node = msa.final_sequences[num + k]
+        if not (np.array_equal(tn, node.tensors) and np.array_equal(wn, msa.final_consensus_weights[num + k])):
+            raise AssertionError(f"flexible progressive node {k} differs: lengths {[len(p) for p in prots]}")
+        sizes.append(tot)
+    return len(joins)
 
 
 def check_progressive(oracle, fam, rng):
@@ -220,7 +270,7 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
     ctx, oracle = engine.Context(0), pyoracle.Oracle()
-    t0, batches, pairs, nodes, flagged, dropins, batched, trees = time.time(), 0, 0, 0, 0, 0, 0, 0
+    t0, batches, pairs, nodes, flagged, dropins, batched, trees, flex_nodes = time.time(), 0, 0, 0, 0, 0, 0, 0, 0
     while time.time() - t0 < seconds:
         fam, _ = random_family(rng)
         n, res = check_batch(ctx, oracle, fam, rng)
@@ -228,6 +278,8 @@ def main():
         flagged += int(np.count_nonzero(res["flags"]))
         if rng.integers(0, 3) == 0:
             nodes += check_progressive(oracle, fam, rng)
+        if rng.integers(0, 5) == 0 and len(fam) <= 12:
+            flex_nodes += check_flexible_progressive(oracle, fam, rng)
         dropins += check_dropins(oracle, rng)
         if rng.integers(0, 4) == 0:
             batched += check_explicit_batch(oracle, rng)
@@ -235,7 +287,7 @@ def main():
             trees += check_neighbor_joining(ctx, oracle, rng)
         batches += 1
     print(f"fuzz_parity: seed {seed}, {batches} batches, {pairs} pairs ({flagged} with a soft-condition flag), "
-          f"{nodes} progressive nodes, {dropins} explicit-matrix drop-in cases, {batched} matrices in batched explicit calls, "
+          f"{nodes} progressive nodes, {flex_nodes} flexible progressive nodes, {dropins} explicit-matrix drop-in cases, {batched} matrices in batched explicit calls, "
           f"{trees} device neighbor joinings: all bit-identical to the oracle")
 
 
