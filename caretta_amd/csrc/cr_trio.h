@@ -48,47 +48,14 @@ namespace cr {
 #ifndef CR_TRIO_PRIO_PROD
 #define CR_TRIO_PRIO_PROD 0
 #endif
-#ifndef CR_TRIO_DYNPRIO
-#define CR_TRIO_DYNPRIO 0
-#endif
-#ifndef CR_TRIO_STEAL
-#define CR_TRIO_STEAL 0
-#endif
 constexpr int kTrioRing = CR_TRIO_RING; // columns (steps) of scores between the producers and the consumer
 constexpr int kTrioBatch = 4;           // columns (steps) per wait / publication of the consumer
 constexpr int kTrioMaxWaves = 5;        // 1 consumer + up to 4 producers (the launch decides: blockDim.x / 64)
 
-// LDS (doubles): exp table | kTrioWords doubles of progress words (ints: prod[0..3], cons, next column to hand out, 8 .. : one
-// "ready" word per ring slot) | ring kTrioRing x R x 64 | resident columns 3 x m (alignment stage)
-constexpr int kTrioWords = 4 + (kTrioRing + 1) / 2 + 2;
+// LDS (doubles): exp table | 8 progress words (prod[0..3], cons) | ring kTrioRing x R x 64 | resident columns 3 x m (alignment stage)
 template <int R>
 __host__ __device__ inline size_t trio_lds_doubles(int m) {
-    return (size_t)kExpDoubles + kTrioWords + (size_t)kTrioRing * R * kWave + (size_t)3 * m;
-}
-
-// (calibration, CR_TRIO_STEAL: the score waves of a pair take the NEXT column (step) nobody has taken -- an LDS counter -- instead
-// of alternate ones, and publish per ring slot; a score wave that its SIMD serves slowly then simply forms fewer columns)
-CR_D int trio_grab(int* words) {
-    int c = 0;
-    // (ds_add_rtn_u32 on the LDS offset itself -- the low half of the generic address: no generic-address dispatch, no address-space cast)
-    if ((threadIdx.x & (kWave - 1)) == 0) {
-        const uint32_t addr = (uint32_t)(uintptr_t)(words + 5);
-        const int one = 1;
-        asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(c) : "v"(addr), "v"(one) : "memory");
-    }
-    return __builtin_amdgcn_readfirstlane(c);
-}
-
-// (calibration, CR_TRIO_DYNPRIO: a score wave whose recurrence wave has caught up with it asks for priority over the score waves
-// of the other pairs on its SIMD, one that is far ahead gives it back -- equalises the pairs' progress)
-CR_D void trio_producer_priority(const int* words, int c, int np) {
-#if CR_TRIO_DYNPRIO
-    const int cons = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int*>(words + 4));
-    const int lead = c - cons;                       // columns (steps) between this wave's column and the last one taken
-    if (lead < 2 * np) __builtin_amdgcn_s_setprio(2);
-    else if (lead < kTrioRing - np) __builtin_amdgcn_s_setprio(1);
-    else __builtin_amdgcn_s_setprio(0);
-#endif
+    return (size_t)kExpDoubles + 4 + (size_t)kTrioRing * R * kWave + (size_t)3 * m;
 }
 
 template <int SLEEP>
@@ -119,32 +86,11 @@ CR_D void trio_seed_producer(const int p, const int np, RbfTensor<R, D>& src, co
             src.col[k] = (full || k < d) ? v : 0.0;
         }
     };
-#if CR_TRIO_STEAL
-    int c = trio_grab(words);
-    if (c < m) fetch(c);
-    CR_DUO_STAMP(p + 1, 0, CR_DUO_NOW());
-#pragma unroll 1
-    while (c < m) {
-        const int cn = trio_grab(words);                 // (the next column now: its features are requested while the exps run)
-        if (c >= kTrioRing) trio_wait<CR_TRIO_PROD_SLEEP>(words + 4, c - kTrioRing + 1, waited);
-        trio_producer_priority(words, c, np);
-        double acc[R];
-#pragma unroll
-        for (int q = 0; q < R; q++) acc[q] = src.dist2_of(q, src.col);
-        fetch(cn < m ? cn : c);
-        double* slot = ring + (size_t)((unsigned)c % (unsigned)kTrioRing) * (R * kWave) + lane;
-#pragma unroll
-        for (int q = 0; q < R; q++) slot[q * kWave] = exp_tab<true>(src.neg_gamma * acc[q], tab);
-        if (lane == 0) duo_publish(words + 8 + (int)((unsigned)c % (unsigned)kTrioRing), c + 1);
-        c = cn;
-    }
-#else
     if (p < m) fetch(p);
     CR_DUO_STAMP(p + 1, 0, CR_DUO_NOW());
 #pragma unroll 1
     for (int c = p; c < m; c += np) {
         if (c >= kTrioRing) trio_wait<CR_TRIO_PROD_SLEEP>(words + 4, c - kTrioRing + 1, waited);          // the slot's last column has been consumed
-        trio_producer_priority(words, c, np);
         double acc[R];
 #pragma unroll
         for (int q = 0; q < R; q++) acc[q] = src.dist2_of(q, src.col);
@@ -154,7 +100,6 @@ CR_D void trio_seed_producer(const int p, const int np, RbfTensor<R, D>& src, co
         for (int q = 0; q < R; q++) slot[q * kWave] = exp_tab<true>(src.neg_gamma * acc[q], tab);
         if (lane == 0) duo_publish(words + p, c + 1);
     }
-#endif
     CR_DUO_STAMP(p + 1, 1, CR_DUO_NOW());
     CR_DUO_STAMP(p + 1, 2, waited);
 }
@@ -218,27 +163,6 @@ struct TrioCols {
 template <int R>
 CR_D void trio_take(const double* ring, int* words, const int np, int j0, int jend, int& r0, double (&sc)[kTrioBatch][R], unsigned long long& waited) {
     const int lane = threadIdx.x & (kWave - 1);
-#if CR_TRIO_STEAL
-    {
-        // the batch's ready words are contiguous (j0 is a multiple of kTrioBatch = 4, the ring of kTrioBatch): one 16-byte read per poll
-#ifdef CR_STAMPS
-        const unsigned long long t0 = CR_DUO_NOW();
-#endif
-        const int len = jend - j0;
-        const volatile int* rd = reinterpret_cast<const volatile int*>(words + 8 + (int)((unsigned)j0 % (unsigned)kTrioRing));
-        for (;;) {
-            bool ok = true;
-            for (int k = 0; k < len; k++) ok = ok && __builtin_amdgcn_readfirstlane(rd[k]) >= j0 + k + 1;
-            if (ok) break;
-            __builtin_amdgcn_s_sleep(CR_TRIO_CONS_SLEEP);
-        }
-        asm volatile("" ::: "memory");
-#ifdef CR_STAMPS
-        waited += CR_DUO_NOW() - t0;
-#endif
-        (void)r0;
-    }
-#else
     const int len = jend - j0;
     for (int k = len - 1; k >= 0 && k >= len - np; k--) {        // the last column of every producer in the batch
         int p = r0 + k;
@@ -247,7 +171,6 @@ CR_D void trio_take(const double* ring, int* words, const int np, int j0, int je
     }
     r0 += kTrioBatch;                                            // (the next batch starts kTrioBatch columns on)
     while (r0 >= np) r0 -= np;
-#endif
     static_assert(kTrioRing % kTrioBatch == 0, "a batch's slots are contiguous");
     const double* slot = ring + (size_t)((unsigned)j0 % (unsigned)kTrioRing) * (R * kWave) + lane;       // (j0 is a multiple of kTrioBatch)
 #pragma unroll
@@ -321,28 +244,9 @@ CR_D void trio_align_producer(const int p, const int np, RbfCoords<R>& src, cons
     src.load_rows(lane * R, n);
     unsigned long long waited = 0;
     CR_DUO_STAMP(p + 1, 4, CR_DUO_NOW());
-#if CR_TRIO_STEAL
-    int t = trio_grab(words);
-#pragma unroll 1
-    while (t < T) {
-        const int tn = trio_grab(words);
-        if (t >= kTrioRing) trio_wait<CR_TRIO_PROD_SLEEP>(words + 4, t - kTrioRing + 1, waited);
-        trio_producer_priority(words, t, np);
-        const int c = t - lane;
-        if ((unsigned)c < (unsigned)m) {
-            src.fetch_resident(cols, m, c);
-            double* slot = ring + (size_t)((unsigned)t % (unsigned)kTrioRing) * (R * kWave) + lane;
-#pragma unroll
-            for (int q = 0; q < R; q++) slot[q * kWave] = src.score(q, tab);
-        }
-        if (lane == 0) duo_publish(words + 8 + (int)((unsigned)t % (unsigned)kTrioRing), t + 1);
-        t = tn;
-    }
-#else
 #pragma unroll 1
     for (int t = p; t < T; t += np) {
         if (t >= kTrioRing) trio_wait<CR_TRIO_PROD_SLEEP>(words + 4, t - kTrioRing + 1, waited);
-        trio_producer_priority(words, t, np);
         const int c = t - lane;
         if ((unsigned)c < (unsigned)m) {
             src.fetch_resident(cols, m, c);
@@ -352,7 +256,6 @@ CR_D void trio_align_producer(const int p, const int np, RbfCoords<R>& src, cons
         }
         if (lane == 0) duo_publish(words + p, t + 1);
     }
-#endif
     CR_DUO_STAMP(p + 1, 5, CR_DUO_NOW());
     CR_DUO_STAMP(p + 1, 6, waited);
 }
@@ -443,26 +346,9 @@ CR_D void trio_score_producer(const int p, const int np, RbfCoords<R>& src, cons
     const int lane = threadIdx.x & (kWave - 1);
     src.load_rows(lane * R, n);
     unsigned long long waited = 0;
-#if CR_TRIO_STEAL
-    int c = trio_grab(words);
-#pragma unroll 1
-    while (c < m) {
-        const int cn = trio_grab(words);
-        if (c >= kTrioRing) trio_wait<CR_TRIO_PROD_SLEEP>(words + 4, c - kTrioRing + 1, waited);
-        trio_producer_priority(words, c, np);
-        src.fetch_resident(cols, m, c);
-        double* slot = ring + (size_t)((unsigned)c % (unsigned)kTrioRing) * (R * kWave) + lane;
-#pragma unroll
-        for (int q = 0; q < R; q++) slot[q * kWave] = src.score(q, tab);
-        if (lane == 0) duo_publish(words + 8 + (int)((unsigned)c % (unsigned)kTrioRing), c + 1);
-        c = cn;
-    }
-}
-#else
 #pragma unroll 1
     for (int c = p; c < m; c += np) {
         if (c >= kTrioRing) trio_wait<CR_TRIO_PROD_SLEEP>(words + 4, c - kTrioRing + 1, waited);
-        trio_producer_priority(words, c, np);
         src.fetch_resident(cols, m, c);                  // wave-uniform address: an LDS broadcast
         double* slot = ring + (size_t)((unsigned)c % (unsigned)kTrioRing) * (R * kWave) + lane;
 #pragma unroll
@@ -470,7 +356,6 @@ CR_D void trio_score_producer(const int p, const int np, RbfCoords<R>& src, cons
         if (lane == 0) duo_publish(words + p, c + 1);
     }
 }
-#endif
 
 template <int R>
 CR_D double trio_score_consumer(const int np, const int n, const int m, const double* ring, int* words) {
@@ -518,12 +403,17 @@ __global__ __launch_bounds__(kTrioMaxWaves* kWave, 2) void k_pair_trio(const Pai
     CR_STAMP(0);
     const PairDesc pd = pairs[blockIdx.x];
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#ifdef CR_STAMPS
+    // where this wave runs (HW_REG_HW_ID: wave, SIMD, CU, SH, SE; HW_REG_XCC_ID): slot 3 of the wave's stamps (tools/stamps.py, STAMPS_PLACEMENT=1)
+    CR_DUO_STAMP(w, 3, ((unsigned long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xf) << 32) |
+                           (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));
+#endif
     const ExpEntry* tab = reinterpret_cast<const ExpEntry*>(lds);
     int* words = reinterpret_cast<int*>(lds + kExpDoubles);
-    double* ring = lds + kExpDoubles + kTrioWords;
+    double* ring = lds + kExpDoubles + 4;
     double* cols = ring + (size_t)kTrioRing * R * kWave;
     load_exp_table(lds, threadIdx.x);
-    if (threadIdx.x < 2 * kTrioWords) words[threadIdx.x] = 0;
+    if (threadIdx.x < 8) words[threadIdx.x] = 0;
     __syncthreads();
     SeedMax sm;
     sm.score = 0.0;
@@ -559,7 +449,7 @@ __global__ __launch_bounds__(kTrioMaxWaves* kWave, 2) void k_pair_trio(const Pai
         src.xf = &s_tr;
         src.neg_gamma = -gamma_coords;
         src.load_resident(cols, pd.m, pd.m, (int)threadIdx.x, (int)blockDim.x);
-        if (threadIdx.x < 2 * kTrioWords) words[threadIdx.x] = 0;
+        if (threadIdx.x < 8) words[threadIdx.x] = 0;
         __syncthreads();
         // The two stages can run with different numbers of score waves (np2 <= blockDim.x / 64 - 1 in the second): the seed's
         // tensor scores are 50 of a cell's 66 instructions, the coordinate scores 23 of 50.  The waves the second stage does not

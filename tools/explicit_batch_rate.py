@@ -31,10 +31,11 @@ def explicit_record(count=8128, n=300, reps=5, with_tracebacks=True):
     t_up = time.perf_counter() - t0
     cells = float(batch.cells)
     rows = float(count) * 2 * n                              # sum of n + m
-    small = 24.0 * rows + 8.0 * count
-    modes = [("smith_waterman_score gap 0 (row sweep)", lambda: batch.smith_waterman_scores(0.0), 8.0 * cells + small),
-             ("smith_waterman_score gap 0.1 (skewed sweep)", lambda: batch.smith_waterman_scores(0.1), 8.0 * cells + small),
-             ("dtw_align_score (skewed sweep, no decisions)", lambda: batch.dtw_align(1.0, 0.01, want_alignments=False), 8.0 * cells + small)]
+    small = 24.0 * rows + 8.0 * count                        # index sequences in, two int64 rows out, the score
+    small_score = 8.0 * rows + 8.0 * count                   # (a score alone writes no rows)
+    modes = [("smith_waterman_score gap 0 (row sweep)", lambda: batch.smith_waterman_scores(0.0), 8.0 * cells + small_score),
+             ("smith_waterman_score gap 0.1 (skewed sweep)", lambda: batch.smith_waterman_scores(0.1), 8.0 * cells + small_score),
+             ("dtw_align_score (skewed sweep, no decisions)", lambda: batch.dtw_align(1.0, 0.01, want_alignments=False), 8.0 * cells + small_score)]
     if with_tracebacks:
         modes += [("dtw_align WITH traceback (4-bit decisions + walk)", lambda: batch.dtw_align(1.0, 0.01, want_alignments=True), 8.5 * cells + small),
                   ("smith_waterman WITH traceback gap 0 (2-bit decisions + walk)", lambda: batch.smith_waterman(0.0), 8.25 * cells + small),

@@ -47,9 +47,10 @@ def main():
     # per FUNCTION of the reference (tools/explicit_batch_rate.py): the kernels of its launch sequence against SURVEY 8(d)'s
     # explicit-mode bytes -- 8 n m + decisions (n m / 2 dtw_align, n m / 4 smith_waterman, none for a score) + 24 (n + m) + 8
     cells, small = float(count) * n * n, 24.0 * count * 2 * n + 8.0 * count
-    functions = {"smith_waterman_score gap 0 (row sweep)": (["k_sw_score_rows<"], 8.0 * cells + small),
-                 "smith_waterman_score gap 0.1 (skewed sweep)": (["k_explicit_stream<1, 2, false>"], 8.0 * cells + small),
-                 "dtw_align_score (skewed sweep, no decisions)": (["k_explicit_stream<1, 4, false>"], 8.0 * cells + small),
+    small_score = 8.0 * count * 2 * n + 8.0 * count          # (a score alone writes no alignment rows)
+    functions = {"smith_waterman_score gap 0 (row sweep)": (["k_sw_score_rows<"], 8.0 * cells + small_score),
+                 "smith_waterman_score gap 0.1 (skewed sweep)": (["k_explicit_stream<1, 2, false>"], 8.0 * cells + small_score),
+                 "dtw_align_score (skewed sweep, no decisions)": (["k_explicit_stream<1, 4, false>"], 8.0 * cells + small_score),
                  "dtw_align WITH traceback (4-bit decisions + walk)": (["k_explicit_stream<1, 4, true>", "k_dtw_trace_batch<"], 8.5 * cells + small),
                  "smith_waterman WITH traceback (2-bit decisions + walk)": (["k_explicit_sw_batch<", "k_sw_trace_batch<"], 8.25 * cells + small)}
     ratios = {}

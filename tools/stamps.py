@@ -60,7 +60,7 @@ def run(names):
         fam = synthetic.make_family(num, length, seed=seed)
         coords, tensors, offsets = synthetic.pack(fam)
         pairs = engine.all_pairs(num)[::stride]
-        b = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
+        b = batch_obj = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
         for _ in range(3):
             b.run(prm)
         ctx.synchronize()
@@ -91,13 +91,53 @@ def run(names):
                           f"align loop {med(ds[:, wv, 5] - ds[:, wv, 4]):9.0f} (start +{med(ds[:, wv, 4] - st[:nb, 4]):7.0f}, waited {med(ds[:, wv, 6]):8.0f})", flush=True)
         tot = st[:, 7] - st[:, 0]                   # (one block's stamps share a clock: the XCDs' counters are not synchronised)
         print("  pair total (launch -> results), min p10 p50 p90 max: " + " ".join(f"{v:8.0f}" for v in np.percentile(tot, [0, 10, 50, 90, 100])), flush=True)
+        if os.environ.get("STAMPS_PLACEMENT") and getattr(lib, "cr_debug_duo_stamps", None) is not None:
+            # where the workgroups ran (k_pair_trio records HW_REG_HW_ID / HW_REG_XCC_ID of every wave): pair time against the
+            # number of workgroups on its CU, per XCD, and against what shares wave 0's SIMD
+            nb = min(len(pairs), 4096)
+            ds = np.zeros((nb, 4, 8), dtype=np.uint64)
+            _capi.check(lib.cr_debug_duo_stamps(ds.ctypes.data_as(C.c_void_p), nb))
+            hw = ds[:, :, 3]
+            if hw[:, 0].any():
+                xcc, low = (hw >> np.uint64(32)).astype(np.int64) & 0xf, hw.astype(np.int64) & 0xffffffff
+                simd, cu, sh, se = (low >> 4) & 3, (low >> 8) & 15, (low >> 12) & 1, (low >> 13) & 7
+                cukey = (xcc[:, 0] << 12) | (se[:, 0] << 8) | (sh[:, 0] << 4) | cu[:, 0]
+                tot_b = tot[:nb]
+                per_cu = {}
+                for k, t in zip(cukey, tot_b):
+                    per_cu.setdefault(int(k), []).append(int(t))
+                by_count = {}
+                for k, v in per_cu.items():
+                    by_count.setdefault(len(v), []).extend(v)
+                print("  workgroups per CU -> CUs, median pair total: " + "; ".join(f"{c}: {sum(1 for v in per_cu.values() if len(v) == c)} CUs, {np.median(by_count[c]):.0f}" for c in sorted(by_count)), flush=True)
+                print("  per XCD: launch ramp (last - first start), finish spread (last - first end), first start -> last end: " + "; ".join(
+                    f"{x}: {int(st[:nb, 0][xcc[:, 0] == x].max() - st[:nb, 0][xcc[:, 0] == x].min())}, {int(st[:nb, 7][xcc[:, 0] == x].max() - st[:nb, 7][xcc[:, 0] == x].min())}, "
+                    f"{int(st[:nb, 7][xcc[:, 0] == x].max() - st[:nb, 0][xcc[:, 0] == x].min())}" for x in range(8) if (xcc[:, 0] == x).any()), flush=True)
+                print("  per XCD (workgroups, median pair total): " + "; ".join(f"{x}: {int((xcc[:, 0] == x).sum())}, {np.median(tot_b[xcc[:, 0] == x]):.0f}" for x in range(8) if (xcc[:, 0] == x).any()), flush=True)
+                waves_used = int((hw != 0).any(axis=0).sum())
+                simd_key = lambda wv: (cukey << 2) | simd[:, wv]
+                cons_per_simd = {}
+                for k in simd_key(0):
+                    cons_per_simd[int(k)] = cons_per_simd.get(int(k), 0) + 1
+                all_per_simd = {}
+                for wv in range(waves_used):
+                    for k in simd_key(wv):
+                        all_per_simd[int(k)] = all_per_simd.get(int(k), 0) + 1
+                g = {}
+                for b in range(nb):
+                    key = (cons_per_simd[int(simd_key(0)[b])], all_per_simd[int(simd_key(0)[b])])
+                    g.setdefault(key, []).append(int(tot_b[b]))
+                print("  (recurrence waves, all waves) on wave 0's SIMD -> pairs, median pair total: " + "; ".join(f"{k}: {len(v)}, {np.median(v):.0f}" for k, v in sorted(g.items())), flush=True)
+                order = np.argsort(tot_b)
+                fast, slow = order[:nb // 10], order[-nb // 10:]
+                print(f"  fastest tenth: block ids min/median/max {fast.min()} {int(np.median(fast))} {fast.max()}; slowest tenth: {slow.min()} {int(np.median(slow))} {slow.max()}", flush=True)
         if os.environ.get("STAMPS_DETAIL"):
             pc = lambda x: " ".join(f"{v:8.0f}" for v in np.percentile(x, [0, 10, 50, 90, 100]))
             t00 = st[:, 0].min()
             print(f"  percentiles (min p10 p50 p90 max): seed start {pc(st[:, 0] - t00)} | seed end {pc(st[:, 3] - t00)}\n"
                   f"      align start {pc(st[:, 4] - t00)} | align end {pc(st[:, 7] - t00)}\n"
                   f"      seed fill {pc(d[:, 0])} | align fill {pc(d[:, 4])}", flush=True)
-        b.close()
+        batch_obj.close()
 
 
 if __name__ == "__main__":
