@@ -70,6 +70,7 @@ SIGNATURES = {
     "cr_batch_layout": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "cr_batch_part_layout": [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64)],
     "cr_config_reload": [],
+    "cr_plan_layout": [_vp, _i64, _i64, _vp, _i64, _vp, _vp, C.POINTER(C.c_int)],
     "cr_batch_destroy": [_vp],
     "cr_multi_create": [_vp, _i32, _pp],
     "cr_multi_device_count": [_vp, C.POINTER(C.c_int)],

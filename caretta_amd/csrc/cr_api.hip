@@ -1612,12 +1612,106 @@ int for_each_part(cr_batch* b, F&& f) {
     return CR_OK;
 }
 
+// What cr_batch_set_pairs decides about a pair list before anything touches the device: the longest rows / columns, the pairs
+// per size class, and whether the list is split into classes.
+//
+// Size classes.  The layout of a list follows from its LONGEST structure, so one 600-residue member moves a family of
+// 150-residue structures to another kernel family (or out of every family built for its size).  A ragged list of at most
+// kClassSplitPairs pairs -- more fill the chip one wave per pair, which groups by rows per lane already -- is therefore split
+// into at most three classes by rows (<= 320 / <= 1 472 / longer; size_class()), each laid out as a list of its own -- when
+// that gives any class another family than one wave per pair and the classes do not all agree with the whole list's family.
+struct ListPlan {
+    int n_max = 0, m_max = 0;
+    int64_t in_class[3] = {0, 0, 0};
+    int cn[3] = {0, 0, 0}, cm[3] = {0, 0, 0};
+    bool split = false;
+    Layout whole;                 // the layout of the list as ONE list
+    Layout of_class[3];           // (split) the layouts of the classes
+};
+
+int plan_list(const int64_t* offsets, int64_t P, int d_pad, const int32_t* pairs, int64_t npairs, const LayoutMask mask, bool may_split,
+              ListPlan& out) {
+    out = ListPlan{};
+    for (int64_t p = 0; p < npairs; p++) {
+        const int64_t i = pairs[2 * p], j = pairs[2 * p + 1];
+        CR_REQUIRE(i >= 0 && i < P && j >= 0 && j < P, "pair index out of range");
+        const int n = (int)(offsets[i + 1] - offsets[i]), m = (int)(offsets[j + 1] - offsets[j]);
+        out.n_max = std::max(out.n_max, n);
+        out.m_max = std::max(out.m_max, m);
+        const int c = size_class(n, m);
+        out.in_class[c]++;
+        out.cn[c] = std::max(out.cn[c], n);
+        out.cm[c] = std::max(out.cm[c], m);
+    }
+    out.whole = choose_layout(out.n_max, out.m_max, d_pad, npairs, mask);
+    const int nclasses = (out.in_class[0] > 0) + (out.in_class[1] > 0) + (out.in_class[2] > 0);
+    if (g_cfg.classes && nclasses >= 2 && npairs <= kClassSplitPairs && may_split) {
+        bool all_same = true, any_special = false;
+        for (int c = 0; c < 3; c++) {
+            if (!out.in_class[c]) continue;
+            out.of_class[c] = choose_layout(out.cn[c], out.cm[c], d_pad, out.in_class[c], mask);
+            all_same = all_same && out.of_class[c].family == out.whole.family;
+            any_special = any_special || out.of_class[c].family != kFamSingle;
+        }
+        out.split = any_special && !all_same;
+    }
+    return CR_OK;
+}
+
+int public_family(const Layout& l) {
+    switch (l.family) {
+        case kFamTeam: return CR_LAYOUT_TEAM;
+        case kFamWide: return CR_LAYOUT_WIDE;
+        case kFamDuo: return CR_LAYOUT_DUO;
+        case kFamTrio: return CR_LAYOUT_TRIO;
+        case kFamStaged: return CR_LAYOUT_STAGED;
+        default: return CR_LAYOUT_SINGLE;
+    }
+}
+
 }  // namespace
 
 extern "C" {
 
 int cr_config_reload(void) {
     g_cfg = crcfg::Calibration::from_env();
+    return CR_OK;
+}
+
+// host only: no device, no context (tests/test_capi_cpu.py pins the layout table and the size classes with it)
+int cr_plan_layout(const int64_t* offsets, int64_t num_structures, int64_t d, const int32_t* pairs, int64_t npairs, int32_t* class_of_pair,
+                   int32_t* parts, int* nparts) {
+    CR_REQUIRE(offsets != nullptr && parts != nullptr && nparts != nullptr, "null argument");
+    CR_REQUIRE(num_structures >= 1 && npairs >= 0 && (npairs == 0 || pairs != nullptr), "bad pair list");
+    CR_REQUIRE(d >= 1 && padded_width(d) != 0, "tensor width > 32 is not supported by this build");
+    ListPlan plan;
+    const int rc = plan_list(offsets, num_structures, padded_width(d), pairs, npairs, LayoutMask{}, true, plan);
+    if (rc) return rc;
+    int count = 0;
+    auto put = [&](const Layout& l, int64_t n) {
+        int32_t* row = parts + 5 * count++;
+        row[0] = public_family(l);
+        row[1] = l.r_seed;
+        row[2] = l.wide_sync ? l.r_b : l.r_seed;
+        row[3] = l.wide_sync ? l.wide_na : 0;
+        row[4] = (int32_t)n;
+    };
+    int part_of_class[3] = {0, 0, 0};
+    if (!plan.split) {
+        put(plan.whole, npairs);
+    } else {
+        for (int c = 0; c < 3; c++)
+            if (plan.in_class[c]) {
+                part_of_class[c] = count;
+                put(plan.of_class[c], plan.in_class[c]);
+            }
+    }
+    if (class_of_pair)
+        for (int64_t p = 0; p < npairs; p++) {
+            const int64_t i = pairs[2 * p], j = pairs[2 * p + 1];
+            class_of_pair[p] = plan.split ? part_of_class[size_class((int)(offsets[i + 1] - offsets[i]), (int)(offsets[j + 1] - offsets[j]))] : 0;
+        }
+    *nparts = count;
     return CR_OK;
 }
 
@@ -1630,38 +1724,11 @@ int cr_batch_set_pairs(cr_batch* b, const int32_t* pairs, int64_t npairs) {
     const LayoutMask mask{g_no_wide, g_no_trio, g_no_duo};
     // (parts of an earlier list may still be running: the blocks they give back wait for the device, DevBuf::release)
     drop_parts(b);
-    int n_max = 0, m_max = 0;
-    int64_t in_class[3] = {0, 0, 0};
-    int cn[3] = {0, 0, 0}, cm[3] = {0, 0, 0};
-    for (int64_t p = 0; p < npairs; p++) {
-        const int64_t i = pairs[2 * p], j = pairs[2 * p + 1];
-        CR_REQUIRE(i >= 0 && i < b->P && j >= 0 && j < b->P, "pair index out of range");
-        const int n = (int)(b->offsets[i + 1] - b->offsets[i]), m = (int)(b->offsets[j + 1] - b->offsets[j]);
-        n_max = std::max(n_max, n);
-        m_max = std::max(m_max, m);
-        const int c = size_class(n, m);
-        in_class[c]++;
-        cn[c] = std::max(cn[c], n);
-        cm[c] = std::max(cm[c], m);
-    }
-    // Size classes.  The layout of a list follows from its LONGEST structure, so one 600-residue member moves a family of
-    // 150-residue structures to another kernel family (or out of every family built for its size).  A ragged list of at
-    // most kClassSplitPairs pairs -- more fill the chip one wave per pair, which groups by rows per lane already -- is
-    // therefore split into at most three classes by rows (<= 320 / <= 1 472 / longer; size_class()), each
-    // laid out as a list of its own -- when that gives any class another family than one wave per pair.
-    const int nclasses = (in_class[0] > 0) + (in_class[1] > 0) + (in_class[2] > 0);
-    bool split = false;
-    if (g_cfg.classes && nclasses >= 2 && npairs <= kClassSplitPairs && !b->is_part) {
-        const Family whole = choose_layout(n_max, m_max, b->d_pad, npairs, mask).family;
-        bool all_same = true, any_special = false;
-        for (int c = 0; c < 3; c++) {
-            if (!in_class[c]) continue;
-            const Family f = choose_layout(cn[c], cm[c], b->d_pad, in_class[c], mask).family;
-            all_same = all_same && f == whole;
-            any_special = any_special || f != kFamSingle;
-        }
-        split = any_special && !all_same;
-    }
+    ListPlan plan;
+    if ((rc = plan_list(b->offsets.data(), b->P, b->d_pad, pairs, npairs, mask, !b->is_part, plan))) return rc;
+    const int n_max = plan.n_max, m_max = plan.m_max;
+    const int64_t* in_class = plan.in_class;
+    const bool split = plan.split;
     if (!split) return set_pairs_one(b, pairs, npairs, nullptr, mask);
     // the parent keeps the totals; every class is a batch of its own
     b->npairs = npairs;

@@ -121,6 +121,15 @@ def reload_config():
     check(_capi.load().cr_config_reload())
 
 
+def plan_layout(offsets, d, pairs):
+    """What ``PairBatch.set_pairs`` would decide for this pair list, without a device (cr_plan_layout): ->
+    ([(kernel family, rows per lane A, rows per lane B, strips with A, pairs)] per part, part index of every pair)."""
+    offsets, pairs = i64(offsets), np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+    parts, cls, n = np.zeros((3, 5), np.int32), np.zeros(len(pairs), np.int32), C.c_int(0)
+    check(_capi.load().cr_plan_layout(ptr(offsets), len(offsets) - 1, int(d), ptr(pairs), len(pairs), ptr(cls), ptr(parts), C.byref(n)))
+    return [(LAYOUT_NAMES[int(r[0])], int(r[1]), int(r[2]), int(r[3]), int(r[4])) for r in parts[:n.value]], cls
+
+
 class PairBatch:
     def __init__(self, ctx: Context, coords, tensors, offsets):
         self.ctx = ctx

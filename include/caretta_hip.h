@@ -162,6 +162,13 @@ int cr_batch_part_layout(cr_batch *b, int part, int *family, int *rows_a, int *r
  * loaded; a measurement tool that changes its environment afterwards calls this to have the change seen.  No reference
  * counterpart (the reference has no tuning knobs on this path). */
 int cr_config_reload(void);
+/* What cr_batch_set_pairs would decide for this pair list, WITHOUT a device or a context (host only): whether the list is split
+ * into size classes and the kernel family of every part.  offsets i64[P + 1]; parts i32[3][5] = (family CR_LAYOUT_*, rows per
+ * lane A, rows per lane B, strips with A, pairs) of every part, *nparts of them (1: one list); class_of_pair i32[npairs] (may be
+ * NULL): the part every pair goes to.  No reference counterpart (the reference's pair loop, multiple_alignment.py:158-170, has
+ * one code path). */
+int cr_plan_layout(const int64_t *offsets, int64_t num_structures, int64_t d, const int32_t *pairs, int64_t npairs,
+                   int32_t *class_of_pair, int32_t *parts, int *nparts);
 int cr_batch_destroy(cr_batch *b);
 
 /* ---- the same matrix over several GPUs of one node, from ONE process ---------------------- */

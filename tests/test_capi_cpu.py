@@ -249,3 +249,72 @@ def test_multi_device_needs_a_gpu(lib):
     assert engine.multi_device() is None
     with pytest.raises(_capi.CarettaHipError):
         engine.MultiDevice([0])
+
+
+# ------------------------------------------------------------------- the layout table and the size classes, host only
+def _equal_family(rows, npairs):
+    """(offsets, pairs) of an equal-length family with `npairs` pairs (both orientations), as test_path_selection_boundaries builds it."""
+    num = 2
+    while num * (num - 1) < npairs:
+        num += 1
+    offsets = np.arange(num + 1, dtype=np.int64) * rows
+    i, j = np.triu_indices(num, 1)
+    fwd = np.stack([i, j], 1).astype(np.int32)
+    return offsets, np.vstack([fwd, fwd[:, ::-1]])[:npairs]
+
+
+@pytest.mark.parametrize("npairs,rows,expect", [
+    (256, 193, "trio"), (257, 257, "trio"), (257, 64, "staged"), (257, 65, "trio"), (160, 300, "staged"), (161, 300, "trio"),
+    (110, 250, "staged"), (111, 250, "trio"), (64, 150, "staged"), (65, 150, "trio"), (1300, 300, "trio"), (1301, 300, "single"),
+    (257, 321, "duo"), (256, 321, "wide"), (1024, 360, "duo"), (1025, 360, "single"), (170, 330, "staged"), (171, 330, "wide"),
+    (300, 1200, "duo"), (1024, 900, "duo"), (1025, 900, "single"), (252, 1200, "wide"), (504, 1200, "duo"), (2016, 1200, "single"),
+    (8128, 300, "single"), (496, 150, "trio"), (1, 300, "staged"), (3, 2049, "single"), (3, 2048, "staged")])
+def test_layout_table_boundaries_on_the_host(lib, npairs, rows, expect):
+    """kLayoutTable / choose_layout (cr_api.hip) through cr_plan_layout, which needs no device: the pair-count and row-count limits
+    at their boundary values (the GPU twin, tests/test_gpu_midsize.py::test_path_selection_boundaries, also runs both sides)."""
+    from caretta_amd import engine
+    offsets, pairs = _equal_family(rows, npairs)
+    parts, cls = engine.plan_layout(offsets, 10, pairs)
+    assert len(parts) == 1 and parts[0][0] == expect and parts[0][4] == npairs, (npairs, rows, parts)
+    assert not cls.any()
+
+
+def test_layout_table_tensor_widths_on_the_host(lib):
+    from caretta_amd import engine
+    offsets, pairs = _equal_family(300, 316)
+    assert engine.plan_layout(offsets, 10, pairs)[0][0][0] == "trio"
+    assert engine.plan_layout(offsets, 16, pairs)[0][0][0] == "duo"              # (no k_pair_trio instance above width 10)
+    assert engine.plan_layout(offsets, 17, pairs)[0][0][0] == "single"           # (no one-workgroup layout above width 16)
+    with pytest.raises(ValueError):
+        engine.plan_layout(offsets, 33, pairs)
+
+
+def test_size_classes_on_the_host(lib, monkeypatch):
+    """A ragged list is up to three lists (cr_batch_set_pairs): 20 domains of 150 residues with chains of 600, 600 and 1 300
+    in it; a ragged family whose classes would all run one wave per pair stays one list; CARETTA_CLASSES=0 switches the split off
+    (the switches are read once: cr_config_reload)."""
+    from caretta_amd import engine
+    lengths = np.array([150] * 20 + [600, 600, 1300], dtype=np.int64)
+    offsets = np.concatenate([[0], np.cumsum(lengths)])
+    i, j = np.triu_indices(len(lengths), 1)
+    fwd = np.stack([i, j], 1).astype(np.int32)
+    pairs = np.vstack([fwd, fwd[:, ::-1]])
+    parts, cls = engine.plan_layout(offsets, 10, pairs)
+    assert [p[0] for p in parts] == ["trio", "staged"] and [p[4] for p in parts] == [420, 86], parts
+    n, m = lengths[pairs[:, 0]], lengths[pairs[:, 1]]
+    assert np.array_equal(cls, np.where((n <= 320) & (m <= 1280), 0, 1))
+    monkeypatch.setenv("CARETTA_CLASSES", "0")
+    parts, cls = engine.plan_layout(offsets, 10, pairs)
+    assert len(parts) == 1 and parts[0][4] == len(pairs) and not cls.any()
+    monkeypatch.delenv("CARETTA_CLASSES")
+    assert len(engine.plan_layout(offsets, 10, pairs)[0]) == 2
+    # 160 structures of 80 .. 520 residues, 12 720 pairs: more than the 4 096 pairs a split is made for
+    rng = np.random.default_rng(3)
+    lengths = rng.integers(80, 521, size=160).astype(np.int64)
+    offsets = np.concatenate([[0], np.cumsum(lengths)])
+    i, j = np.triu_indices(160, 1)
+    parts, _ = engine.plan_layout(offsets, 10, np.stack([i, j], 1).astype(np.int32))
+    assert len(parts) == 1 and parts[0][0] == "single"
+    # a pair index out of range is an argument error, as in cr_batch_set_pairs
+    with pytest.raises(ValueError):
+        engine.plan_layout(offsets, 10, np.array([[0, 160]], np.int32))
