@@ -9,8 +9,9 @@ mkdir -p "$OUT"
 cd "$ROOT/caretta_amd/csrc"
 COMMON="--offload-arch=gfx950 -ffp-contract=off -fPIC -std=c++17 -pthread"
 hipcc $COMMON -O1 -g -fsanitize=address,undefined -fno-gpu-sanitize -fno-omit-frame-pointer -c cr_api.hip -o "$OUT/api.o"
-hipcc $COMMON -O3 -c cr_kernels_ilp.hip -o "$OUT/ilp.o"
-hipcc --offload-arch=gfx950 -shared -fPIC -pthread -fsanitize=address,undefined -fno-gpu-sanitize "$OUT/api.o" "$OUT/ilp.o" -o "$OUT/libcaretta_hip_asan.so"
+# (the kernel-only translation units come from the product build: obj/*.o of __graft_entry__.build())
+python -c "import __graft_entry__ as g; g.build()" >/dev/null 2>&1 || true
+hipcc --offload-arch=gfx950 -shared -fPIC -pthread -fsanitize=address,undefined -fno-gpu-sanitize "$OUT/api.o" obj/cr_kernels_ilp.hip.o obj/cr_kernels_duo.hip.o -o "$OUT/libcaretta_hip_asan.so"
 RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
 cd "$ROOT"
 ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 LD_PRELOAD=$RT CARETTA_HIP_LIB="$OUT/libcaretta_hip_asan.so" CARETTA_SYSTEM_HIP=1 \
