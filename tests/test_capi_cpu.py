@@ -270,7 +270,7 @@ def _equal_family(rows, npairs):
     (300, 1200, "duo"), (1024, 900, "duo"), (1025, 900, "single"), (252, 1200, "wide"), (504, 1200, "duo"), (2016, 1200, "single"),
     (8128, 300, "single"), (496, 150, "trio"), (1, 300, "staged"), (3, 2049, "single"), (3, 2048, "staged")])
 def test_layout_table_boundaries_on_the_host(lib, npairs, rows, expect):
-    """kLayoutTable / choose_layout (cr_api.hip) through cr_plan_layout, which needs no device: the pair-count and row-count limits
+    """kLayoutTable / choose_layout (cr_layout.h) through cr_plan_layout, which needs no device: the pair-count and row-count limits
     at their boundary values (the GPU twin, tests/test_gpu_midsize.py::test_path_selection_boundaries, also runs both sides)."""
     from caretta_amd import engine
     offsets, pairs = _equal_family(rows, npairs)
