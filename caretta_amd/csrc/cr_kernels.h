@@ -518,6 +518,19 @@ CR_D double vmax(double a, double b) {
 
 enum : int { kSwTrace = 1, kSwScore = 2, kDtw = 4, kZeroGap = 8 };   // kZeroGap: sw_gap == 0.0
 
+// Diagnostic builds only (tools/step_probe.hip): what a step of the sweeps costs without its decision packing / without
+// the hand-off writes of the lanes that hand nothing down.  Never defined in the library.
+#ifdef CR_PROBE_NO_DECISIONS
+constexpr bool kProbeNoDecisions = true;
+#else
+constexpr bool kProbeNoDecisions = false;
+#endif
+#ifdef CR_PROBE_NO_DUMP
+constexpr bool kProbeNoDump = true;
+#else
+constexpr bool kProbeNoDump = false;
+#endif
+
 struct SweepParams {
     double sw_gap, gap_open, gap_extend;
 };
@@ -561,7 +574,7 @@ CR_D void dp_column(const Src& src, DpState<R>& st, const SweepParams& prm, cons
             const double up = ZG ? h_up : h_up - prm.sw_gap;
             const double h = NOFLOOR ? vmax(vmax(dg[q], lf), up)
                                      : vmax(vmax(vmax(0.0, dg[q]), lf), up);
-            if constexpr (TRACE) {
+            if constexpr (TRACE && !kProbeNoDecisions) {
                 // decision replayed by the traceback's equality tests (:255-277)
                 uint32_t code = (h == dg[q]) ? 1u : (h == lf) ? 2u : 3u;
                 code = (h > 0.0) ? code : 0u;
@@ -594,8 +607,10 @@ CR_D void dp_column(const Src& src, DpState<R>& st, const SweepParams& prm, cons
             const double m01 = vmax(m0, c1[q]);
             const bool g2 = m2n[q] > m01;
             const double m1 = vmax(m01, m2n[q]);
-            const uint32_t nib = (b0 ? 1u : 0u) | (g2 ? 4u : (g1 ? 2u : 0u)) | (b2[q] ? 8u : 0u);
-            st.dtbits[q] |= nib << sh4;
+            if constexpr (!kProbeNoDecisions) {
+                const uint32_t nib = (b0 ? 1u : 0u) | (g2 ? 4u : (g1 ? 2u : 0u)) | (b2[q] ? 8u : 0u);
+                st.dtbits[q] |= nib << sh4;
+            }
             m0_up = m0;
             m1_up = m1;
             st.m0_left[q] = m0;
@@ -1712,8 +1727,8 @@ __host__ __device__ inline size_t sweep_wide_lds_doubles(int waves, int m_max) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// The wide sweep on scores that another launch has already formed (cr_staged.h): ONE row per lane up to 512 rows, then
-// two, three, four (up to 2048 rows; blocks of 8 steps from three rows on).
+// The wide sweep on scores that another launch has already formed (cr_staged.h): ONE row per lane up to 320 rows (five
+// strips), then two, three, four (up to 2048 rows; blocks of 8 steps from three rows on).
 //
 // When a launch has few workgroups -- a level of the progressive alignment, a short pair list -- the fused kernels are
 // bound by the instruction issue of the few waves that hold the recurrence, and 50 of a seed step's 59 instructions (30
@@ -2004,10 +2019,12 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
 #pragma unroll
                     for (int q = 0; q < R; q++) src.v[q] = cur[k][q];
                     dp_column<R, MODE>(src, st, prm, nullptr, c, rowbase, n, ((tb * B + k) & 15) * 2, (k & 7) * 4, h_top, m0_top, m1_top);
-                    if constexpr (SW) wr[PH + k] = st.h_left[R - 1];
-                    if constexpr (DTW) {
-                        wr[PM0 + k] = st.m0_left[R - 1];
-                        wr[PM1 + k] = st.m1_left[R - 1];
+                    if constexpr (!kProbeNoDump) {
+                        if constexpr (SW) wr[PH + k] = st.h_left[R - 1];
+                        if constexpr (DTW) {
+                            wr[PM0 + k] = st.m0_left[R - 1];
+                            wr[PM1 + k] = st.m1_left[R - 1];
+                        }
                     }
                 }
                 f_h = g_h;
