@@ -530,6 +530,21 @@ constexpr bool kProbeNoDump = true;
 #else
 constexpr bool kProbeNoDump = false;
 #endif
+#ifdef CR_PROBE_NO_BARRIER
+constexpr bool kProbeNoBarrier = true;     // (wrong results: what the strips would take if nothing coupled them)
+#else
+constexpr bool kProbeNoBarrier = false;
+#endif
+#ifdef CR_PROBE_MASKED_HANDOFF
+constexpr bool kProbeMaskedHandoff = true;
+#else
+constexpr bool kProbeMaskedHandoff = false;
+#endif
+#ifdef CR_PROBE_MASKED_RAMPS
+constexpr bool kProbeMaskedRamps = true;
+#else
+constexpr bool kProbeMaskedRamps = false;
+#endif
 
 struct SweepParams {
     double sw_gap, gap_open, gap_extend;
@@ -1962,9 +1977,29 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
             }
     }
     const int GB = LAGB * (nstrips - 1) + (m + kWave - 1 + B - 1) / B;
+    // RAMPS WITHOUT MASKS.  A lane's column t - lane is outside [0, m) in the first 63 and the last 63 steps of its strip; a
+    // block in which that happens for any lane runs the EXEC-masked step (269 against 206 cycles for the DTW, 250 against
+    // 156 for the SW, tools/step_probe.hip) -- and with the strips 80 steps apart nearly every block of the WORKGROUP has
+    // some strip in a ramp, so the whole fill ran at the masked step's pace.  The masks are not needed where the staging
+    // kernels have written exact zeros for the columns outside [0, m) (cr_staged.h, stage_block) and the penalties are not
+    // negative:
+    //  * before its column 0 a lane then sits at a fixed point that its first real step cannot tell from the DP border:
+    //    SW: h = max(0 + 0, 0, 0) = 0, decision code 0, no row maximum.  DTW: c1 = 0 + 0, the layer above gives
+    //    m0 = max(m0' - extend, 0 - open) <= 0, m2 = max(0 - open, m2 - extend) = -open from the first such step on, so
+    //    m1 = max(max(m0, 0), -open) = +0.0 = M[i][0][1]; the first real step reads m2 - extend, which is below 0 - open
+    //    for -open as for the border's MIN - open (same maximum, same decision bit);
+    //  * behind column m - 1 a lane's state is dead: its decision bits lie at positions no walk reads, the values it hands
+    //    down belong to columns the strip below does not have; SW with gap 0 repeats the row's last value (no new row
+    //    maximum), a global SW maximum only ever sees values of real cells again.  Two things do outlive the last column:
+    //    the DTW layers of row n - 1 (the score) and, for an SW with a gap, each row's first maximum -- hence the LAST
+    //    block of every strip stays masked (the owner of row n - 1 is the last lane of its strip to finish), and the SW
+    //    trace with a gap keeps its masks altogether.
+    // Explicit score matrices (RBF = false: any sign, caller's penalties) keep the masks.
+    const bool unmasked = !kProbeMaskedRamps && RBF && !(TRACE && !(MODE & kZeroGap)) && prm.sw_gap >= 0.0 && prm.gap_open >= 0.0 &&
+                          prm.gap_extend >= 0.0;
 #pragma unroll 1
     for (int gb = 0; gb < GB; gb++) {
-        lds_barrier();                                     // hand-off values of the last block visible to the next strip
+        if constexpr (!kProbeNoBarrier) lds_barrier();     // hand-off values of the last block visible to the next strip
         const int tb = gb - LAGB * w;
         if (tb < 0 || tb >= my_blocks) continue;
         const double* __restrict__ ahead = line + (int64_t)(tb + (FAR ? 2 : 1)) * (B * R * kWave);
@@ -1989,6 +2024,7 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
         // the strip's last row: lane 63 writes its values of step k to slot q4 + k of the ring, the other lanes write theirs
         // to a dump (one LDS instruction per step with no EXEC juggling)
         double* wr = (lane == kWave - 1 && w + 1 < nstrips) ? ring_out + q4 : dump + lane;
+        const bool hands_down = lane == kWave - 1 && w + 1 < nstrips;
         double f_h = 0.0, f_m0 = 0.0, f_m1 = 0.0;
         if constexpr (SW) f_h = ring_in[PH + slot0];
         if constexpr (DTW) {
@@ -2019,7 +2055,15 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
 #pragma unroll
                     for (int q = 0; q < R; q++) src.v[q] = cur[k][q];
                     dp_column<R, MODE>(src, st, prm, nullptr, c, rowbase, n, ((tb * B + k) & 15) * 2, (k & 7) * 4, h_top, m0_top, m1_top);
-                    if constexpr (!kProbeNoDump) {
+                    if constexpr (kProbeMaskedHandoff) {
+                        if (hands_down) {
+                            if constexpr (SW) ring_out[q4 + PH + k] = st.h_left[R - 1];
+                            if constexpr (DTW) {
+                                ring_out[q4 + PM0 + k] = st.m0_left[R - 1];
+                                ring_out[q4 + PM1 + k] = st.m1_left[R - 1];
+                            }
+                        }
+                    } else if constexpr (!kProbeNoDump) {
                         if constexpr (SW) wr[PH + k] = st.h_left[R - 1];
                         if constexpr (DTW) {
                             wr[PM0 + k] = st.m0_left[R - 1];
@@ -2042,7 +2086,7 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
                 }
             });
         };
-        if (tb * B >= kWave - 1 && tb * B + B - 1 < m) steps(std::true_type{});
+        if (unmasked ? tb != my_blocks - 1 : (tb * B >= kWave - 1 && tb * B + B - 1 < m)) steps(std::true_type{});
         else steps(std::false_type{});
         if constexpr (TRACE) {
             if ((((tb + 1) * B) & 15) == 0 || tb == my_blocks - 1) {      // a decision word holds 16 steps

@@ -39,7 +39,10 @@ CR_D void stage_block(Src& src, const int n, const int m, const int tc, double* 
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int t0 = (int)blockIdx.x * tc;
-    if (t0 >= m + kBack) return;                           // (whole workgroup) past the last step of this pair
+    // SKEW: the lines of every block of 16 steps a strip runs through, with EXACT ZEROS where a lane's column is outside
+    // [0, m) -- sweep_staged runs its ramps without masks on them (cr_kernels.h)
+    const int t_end = SKEW ? (m + kBack + kStagedBlock - 1) / kStagedBlock * kStagedBlock : m;
+    if (t0 >= t_end) return;                               // (whole workgroup) past the last step of this pair
     const int c_lo = t0 - kBack > 0 ? t0 - kBack : 0;
     const int c_hi = t0 + tc < m ? t0 + tc : m;
     const int stride = tc + kBack;
@@ -52,13 +55,16 @@ CR_D void stage_block(Src& src, const int n, const int m, const int tc, double* 
     __syncthreads();
     if (!mine) return;
     double* __restrict__ out = pair_base + (int64_t)w * shape.strip_doubles() + lane;
-    const int t1 = t0 + tc < m + kBack ? t0 + tc : m + kBack;
+    const int t1 = t0 + tc < t_end ? t0 + tc : t_end;
     for (int t = t0; t < t1; t++) {
         const int c = SKEW ? t - lane : t;
         if ((unsigned)c < (unsigned)m) {
             src.fetch_resident(res, stride, c - c_lo);
 #pragma unroll
             for (int q = 0; q < R; q++) out[((int64_t)t * R + q) * kWave] = src.score(q, tab);
+        } else if (SKEW) {
+#pragma unroll
+            for (int q = 0; q < R; q++) out[((int64_t)t * R + q) * kWave] = 0.0;
         }
     }
 }
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_stage_coords(const P
     stage_block<true, R>(src, pd.n, pd.m, tc, staged + (int64_t)blockIdx.y * shape.pair_doubles(), shape, lds);
 }
 
-// Seed stage on staged scores: SW fill with one wave per strip (gap 0: the column sweep on the unskewed layout), then
+// Seed stage on staged scores: SW fill with one wave per strip (gap 0 with two rows per lane: the column sweep on the unskewed layout), then
 // traceback (wave 0) + seed Kabsch (the ordered sums by the whole workgroup), as the first half of k_pair_wide.
 template <bool ZG, int R>
 __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_seed_staged(const PairDesc* __restrict__ pairs,
@@ -168,8 +174,10 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_seed_staged(const Pa
         const double* strip = staged + (int64_t)blockIdx.x * shape.pair_doubles() + (int64_t)w * shape.strip_doubles();
         const StripGeom geom = WidePlan<R>{0}.geom(w, pd.n);
         SweepParams prm{sw_gap, 0.0, 0.0};
-        // (three and four rows per lane: the column sweep's chunks of score lines do not fit the registers beside its state)
-        if constexpr (ZG && R <= 2) sweep_cols_staged<R>(strip, pd.n, pd.m, lds, dirs + pd.dirs_off, sm, geom);
+        // One row per lane: the skewed sweep, whose ramps run without masks since round 5 (340 x 330: 161 k cycles against the
+        // column sweep's 196 k, tools/step_probe.hip); two: the column sweep (three and four rows per lane: its chunks of
+        // score lines do not fit the registers beside its state)
+        if constexpr (ZG && R == 2) sweep_cols_staged<R>(strip, pd.n, pd.m, lds, dirs + pd.dirs_off, sm, geom);
         else sweep_staged<R, kSwTrace | (ZG ? kZeroGap : 0)>(strip, pd.n, pd.m, prm, lds, dirs + pd.dirs_off, nullptr, sm, unused, geom);
     }
     // wave 0 walks (the others wait at the barrier); the position-ordered sums behind the walk are taken by everybody
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_seed_staged(const Pa
         CR_STAMP(1);
         int k, len;
         uint32_t fl;
-        seed_walk<R, (ZG && R <= 2) ? 0 : 1>(pd, dirs, sm, seed_list, 0, k, len, fl);
+        seed_walk<R, (ZG && R == 2) ? 0 : 1>(pd, dirs, sm, seed_list, 0, k, len, fl);
         if (threadIdx.x == 0) {
             s_walk[0] = k;
             s_walk[1] = len;
@@ -492,7 +500,7 @@ inline cr::StagedShape staged_shape(int n_bound, int m_bound) {
 
 template <int D>
 int launch_stage_tensor_d(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, double* staged, const cr::StagedShape shape) {
-    const bool skew = prm.sw_gap != 0.0 || shape.r > 2;    // gap 0, one or two rows per lane: the seed is a column sweep
+    const bool skew = prm.sw_gap != 0.0 || shape.r != 2;   // gap 0, two rows per lane: the seed is a column sweep (k_seed_staged)
     const int steps = ck.m_max + (skew ? cr::kWave - 1 : 0), tc = stage_steps(ck.count, steps);
     const size_t lds = sizeof(double) * cr::stage_lds_doubles(D, tc);
     const unsigned chunks = (unsigned)((steps + tc - 1) / tc);

@@ -57,6 +57,12 @@ static void run(const char* name, int n, int m) {
         x ^= x << 17;
         v = (double)(x >> 11) * (1.0 / 9007199254740992.0);
     }
+    if (MODE != 2)           // skewed layout: line t, row slot q, lane l = S(row, column t - l); exact zeros outside [0, m), as stage_block writes them
+        for (int w = 0; w < waves; w++)
+            for (int64_t t = 0; t < strip_doubles / (kWave * R); t++)
+                for (int q = 0; q < R; q++)
+                    for (int l = 0; l < kWave; l++)
+                        if (t - l < 0 || t - l >= m) h[(size_t)w * strip_doubles + ((size_t)t * R + q) * kWave + l] = 0.0;
     double *d, *out;
     uint32_t* words;
     unsigned long long* cyc;
@@ -92,6 +98,8 @@ int main() {
     printf("== without decision packing\n");
 #elif defined(CR_PROBE_NO_DUMP)
     printf("== without hand-off writes\n");
+#elif defined(CR_PROBE_MASKED_RAMPS)
+    printf("== every block in which a lane is outside [0, m) with the EXEC-masked step (the library until round 5)\n");
 #else
     printf("== as in the library\n");
 #endif

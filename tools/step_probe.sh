@@ -9,7 +9,9 @@ build)
   hipcc $FLAGS -DCR_PROBE_NO_DECISIONS tools/step_probe.hip -o tools/step_probe_nodec.bin &
   hipcc $FLAGS -DCR_PROBE_NO_DUMP tools/step_probe.hip -o tools/step_probe_nodump.bin &
   hipcc $FLAGS -DCR_PROBE_NO_DECISIONS -DCR_PROBE_NO_DUMP tools/step_probe.hip -o tools/step_probe_neither.bin &
+  hipcc $FLAGS -DCR_PROBE_MASKED_RAMPS tools/step_probe.hip -o tools/step_probe_masked.bin &
+  hipcc $FLAGS -DCR_PROBE_ROWS tools/step_probe.hip -o tools/step_probe_rows.bin &
   wait ;;
 run)
-  for v in lib nodec nodump neither; do tools/step_probe_$v.bin; done ;;
+  for v in lib masked nodec nodump neither rows; do tools/step_probe_$v.bin; done ;;
 esac
