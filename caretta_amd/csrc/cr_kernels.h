@@ -530,16 +530,6 @@ constexpr bool kProbeNoDump = true;
 #else
 constexpr bool kProbeNoDump = false;
 #endif
-#ifdef CR_PROBE_NO_BARRIER
-constexpr bool kProbeNoBarrier = true;     // (wrong results: what the strips would take if nothing coupled them)
-#else
-constexpr bool kProbeNoBarrier = false;
-#endif
-#ifdef CR_PROBE_MASKED_HANDOFF
-constexpr bool kProbeMaskedHandoff = true;
-#else
-constexpr bool kProbeMaskedHandoff = false;
-#endif
 #ifdef CR_PROBE_MASKED_RAMPS
 constexpr bool kProbeMaskedRamps = true;
 #else
@@ -1999,7 +1989,7 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
                           prm.gap_extend >= 0.0;
 #pragma unroll 1
     for (int gb = 0; gb < GB; gb++) {
-        if constexpr (!kProbeNoBarrier) lds_barrier();     // hand-off values of the last block visible to the next strip
+        lds_barrier();                                     // hand-off values of the last block visible to the next strip
         const int tb = gb - LAGB * w;
         if (tb < 0 || tb >= my_blocks) continue;
         const double* __restrict__ ahead = line + (int64_t)(tb + (FAR ? 2 : 1)) * (B * R * kWave);
@@ -2024,7 +2014,6 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
         // the strip's last row: lane 63 writes its values of step k to slot q4 + k of the ring, the other lanes write theirs
         // to a dump (one LDS instruction per step with no EXEC juggling)
         double* wr = (lane == kWave - 1 && w + 1 < nstrips) ? ring_out + q4 : dump + lane;
-        const bool hands_down = lane == kWave - 1 && w + 1 < nstrips;
         double f_h = 0.0, f_m0 = 0.0, f_m1 = 0.0;
         if constexpr (SW) f_h = ring_in[PH + slot0];
         if constexpr (DTW) {
@@ -2055,15 +2044,7 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
 #pragma unroll
                     for (int q = 0; q < R; q++) src.v[q] = cur[k][q];
                     dp_column<R, MODE>(src, st, prm, nullptr, c, rowbase, n, ((tb * B + k) & 15) * 2, (k & 7) * 4, h_top, m0_top, m1_top);
-                    if constexpr (kProbeMaskedHandoff) {
-                        if (hands_down) {
-                            if constexpr (SW) ring_out[q4 + PH + k] = st.h_left[R - 1];
-                            if constexpr (DTW) {
-                                ring_out[q4 + PM0 + k] = st.m0_left[R - 1];
-                                ring_out[q4 + PM1 + k] = st.m1_left[R - 1];
-                            }
-                        }
-                    } else if constexpr (!kProbeNoDump) {
+                    if constexpr (!kProbeNoDump) {
                         if constexpr (SW) wr[PH + k] = st.h_left[R - 1];
                         if constexpr (DTW) {
                             wr[PM0 + k] = st.m0_left[R - 1];
