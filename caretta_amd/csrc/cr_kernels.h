@@ -1746,7 +1746,7 @@ __host__ __device__ inline size_t sweep_wide_lds_doubles(int waves, int m_max) {
 // 48 lines in flight per wave); shifts, word boundaries and the one barrier of a block are fixed at compile time.  The
 // strips lag each other by 80 steps (a multiple of the block, >= 63 + 16), so every wave's blocks are the workgroup's
 // blocks.  The strip region has staged_steps(m_max) lines: the requests two blocks past the last step stay inside it.
-// LDS (doubles): NW + 1 hand-off rings of NB * kWideEdge | NW * 8 | NW dumps.  Decision words: as every other skewed sweep.
+// LDS (doubles): NW + 1 hand-off rings of NB * kStagedRing | NW * 8 | NW dumps | progress words.  Decision words: as every other skewed sweep.
 // ---------------------------------------------------------------------------------------------
 constexpr int kStagedBlock = 16;         // steps per block with one or two rows per lane; 8 with three or four (registers)
 constexpr int kStagedMaxWaves = 8;       // the blocks of score lines in registers need more than the 128 VGPRs of a 16-wave
@@ -1915,7 +1915,18 @@ CR_D void sweep_cols_staged(const double* __restrict__ strip, const int n, const
 __host__ __device__ inline size_t sweep_cols_staged_lds_doubles(int waves) { return (size_t)waves * (2 * kColChunk + 4); }
 
 // doubles per wave that take the hand-off writes of lanes 0 .. 62: dump[lane + plane * 64 + step], up to three planes
-constexpr int kStagedDump = kWave + 2 * kWideEdge + kStagedBlock;
+constexpr int kStagedRing = 128;          // steps a plane of a hand-off ring of the staged sweeps holds
+constexpr int kStagedDump = kWave + 2 * kStagedRing + kStagedBlock;
+
+// progress words of the staged sweeps (as cr_duo.h paces its strips): blocks a strip has completed
+CR_D void staged_publish(int* word, int blocks_done) {
+    asm volatile("" ::: "memory");       // (compiler: the hand-off values of the block are written first)
+    *reinterpret_cast<volatile int*>(word) = blocks_done;
+}
+CR_D void staged_wait(const int* word, int need) {
+    while (__builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int*>(word)) < need) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");       // (compiler: hand-off values are read behind the word)
+}
 
 template <int R, int MODE, bool RBF = true>
 CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int m, const SweepParams prm, double* lds,
@@ -1928,16 +1939,18 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
     constexpr int B = R <= 2 ? kStagedBlock : 8;          // steps per block (the block's R * B score lines sit in registers)
     constexpr int LAGB = R <= 2 ? 5 : 9;                  // blocks a strip lags the one above: 80 / 72 steps (>= 63 + B)
     constexpr bool FAR = R == 1;                          // score lines two blocks ahead (R >= 2: one, the registers are taken)
-    constexpr int PH = 0, PM0 = (NB - 2) * kWideEdge, PM1 = (NB - 1) * kWideEdge;   // planes of a ring
+    constexpr int RING = kStagedRing;                     // slots of a plane of a hand-off ring
+    constexpr int PH = 0, PM0 = (NB - 2) * RING, PM1 = (NB - 1) * RING;             // planes of a ring
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int NW = (int)(blockDim.x >> 6);
     // Hand-off rings, indexed by the WRITER's step (t & 63: a block's 16 slots are contiguous): ring 0 holds the DP border
     // above row 0 (constants), ring w + 1 the last row of strip w.  Strip w reads ring w: no special case for the first.
-    const double* ring_in = lds + w * (NB * kWideEdge);
-    double* ring_out = lds + (w + 1) * (NB * kWideEdge);
-    double* red = lds + (NW + 1) * (NB * kWideEdge);
+    const double* ring_in = lds + w * (NB * RING);
+    double* ring_out = lds + (w + 1) * (NB * RING);
+    double* red = lds + (NW + 1) * (NB * RING);
     double* dump = red + NW * 8 + w * kStagedDump;
+    int* prog = reinterpret_cast<int*>(red + NW * 8 + NW * kStagedDump);     // prog[w]: blocks strip w has completed
 
     const int nstrips = geom.nstrips;                    // <= NW, guaranteed by the launcher
     const int TB_SW = tblocks(m, 16), TB_DTW = tblocks(m, 8);
@@ -1947,7 +1960,11 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
     const int rows_here = n - geom.rowbase0;
     const int lanes_here = rows_here >= kWave * R ? kWave : (rows_here + R - 1) / R;
     const int my_blocks = mine ? (m + lanes_here - 1 + B - 1) / B : 0;
-    for (int x = threadIdx.x; x < NB * kWideEdge; x += blockDim.x) lds[x] = (DTW && x / kWideEdge == NB - 2) ? col0_m2 : 0.0;
+    // every ring starts as the DP border: ring 0 IS the border; in the others a lane 0 that is past its last column (the
+    // ramps run unmasked) may read a slot its writer never reaches -- e.g. the one step of the writer's masked last block
+    // in which its lane 63 is past the last column -- and must not find whatever the LDS held
+    for (int x = threadIdx.x; x < (NW + 1) * NB * RING; x += blockDim.x) lds[x] = (DTW && (x / RING) % NB == NB - 2) ? col0_m2 : 0.0;
+    if (threadIdx.x < kStagedMaxWaves) prog[threadIdx.x] = 0;
 
     DpState<R> st;
     st.sw_max = 0.0;
@@ -1966,7 +1983,8 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
                 if constexpr (FAR) nx2[k][q] = line[((B + k) * R + q) * kWave];
             }
     }
-    const int GB = LAGB * (nstrips - 1) + (m + kWave - 1 + B - 1) / B;
+    const int blocks_above = (m + kWave - 1 + B - 1) / B;    // blocks of the strip above (it has all 64 lanes)
+    const bool hand_out = w + 1 < nstrips;
     // RAMPS WITHOUT MASKS.  A lane's column t - lane is outside [0, m) in the first 63 and the last 63 steps of its strip; a
     // block in which that happens for any lane runs the EXEC-masked step (269 against 206 cycles for the DTW, 250 against
     // 156 for the SW, tools/step_probe.hip) -- and with the strips 80 steps apart nearly every block of the WORKGROUP has
@@ -1987,11 +2005,19 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
     // Explicit score matrices (RBF = false: any sign, caller's penalties) keep the masks.
     const bool unmasked = !kProbeMaskedRamps && RBF && !(TRACE && !(MODE & kZeroGap)) && prm.sw_gap >= 0.0 && prm.gap_open >= 0.0 &&
                           prm.gap_extend >= 0.0;
+    // PACING.  The strips form a chain -- strip w needs, for its block tb, the last row of the strip above up to that
+    // strip's step 16 tb + 15 + 63, i.e. its blocks up to tb + LAGB - 1 -- and used to advance together behind one
+    // s_barrier per block: every block took what the slowest strip's block took.  Now every strip publishes the number of
+    // blocks it has completed (an LDS word, written behind the block's hand-off values: the LDS serves a wave's requests in
+    // order) and waits only for the strip above; a writer also waits until the strip below is past the values a block will
+    // overwrite (the rings hold RING = 128 steps: five blocks of slack on top of the five of lag).
+    lds_barrier();                                         // border ring and progress words
 #pragma unroll 1
-    for (int gb = 0; gb < GB; gb++) {
-        lds_barrier();                                     // hand-off values of the last block visible to the next strip
-        const int tb = gb - LAGB * w;
-        if (tb < 0 || tb >= my_blocks) continue;
+    for (int tb = 0; tb < my_blocks; tb++) {
+        if (w > 0) staged_wait(prog + w - 1, tb + LAGB < blocks_above ? tb + LAGB : blocks_above);
+        // (this block overwrites the values of block tb - RING / B, whose last one the strip below reads in its step
+        // B (tb - RING / B) + B - 1 - 63)
+        if (hand_out && tb >= RING / B + LAGB - 2) staged_wait(prog + w + 1, tb - (RING / B + LAGB - 3));
         const double* __restrict__ ahead = line + (int64_t)(tb + (FAR ? 2 : 1)) * (B * R * kWave);
 #pragma unroll
         for (int k = 0; k < B; k++)
@@ -2008,9 +2034,11 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
         // The row above the strip.  Lane 0's column at step t is t itself, written by the strip above at ITS step t + 63:
         // slot (t - 1) & 63.  Every lane reads it (one address: a broadcast) and hands it to the shift as lane 0's fill;
         // the read of step k + 1 is issued before the arithmetic of step k.
-        const int q4 = (tb & (kWideEdge / B - 1)) * B;
-        const double* fills = ring_in + q4 - 1;            // step k >= 1: fills[k]
-        const int slot0 = (tb * B - 1) & (kWideEdge - 1);
+        // (the slots of a ring are the WRITER's steps mod RING; lane 0's column at step t is t, written above at step t + 63)
+        const int q4 = (tb * B) & (RING - 1);              // this strip writes the slots q4 + k
+        const int q4r = (tb * B + kWave) & (RING - 1);     // ... and reads slot0, then q4r + k - 1 for its step k >= 1
+        const double* fills = ring_in + q4r - 1;           // step k >= 1: fills[k]
+        const int slot0 = (tb * B + kWave - 1) & (RING - 1);
         // the strip's last row: lane 63 writes its values of step k to slot q4 + k of the ring, the other lanes write theirs
         // to a dump (one LDS instruction per step with no EXEC juggling)
         double* wr = (lane == kWave - 1 && w + 1 < nstrips) ? ring_out + q4 : dump + lane;
@@ -2069,6 +2097,7 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
         };
         if (unmasked ? tb != my_blocks - 1 : (tb * B >= kWave - 1 && tb * B + B - 1 < m)) steps(std::true_type{});
         else steps(std::false_type{});
+        if (nstrips > 1 && lane == 0) staged_publish(prog + w, tb + 1);    // (the strip below follows it, the strip above must not lap it)
         if constexpr (TRACE) {
             if ((((tb + 1) * B) & 15) == 0 || tb == my_blocks - 1) {      // a decision word holds 16 steps
                 const int64_t base = ((int64_t)geom.slot0 * TB_SW + (int64_t)((tb * B) >> 4) * R) * kWave + lane;
@@ -2086,7 +2115,7 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
 template <int MODE>
 __host__ __device__ inline size_t sweep_staged_lds_doubles(int waves) {
     constexpr int NB = ((MODE & (kSwTrace | kSwScore)) ? 1 : 0) + ((MODE & kDtw) ? 2 : 0);
-    return (size_t)(waves + 1) * (NB * kWideEdge) + (size_t)waves * (8 + kStagedDump);
+    return (size_t)(waves + 1) * (NB * kStagedRing) + (size_t)waves * (8 + kStagedDump) + kStagedMaxWaves / 2;
 }
 
 CR_D uint32_t lookup_bits(const uint32_t* __restrict__ words, int R, int TB, int per_word_log2, int bits,
