@@ -1743,9 +1743,9 @@ __host__ __device__ inline size_t sweep_wide_lds_doubles(int waves, int m_max) {
 // Layout of one strip (64 rows): element t * 64 + lane = S(row lane, column t - lane), t = 0 .. m + 62: the line a wave
 // needs at step t is one coalesced 512-byte read.  The loop runs in blocks of kStagedBlock = 16 steps, unrolled: the
 // block's 16 lines sit in registers, requested TWO blocks ahead (the scores are in L2 / MALL, 200 .. 900 cycles away;
-// 48 lines in flight per wave); shifts, word boundaries and the one barrier of a block are fixed at compile time.  The
-// strips lag each other by 80 steps (a multiple of the block, >= 63 + 16), so every wave's blocks are the workgroup's
-// blocks.  The strip region has staged_steps(m_max) lines: the requests two blocks past the last step stay inside it.
+// 48 lines in flight per wave); shifts and word boundaries of a block are fixed at compile time.  A strip follows the
+// one above by at least five blocks (63 + 16 steps), paced by progress words (below).  The strip region has
+// staged_steps(m_max) lines: the requests two blocks past the last step stay inside it.
 // LDS (doubles): NW + 1 hand-off rings of NB * kStagedRing | NW * 8 | NW dumps | progress words.  Decision words: as every other skewed sweep.
 // ---------------------------------------------------------------------------------------------
 constexpr int kStagedBlock = 16;         // steps per block with one or two rows per lane; 8 with three or four (registers)
@@ -1763,156 +1763,6 @@ struct StagedScore {                               // what dp_column sees: the s
     double v[R];
     CR_D double score(int q, const ExpEntry*) const { return v[q]; }
 };
-
-// The seed's Smith-Waterman with gap 0 on staged scores: the COLUMN sweep of sweep_cols_team (one step per column, the
-// `up` dependency a prefix maximum across the lanes, strips kColChunk columns apart instead of 80 steps) with the score
-// read instead of formed.  Layout of a strip: element c * 64 + lane = S(row lane, column c) (not skewed).  A chunk's 8
-// lines sit in registers, requested two chunks ahead.  LDS (doubles): NW rings of 2 * kColChunk | NW * 4.
-// Decision words: the column sweeps' layout (Walker SKEW = 0).
-template <int R>
-CR_D void sweep_cols_staged(const double* __restrict__ strip, const int n, const int m, double* lds,
-                            uint32_t* __restrict__ sw_dirs, SeedMax& seed_out, const StripGeom geom) {
-    constexpr int C = kColChunk;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int NW = (int)(blockDim.x >> 6);
-    double* ring_out = lds + w * (2 * C);
-    const double* ring_in = lds + (w > 0 ? w - 1 : 0) * (2 * C);
-    double* red = lds + NW * (2 * C);
-    const int nstrips = geom.nstrips;                    // <= NW, guaranteed by the launcher
-    const int TB = (m + 15) >> 4;
-    const bool mine = w < nstrips;
-    const int rowbase = geom.rowbase0 + lane * R;
-    const bool hand_out = w + 1 < nstrips;
-    const int chunks = (m + C - 1) / C;
-    const int phases = chunks + nstrips - 1;
-    double hprev[R], eprev = 0.0;
-    int rowfirst[R];
-    uint32_t bits[R];
-#pragma unroll
-    for (int q = 0; q < R; q++) {
-        hprev[q] = 0.0;
-        rowfirst[q] = 0;
-        bits[q] = 0;
-    }
-    const double* __restrict__ line = strip + lane;      // line c: R sub-lines of 64 doubles (row slot q, lane)
-    constexpr bool FAR = R <= 2;                          // score lines two chunks ahead (R >= 3: one, the registers are taken)
-    double cur[C][R], nxt[C][R], nx2[FAR ? C : 1][R];
-    if (mine) {
-#pragma unroll
-        for (int k = 0; k < C; k++)
-#pragma unroll
-            for (int q = 0; q < R; q++) {
-                nxt[k][q] = line[(k * R + q) * kWave];
-                if constexpr (FAR) nx2[k][q] = line[((C + k) * R + q) * kWave];
-            }
-    }
-    auto run = [&](auto top_tag) {
-        constexpr bool TOP = decltype(top_tag)::value;
-#pragma unroll 1
-        for (int g = 0; g < phases; g++) {
-            lds_barrier();                                 // the chunk written in phase g - 1 is visible to the strip below
-            const int c = g - w;
-            if (!mine || c < 0 || c >= chunks) continue;
-            const double* __restrict__ ahead = line + (int64_t)(c + (FAR ? 2 : 1)) * (C * R * kWave);
-#pragma unroll
-            for (int k = 0; k < C; k++)
-#pragma unroll
-                for (int q = 0; q < R; q++) {
-                    cur[k][q] = nxt[k][q];
-                    if constexpr (FAR) {
-                        nxt[k][q] = nx2[k][q];
-                        nx2[k][q] = ahead[(k * R + q) * kWave];
-                    } else {
-                        nxt[k][q] = ahead[(k * R + q) * kWave];
-                    }
-                }
-            double top_vec = 0.0;                          // the row above the strip for this chunk: lane x = column j0 + x
-            if (TOP && lane < C) top_vec = ring_in[(c & 1) * C + lane];
-            const int j0 = c * C;
-            auto columns = [&](auto all_tag) {
-                constexpr bool ALL = decltype(all_tag)::value;
-                static_for<0, C>([&](auto k_tag) {
-                    constexpr int k = decltype(k_tag)::value;
-                    const int j = j0 + k;
-                    if (ALL || j < m) {
-                        // dynamic_time_warping.py:226-247 with gap 0, as ColSweep::step
-                        double dg[R], p[R];
-#pragma unroll
-                        for (int q = 0; q < R; q++) {
-                            dg[q] = (q == 0 ? eprev : hprev[q - 1]) + cur[k][q];
-                            const double b = vmax(dg[q], hprev[q]);
-                            p[q] = q == 0 ? b : vmax(p[q - 1], b);
-                        }
-                        double e = wave_shr1(wave_scan_max(p[R - 1]), 0.0);
-                        if constexpr (TOP) e = vmax(e, lane_value(top_vec, k));
-#pragma unroll
-                        for (int q = 0; q < R; q++) {
-                            const double h = vmax(p[q], e);
-                            const bool same = h == hprev[q];
-                            uint32_t code = (h == dg[q]) ? 1u : same ? 2u : 3u;
-                            code = (h > 0.0) ? code : 0u;
-                            bits[q] |= code << ((j & 15) * 2);
-                            rowfirst[q] = same ? rowfirst[q] : j;
-                            hprev[q] = h;
-                        }
-                        eprev = e;
-                        if (hand_out && lane == kWave - 1) ring_out[(c & 1) * C + k] = hprev[R - 1];
-                    }
-                });
-            };
-            if (j0 + C <= m) columns(std::true_type{});
-            else columns(std::false_type{});
-            const int jend = j0 + C < m ? j0 + C : m;
-            if (((jend - 1) & 15) == 15 || jend == m) {    // a decision word holds 16 columns
-                const int64_t base = ((int64_t)geom.slot0 * TB + (int64_t)((jend - 1) >> 4) * R) * kWave + lane;
-#pragma unroll
-                for (int q = 0; q < R; q++) {
-                    sw_dirs[base + q * kWave] = bits[q];
-                    bits[q] = 0;
-                }
-            }
-        }
-    };
-    if (w == 0) run(std::false_type{});
-    else run(std::true_type{});
-
-    double best_v = 0.0;
-    int best_i = 0x7fffffff, best_j = 0x7fffffff;
-    if (mine) {                                            // a row's maximum is its last value (non-decreasing rows)
-#pragma unroll
-        for (int q = 0; q < R; q++) {
-            const bool gt = hprev[q] > best_v;
-            best_v = gt ? hprev[q] : best_v;
-            best_i = gt ? rowbase + q : best_i;
-            best_j = gt ? rowfirst[q] : best_j;
-        }
-    }
-    wave_first_max(best_v, best_i, best_j);
-    if (lane == 0) {
-        red[w * 4 + 0] = best_v;
-        red[w * 4 + 1] = (double)best_i;
-        red[w * 4 + 2] = (double)best_j;
-    }
-    __threadfence();                                   // decision words of every wave visible to wave 0's walk
-    __syncthreads();
-    best_v = 0.0;
-    best_i = best_j = 0x7fffffff;
-    for (int x = 0; x < nstrips; x++) {
-        const double ov = red[x * 4 + 0];
-        const int oi = (int)red[x * 4 + 1], oj = (int)red[x * 4 + 2];
-        const bool take = ov > best_v || (ov == best_v && (oi < best_i || (oi == best_i && oj < best_j)));
-        best_v = take ? ov : best_v;
-        best_i = take ? oi : best_i;
-        best_j = take ? oj : best_j;
-    }
-    seed_out.score = best_v;
-    seed_out.i = best_v > 0.0 ? best_i + 1 : 0;
-    seed_out.j = best_v > 0.0 ? best_j + 1 : 0;
-    __syncthreads();
-}
-
-__host__ __device__ inline size_t sweep_cols_staged_lds_doubles(int waves) { return (size_t)waves * (2 * kColChunk + 4); }
 
 // doubles per wave that take the hand-off writes of lanes 0 .. 62: dump[lane + plane * 64 + step], up to three planes
 constexpr int kStagedRing = 128;          // steps a plane of a hand-off ring of the staged sweeps holds

@@ -1,6 +1,6 @@
 // Launches with few workgroups -- a level of the progressive alignment, a short pair list, a single explicit score matrix:
 // the scores are formed (or gathered) by their own launch on every CU of the chip and the sweeps that hold the recurrence
-// read them back (cr::sweep_staged, cr::sweep_cols_staged in cr_kernels.h).  DESIGN.md section 4.1d.
+// read them back (cr::sweep_staged in cr_kernels.h).  DESIGN.md section 4.1d.
 //
 // Why: one tree level is 1 .. P/2 nodes, every node one workgroup, and its levels come one after the other
 // (multiple_alignment.py:193-234 needs both children).  In the fused kernels the 4 .. 8 waves of a node form the scores AND
@@ -29,19 +29,19 @@ struct StagedShape {       // the same for every pair of a launch (sized for the
     CR_HD int64_t pair_doubles() const { return (int64_t)waves * strip_doubles(); }
 };
 
-// One workgroup = the steps [t0, t0 + tc) of every strip of one pair (wave w = strip w = rows 64 R w ..; lane l: R rows).  SKEW: the layout of
+// One workgroup = the steps [t0, t0 + tc) of every strip of one pair (wave w = strip w = rows 64 R w ..; lane l: R rows) in the layout of
 // sweep_staged -- line t holds column t - lane, the workgroup needs the columns [t0 - 63, t0 + tc), which go through LDS
-// once for all strips; otherwise the layout of sweep_cols_staged -- line t holds column t for every lane.
-template <bool SKEW, int R, class Src>
+// once for all strips.
+template <int R, class Src>
 CR_D void stage_block(Src& src, const int n, const int m, const int tc, double* __restrict__ pair_base,
                       const StagedShape shape, double* lds) {
-    constexpr int kBack = SKEW ? kWave - 1 : 0;
+    constexpr int kBack = kWave - 1;
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int t0 = (int)blockIdx.x * tc;
-    // SKEW: the lines of every block of 16 steps a strip runs through, with EXACT ZEROS where a lane's column is outside
+    // the lines of every block of 16 steps a strip runs through, with EXACT ZEROS where a lane's column is outside
     // [0, m) -- sweep_staged runs its ramps without masks on them (cr_kernels.h)
-    const int t_end = SKEW ? (m + kBack + kStagedBlock - 1) / kStagedBlock * kStagedBlock : m;
+    const int t_end = (m + kBack + kStagedBlock - 1) / kStagedBlock * kStagedBlock;
     if (t0 >= t_end) return;                               // (whole workgroup) past the last step of this pair
     const int c_lo = t0 - kBack > 0 ? t0 - kBack : 0;
     const int c_hi = t0 + tc < m ? t0 + tc : m;
@@ -57,12 +57,12 @@ CR_D void stage_block(Src& src, const int n, const int m, const int tc, double* 
     double* __restrict__ out = pair_base + (int64_t)w * shape.strip_doubles() + lane;
     const int t1 = t0 + tc < t_end ? t0 + tc : t_end;
     for (int t = t0; t < t1; t++) {
-        const int c = SKEW ? t - lane : t;
+        const int c = t - lane;
         if ((unsigned)c < (unsigned)m) {
             src.fetch_resident(res, stride, c - c_lo);
 #pragma unroll
             for (int q = 0; q < R; q++) out[((int64_t)t * R + q) * kWave] = src.score(q, tab);
-        } else if (SKEW) {
+        } else {
 #pragma unroll
             for (int q = 0; q < R; q++) out[((int64_t)t * R + q) * kWave] = 0.0;
         }
@@ -74,7 +74,7 @@ __host__ __device__ inline size_t stage_lds_doubles(int col_doubles, int tc) {
 }
 
 // tensor RBF of a pair's two structures / a node's two children (multiple_alignment.py:328-335)
-template <int D, bool SKEW, int R>
+template <int D, int R>
 __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_stage_tensor(const PairDesc* __restrict__ pairs,
                                                                       const double* __restrict__ tensors, int d,
                                                                       double gamma, int tc, double* __restrict__ staged,
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_stage_tensor(const P
     src.cols_g = tensors + pd.off_j * d;
     src.d = d;
     src.neg_gamma = -gamma;
-    stage_block<SKEW, R>(src, pd.n, pd.m, tc, staged + (int64_t)blockIdx.y * shape.pair_doubles(), shape, lds);
+    stage_block<R>(src, pd.n, pd.m, tc, staged + (int64_t)blockIdx.y * shape.pair_doubles(), shape, lds);
 }
 
 // node score of the progressive alignment (multiple_alignment.py:204-210) in the frame of the node's seed superposition
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_stage_node(const Pai
     src.mult1 = nd.mult1;
     src.mult2 = nd.mult2;
     src.neg_gamma_w = -gamma_weight;
-    stage_block<true, R>(src, pd.n, pd.m, tc, staged + (int64_t)blockIdx.y * shape.pair_doubles(), shape, lds);
+    stage_block<R>(src, pd.n, pd.m, tc, staged + (int64_t)blockIdx.y * shape.pair_doubles(), shape, lds);
 }
 
 // node score of the progressive alignment with flexible=True (multiple_alignment.py:323-326 + :207-210): tensor RBF + weight RBF
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_stage_flex(const Pai
     src.mult1 = nd.mult1;
     src.mult2 = nd.mult2;
     src.neg_gamma_w = -gamma_weight;
-    stage_block<true, R>(src, pd.n, pd.m, tc, staged + (int64_t)blockIdx.y * shape.pair_doubles(), shape, lds);
+    stage_block<R>(src, pd.n, pd.m, tc, staged + (int64_t)blockIdx.y * shape.pair_doubles(), shape, lds);
 }
 
 // coordinate RBF of a pair in the frame of its seed superposition (multiple_alignment.py:158-170, Protein.score_function)
@@ -152,10 +152,10 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_stage_coords(const P
     src.cols_g = coords + pd.off_j * 3;
     src.xf = xfs + blockIdx.y;
     src.neg_gamma = -gamma;
-    stage_block<true, R>(src, pd.n, pd.m, tc, staged + (int64_t)blockIdx.y * shape.pair_doubles(), shape, lds);
+    stage_block<R>(src, pd.n, pd.m, tc, staged + (int64_t)blockIdx.y * shape.pair_doubles(), shape, lds);
 }
 
-// Seed stage on staged scores: SW fill with one wave per strip (gap 0 with two rows per lane: the column sweep on the unskewed layout), then
+// Seed stage on staged scores: SW fill with one wave per strip, then
 // traceback (wave 0) + seed Kabsch (the ordered sums by the whole workgroup), as the first half of k_pair_wide.
 template <bool ZG, int R>
 __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_seed_staged(const PairDesc* __restrict__ pairs,
@@ -174,11 +174,10 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_seed_staged(const Pa
         const double* strip = staged + (int64_t)blockIdx.x * shape.pair_doubles() + (int64_t)w * shape.strip_doubles();
         const StripGeom geom = WidePlan<R>{0}.geom(w, pd.n);
         SweepParams prm{sw_gap, 0.0, 0.0};
-        // One row per lane: the skewed sweep, whose ramps run without masks since round 5 (340 x 330: 161 k cycles against the
-        // column sweep's 196 k, tools/step_probe.hip); two: the column sweep (three and four rows per lane: its chunks of
-        // score lines do not fit the registers beside its state)
-        if constexpr (ZG && R == 2) sweep_cols_staged<R>(strip, pd.n, pd.m, lds, dirs + pd.dirs_off, sm, geom);
-        else sweep_staged<R, kSwTrace | (ZG ? kZeroGap : 0)>(strip, pd.n, pd.m, prm, lds, dirs + pd.dirs_off, nullptr, sm, unused, geom);
+        // (until round 5 the gap-0 seed of one or two rows per lane was a column sweep on an unskewed layout; the skewed sweep
+        // without masks in its ramps and paced by progress words is faster at every size: 340 x 330 161 k -> 149 k cycles against
+        // 196 k, 1 024 x 700 at two rows per lane 456 k against 597 k, tools/step_probe.hip)
+        sweep_staged<R, kSwTrace | (ZG ? kZeroGap : 0)>(strip, pd.n, pd.m, prm, lds, dirs + pd.dirs_off, nullptr, sm, unused, geom);
     }
     // wave 0 walks (the others wait at the barrier); the position-ordered sums behind the walk are taken by everybody
     __shared__ int s_walk[4];
@@ -188,7 +187,7 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_seed_staged(const Pa
         CR_STAMP(1);
         int k, len;
         uint32_t fl;
-        seed_walk<R, (ZG && R == 2) ? 0 : 1>(pd, dirs, sm, seed_list, 0, k, len, fl);
+        seed_walk<R, 1>(pd, dirs, sm, seed_list, 0, k, len, fl);
         if (threadIdx.x == 0) {
             s_walk[0] = k;
             s_walk[1] = len;
@@ -500,8 +499,7 @@ inline cr::StagedShape staged_shape(int n_bound, int m_bound) {
 
 template <int D>
 int launch_stage_tensor_d(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, double* staged, const cr::StagedShape shape) {
-    const bool skew = prm.sw_gap != 0.0 || shape.r != 2;   // gap 0, two rows per lane: the seed is a column sweep (k_seed_staged)
-    const int steps = ck.m_max + (skew ? cr::kWave - 1 : 0), tc = stage_steps(ck.count, steps);
+    const int steps = ck.m_max + cr::kWave - 1, tc = stage_steps(ck.count, steps);
     const size_t lds = sizeof(double) * cr::stage_lds_doubles(D, tc);
     const unsigned chunks = (unsigned)((steps + tc - 1) / tc);
     auto go = [&](auto kernel) -> int {
@@ -512,7 +510,7 @@ int launch_stage_tensor_d(cr_batch* b, const cr_batch::Chunk& ck, const cr_param
     };
     return by_rows(shape.r, [&](auto rt) {
         constexpr int R = decltype(rt)::value;
-        return skew ? go(cr::k_stage_tensor<D, true, R>) : go(cr::k_stage_tensor<D, false, R>);
+        return go(cr::k_stage_tensor<D, R>);
     });
 }
 
@@ -530,7 +528,7 @@ int launch_stage_tensor(cr_batch* b, const cr_batch::Chunk& ck, const cr_params&
 
 int launch_seed_staged(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, const double* staged, const cr::StagedShape shape) {
     const int entries = std::min(ck.n_max, ck.m_max);
-    const size_t fill = std::max(cr::sweep_cols_staged_lds_doubles(shape.waves), cr::sweep_staged_lds_doubles<cr::kSwTrace>(shape.waves));
+    const size_t fill = cr::sweep_staged_lds_doubles<cr::kSwTrace>(shape.waves);
     const size_t lds = sizeof(double) * std::max(fill, (size_t)cr::kExpDoubles + cr::trace_team_lds_doubles(entries));
     auto go = [&](auto kernel) -> int {
         int rc = allow_lds(kernel, lds);

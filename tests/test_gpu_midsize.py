@@ -273,6 +273,32 @@ def test_row_limits_of_the_staged_sweeps(ctx, oracle, rows):
     assert_bit_identical(res, aln, *oracle.pairwise_batch(coords, tensors, offsets, pairs, nthreads=3))
 
 
+@pytest.mark.parametrize("go,ge,gap", [(1.0, 0.01, 0.0), (0.0, 0.0, 0.0), (0.0, 0.5, 0.0), (3.0, 0.0, 0.1), (-0.5, 0.01, 0.0), (1.0, -0.01, 0.0)])
+def test_staged_sweeps_ramps_without_masks(ctx, oracle, go, ge, gap):
+    """The sweeps on staged scores run the ramps of their strips without EXEC masks (cr_kernels.h, sweep_staged): staged zeros
+    outside [0, m), a fixed point before a lane's column 0 that needs non-negative penalties, the last block of every strip
+    masked.  Short lists (the staged family) whose ramps are most of the sweep: fewer columns than a wave has lanes, one to six
+    strips, single rows; penalties of 0 (the fixed point with equal candidates), a Smith-Waterman gap (the seed keeps its
+    masks) and NEGATIVE penalties (every mask back) -- all against the oracle."""
+    from caretta_amd import engine
+    from oracle.pyoracle import default_params
+    fam = synthetic.make_family(9, 330, seed=9301, clades=2)
+    cuts = [330, 5, 40, 64, 65, 1, 129, 200, 321]
+    for s, cut in zip(fam, cuts):
+        s.coordinates, s.tensors = s.coordinates[:cut].copy(), s.tensors[:cut].copy()
+    coords, tensors, offsets = synthetic.pack(fam)
+    fwd = engine.all_pairs(9)
+    pairs = np.vstack([fwd, fwd[:, ::-1]])
+    batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
+    assert all(x[0] == "staged" for x in batch.part_layouts()) or layout_of(batch)[0] == "staged", (layout_of(batch), batch.part_layouts())
+    prm = dict(gap_open=go, gap_extend=ge, sw_gap=gap)
+    batch.run(engine.make_params(**prm))
+    res, aln = batch.fetch()
+    batch.close()
+    ref, ref_aln = oracle.pairwise_batch(coords, tensors, offsets, pairs, params=default_params(**prm), nthreads=8)
+    assert_bit_identical(res, aln, ref, ref_aln)
+
+
 @pytest.mark.parametrize("dim", [16, 17])
 def test_tensor_width_limit_of_the_one_workgroup_layouts(ctx, oracle, dim):
     """Widths up to 16 have wide / mid-size instances, 17 and more run one wave per pair (or four-wave teams)."""

@@ -1,4 +1,4 @@
-// What a step of the staged sweeps (cr::sweep_staged / cr::sweep_cols_staged, one row per lane: the fills of a level of
+// What a step of the staged sweeps (cr::sweep_staged, one row per lane: the fills of a level of
 // the progressive alignment) costs, and what it would cost without its decision packing / its hand-off writes: ONE
 // workgroup of eight waves on an otherwise idle chip, n rows (1 .. 8 strips) x m columns, scores from an L2-resident
 // buffer, shader clock (s_memtime) around the sweep.
@@ -32,11 +32,9 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_probe(const double* 
     if constexpr (MODE == 0) {
         SweepParams prm{0.0, 1.0, 0.01};
         sweep_staged<R, kDtw>(staged + (int64_t)w * strip_doubles, n, m, prm, lds, nullptr, words, sm, e, geom);
-    } else if constexpr (MODE == 1) {
+    } else {
         SweepParams prm{0.0, 0.0, 0.0};
         sweep_staged<R, kSwTrace | kZeroGap>(staged + (int64_t)w * strip_doubles, n, m, prm, lds, words, nullptr, sm, e, geom);
-    } else {
-        sweep_cols_staged<R>(staged + (int64_t)w * strip_doubles, n, m, lds, words, sm, geom);
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
     if (threadIdx.x == 0) {
@@ -57,12 +55,13 @@ static void run(const char* name, int n, int m) {
         x ^= x << 17;
         v = (double)(x >> 11) * (1.0 / 9007199254740992.0);
     }
-    if (MODE != 2)           // skewed layout: line t, row slot q, lane l = S(row, column t - l); exact zeros outside [0, m), as stage_block writes them
-        for (int w = 0; w < waves; w++)
+    // skewed layout: line t, row slot q, lane l = S(row, column t - l); exact zeros outside [0, m), as stage_block writes them
+    for (int w = 0; w < waves; w++) {
             for (int64_t t = 0; t < strip_doubles / (kWave * R); t++)
                 for (int q = 0; q < R; q++)
                     for (int l = 0; l < kWave; l++)
                         if (t - l < 0 || t - l >= m) h[(size_t)w * strip_doubles + ((size_t)t * R + q) * kWave + l] = 0.0;
+    }
     double *d, *out;
     uint32_t* words;
     unsigned long long* cyc;
@@ -71,7 +70,7 @@ static void run(const char* name, int n, int m) {
     hipMalloc(&words, (size_t)waves * (m + 128) * kWave * 4 * R);
     hipMalloc(&cyc, 8);
     hipMalloc(&out, 8);
-    size_t lds = (MODE == 2 ? sweep_cols_staged_lds_doubles(waves) : (MODE == 0 ? sweep_staged_lds_doubles<kDtw>(waves) : sweep_staged_lds_doubles<kSwTrace>(waves))) * 8 + 4096;
+    size_t lds = (MODE == 0 ? sweep_staged_lds_doubles<kDtw>(waves) : sweep_staged_lds_doubles<kSwTrace>(waves)) * 8 + 4096;
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_probe<MODE, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     unsigned long long best = ~0ull;
     for (int rep = 0; rep < 5; rep++) {
@@ -82,7 +81,7 @@ static void run(const char* name, int n, int m) {
         if (c < best) best = c;
     }
     const int strips = (n + 64 * R - 1) / (64 * R);
-    const int steps = MODE == 2 ? (m + 7) / 8 * 8 + (strips - 1) * 8 : (R <= 2 ? 80 : 72) * (strips - 1) + (m + 63 + 15) / 16 * 16;
+    const int steps = (R <= 2 ? 80 : 72) * (strips - 1) + (m + 63 + 15) / 16 * 16;
     printf("%-22s R %d n %4d (%d strips) m %4d : %8llu cycles, %4d steps, %6.1f cycles per step\n", name, R, n, strips, m, best, steps,
            (double)best / steps);
     hipFree(d);
@@ -109,15 +108,13 @@ int main() {
         run<0, 1>("DTW skewed", n, 330);
         run<0, 2>("DTW skewed", n, 330);
         if (n > 256) run<0, 3>("DTW skewed", n, 330);
-        run<2, 1>("SW gap 0 column sweep", n, 330);
-        run<2, 2>("SW gap 0 column sweep", n, 330);
         run<1, 1>("SW gap 0 skewed", n, 330);
         run<1, 2>("SW gap 0 skewed", n, 330);
     }
     for (int n : {640, 704, 768, 900, 1024}) {
         run<0, 2>("DTW skewed", n, 700);
         run<0, 3>("DTW skewed", n, 700);
-        run<2, 2>("SW gap 0 column sweep", n, 700);
+        run<1, 2>("SW gap 0 skewed", n, 700);
         run<1, 3>("SW gap 0 skewed", n, 700);
     }
     for (int n : {1100, 1300, 1536}) {
@@ -130,10 +127,8 @@ int main() {
     const int ns[] = {64, 128, 256, 320, 340, 512};
     for (int n : ns) run<0>("DTW skewed", n, 330);
     for (int n : ns) run<1>("SW gap 0 skewed", n, 330);
-    for (int n : ns) run<2>("SW gap 0 column sweep", n, 330);
     run<0>("DTW skewed", 64, 1200);
     run<1>("SW gap 0 skewed", 64, 1200);
-    run<2>("SW gap 0 column sweep", 64, 1200);
 #endif
     return 0;
 }
