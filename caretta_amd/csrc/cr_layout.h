@@ -41,9 +41,11 @@ constexpr int64_t kClassSplitPairs = 4096;     // a ragged list of at most this 
 
 constexpr LayoutRule kLayoutTable[] = {
     // split by FUNCTION (cr_trio.h): one strip of 2 .. 5 rows per lane; its time does not depend on the pair count while the
-    // chip is not full, the one-pair-per-CU layouts and staged scores grow with it -- hence "from" 65 / 111 / 161 pairs
+    // chip is not full, the one-pair-per-CU layouts and staged scores grow with it -- hence "from" 65 / 161 / 161 pairs
+    // (193 .. 256 rows: from 111 pairs until the staged sweeps lost the masks of their ramps and their barriers, round 5:
+    // 128 pairs of 250 rows 0.258 ms on staged scores against 0.276-0.282, 160 pairs 0.280 / 0.279; profiles/r05/staged_vs_trio.txt)
     {kFamTrio, 65, 192, 65, kTrioPairLimit, kMidMaxColumns, 10, "profiles/r04/trio_few.txt, trio_sizes.txt"},
-    {kFamTrio, 193, 256, 111, kTrioPairLimit, kMidMaxColumns, 10, "profiles/r04/trio_few.txt, trio_sizes.txt"},
+    {kFamTrio, 193, 256, 161, kTrioPairLimit, kMidMaxColumns, 10, "profiles/r05/staged_vs_trio.txt"},
     {kFamTrio, 257, 320, 161, kTrioPairLimit, kMidMaxColumns, 10, "profiles/r04/trio_few.txt, c3_share.txt, c3_share_limit.txt"},
     // staged scores (cr_staged.h): at most one wave per SIMD of the chip (pairs x strips <= 1 024: checked by fits)
     {kFamStaged, 1, cr::kStagedMaxRows, 1, kStagedWaveLimit, kAnyLength, 32, "profiles/r03/calibrate_staged.txt"},

@@ -265,7 +265,7 @@ def _equal_family(rows, npairs):
 
 @pytest.mark.parametrize("npairs,rows,expect", [
     (256, 193, "trio"), (257, 257, "trio"), (257, 64, "staged"), (257, 65, "trio"), (160, 300, "staged"), (161, 300, "trio"),
-    (110, 250, "staged"), (111, 250, "trio"), (64, 150, "staged"), (65, 150, "trio"), (1300, 300, "trio"), (1301, 300, "single"),
+    (160, 250, "staged"), (161, 250, "trio"), (64, 150, "staged"), (65, 150, "trio"), (1300, 300, "trio"), (1301, 300, "single"),
     (257, 321, "duo"), (256, 321, "wide"), (1024, 360, "duo"), (1025, 360, "single"), (170, 330, "staged"), (171, 330, "wide"),
     (300, 1200, "duo"), (1024, 900, "duo"), (1025, 900, "single"), (252, 1200, "wide"), (504, 1200, "duo"), (2016, 1200, "single"),
     (8128, 300, "single"), (496, 150, "trio"), (1, 300, "staged"), (3, 2049, "single"), (3, 2048, "staged")])

@@ -124,7 +124,7 @@ def test_midsize_lists_one_strip_by_function(ctx, oracle, monkeypatch, dim, seed
 
 
 def test_few_pairs_by_function_and_again_with_a_gap(ctx, oracle):
-    """Lists the split by function takes from the one-pair-per-CU layouts (more than 160 / 110 / 64 pairs, at most 256): 182 pairs of
+    """Lists the split by function takes from the one-pair-per-CU layouts (more than 160 / 160 / 64 pairs, at most 256): 182 pairs of
     up to 300 rows run on k_pair_trio; with a Smith-Waterman gap the SAME batch object is laid out again for the layouts that
     have a skewed seed sweep (cr_batch_run), and goes on giving the oracle's results -- also back at gap 0."""
     from caretta_amd import engine
@@ -224,7 +224,7 @@ def test_size_classes_of_a_mixed_list(ctx, oracle):
 @pytest.mark.parametrize("npairs,rows,expect", [
     (256, 193, ("trio",)), (257, 193, ("trio",)), (257, 256, ("trio",)), (257, 257, ("trio",)), (256, 257, ("trio",)),
     (257, 64, ("single", "staged")), (257, 65, ("trio",)), (300, 128, ("trio",)), (300, 129, ("trio",)),
-    (160, 300, ("wide", "staged")), (161, 300, ("trio",)), (110, 250, ("wide", "staged")), (111, 250, ("trio",)), (64, 150, ("single", "staged")), (65, 150, ("trio",)),
+    (160, 300, ("wide", "staged")), (161, 300, ("trio",)), (160, 250, ("wide", "staged")), (161, 250, ("trio",)), (64, 150, ("single", "staged")), (65, 150, ("trio",)),
     (700, 320, ("trio",)), (701, 320, ("trio",)), (257, 321, ("duo",)), (256, 321, ("wide", "staged")), (1300, 300, ("trio",)), (1301, 300, ("single",)), (1024, 360, ("duo",)),
     (1025, 360, ("single",)),
     (256, 64, ("single", "staged")), (170, 330, ("staged",)), (171, 330, ("wide",)),
