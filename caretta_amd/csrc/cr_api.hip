@@ -1064,7 +1064,7 @@ static int batch_create(cr_context* ctx, const double* coords, const double* ten
     b->total = offsets[num_structures];
     b->offsets.assign(offsets, offsets + num_structures + 1);
     hipError_t e = b->coords.ensure((size_t)b->total * 3);
-    // (+ d_pad doubles of slack: the column sweep always reads a padded row of features, cr_kernels.h sweep_cols)
+    // (+ d_pad doubles of slack: the column sweep always reads a padded row of features, cr_sweep_cols.h sweep_cols)
     if (e == hipSuccess) e = b->tensors.ensure((size_t)b->total * d + (size_t)b->d_pad);
     if (e != hipSuccess) {
         delete b;

@@ -363,7 +363,7 @@ struct ExplicitStream {
 };
 
 // ---------------------------------------------------------------------------------------------
-// The time-skewed sweep over ExplicitStream, written for it (sweep() of cr_kernels.h serves every provider): the wave
+// The time-skewed sweep over ExplicitStream, written for it (sweep() of cr_sweep.h serves every provider): the wave
 // is bound by instruction issue -- one row per lane leaves ~50 instructions per cell of which 13 are the recurrence -- so
 //   * eight steps per loop body: the positions inside a decision word and the window boundaries are compile-time;
 //   * the streams' window state lives in registers (ExplicitStream::window_advance: 4 instructions per load instead of 17);

@@ -1,6 +1,6 @@
 // Launches with few workgroups -- a level of the progressive alignment, a short pair list, a single explicit score matrix:
 // the scores are formed (or gathered) by their own launch on every CU of the chip and the sweeps that hold the recurrence
-// read them back (cr::sweep_staged in cr_kernels.h).  DESIGN.md section 4.1d.
+// read them back (cr::sweep_staged in cr_sweep_wide.h).  DESIGN.md section 4.1d.
 //
 // Why: one tree level is 1 .. P/2 nodes, every node one workgroup, and its levels come one after the other
 // (multiple_alignment.py:193-234 needs both children).  In the fused kernels the 4 .. 8 waves of a node form the scores AND
@@ -40,7 +40,7 @@ CR_D void stage_block(Src& src, const int n, const int m, const int tc, double* 
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int t0 = (int)blockIdx.x * tc;
     // the lines of every block of 16 steps a strip runs through, with EXACT ZEROS where a lane's column is outside
-    // [0, m) -- sweep_staged runs its ramps without masks on them (cr_kernels.h)
+    // [0, m) -- sweep_staged runs its ramps without masks on them (cr_sweep_wide.h)
     const int t_end = (m + kBack + kStagedBlock - 1) / kStagedBlock * kStagedBlock;
     if (t0 >= t_end) return;                               // (whole workgroup) past the last step of this pair
     const int c_lo = t0 - kBack > 0 ? t0 - kBack : 0;

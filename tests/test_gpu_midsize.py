@@ -275,7 +275,7 @@ def test_row_limits_of_the_staged_sweeps(ctx, oracle, rows):
 
 @pytest.mark.parametrize("go,ge,gap", [(1.0, 0.01, 0.0), (0.0, 0.0, 0.0), (0.0, 0.5, 0.0), (3.0, 0.0, 0.1), (-0.5, 0.01, 0.0), (1.0, -0.01, 0.0)])
 def test_staged_sweeps_ramps_without_masks(ctx, oracle, go, ge, gap):
-    """The sweeps on staged scores run the ramps of their strips without EXEC masks (cr_kernels.h, sweep_staged): staged zeros
+    """The sweeps on staged scores run the ramps of their strips without EXEC masks (cr_sweep_wide.h, sweep_staged): staged zeros
     outside [0, m), a fixed point before a lane's column 0 that needs non-negative penalties, the last block of every strip
     masked.  Short lists (the staged family) whose ramps are most of the sweep: fewer columns than a wave has lanes, one to six
     strips, single rows; penalties of 0 (the fixed point with equal candidates), a Smith-Waterman gap (the seed keeps its
