@@ -415,13 +415,18 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_stage_explicit(const
     }
     double* __restrict__ out = staged + (int64_t)w * shape.strip_doubles() + lane;
     const int t0 = (int)blockIdx.x * tc;
-    const int t1 = t0 + tc < m + kWave - 1 ? t0 + tc : m + kWave - 1;
+    // (every block of 16 steps a strip runs through, zeros where a lane's column is outside [0, m): as stage_block)
+    const int t_end = (m + kWave - 1 + kStagedBlock - 1) / kStagedBlock * kStagedBlock;
+    const int t1 = t0 + tc < t_end ? t0 + tc : t_end;
     for (int t = t0; t < t1; t++) {
         const int c = t - lane;
         if ((unsigned)c < (unsigned)m) {
             const int64_t col = seq2[c];
 #pragma unroll
             for (int q = 0; q < R; q++) out[((int64_t)t * R + q) * kWave] = rowoff[q] >= 0 ? S[rowoff[q] + col] : 0.0;
+        } else {
+#pragma unroll
+            for (int q = 0; q < R; q++) out[((int64_t)t * R + q) * kWave] = 0.0;
         }
     }
 }

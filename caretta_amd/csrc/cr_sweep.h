@@ -103,16 +103,20 @@ CR_D void dp_column(const Src& src, DpState<R>& st, const SweepParams& prm, cons
                                      : vmax(vmax(vmax(0.0, dg[q]), lf), up);
             if constexpr (TRACE && !kProbeNoDecisions) {
                 // decision replayed by the traceback's equality tests (:255-277)
-                uint32_t code = (h == dg[q]) ? 1u : (h == lf) ? 2u : 3u;
+                const bool same = h == lf;
+                uint32_t code = (h == dg[q]) ? 1u : same ? 2u : 3u;
                 code = (h > 0.0) ? code : 0u;
-                bool gt = h > st.rowmax[q];
+                // (gap 0 on non-negative scores: a row never decreases, its running maximum IS its last value -- a new
+                // first maximum is a strict increase, which the decision's own comparison has already found)
+                bool gt = NOFLOOR ? !same : h > st.rowmax[q];
                 if constexpr (Src::kMaskRows) {
                     const bool rv = rowbase + q < n;
                     gt = gt & rv;
                     code = rv ? code : 0u;
                 }
                 st.swbits[q] |= code << sh2;
-                if constexpr (Src::kMaskRows) st.rowmax[q] = gt ? h : st.rowmax[q];
+                if constexpr (NOFLOOR) st.rowmax[q] = h;          // (no instruction: the value h_left takes anyway)
+                else if constexpr (Src::kMaskRows) st.rowmax[q] = gt ? h : st.rowmax[q];
                 else st.rowmax[q] = vmax(st.rowmax[q], h);       // same value as the select, one instruction
                 st.rowarg[q] = gt ? c : st.rowarg[q];
             } else {

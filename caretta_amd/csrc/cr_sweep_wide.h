@@ -577,8 +577,9 @@ CR_D void sweep_staged(const double* __restrict__ strip, const int n, const int 
     //    the DTW layers of row n - 1 (the score) and, for an SW with a gap, each row's first maximum -- hence the LAST
     //    block of every strip stays masked (the owner of row n - 1 is the last lane of its strip to finish), and the SW
     //    trace with a gap keeps its masks altogether.
-    // Explicit score matrices (RBF = false: any sign, caller's penalties) keep the masks.
-    const bool unmasked = !kProbeMaskedRamps && RBF && !(TRACE && !(MODE & kZeroGap)) && prm.sw_gap >= 0.0 && prm.gap_open >= 0.0 &&
+    // Explicit score matrices (RBF = false: scores of any sign, so a row of an SW is not monotone): the DTW and the SW
+    // score run unmasked as well (neither argument above needs the sign of a REAL score), the SW trace keeps its masks.
+    const bool unmasked = !kProbeMaskedRamps && !(TRACE && (!RBF || !(MODE & kZeroGap))) && prm.sw_gap >= 0.0 && prm.gap_open >= 0.0 &&
                           prm.gap_extend >= 0.0;
     // PACING.  The strips form a chain -- strip w needs, for its block tb, the last row of the strip above up to that
     // strip's step 16 tb + 15 + 63, i.e. its blocks up to tb + LAGB - 1 -- and used to advance together behind one
