@@ -419,7 +419,7 @@ __global__ void k_plan_level_t(const PlanNode* __restrict__ prev, int prev_count
         off[prev[x].id] = prev_desc[x].out_off + prev_out[x].first;
     }
     __threadfence_block();
-    wave_sync();
+    __syncthreads();                                   // (four waves: a level of more than 64 nodes is spread over all of them)
     for (int x = threadIdx.x; x < count; x += blockDim.x) {
         int64_t n = len[cur[x].c1], m = len[cur[x].c2];
         if (n > bound || m > bound || n < 1 || m < 1) {
@@ -440,7 +440,7 @@ __global__ void k_plan_level_t(const PlanNode* __restrict__ prev, int prev_count
         nodes[x].mult2 = cur[x].mult2;
     }
     __threadfence_block();
-    wave_sync();
+    __syncthreads();
     if (threadIdx.x == 0) {
         int64_t dirs_off = 0, bt_off = 0, aln_off = aln_base, rows = *used;
         for (int x = 0; x < count; x++) {

@@ -874,6 +874,39 @@ def test_progressive_resident_vs_oracle_and_single_node(oracle, num, length, rag
     assert np.array_equal(np.array([aln[q] for q in order]), rows[-1])
 
 
+def test_progressive_levels_of_more_than_64_nodes(oracle):
+    """A tree whose first levels hold more than 64 nodes: the one-workgroup planning kernel (k_plan_level: lengths, arena offsets and
+    decision-scratch offsets of a level from the lengths the level before produced) then spreads a level over all four of
+    its waves -- its phases are separated by workgroup barriers, not wave barriers.  360 short structures (178 cherries in
+    the first level), every join replayed by the oracle on the device's own children."""
+    from caretta_amd import multiple_alignment as ma, neighbor_joining as nj, synthetic
+    num = 360
+    fam = synthetic.make_family(num, 36, seed=4242, ragged=True, clades=8)
+    prots = [ma.Protein(s.name, s.tensors, s.coordinates, "") for s in fam]
+    msa = ma.MultipleAlignment(prots)
+    prm = dict(flexible=False, gamma_tensor=7.0, gamma_coords=0.03, verbose=False)
+    m = msa.make_pairwise_matrix(prm)
+    tree, _ = nj.neighbor_joining(m.max() - m)
+    for rep in range(3):                                   # (a race would not show every time)
+        aln = msa.progressive_align(tree, 1.0, 0.01, 1.0, 1.0, prm, dict(flexible=False, verbose=False))
+        levels = msa.node_table[:, 3]
+        assert np.bincount(levels).max() > 64, np.bincount(levels)
+        width = len(aln[prots[0].name])
+        for q in prots:
+            row = aln[q.name]
+            assert len(row) == width and np.array_equal(row[row != -1], np.arange(len(q)))
+        sizes = [1] * num
+        for k, (n1, n2) in enumerate(_replay_tree(msa, tree, num)):
+            tot = sizes[n1] + sizes[n2]
+            s1, s2 = msa.final_sequences[n1], msa.final_sequences[n2]
+            _, _, xn, tn, wn, _ = oracle.progressive_node(s1.coordinates, s1.tensors, msa.final_consensus_weights[n1], s2.coordinates, s2.tensors,
+                                                          msa.final_consensus_weights[n2], sizes[n2] / (2 * tot), sizes[n1] / (2 * tot))
+            node = msa.final_sequences[num + k]
+            assert np.array_equal(xn, node.coordinates) and np.array_equal(tn, node.tensors), f"node {k} (level {levels[k]})"
+            assert np.array_equal(wn, msa.final_consensus_weights[num + k])
+            sizes.append(tot)
+
+
 @pytest.mark.parametrize("num,length,ragged,seed", [(12, 300, False, 21), (5, 335, False, 22), (7, 200, True, 23), (9, 140, True, 24),
                                                     (5, 600, True, 25), (3, 675, False, 26), (4, 400, False, 27),
                                                     (3, 900, False, 28), (3, 1300, True, 29)])
