@@ -33,6 +33,10 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/explicit_ktrace -o kt -- python3 tools/explicit_batch_rate.py 8128 300 > $O/explicit_ktrace.log 2>&1
 python tools/pmc_explicit_summary.py $O > $O/explicit_batch_pmc.json
+# the staged sweeps of a tree level in one workgroup (binaries built by `bash tools/step_probe.sh build` before the snapshot), short lists
+# on staged scores against the split by function
+if [ -x tools/step_probe_lib.bin ]; then bash tools/step_probe.sh run > $O/step_probe_run.txt 2>&1; fi
+python tools/staged_vs_trio.py > $O/staged_vs_trio.txt 2>&1
 STAMPS_DETAIL=1 python tools/stamps.py run c3share > $O/stamps_c3share.txt 2>&1
 python tools/stamps.py run c5share tree128 > $O/stamps.txt 2>&1
 tail -n 2 $O/msa_128.txt $O/msa_512.txt $O/explicit_batch_rate.txt
