@@ -771,7 +771,10 @@ int launch_pair_duo(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm
     }
 }
 
-// ---- k_pair_trio (cr_trio.h): gap 0, pairs of at most 320 rows, tensor widths padded to at most 10 ----------------------
+// ---- k_pair_trio (cr_trio.h): gap 0, pairs of at most 320 rows, tensor widths padded to at most 16 ----------------------
+// the padded width of the score waves' registers (cr_duo_instances.h), from the STORED width
+int trio_width(int64_t d) { return d <= 4 ? 4 : d <= 8 ? 8 : d <= 10 ? 10 : d <= 12 ? 12 : d <= 16 ? 16 : 0; }
+
 template <int R, int D, bool SC>
 int launch_pair_trio_t(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm) {
     const int seed_entries = std::min(ck.n_max, ck.m_max), align_entries = ck.max_aln;
@@ -798,10 +801,12 @@ int launch_pair_trio_t(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& 
 
 template <int R>
 int launch_pair_trio_r(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, bool scores) {
-    switch (b->d_pad) {
+    switch (trio_width(b->d)) {
         case 4: return scores ? launch_pair_trio_t<R, 4, true>(b, ck, prm) : launch_pair_trio_t<R, 4, false>(b, ck, prm);
         case 8: return scores ? launch_pair_trio_t<R, 8, true>(b, ck, prm) : launch_pair_trio_t<R, 8, false>(b, ck, prm);
         case 10: return scores ? launch_pair_trio_t<R, 10, true>(b, ck, prm) : launch_pair_trio_t<R, 10, false>(b, ck, prm);
+        case 12: return scores ? launch_pair_trio_t<R, 12, true>(b, ck, prm) : launch_pair_trio_t<R, 12, false>(b, ck, prm);
+        case 16: return scores ? launch_pair_trio_t<R, 16, true>(b, ck, prm) : launch_pair_trio_t<R, 16, false>(b, ck, prm);
         default: return fail(CR_ERR_STATE, "no k_pair_trio instance for this tensor width");
     }
 }

@@ -44,9 +44,9 @@ constexpr LayoutRule kLayoutTable[] = {
     // chip is not full, the one-pair-per-CU layouts and staged scores grow with it -- hence "from" 65 / 161 / 161 pairs
     // (193 .. 256 rows: from 111 pairs until the staged sweeps lost the masks of their ramps and their barriers, round 5:
     // 128 pairs of 250 rows 0.258 ms on staged scores against 0.276-0.282, 160 pairs 0.280 / 0.279; profiles/r05/staged_vs_trio.txt)
-    {kFamTrio, 65, 192, 65, kTrioPairLimit, kMidMaxColumns, 10, "profiles/r04/trio_few.txt, trio_sizes.txt"},
-    {kFamTrio, 193, 256, 161, kTrioPairLimit, kMidMaxColumns, 10, "profiles/r05/staged_vs_trio.txt"},
-    {kFamTrio, 257, 320, 161, kTrioPairLimit, kMidMaxColumns, 10, "profiles/r04/trio_few.txt, c3_share.txt, c3_share_limit.txt"},
+    {kFamTrio, 65, 192, 65, kTrioPairLimit, kMidMaxColumns, 16, "profiles/r04/trio_few.txt, trio_sizes.txt"},
+    {kFamTrio, 193, 256, 161, kTrioPairLimit, kMidMaxColumns, 16, "profiles/r05/staged_vs_trio.txt"},
+    {kFamTrio, 257, 320, 161, kTrioPairLimit, kMidMaxColumns, 16, "profiles/r04/trio_few.txt, c3_share.txt, c3_share_limit.txt"},
     // staged scores (cr_staged.h): at most one wave per SIMD of the chip (pairs x strips <= 1 024: checked by fits)
     {kFamStaged, 1, cr::kStagedMaxRows, 1, kStagedWaveLimit, kAnyLength, 32, "profiles/r03/calibrate_staged.txt"},
     // one pair per CU, up to 16 waves, barrier every 8 steps (k_pair_wide)

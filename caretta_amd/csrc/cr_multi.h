@@ -137,6 +137,7 @@ struct cr_multi {
     std::function<void(int)> job;
     uint64_t generation = 0;
     int pending = 0;
+    int started = 0;                    // host threads that have pinned themselves and parked (cr_multi_create waits for all)
     bool stop = false;
 };
 
@@ -213,7 +214,13 @@ int pin_thread_to_device_numa(int device) {
 }
 
 void multi_worker(cr_multi* m, int g) {
-    if (g_cfg.multi_numa) m->numa_node[(size_t)g] = pin_thread_to_device_numa(m->devices[(size_t)g]);
+    {
+        // pinned BEFORE cr_multi_create returns, and recorded under the mutex: cr_multi_numa_nodes reads from the caller's thread
+        const int node = g_cfg.multi_numa ? pin_thread_to_device_numa(m->devices[(size_t)g]) : -1;
+        std::lock_guard<std::mutex> lk(m->mu);
+        m->numa_node[(size_t)g] = node;
+        if (++m->started == (int)m->devices.size()) m->cv_done.notify_all();
+    }
     uint64_t seen = 0;
     for (;;) {
         std::function<void(int)> fn;
@@ -349,8 +356,11 @@ int cr_multi_create(const int* devices, int ndev, cr_multi** out) {
         }
     }
     m->numa_node.assign((size_t)G, -1);
-    if (G > 1)
+    if (G > 1) {
         for (int g = 0; g < G; g++) m->threads.emplace_back(multi_worker, m, g);
+        std::unique_lock<std::mutex> lk(m->mu);
+        m->cv_done.wait(lk, [&] { return m->started == G; });
+    }
     *out = m;
     return CR_OK;
 }
@@ -363,6 +373,7 @@ int cr_multi_device_count(cr_multi* m, int* ndev) {
 
 int cr_multi_numa_nodes(cr_multi* m, int* nodes) {
     CR_REQUIRE(m && nodes, "null argument");
+    std::lock_guard<std::mutex> lk(m->mu);
     for (size_t g = 0; g < m->devices.size(); g++) nodes[g] = g < m->numa_node.size() ? m->numa_node[g] : -1;
     return CR_OK;
 }

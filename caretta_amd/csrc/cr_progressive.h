@@ -155,14 +155,17 @@ int run_level(cr_progressive* h, const std::vector<int64_t>& ids, const cr_param
 // (staged scores: bound <= 2048; team kernels: 192 < bound <= 1280) or a node outgrew it: the caller then runs the
 // level-by-level path.
 int run_tree_planned(cr_progressive* h, const std::vector<std::vector<int64_t>>& by_level, const cr_params& prm,
-                     double gamma_weight) {
+                     double gamma_weight, const char** why) {
     cr_batch& b = h->scratch;
     hipStream_t stream = h->ctx->stream;
     const int64_t P = h->P, total = h->used, num_nodes = P - 1;
     int64_t longest = 0;
     for (int64_t s = 0; s < P; s++) longest = std::max(longest, h->len[(size_t)s]);
     const int bound = (int)std::min<int64_t>(cr::kStagedMaxRows, (longest * 3 + 1) / 2 + 8);
-    if (longest > bound || g_cfg.no_team) return 1;
+    *why = "the longest structure exceeds the 2048 columns the resident tree is sized for";
+    if (longest > bound) return 1;
+    *why = "CARETTA_NO_TEAM is set";
+    if (g_cfg.no_team) return 1;
     int64_t widest_level = 0;
     for (int64_t lv = 1; lv <= h->levels; lv++) widest_level = std::max<int64_t>(widest_level, (int64_t)by_level[(size_t)lv].size());
     // Scores formed by their own launches (cr_staged.h) while up to four rows per lane fit the 8 waves of its workgroups
@@ -174,6 +177,8 @@ int run_tree_planned(cr_progressive* h, const std::vector<std::vector<int64_t>>&
         CR_HIP(hipMemGetInfo(&free_b, &total_b));
         staged = (double)widest_level * (double)shape.pair_doubles() * sizeof(double) <= (double)total_b / 10.0;
     }
+    *why = !g_cfg.staged ? "CARETTA_STAGED=0" : widest_level > 65535 ? "a tree level of more than 65535 nodes"
+                                                               : "the staged scores of the widest tree level exceed a tenth of the device memory";
     if (h->flexible && !staged) return 1;                    // (flexible=True runs on staged scores only)
     if (!staged && (bound <= 3 * cr::kWave || bound > 5 * cr::kTeamWaves * cr::kWave)) return 1;     // (the four-wave team kernels: 193 .. 1280 rows)
     const int R = staged ? shape.r : (bound + cr::kTeamWaves * cr::kWave - 1) / (cr::kTeamWaves * cr::kWave);
@@ -314,6 +319,7 @@ int run_tree_planned(cr_progressive* h, const std::vector<std::vector<int64_t>>&
         std::memcpy(&overflow, land + a_tail + (o_over - o_len), sizeof(int32_t));
         if (b_rows) std::memcpy(rows_host.data(), land + a_rows, b_rows);
     }
+    *why = "a tree node outgrew the launch bound (1.5 x the longest structure, at most 2048 columns)";
     if (overflow) return 1;
     h->len = len;
     h->off = off;
@@ -373,7 +379,8 @@ static int progressive_align_impl(cr_context* ctx, const double* coords, const d
         CR_REQUIRE(offsets[s + 1] > offsets[s] && offsets[s + 1] - offsets[s] <= cr::kMaxLength,
                    "every structure needs 1 .. 65534 residues");
     const cr_params prm = *params;
-    CR_REQUIRE(gamma_ok(prm.gamma_tensor) && gamma_ok(prm.gamma_coords) && std::isfinite(prm.gap_open) && std::isfinite(prm.gap_extend) &&
+    // (flexible=True never forms a coordinate score: multiple_alignment.py:323-326 returns the tensor matrix alone)
+    CR_REQUIRE(gamma_ok(prm.gamma_tensor) && (flexible || gamma_ok(prm.gamma_coords)) && std::isfinite(prm.gap_open) && std::isfinite(prm.gap_extend) &&
                    std::isfinite(prm.sw_gap),
                "parameters must be finite, gamma_tensor and gamma_coords >= 1e-290 (below that every score is exactly 1.0)");
     CR_REQUIRE(std::isfinite(gamma_weight) && gamma_weight >= 0.0 && std::isfinite(consensus_weight),
@@ -455,11 +462,11 @@ static int progressive_align_impl(cr_context* ctx, const double* coords, const d
     }
     std::vector<std::vector<int64_t>> by_level((size_t)h->levels + 1);
     for (int64_t id = P; id < num_ids; id++) by_level[(size_t)h->level[(size_t)id]].push_back(id);
-    rc = g_cfg.sync_levels ? 1 : run_tree_planned(h, by_level, prm, gamma_weight);
+    const char* why = "CARETTA_SYNC_LEVELS is set";
+    rc = g_cfg.sync_levels ? 1 : run_tree_planned(h, by_level, prm, gamma_weight, &why);
     if (rc < 0) return rc;
-    if (rc == 1 && flexible)
-        return fail(CR_ERR_STATE, "flexible progressive alignment: a tree node outgrew what the device path is sized for (1.5 x the "
-                                  "longest structure, at most 2048 columns)");       // (the host module then walks the tree itself)
+    if (rc == 1 && flexible)                         // (CR_ERR_STATE = "not served by the device path": the host module then walks the tree itself)
+        return fail(CR_ERR_STATE, std::string("flexible progressive alignment is not served by the resident-tree path here: ") + why);
     if (rc == 1) {                                  // not applicable, or a node outgrew the bound: level by level
         h->used = total;
         h->any_flags = 0;

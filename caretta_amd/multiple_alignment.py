@@ -90,6 +90,8 @@ class Protein(SequenceBase):
         xi, ti, xj, tj = f64(self.coordinates), f64(self.tensors), f64(other.coordinates), f64(other.tensors)
         if ti.shape[1] != tj.shape[1]:
             raise ValueError("tensor widths differ")
+        if ti.shape[1] > MAX_FUSED_TENSOR_WIDTH:
+            return self._score_function_wide(xi, ti, xj, tj, other, gamma_tensor, gamma_coords, verbose)
         s = np.empty((xi.shape[0], xj.shape[0]))
         flags = C.c_uint32(0)
         check(_capi.load().cr_protein_score_function(default_context()._h, ptr(xi), ptr(ti), xi.shape[0], ptr(xj),
@@ -100,6 +102,22 @@ class Protein(SequenceBase):
         if (flags.value & _capi.FLAG_SEED_SKIPPED) and verbose:
             print(f"Too few aligning positions for {self.name} and {other.name}, continuing without superposition")
         return s
+
+    def _score_function_wide(self, xi, ti, xj, tj, other, gamma_tensor, gamma_coords, verbose):
+        """multiple_alignment.py:328-349 for tensors wider than the fused kernels are instantiated for (the reference takes any
+        (L, d) array, :312-319): the same five steps, each by the drop-in of the function the reference calls there --
+        make_score_matrix (any width) -> smith_waterman -> get_common_positions -> paired_svd_superpose_with_subset ->
+        make_score_matrix on the superposed frames.  Same values as the fused path computes for d <= 32."""
+        tensor_scores = score_functions.make_score_matrix(ti, tj, score_functions.get_gaussian_score, gamma_tensor)
+        aln_1, aln_2, _ = dtw.smith_waterman(np.arange(ti.shape[0]), np.arange(tj.shape[0]), tensor_scores)
+        pos_1, pos_2 = helper.get_common_positions(aln_1, aln_2)
+        if len(pos_1) > 3:
+            frame_1, frame_2, _ = superposition_functions.paired_svd_superpose_with_subset(xi, xj, xi[pos_1], xj[pos_2])
+        else:
+            if verbose:
+                print(f"Too few aligning positions for {self.name} and {other.name}, continuing without superposition")
+            frame_1, frame_2 = xi, xj
+        return score_functions.make_score_matrix(frame_1, frame_2, score_functions.get_gaussian_score, gamma_coords)
 
     def mean_function(self, other: "Protein", aln_1: np.ndarray, aln_2: np.ndarray, name_int: str, flexible=False,
                       verbose=True) -> "Protein":
@@ -216,6 +234,11 @@ class _NodeAttribute:
         obj.__dict__[self.slot] = value
 
 
+# Tensor widths the fused pipeline kernels are instantiated for (csrc/cr_api.hip padded_width).  The reference takes any (L, d)
+# array (multiple_alignment.py:312-319): wider tensors run the same steps through the per-function drop-ins (the plugin route of
+# make_pairwise_matrix / the host walk of progressive_align with Protein._score_function_wide), never an error.
+MAX_FUSED_TENSOR_WIDTH = 32
+
 _PLUGIN_BATCH_BYTES = 1 << 30      # score matrices of plugin sequences gathered on the host per batched launch
 
 
@@ -271,6 +294,11 @@ class MultipleAlignment:
     # -- batched GPU path ---------------------------------------------------------------------
     def _all_proteins(self, need_coordinates: bool = True) -> bool:
         return all(type(s) is Protein and (s.coordinates is not None or not need_coordinates) for s in self.sequences)
+
+    def _fused_width(self) -> bool:
+        """One tensor width for all sequences, and one the fused kernels are instantiated for."""
+        widths = {np.shape(s.tensors)[1] for s in self.sequences}
+        return len(widths) == 1 and next(iter(widths)) <= MAX_FUSED_TENSOR_WIDTH
 
     def pairwise(self, score_function_params=None, gap_open_penalty=1.0, gap_extend_penalty=0.01, pairs=None,
                  want_alignments=True, context: typing.Optional[Context] = None,
@@ -338,7 +366,7 @@ class MultipleAlignment:
         num = len(self.sequences)
         if num < 2:
             return np.zeros((num, num))
-        if self._all_proteins() and not score_function_params.get("flexible", False):
+        if self._all_proteins() and self._fused_width() and not score_function_params.get("flexible", False):
             from . import engine
             npairs = num * (num - 1) // 2
             if npairs >= engine.MULTI_DEVICE_MIN_PAIRS:
@@ -356,8 +384,7 @@ class MultipleAlignment:
             out = self.pairwise(score_function_params, want_alignments=False, scores_only=True)
             return assemble_matrix(out.pairs, out.results["sw"], num)
         if (score_function_params.get("flexible", False) and self._all_proteins(need_coordinates=False)
-                and len({np.shape(s.tensors)[1] for s in self.sequences}) == 1
-                and np.shape(self.sequences[0].tensors)[1] <= 32):      # (wider tensors: the plugin route below, as before)
+                and self._fused_width()):      # (wider tensors: the plugin route below)
             # flexible=True: smith_waterman_score of the tensor score matrix of every pair (multiple_alignment.py:323-326,
             # :164), one launch over the pair list (cr_batch_run_tensor_scores)
             out = self.pairwise(score_function_params, want_alignments=False, scores_only=True)
@@ -397,13 +424,12 @@ class MultipleAlignment:
         flex_score, flex_mean = bool(score_function_params.get("flexible", False)), bool(mean_function_params.get("flexible", False))
         if (len(self.sequences) >= 2 and tree.shape == (2 * len(self.sequences) - 3, 2)
                 and all(type(s) is Protein and s.coordinates is not None for s in self.sequences)
-                and not flex_score and not flex_mean):
+                and self._fused_width() and not flex_score and not flex_mean):
             # every node of the tree on the device, one launch pair per tree level (cr_progressive_align)
             return self._progressive_align_resident(tree, gap_open_penalty, gap_extend_penalty, consensus_weight,
                                                     gamma_weight, score_function_params, mean_function_params)
         if (len(self.sequences) >= 2 and tree.shape == (2 * len(self.sequences) - 3, 2) and flex_score and flex_mean
-                and self._all_proteins(need_coordinates=False) and len({np.shape(s.tensors)[1] for s in self.sequences}) == 1
-                and np.shape(self.sequences[0].tensors)[1] <= 32):
+                and self._all_proteins(need_coordinates=False) and self._fused_width()):
             # flexible=True in score AND mean function (multiple_alignment.py:323-326, :351-362): nodes are tensors and consensus
             # weights only -- the same resident tree without the seed stage (cr_progressive_align_flexible).  A node that outgrows
             # the launch bound sends the tree to the host walk below.
@@ -422,7 +448,7 @@ class MultipleAlignment:
             size_1, size_2 = len(walk.members[s1.name]), len(walk.members[s2.name])
             mult_1, mult_2 = size_2 / (2 * (size_1 + size_2)), size_1 / (2 * (size_1 + size_2))       # :199-202
             if (fusable and type(s1) is Protein and type(s2) is Protein and s1.coordinates is not None
-                    and s2.coordinates is not None):
+                    and s2.coordinates is not None and np.shape(s1.tensors)[1] <= MAX_FUSED_TENSOR_WIDTH):
                 # the whole node (score matrices, dtw_align, mean_function, get_mean_weights) in two launches
                 return _progressive_node(s1, s2, w1, w2, mult_1, mult_2, name_int, gap_open_penalty, gap_extend_penalty,
                                          gamma_weight, score_function_params, mean_function_params)
@@ -560,7 +586,8 @@ class MultipleAlignment:
         """multiple_alignment.py:255-285"""
         mean_function_params = mean_function_params or {}
         score_function_params = score_function_params or {}
-        if len(self.sequences) == 2 and self._all_proteins() and not score_function_params.get("flexible", False):
+        if (len(self.sequences) == 2 and self._all_proteins() and self._fused_width()
+                and not score_function_params.get("flexible", False)):
             # :263-275 is pipeline H of this one pair: both score matrices, the seed and dtw_align in two launches
             out = self.pairwise(score_function_params, gap_open_penalty, gap_extend_penalty)
             if score_function_params.get("verbose", True) and out.results["flags"][0] & _capi.FLAG_SEED_SKIPPED:

@@ -159,8 +159,9 @@ enum { CR_LAYOUT_SINGLE = 0, CR_LAYOUT_TEAM = 1, CR_LAYOUT_WIDE = 2, CR_LAYOUT_S
 int cr_batch_layout(cr_batch *b, int *family, int *rows_a, int *rows_b, int *strips_a);
 int cr_batch_part_layout(cr_batch *b, int part, int *family, int *rows_a, int *rows_b, int *strips_a, int64_t *npairs);
 /* The calibration switches (CARETTA_* environment variables: caretta_amd/csrc/cr_config.h) are read ONCE, when the library is
- * loaded; a measurement tool that changes its environment afterwards calls this to have the change seen.  No reference
- * counterpart (the reference has no tuning knobs on this path). */
+ * loaded; a measurement tool that changes its environment afterwards calls this to have the change seen.  NOT thread-safe:
+ * call it only while no other library call is in flight on any thread (the struct it replaces is read without a lock by
+ * every call, cr_multi's host threads included).  No reference counterpart (the reference has no tuning knobs on this path). */
 int cr_config_reload(void);
 /* What cr_batch_set_pairs would decide for this pair list, WITHOUT a device or a context (host only): whether the list is split
  * into size classes and the kernel family of every part.  offsets i64[P + 1]; parts i32[3][5] = (family CR_LAYOUT_*, rows per

@@ -1275,6 +1275,39 @@ def test_rccl_all_gather_single_rank():
     assert "rccl single-rank matrix ok" in out.stdout
 
 
+def test_bench_line_of_an_n_rank_run_proves_itself():
+    """Every branch an N-rank `bench.py` line runs, on the one-GPU box: ONE rank under torch.distributed.run with
+    CARETTA_FORCE_DIST=1 (process group over RCCL, all-gather, barrier, max-reduce).  The line must carry, for BASELINE configs
+    3, 4 and 5, `multi_gpu_gate` (gathered score vector = the one-GPU vector bit for bit, identical neighbor-joining trees),
+    the oracle's `pair_gate_own_share`, the all-gather's own time, the rank -> device records with the RCCL version, `value` =
+    the FIXED 128 x 300 pair set (scaling "strong"), no failed gate, exit code 0 -- and `shares` as its LAST key."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, CARETTA_FORCE_DIST="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", str(root / "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--repeats", "2"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(root))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert list(rec)[-1] == "shares" and rec["gates_failed"] == []
+    assert rec["scaling"] == "strong" and rec["config"]["pairs"] == 8128 and rec["config"]["structures"] == 128 and rec["value_weak"] == rec["value"]
+    assert rec["ranks"]["ranks"][0]["rank"] == 0 and rec["ranks"]["ranks"][0]["pci_bus_id"] and rec["ranks"]["collective"]["backend"] == "nccl"
+    assert rec["ranks"]["collective"]["rccl_version"]
+    for key, taxa in (("c3", 128), ("c4", 512), ("c5", 64)):
+        sh = rec[f"{key}_sharded"]
+        gate = sh["multi_gpu_gate"]
+        assert gate["matrix_equal"] is True and gate["trees_identical"] is True and gate["nan_scores"] == 0 and gate["tree_rows"] == 2 * taxa - 3
+        assert sh["pair_gate_own_share"]["mismatches"] == 0 and sh["pair_gate_own_share"]["fraction"] >= 0.01
+        assert isinstance(sh["all_gather_ms"], float) and sh["all_gather_ms"] > 0
+        assert sh["nj_gate"]["trees_identical"] and sh["pair_gate"]["mismatches"] == 0            # (the N = 1 gates stay)
+        row = rec["shares"][key]
+        assert row["measured_1"][3] is True and row["measured_1"][4] is True and row["measured_1"][5] == 0 and len(row["8"]) == 2
+
+
 def test_single_process_multi_device_path_equals_the_batch(ctx):
     """cr_multi_pairwise_scores (one process, a context per listed GPU, cr_partition_pairs, one grouped RCCL all-gather)
     with the device list [0]: scores and flags equal cr_batch_run_scores bit for bit, ragged (scatter kernel) and equal

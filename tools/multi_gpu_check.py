@@ -79,6 +79,8 @@ def run_child(args, env, limit):
     rec = json.loads(lines[-1]) if lines else None
     if proc.returncode != 0:
         return rec, f"exit code {proc.returncode}; stderr tail: {err[-400:]}"
+    if rec is None:                                    # exit 0 without a record is a failure too, never an empty success
+        return None, f"no JSON line from the child; stdout tail: {out[-200:]!r}; stderr tail: {err[-400:]}"
     return rec, None
 
 

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Regenerate the measured files of profiles/<round> on the GPU box:  gpurun -- 'bash tools/refresh_profiles.sh r05'
+# Regenerate the measured files of profiles/<round> on the GPU box:  gpurun -- 'bash tools/refresh_profiles.sh r06'
 # (writes under gpurun_out/<round>/; copy what is to be judged into profiles/<round>/).  Every rocprofv3 run has the program
 # itself behind `--` (python3 <script>); counters are collected in their own passes (--kernel-trace only).
-R=${1:-r05}
+R=${1:-r06}
 set -x
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R

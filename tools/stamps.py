@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """In-kernel phase timing of the batch kernels (diagnostic build, never shipped).
 
-    python tools/stamps.py build                      hipcc -DCR_STAMPS -> caretta_amd/csrc/libcaretta_hip_stamps.so (run HERE)
+    python tools/stamps.py build                      hipcc -DCR_STAMPS -> gpurun_out/lib/libcaretta_hip_stamps.so (scratch: never part of the tree;
+                                                      `run` builds it on the GPU box when it is missing)
     python tools/stamps.py run [workload ...]         on the GPU box: medians of fill / walk / rest per kernel, in shader cycles and us
 
 The stamped library is ONE translation unit with the default instruction scheduler, so its absolute times differ a
@@ -15,10 +16,11 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
 CSRC = ROOT / "caretta_amd" / "csrc"
-LIB = CSRC / "libcaretta_hip_stamps.so"
+LIB = ROOT / "gpurun_out" / "lib" / "libcaretta_hip_stamps.so"
 
 
 def build():
+    LIB.parent.mkdir(parents=True, exist_ok=True)
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-pthread", "-DCR_STAMPS",
            "-shared", str(CSRC / "cr_api.hip"), "-o", str(LIB)]
     print(" ".join(cmd))
@@ -26,6 +28,8 @@ def build():
 
 
 def run(names):
+    if not LIB.exists():
+        build()
     os.environ["CARETTA_HIP_LIB"] = str(LIB)
     sys.path.insert(0, str(ROOT))
     import numpy as np

@@ -1,16 +1,16 @@
 #!/bin/bash
 # Calibration builds of the library with other constants of cr_trio.h:  bash tools/trio_variants.sh name "-DCR_TRIO_RING=12" [name flags ...]
-# -> caretta_amd/csrc/variants/lib_<name>.so (not part of the tree; CARETTA_HIP_LIB=<that file> selects it at run time).
+# -> gpurun_out/variants/lib_<name>.so (scratch, never part of the tree: run it ON the GPU box; CARETTA_HIP_LIB=<that file> selects it at run time).
 cd "$(dirname "$0")/.." || exit 1
 C=caretta_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -Wall -Wno-unused-variable -pthread"
-mkdir -p $C/variants
+V=gpurun_out/variants; mkdir -p $V
 build_one() {
-  name=$1; extra=$2; o=$C/obj/var_$name; mkdir -p $o
+  name=$1; extra=$2; o=$V/obj_$name; mkdir -p $o
   /opt/rocm/bin/hipcc $FLAGS $extra -c $C/cr_api.hip -o $o/cr_api.o &
   /opt/rocm/bin/hipcc $FLAGS $extra -mllvm -amdgpu-sched-strategy=iterative-ilp -c $C/cr_kernels_duo.hip -o $o/cr_kernels_duo.o &
   wait
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread $o/cr_api.o $C/obj/cr_kernels_ilp.hip.o $o/cr_kernels_duo.o -o $C/variants/lib_$name.so && echo "built $name ($extra)"
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread $o/cr_api.o $C/obj/cr_kernels_ilp.hip.o $o/cr_kernels_duo.o -o $V/lib_$name.so && echo "built $name ($extra)"
 }
 while [ $# -ge 2 ]; do
   build_one "$1" "$2" &
