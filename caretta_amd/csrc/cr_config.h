@@ -35,6 +35,11 @@ struct Calibration {
     // ---- which kernel family serves a pair list (cr_batch_set_pairs: choose_layout) ----
     bool no_team = false;            // CARETTA_NO_TEAM: no multi-wave layouts at all
     bool no_wide = false;            // CARETTA_NO_WIDE
+    bool sw_rows_nowalk = false;     // CARETTA_SW_ROWS_NOWALK: measurement only -- the fill of k_sw_trace_rows without its walk (results are then wrong)
+    int sw_rows_waves = 0;           // CARETTA_SW_ROWS_WAVES=3|5: measurement only -- k_sw_trace_rows<5> built for that many waves per SIMD
+    bool no_walk_service = false;    // CARETTA_NO_WALK_SERVICE: the walks of explicit-matrix lists in their fill's wave (as before round 6)
+    bool force_walk_service = false; // CARETTA_FORCE_WALK_SERVICE: ... beside the fill also for short lists (tests)
+    bool no_sw_rows = false;         // CARETTA_NO_SW_ROWS: smith_waterman lists with gap 0 on the skewed sweep + walk launch (the path before round 6)
     bool trio = true;                // CARETTA_TRIO=0 switches the split by function off
     bool mid = true;                 // CARETTA_MID=0 switches the mid-size row split off
     bool mid_any = false;            // CARETTA_MID_ANY: k_pair_duo also with a single strip (measurements)
@@ -87,6 +92,10 @@ struct Calibration {
         Calibration c;
         c.no_team = env_set("CARETTA_NO_TEAM");
         c.no_wide = env_set("CARETTA_NO_WIDE");
+        c.no_sw_rows = env_set("CARETTA_NO_SW_ROWS");
+        c.no_walk_service = env_set("CARETTA_NO_WALK_SERVICE");
+        c.force_walk_service = env_set("CARETTA_FORCE_WALK_SERVICE");
+        c.sw_rows_nowalk = env_set("CARETTA_SW_ROWS_NOWALK");
         c.trio = env_on("CARETTA_TRIO");
         c.mid = env_on("CARETTA_MID");
         c.mid_any = env_set("CARETTA_MID_ANY");
@@ -109,6 +118,7 @@ struct Calibration {
         c.scratch_mb = env_ll("CARETTA_SCRATCH_MB", 0);
         c.stream_lds_kb = (int)env_ll("CARETTA_STREAM_LDS_KB", 0);
         c.stream_r = (int)env_ll("CARETTA_STREAM_R", 0);
+        c.sw_rows_waves = (int)env_ll("CARETTA_SW_ROWS_WAVES", 0);
         c.host_small_k = env_ll("CARETTA_HOST_SMALL_K", 4096);
         c.nj_threads = (int)env_ll("CARETTA_NJ_THREADS", 0);
         c.nj_groups = (int)env_ll("CARETTA_NJ_GROUPS", 0);

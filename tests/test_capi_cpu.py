@@ -283,7 +283,8 @@ def test_layout_table_tensor_widths_on_the_host(lib):
     from caretta_amd import engine
     offsets, pairs = _equal_family(300, 316)
     assert engine.plan_layout(offsets, 10, pairs)[0][0][0] == "trio"
-    assert engine.plan_layout(offsets, 16, pairs)[0][0][0] == "duo"              # (no k_pair_trio instance above width 10)
+    assert engine.plan_layout(offsets, 12, pairs)[0][0][0] == "trio"             # (k_pair_trio: score waves for widths 12 and 16 since round 6)
+    assert engine.plan_layout(offsets, 16, pairs)[0][0][0] == "trio"
     assert engine.plan_layout(offsets, 17, pairs)[0][0][0] == "single"           # (no one-workgroup layout above width 16)
     with pytest.raises(ValueError):
         engine.plan_layout(offsets, 33, pairs)

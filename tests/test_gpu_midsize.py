@@ -301,13 +301,14 @@ def test_staged_sweeps_ramps_without_masks(ctx, oracle, go, ge, gap):
 
 @pytest.mark.parametrize("dim", [16, 17])
 def test_tensor_width_limit_of_the_one_workgroup_layouts(ctx, oracle, dim):
-    """Widths up to 16 have wide / mid-size instances, 17 and more run one wave per pair (or four-wave teams)."""
+    """Widths up to 16 have wide / mid-size instances (the split by function included, since round 6), 17 and more run one
+    wave per pair (or four-wave teams)."""
     from caretta_amd import engine
     fam = synthetic.make_family(24, 300, dim=dim, seed=7200 + dim, clades=2)
     coords, tensors, offsets = synthetic.pack(fam)
     pairs = np.vstack([engine.all_pairs(24), engine.all_pairs(24)[:40, ::-1]])       # 316 pairs
     batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(pairs)
-    assert layout_of(batch)[0] == ("duo" if dim <= 16 else "single")            # (10 < d <= 16: no k_pair_trio instance)
+    assert layout_of(batch)[0] == ("trio" if dim <= 16 else "single")
     batch.run()
     res, aln = batch.fetch()
     batch.close()
@@ -381,6 +382,110 @@ def test_smith_waterman_batch_vs_oracle(oracle, golden):
         dtw.smith_waterman_batch([(np.arange(4), np.arange(5), np.ones((4, 5))), (np.arange(3), np.arange(3), -np.ones((3, 3)))], 0.0)
 
 
+def test_smith_waterman_gap0_traceback_on_the_row_sweep(oracle, monkeypatch):
+    """smith_waterman's default call (gap 0, dynamic_time_warping.py:226-278; multiple_alignment.py:332-334) over a list runs
+    fill, decisions, first maximum and walk in ONE launch of the row sweep (k_sw_trace_rows: a lane owns columns, the walk reads
+    the transposed blocks).  Tie-heavy matrices (constant, 0/1, small integers: the diag -> left -> up priority and the
+    row-major FIRST maximum decide every step), column strips (m > 64 x 8), single rows / columns, zero borders, negative
+    scores -- against the oracle, and against the skewed sweep + walk launch it replaces (CARETTA_NO_SW_ROWS=1)."""
+    from caretta_amd import dynamic_time_warping as dtw, engine
+    rng = np.random.default_rng(9501)
+    ar = np.arange
+    problems = []
+    for n, m in [(1, 1), (1, 70), (70, 1), (17, 17), (64, 64), (65, 320), (300, 300), (33, 513), (300, 1030), (129, 1500)]:
+        problems.append((ar(n), ar(m), np.ones((n, m))))                                     # every cell ties
+        problems.append((ar(n), ar(m), rng.integers(-1, 2, size=(n, m)).astype(np.float64)))   # -1 / 0 / 1
+        problems.append((ar(n), ar(m), (rng.uniform(size=(n, m)) < 0.1).astype(np.float64)))   # sparse ones: long flat runs
+        problems.append((ar(n), ar(m), rng.uniform(size=(n, m)) ** 2 - 0.3))
+    z = np.zeros((40, 50))
+    z[20:30, 10:20] = np.eye(10)                                                             # a maximum reached first in the interior
+    problems.append((ar(40), ar(50), z))
+    z2 = np.zeros((90, 700))
+    z2[5, 600] = 2.0                                                                         # first maximum in the second column strip, early row
+    z2[50, 3] = 2.0
+    problems.append((ar(90), ar(700), z2))
+    sub = rng.integers(-2, 3, size=(20, 20)).astype(np.float64)                              # alphabet mode (gathered columns), ties
+    for n, m in [(40, 55), (200, 333), (7, 600)]:
+        problems.append((rng.integers(0, 20, size=n), rng.integers(0, 20, size=m), sub))
+    want = [oracle.smith_waterman(s1, s2, mat, 0.0) for s1, s2, mat in problems]
+    keep = [k for k, w in enumerate(want) if not w[3]]                                       # (all-zero matrices raise: tested elsewhere)
+    problems, want = [problems[k] for k in keep], [want[k] for k in keep]
+
+    def check(got):
+        for k, ((a1, a2, score), (r1, r2, rs, _none)) in enumerate(zip(got, want)):
+            assert np.array_equal(a1, r1) and np.array_equal(a2, r2) and score == rs, (k, problems[k][2].shape)
+    check(dtw.smith_waterman_batch(problems, 0.0))
+    # many problems per launch (one per wave, several waves per CU walking while others stream)
+    got = dtw.smith_waterman_batch(problems * 30, 0.0)
+    check(got[:len(problems)])
+    check(got[-len(problems):])
+    monkeypatch.setenv("CARETTA_NO_SW_ROWS", "1")
+    engine.reload_config()
+    try:
+        check(dtw.smith_waterman_batch(problems, 0.0))
+    finally:
+        monkeypatch.delenv("CARETTA_NO_SW_ROWS")
+        engine.reload_config()
+
+
+def test_walk_service_beside_the_fill(oracle, monkeypatch):
+    """Lists that fill the chip run their walks by persistent walker waves on a second stream BESIDE the fill launch (the walk
+    service: a queue of finished problems, decision words written through and copied into the walker's LDS) -- smith_waterman
+    with gap 0 on the row sweep by default from 2 048 problems on, dtw_align only when forced (it loses there).  Against the
+    oracle: ragged problems, ties, single rows; forced for a short list; a list whose largest decision array does not fit the
+    walkers' LDS (falls back to the walk in the fill's wave); 2 600 problems (more than the 768 walkers); and switched off."""
+    from caretta_amd import dynamic_time_warping as dtw, engine
+    rng = np.random.default_rng(9601)
+    ar = np.arange
+    small = [(1, 1), (5, 64), (64, 65), (37, 128), (150, 150), (300, 300), (90, 320), (300, 17), (1, 70), (70, 1)]
+    big = small + [(33, 700), (257, 513), (12, 1100)]
+    def make(shapes):
+        out = [(ar(n), ar(m), rng.uniform(size=(n, m)) ** 3 - 0.1) for n, m in shapes]
+        return out + [(ar(n), ar(m), rng.integers(0, 2, size=(n, m)).astype(np.float64)) for n, m in shapes[2:8]]
+    def check(batch, problems, want_sw, want_dtw, sw_service, dtw_service):
+        got = batch.smith_waterman(0.0)
+        assert batch.last_walk_service() == sw_service
+        for k in list(range(len(problems))) + list(range(len(got) - len(problems), len(got))):
+            a1, a2, score = got[k]
+            r1, r2, rs, _none = want_sw[k % len(problems)]
+            assert np.array_equal(a1, r1) and np.array_equal(a2, r2) and score == rs, ("sw", k)
+        got = batch.dtw_align(1.0, 0.01)
+        assert batch.last_walk_service() == dtw_service
+        for k in list(range(len(problems))) + list(range(len(got) - len(problems), len(got))):
+            a1, a2, score = got[k]
+            r1, r2, rs = want_dtw[k % len(problems)][:3]
+            assert np.array_equal(a1, r1) and np.array_equal(a2, r2) and score == rs, ("dtw", k)
+    p_small, p_big = make(small), make(big)
+    oracle_of = lambda ps: ([oracle.smith_waterman(*p, 0.0) for p in ps], [oracle.dtw_align(*p, 1.0, 0.01) for p in ps])
+    w_small, w_big = oracle_of(p_small), oracle_of(p_big)
+    try:
+        # default: a short list walks in the fill's wave; 2 608 problems: smith_waterman on the service, dtw_align not
+        b = dtw.ExplicitBatch(p_small)
+        check(b, p_small, *w_small, False, False)
+        b.close()
+        b = dtw.ExplicitBatch(p_small * 163)
+        check(b, p_small, *w_small, True, False)
+        b.close()
+        monkeypatch.setenv("CARETTA_FORCE_WALK_SERVICE", "1")
+        engine.reload_config()
+        b = dtw.ExplicitBatch(p_small)
+        check(b, p_small, *w_small, True, True)
+        b.close()
+        b = dtw.ExplicitBatch(p_big)                   # 257 x 513: 70 KB of decision words -- no walker holds them
+        check(b, p_big, *w_big, False, True)
+        b.close()
+        monkeypatch.delenv("CARETTA_FORCE_WALK_SERVICE")
+        monkeypatch.setenv("CARETTA_NO_WALK_SERVICE", "1")
+        engine.reload_config()
+        b = dtw.ExplicitBatch(p_small * 163)
+        check(b, p_small, *w_small, False, False)
+        b.close()
+    finally:
+        monkeypatch.delenv("CARETTA_FORCE_WALK_SERVICE", raising=False)
+        monkeypatch.delenv("CARETTA_NO_WALK_SERVICE", raising=False)
+        engine.reload_config()
+
+
 @pytest.mark.parametrize("num,length,seed,limit", [(512, 300, 20243, 1.5), (64, 1200, 20244, None)])
 def test_multi_device_loopback_eight_shares(ctx, num, length, seed, limit, monkeypatch):
     """cr_multi_* with EIGHT shares on the one GPU of the box (loopback: the gather is device copies; the deal, the parked host
@@ -431,3 +536,66 @@ def test_multi_device_loopback_eight_shares(ctx, num, length, seed, limit, monke
     assert min(times[1:]) <= times[0] * 1.25
     if limit is not None:
         assert min(times[1:]) <= t_one * limit, (min(times[1:]), t_one)
+
+
+@pytest.mark.parametrize("dim", [12, 16])
+def test_by_function_layout_serves_tensor_widths_up_to_16(ctx, oracle, dim):
+    """Protein accepts any (L, d) tensor array (multiple_alignment.py:312-319, :328-331).  Lists of 65 .. 320 rows with
+    d = 11 .. 16 used to fall back to one wave per pair / the row split: k_pair_trio is instantiated for the padded widths 12
+    and 16 (its score waves pad the STORED width, not the batch's).  One, three and five rows per lane, every output."""
+    from caretta_amd import engine
+    for num, length in ((13, 90), (24, 150), (20, 300)):
+        fam = synthetic.make_family(num, length, dim=dim, seed=6100 + dim + length)
+        coords, tensors, offsets = synthetic.pack(fam)
+        run_all_ways(ctx, oracle, coords, tensors, offsets, engine.all_pairs(num), "trio")
+    # a ragged list in the same regime (rows past n, unequal columns)
+    fam = synthetic.make_ragged_family(16, 120, 250, dim=dim, seed=6200 + dim)
+    coords, tensors, offsets = synthetic.pack(fam)
+    run_all_ways(ctx, oracle, coords, tensors, offsets, engine.all_pairs(16), ("trio", "staged", "single"))
+
+
+@pytest.mark.parametrize("dim", [33, 48])
+def test_tensors_wider_than_the_fused_kernels_take_the_dropin_route(oracle, dim):
+    """d > 32 (multiple_alignment.py:312-331 takes any width): the pairwise matrix, the score function, the two-structure
+    alignment and the progressive alignment run through the per-function drop-ins instead of raising -- make_score_matrix
+    (any width) -> smith_waterman -> Kabsch on the seed -> make_score_matrix -> smith_waterman_score over the list / dtw_align --
+    with the oracle's values bit for bit."""
+    from caretta_amd import engine
+    from caretta_amd import multiple_alignment as ma
+    from oracle.pyoracle import default_params
+    fam = synthetic.make_family(6, 64, dim=dim, seed=7000 + dim, ragged=True)
+    coords, tensors, offsets = synthetic.pack(fam)
+    pairs = engine.all_pairs(len(fam))
+    prm = dict(gamma_tensor=7.0 / dim * 10, gamma_coords=0.03, verbose=False)
+    oprm = default_params(gamma_tensor=prm["gamma_tensor"], gamma_coords=0.03)
+    ref, ref_aln = oracle.pairwise_batch(coords, tensors, offsets, pairs, params=oprm)
+    prots = [ma.Protein(s.name, s.tensors, s.coordinates, s.sequence) for s in fam]
+    msa = ma.MultipleAlignment(prots)
+    matrix = msa.make_pairwise_matrix(prm)
+    assert np.array_equal(matrix, engine.assemble_matrix(pairs, ref["sw"], len(fam)))
+    # the two-structure alignment (multiple_alignment.py:263-275): pipeline H's dtw_align of the pair
+    two = ma.MultipleAlignment(prots[:2])
+    aln = two.multiple_align(None, 1.0, 0.01, 1.0, 1.0, prm, dict(verbose=False))
+    ln = int(ref["aln_len"][0])
+    assert np.array_equal(aln[prots[0].name], ref_aln[0, 0, :ln]) and np.array_equal(aln[prots[1].name], ref_aln[0, 1, :ln])
+    # the progressive alignment: every node replayed by the oracle on the walk's own children
+    full = msa.multiple_align(matrix.max() - matrix, 1.0, 0.01, 1.0, 1.0, prm, dict(verbose=False))
+    width = {len(v) for v in full.values()}
+    assert len(width) == 1
+    for s in fam:                                              # every residue exactly once, in order
+        row = np.asarray(full[s.name])
+        assert np.array_equal(row[row >= 0], np.arange(len(s.coordinates)))
+    tree = np.asarray(msa.tree).astype(np.int64)
+    joins = [(int(tree[x, 0]), int(tree[x + 1, 0])) for x in range(0, tree.shape[0] - 1, 2)] + [(int(tree[-1, 0]), int(tree[-1, 1]))]
+    num = len(fam)
+    sizes = [1] * num
+    for k, (n1, n2) in enumerate(joins):
+        tot = sizes[n1] + sizes[n2]
+        s1, s2 = msa.final_sequences[n1], msa.final_sequences[n2]
+        w1, w2 = np.ravel(msa.final_consensus_weights[n1]), np.ravel(msa.final_consensus_weights[n2])
+        _a1, _a2, xn, tn, wn, _f = oracle.progressive_node(s1.coordinates, s1.tensors, w1, s2.coordinates, s2.tensors, w2,
+                                                          sizes[n2] / (2 * tot), sizes[n1] / (2 * tot), params=oprm)
+        node = msa.final_sequences[num + k]
+        assert np.array_equal(tn, node.tensors) and np.array_equal(np.ravel(wn), np.ravel(msa.final_consensus_weights[num + k]))
+        assert np.allclose(xn, node.coordinates, rtol=0, atol=1e-9)          # (host mean_function: numpy's matmul in the frame change)
+        sizes.append(tot)
