@@ -98,7 +98,6 @@ SIGNATURES = {
     "cr_explicit_batch_create": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _pp],
     "cr_explicit_batch_destroy": [_vp],
     "cr_explicit_batch_last_ms": [_vp, C.POINTER(C.c_float)],
-    "cr_explicit_batch_last_service": [_vp, C.POINTER(C.c_int)],
     "cr_smith_waterman_score_batch": [_vp, _f64, _vp],
     "cr_dtw_align_batch": [_vp, _f64, _f64, _vp, _i64, _vp, _vp],
     "cr_smith_waterman_batch": [_vp, _f64, _vp, _i64, _vp, _vp, _vp],

@@ -37,8 +37,6 @@ struct Calibration {
     bool no_wide = false;            // CARETTA_NO_WIDE
     bool sw_rows_nowalk = false;     // CARETTA_SW_ROWS_NOWALK: measurement only -- the fill of k_sw_trace_rows without its walk (results are then wrong)
     int sw_rows_waves = 0;           // CARETTA_SW_ROWS_WAVES=3|5: measurement only -- k_sw_trace_rows<5> built for that many waves per SIMD
-    bool no_walk_service = false;    // CARETTA_NO_WALK_SERVICE: the walks of explicit-matrix lists in their fill's wave (as before round 6)
-    bool force_walk_service = false; // CARETTA_FORCE_WALK_SERVICE: ... beside the fill also for short lists (tests)
     bool no_sw_rows = false;         // CARETTA_NO_SW_ROWS: smith_waterman lists with gap 0 on the skewed sweep + walk launch (the path before round 6)
     bool trio = true;                // CARETTA_TRIO=0 switches the split by function off
     bool mid = true;                 // CARETTA_MID=0 switches the mid-size row split off
@@ -93,8 +91,6 @@ struct Calibration {
         c.no_team = env_set("CARETTA_NO_TEAM");
         c.no_wide = env_set("CARETTA_NO_WIDE");
         c.no_sw_rows = env_set("CARETTA_NO_SW_ROWS");
-        c.no_walk_service = env_set("CARETTA_NO_WALK_SERVICE");
-        c.force_walk_service = env_set("CARETTA_FORCE_WALK_SERVICE");
         c.sw_rows_nowalk = env_set("CARETTA_SW_ROWS_NOWALK");
         c.trio = env_on("CARETTA_TRIO");
         c.mid = env_on("CARETTA_MID");

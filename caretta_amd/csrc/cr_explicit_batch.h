@@ -20,70 +20,6 @@ struct BatchTrace {      // a walk's result: entries, first entry of the back-to
     int32_t len, start;
 };
 
-// ---------------------------------------------------------------------------------------------
-// The walk service.  The fills of a list are bound by how many waves stream rows; a wave that walks streams nothing, and a
-// walk is a chain of dependent scalar lookups that needs 16 - 40 VGPRs where a fill holds 100 - 115.  So for lists that fill
-// the chip the walks move to a SECOND launch on a second stream, running BESIDE the fill: a few persistent waves per CU in
-// the registers the fill's waves leave over.  A fill wave that has finished a problem -- decision words and end record
-// stored with device-scope (written-through) stores and acknowledged -- appends the problem to a queue; a walker wave takes
-// the next ticket, polls its queue slot, and walks on device-scope loads.  The fill is launched FIRST: if the two launches
-// do not overlap the walkers simply find a full queue.  A poll that does not end gives up (abort word) and the host runs the
-// walks again behind the fill.
-// queue words: [0] head (tickets handed to walkers) [1] tail (problems appended) [2] abort [3] - [4 + t] problem + 1 of ticket t
-// ---------------------------------------------------------------------------------------------
-constexpr uint32_t kWalkSpinLimit = 1u << 21;             // polls of ~4 us: ~8 s
-
-CR_D void agent_store_u32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-CR_D uint32_t agent_load_u32(const uint32_t* p) { return __hip_atomic_load(const_cast<uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-CR_D void agent_store_u64(void* p, unsigned long long v) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-CR_D unsigned long long agent_load_u64(const void* p) {
-    return __hip_atomic_load(reinterpret_cast<unsigned long long*>(const_cast<void*>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// a record of N 8-byte words, device scope (every lane stores / loads the same words: wave-uniform callers use lane 0)
-template <class T>
-CR_D void agent_store_record(T* dst, const T& v) {
-    static_assert(sizeof(T) % 8 == 0, "records are whole 8-byte words");
-    unsigned long long w[sizeof(T) / 8];
-    __builtin_memcpy(w, &v, sizeof(T));
-#pragma unroll
-    for (size_t k = 0; k < sizeof(T) / 8; k++) agent_store_u64(reinterpret_cast<unsigned long long*>(dst) + k, w[k]);
-}
-template <class T>
-CR_D T agent_load_record(const T* src) {
-    unsigned long long w[sizeof(T) / 8];
-#pragma unroll
-    for (size_t k = 0; k < sizeof(T) / 8; k++) w[k] = agent_load_u64(reinterpret_cast<const unsigned long long*>(src) + k);
-    T v;
-    __builtin_memcpy(&v, w, sizeof(T));
-    return v;
-}
-// fill side: this wave's stores have been acknowledged -> append problem `p` to the queue
-CR_D void walk_queue_push(uint32_t* queue, int p) {
-    __builtin_amdgcn_s_waitcnt(0);                         // vmcnt(0): the written-through words are where a device-scope load finds them
-    if (threadIdx.x == 0) {
-        const uint32_t t = __hip_atomic_fetch_add(queue + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        agent_store_u32(queue + 4 + t, (uint32_t)p + 1u);
-    }
-}
-// walker side: the next problem, or -1 when every ticket has been handed out / the service was aborted
-CR_D int walk_queue_pop(uint32_t* queue, int count) {
-    uint32_t t = 0;
-    if (threadIdx.x == 0) t = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-    if (t >= (uint32_t)count) return -1;
-    uint32_t spins = 0, v;
-    while ((v = (uint32_t)__builtin_amdgcn_readfirstlane((int)agent_load_u32(queue + 4 + t))) == 0u) {
-        __builtin_amdgcn_s_sleep(127);
-        if (++spins > kWalkSpinLimit || ((spins & 63u) == 0u && agent_load_u32(queue + 2) != 0u)) {
-            agent_store_u32(queue + 2, 1u);
-            return -1;
-        }
-    }
-    return (int)v - 1;
-}
-
 // 16 bytes of a row that is only 8-byte aligned
 struct __attribute__((packed, aligned(8))) Pair8 {
     double a, b;
@@ -300,7 +236,7 @@ __global__ __launch_bounds__(kWave) void k_sw_score_rows(const ExplicitProblem* 
 // The walk follows the fill in the same wave (as in k_seed): a launch, and the walks of the waves that finish first hide
 // under the row streams of the others.
 // ---------------------------------------------------------------------------------------------
-template <int CC, bool AGENT>
+template <int CC>
 CR_D void sw_walk_transposed(const uint32_t* __restrict__ words, const int n, const int m, const SeedMax sm, double* lds,
                              int32_t* __restrict__ a1, BatchTrace* __restrict__ out);
 
@@ -309,8 +245,7 @@ __global__ __launch_bounds__(kWave, WAVES) void k_sw_trace_rows(const ExplicitPr
                                                         const double* __restrict__ S, const int32_t* __restrict__ seqs,
                                                         double* __restrict__ hand, uint32_t* __restrict__ dirs,
                                                         SeedMax* __restrict__ seeds, int32_t* __restrict__ aln,
-                                                        BatchTrace* __restrict__ out, const int walk,
-                                                        uint32_t* __restrict__ queue) {
+                                                        BatchTrace* __restrict__ out, const int walk) {
     using RS = RowSweep<CC>;
     extern __shared__ double lds[];                      // two row buffers; then the walk's packed entries
     const ExplicitProblem pb = probs[blockIdx.x];
@@ -347,10 +282,7 @@ __global__ __launch_bounds__(kWave, WAVES) void k_sw_trace_rows(const ExplicitPr
                     const int64_t base = ((int64_t)(cs * TB + (i >> 4)) * CC) * kWave + lane;
 #pragma unroll
                     for (int x = 0; x < CC; x++) {
-                        if (used) {
-                            if (walk == 2) agent_store_u32(words + base + x * kWave, bits[x]);     // (read by another workgroup while this launch runs)
-                            else words[base + x * kWave] = bits[x];
-                        }
+                        if (used) words[base + x * kWave] = bits[x];
                         bits[x] = 0;
                     }
                 }
@@ -448,18 +380,13 @@ __global__ __launch_bounds__(kWave, WAVES) void k_sw_trace_rows(const ExplicitPr
     sm.score = best_v;
     sm.i = best_v > 0.0 ? best_i + 1 : 0;
     sm.j = best_v > 0.0 ? best_j + 1 : 0;
-    if (walk == 2) {                                     // the walk service takes it from here
-        if (lane == 0) agent_store_record(seeds + blockIdx.x, sm);
-        walk_queue_push(queue, (int)blockIdx.x);
-        return;
-    }
     if (lane == 0) seeds[blockIdx.x] = sm;
-    if (walk) sw_walk_transposed<CC, false>(words, n, m, sm, lds, aln + pb.aln_off, out + blockIdx.x);   // (walk == 0: calibration only)
+    if (walk) sw_walk_transposed<CC>(words, n, m, sm, lds, aln + pb.aln_off, out + blockIdx.x);   // (walk == 0: calibration only)
 }
 
 // The walk of smith_waterman (:249-278) on the decision words of the row sweep: the transposed view -- block row = column of
 // the matrix, block step = row of the matrix.  One wave; rows to HBM back to front, the record to *out.
-template <int CC, bool AGENT>
+template <int CC>
 CR_D void sw_walk_transposed(const uint32_t* __restrict__ words, const int n, const int m, const SeedMax sm, double* lds,
                              int32_t* __restrict__ a1, BatchTrace* __restrict__ out) {
     const int lane = threadIdx.x;
@@ -468,7 +395,7 @@ CR_D void sw_walk_transposed(const uint32_t* __restrict__ words, const int n, co
     const int cap = n + m;
     int idx = 0;
     if (sm.i > 0) {
-        Walker<CC, 2, 0, CC, AGENT> wk;
+        Walker<CC, 2, 0> wk;
         wk.init(words, TB, lane);
         int i = __builtin_amdgcn_readfirstlane(sm.i), j = __builtin_amdgcn_readfirstlane(sm.j);
         wk.set_row(j - 1);
@@ -511,48 +438,6 @@ CR_D void sw_walk_transposed(const uint32_t* __restrict__ words, const int n, co
     if (lane == 0) {
         out->len = idx;
         out->start = first;
-    }
-    wave_sync();                                         // (a persistent walker reuses the LDS for its next problem)
-}
-
-// the walkers of the service for k_sw_trace_rows: persistent waves, one problem per ticket.  Under the fill's row streams the
-// memory system is saturated and a round trip takes microseconds: a walk that gathers its decision blocks one dependent load
-// after the other (30 - 40 of them) took 190 us beside the fill where it takes 19 us alone.  So a walker first copies the
-// problem's WHOLE decision array into LDS -- a few back-to-back 16-byte loads per lane, device scope (the words were written
-// through by a workgroup of the other launch), ONE round trip -- and then walks on LDS.  Dynamic LDS: entries (cap_max words)
-// | decision words (words_max).
-template <int CC>
-__global__ __launch_bounds__(kWave) void k_sw_walk_service(const ExplicitProblem* __restrict__ probs, const int64_t* __restrict__ dirs_off,
-                                                          const uint32_t* __restrict__ dirs, const SeedMax* __restrict__ seeds,
-                                                          uint32_t* __restrict__ queue, const int count, const int cap_max,
-                                                          int32_t* __restrict__ aln, BatchTrace* __restrict__ out) {
-    extern __shared__ double lds[];
-    typedef uint32_t Quad __attribute__((ext_vector_type(4)));
-    Quad* const ldsq = reinterpret_cast<Quad*>(lds + (((size_t)cap_max + 3) / 4) * 2);           // 16-byte aligned, behind the entries
-    const int lane = threadIdx.x;
-    constexpr int kBatch = 4;                              // 16-byte loads in flight per lane (a walker must fit the 32 VGPRs four fill waves of 120 leave on a SIMD)
-    for (;;) {
-        const int p = walk_queue_pop(queue, count);
-        if (p < 0) return;
-        const ExplicitProblem pb = probs[p];
-        const SeedMax sm = agent_load_record(seeds + p);
-        const int strips = (pb.m + kWave * CC - 1) / (kWave * CC);
-        const int quads = strips * ((pb.n + 15) >> 4) * CC * (kWave / 4);       // words / 4
-        const uint32_t* src = dirs + dirs_off[p];
-        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)src);
-        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uintptr_t)src >> 32));
-        auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uintptr_t)hi << 32) | lo), 0, quads * 16, 0x00020000);
-        for (int base = 0; base < quads; base += kBatch * kWave) {
-            Quad v[kBatch];
-#pragma unroll
-            for (int k = 0; k < kBatch; k++)               // (past the array: the range check returns zeros)
-                v[k] = __builtin_bit_cast(Quad, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (base + k * kWave + lane) * 16, 0, /*sc1*/ 16));
-#pragma unroll
-            for (int k = 0; k < kBatch; k++)
-                if (base + k * kWave + lane < quads) ldsq[base + k * kWave + lane] = v[k];
-        }
-        wave_sync();
-        sw_walk_transposed<CC, false>(reinterpret_cast<const uint32_t*>(ldsq), pb.n, pb.m, sm, lds, aln + pb.aln_off, out + p);
     }
 }
 
@@ -758,7 +643,7 @@ __host__ __device__ inline size_t stream_lds_doubles() {
 
 template <int R, int MODE, bool STORE>
 CR_D void sweep_stream(ExplicitStream<R>& src, const int n, const int m, const SweepParams prm, double* lds,
-                       uint32_t* __restrict__ dtw_bits, double* __restrict__ hand_g, AlignEnd& end_out, const bool svc = false) {
+                       uint32_t* __restrict__ dtw_bits, double* __restrict__ hand_g, AlignEnd& end_out) {
     constexpr bool SW = (MODE & kSwScore) != 0;
     constexpr bool DTW = (MODE & kDtw) != 0;
     constexpr int NB = (SW ? 1 : 0) + (DTW ? 2 : 0);
@@ -868,8 +753,7 @@ CR_D void sweep_stream(ExplicitStream<R>& src, const int n, const int m, const S
                 const int64_t base = ((int64_t)(s * TB_DTW + (t0 >> 3)) * R) * kWave + lane;
 #pragma unroll
                 for (int q = 0; q < R; q++) {
-                    if (svc) agent_store_u32(dtw_bits + base + q * kWave, st.dtbits[q]);      // (walk service: read by another workgroup of a running launch)
-                    else dtw_bits[base + q * kWave] = st.dtbits[q];
+                    dtw_bits[base + q * kWave] = st.dtbits[q];
                     st.dtbits[q] = 0;
                 }
             }
@@ -922,8 +806,7 @@ __global__ __launch_bounds__(kWave) void k_explicit_stream(const ExplicitProblem
                                                           const int32_t* __restrict__ seqs, SweepParams prm,
                                                           uint32_t* __restrict__ bits, double* __restrict__ hand,
                                                           AlignEnd* __restrict__ ends, int max_entries = 0,
-                                                          int32_t* __restrict__ aln = nullptr, BatchTrace* __restrict__ trace = nullptr,
-                                                          uint32_t* __restrict__ queue = nullptr) {
+                                                          int32_t* __restrict__ aln = nullptr, BatchTrace* __restrict__ trace = nullptr) {
     extern __shared__ double lds[];
     const ExplicitProblem pb = probs[blockIdx.x];
     ExplicitStream<R> src;
@@ -939,14 +822,7 @@ __global__ __launch_bounds__(kWave) void k_explicit_stream(const ExplicitProblem
     AlignEnd ae;
     ae.sw = ae.dtw_score = 0.0;
     ae.start_layer = ae.pad = 0;
-    if (pb.m > 0) sweep_stream<R, MODE, STORE>(src, pb.n, pb.m, prm, lds, STORE ? bits + pb.bits_off_s : nullptr, hand + pb.hand_off, ae, queue != nullptr);
-    if constexpr (STORE && (MODE & kDtw) != 0) {
-        if (queue) {                                      // (uniform) the walk service takes it from here
-            if (threadIdx.x == 0) agent_store_record(ends + blockIdx.x, ae);
-            walk_queue_push(queue, (int)blockIdx.x);
-            return;
-        }
-    }
+    if (pb.m > 0) sweep_stream<R, MODE, STORE>(src, pb.n, pb.m, prm, lds, STORE ? bits + pb.bits_off_s : nullptr, hand + pb.hand_off, ae);
     if (threadIdx.x == 0) ends[blockIdx.x] = ae;
     if constexpr (STORE && (MODE & kDtw) != 0) {
         if (aln) {                                        // (uniform) the walk on this wave's own decision words
@@ -976,27 +852,6 @@ __global__ __launch_bounds__(kWave) void k_dtw_trace_batch(const ExplicitProblem
     if (threadIdx.x == 0) {
         out[blockIdx.x].len = len;
         out[blockIdx.x].start = pb.n + pb.m - len;
-    }
-}
-
-// the walkers of the service for k_explicit_stream (dtw_align with its traceback): persistent waves, one problem per ticket
-template <int R>
-__global__ __launch_bounds__(kWave) void k_dtw_walk_service(const ExplicitProblem* __restrict__ probs, const uint32_t* __restrict__ bits,
-                                                           const AlignEnd* __restrict__ ends, uint32_t* __restrict__ queue, const int count,
-                                                           int max_entries, int32_t* __restrict__ aln, BatchTrace* __restrict__ out) {
-    extern __shared__ double lds[];
-    for (;;) {
-        const int p = walk_queue_pop(queue, count);
-        if (p < 0) return;
-        const ExplicitProblem pb = probs[p];
-        const AlignEnd ae = agent_load_record(ends + p);
-        int len, pairs;
-        dtw_walk<R, R, true>(pb.n, pb.m, max_entries, bits + pb.bits_off_s, ae.start_layer, lds, aln + pb.aln_off, len, pairs);
-        if (threadIdx.x == 0) {
-            out[p].len = len;
-            out[p].start = pb.n + pb.m - len;
-        }
-        wave_sync();                                     // (the LDS is reused for the next problem)
     }
 }
 
@@ -1125,8 +980,6 @@ struct cr_explicit_batch {
     DevBuf<uint32_t> sw_dirs;           // ... its 2-bit decisions
     DevBuf<int64_t> sw_dirs_off;        // ... word offset of every problem (laid out for the rows per lane of the launch)
     int sw_dirs_r = 0;                  // ... rows per lane the offsets were laid out for (0: not yet)
-    DevBuf<uint32_t> walk_queue;        // the walk service: head, tail, abort, -, one slot per problem
-    bool last_walk_service = false;     // ... the last traced call ran its walks beside its fill (reported by cr_explicit_batch_last_service)
     int64_t s_elems = 0;
     float last_ms = 0.f;             // device time of the last batch kernel (HIP events on the context's stream)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1147,37 +1000,17 @@ int launch_sw_rows(cr_explicit_batch* b) {
 
 // the streaming sweep (contiguous columns) with R rows per lane; bits == nullptr: no decision words (scores alone)
 // (walk_entries > 0: dtw_align's traceback in the same launch -- rows into b->aln, lengths into b->trace)
-// Lists from this many problems on run their walks beside the fill (the walk service above): below it the chip is not full
-// and a walking wave takes nobody's place.
-constexpr int64_t kWalkServiceMin = 2048;
-constexpr int kWalkServiceWaves = 768;                   // persistent walker waves (the LDS lets two or three share a CU with the fill)
-constexpr size_t kWalkLdsLimit = 40 * 1024;
-
-bool use_walk_service(const cr_explicit_batch* b) {
-    return !g_cfg.no_walk_service && (b->count >= kWalkServiceMin || g_cfg.force_walk_service);
-}
-
-// zeroed queue on the context's stream, then the side stream forked behind it
-int walk_service_begin(cr_explicit_batch* b, hipStream_t* side) {
-    CR_HIP(b->walk_queue.ensure((size_t)b->count + 4));
-    CR_HIP(hipMemsetAsync(b->walk_queue.p, 0, sizeof(uint32_t) * ((size_t)b->count + 4), b->ctx->stream));
-    int rc = fork_lanes(b->ctx, 2);
-    if (rc) return rc;
-    return lane_stream(b->ctx, 1, side);
-}
-
 template <int R, int MODE>
-int launch_stream(cr_explicit_batch* b, const cr::ExplicitProblem* probs, const cr::SweepParams& prm, uint32_t* bits, int walk_entries = 0,
-                  bool service = false) {
+int launch_stream(cr_explicit_batch* b, const cr::ExplicitProblem* probs, const cr::SweepParams& prm, uint32_t* bits, int walk_entries = 0) {
     size_t lds = cr::stream_lds_doubles<R, MODE>() * sizeof(double);
-    if (walk_entries > 0 && !service) lds = std::max(lds, sizeof(double) * cr::trace_lds_doubles(R, walk_entries));
+    if (walk_entries > 0) lds = std::max(lds, sizeof(double) * cr::trace_lds_doubles(R, walk_entries));
     if (g_cfg.stream_lds_kb > 0) lds = std::max(lds, (size_t)g_cfg.stream_lds_kb * 1024);   // calibration: waves per CU
     auto go = [&](auto kernel) -> int {
         int rc = allow_lds(kernel, lds);
         if (rc) return rc;
         CR_LAUNCH(kernel, dim3((unsigned)b->count), dim3(cr::kWave), lds, b->ctx->stream, probs, b->S.p + kSlackFront, b->seqs.p, prm, bits,
                   b->hand.p, b->ends.p, walk_entries, walk_entries > 0 ? b->aln.p : (int32_t*)nullptr,
-                  walk_entries > 0 ? b->trace.p : (cr::BatchTrace*)nullptr, service ? b->walk_queue.p : (uint32_t*)nullptr);
+                  walk_entries > 0 ? b->trace.p : (cr::BatchTrace*)nullptr);
         CR_HIP(hipGetLastError());
         return CR_OK;
     };
@@ -1188,43 +1021,10 @@ int launch_stream(cr_explicit_batch* b, const cr::ExplicitProblem* probs, const 
 }
 
 template <int MODE>
-int launch_stream_r(int R, cr_explicit_batch* b, const cr::ExplicitProblem* probs, const cr::SweepParams& prm, uint32_t* bits, int walk_entries = 0,
-                    bool service = false) {
-    return R == 1 ? launch_stream<1, MODE>(b, probs, prm, bits, walk_entries, service) : R == 2 ? launch_stream<2, MODE>(b, probs, prm, bits, walk_entries, service)
-         : R == 3 ? launch_stream<3, MODE>(b, probs, prm, bits, walk_entries, service) : R == 4 ? launch_stream<4, MODE>(b, probs, prm, bits, walk_entries, service)
-         : launch_stream<5, MODE>(b, probs, prm, bits, walk_entries, service);
-}
-
-// the walkers of dtw_align's service on `st` (the side stream beside the fill, or the context's stream behind it: the fallback)
-template <int R>
-int launch_dtw_walkers(cr_explicit_batch* b, hipStream_t st, int entries) {
-    const size_t lds = sizeof(double) * cr::trace_lds_doubles(R, entries);
-    int rc = allow_lds(cr::k_dtw_walk_service<R>, lds);
-    if (rc) return rc;
-    const unsigned waves = (unsigned)std::min<int64_t>(b->count, kWalkServiceWaves);
-    CR_LAUNCH(cr::k_dtw_walk_service<R>, dim3(waves), dim3(cr::kWave), lds, st, b->probs.p, b->bits.p, b->ends.p, b->walk_queue.p, (int)b->count,
-              entries, b->aln.p, b->trace.p);
-    CR_HIP(hipGetLastError());
-    return CR_OK;
-}
-int launch_dtw_walkers_r(int R, cr_explicit_batch* b, hipStream_t st, int entries) {
-    return R == 1 ? launch_dtw_walkers<1>(b, st, entries) : R == 2 ? launch_dtw_walkers<2>(b, st, entries) : R == 3 ? launch_dtw_walkers<3>(b, st, entries)
-         : R == 4 ? launch_dtw_walkers<4>(b, st, entries) : launch_dtw_walkers<5>(b, st, entries);
-}
-
-// Did a walker give up?  (Never seen; then every walk is run again behind the fill, whose queue is complete by now.)
-template <class Relaunch>
-int walk_service_finish(cr_explicit_batch* b, Relaunch relaunch) {
-    uint32_t head[4] = {0, 0, 0, 0};
-    CR_DOWNLOAD(b->ctx, head, b->walk_queue.p, sizeof(head));
-    CR_HIP(hipStreamSynchronize(b->ctx->stream));
-    if (head[2] == 0 && head[1] == (uint32_t)b->count) return CR_OK;
-    if (head[1] != (uint32_t)b->count) return fail(CR_ERR_STATE, "walk service: the fill appended fewer problems than the list holds");
-    CR_HIP(hipMemsetAsync(b->walk_queue.p, 0, sizeof(uint32_t) * 4, b->ctx->stream));        // tickets from 0 again, the slots stay
-    int rc = relaunch(b->ctx->stream);
-    if (rc) return rc;
-    CR_HIP(hipStreamSynchronize(b->ctx->stream));
-    return CR_OK;
+int launch_stream_r(int R, cr_explicit_batch* b, const cr::ExplicitProblem* probs, const cr::SweepParams& prm, uint32_t* bits, int walk_entries = 0) {
+    return R == 1 ? launch_stream<1, MODE>(b, probs, prm, bits, walk_entries) : R == 2 ? launch_stream<2, MODE>(b, probs, prm, bits, walk_entries)
+         : R == 3 ? launch_stream<3, MODE>(b, probs, prm, bits, walk_entries) : R == 4 ? launch_stream<4, MODE>(b, probs, prm, bits, walk_entries)
+         : launch_stream<5, MODE>(b, probs, prm, bits, walk_entries);
 }
 
 template <int R, bool STREAM>
@@ -1276,43 +1076,15 @@ int columns_per_lane(int m_max) {
 }
 
 // smith_waterman with gap 0 over the list: fill with decisions, first maximum and the walk in ONE launch of the row sweep
-// bytes of LDS a walker of the row sweep's service needs: the entries and the largest problem's decision words
-template <int CC>
-size_t sw_walker_lds(const cr_explicit_batch* b) {
-    const size_t strips = ((size_t)b->m_max + cr::kWave * CC - 1) / (cr::kWave * CC);
-    return sizeof(double) * (((size_t)b->cap_max + 3) / 4) * 2 + sizeof(uint32_t) * strips * (((size_t)b->n_max + 15) / 16) * CC * cr::kWave;
-}
-
-template <int CC>
-int launch_sw_walkers(cr_explicit_batch* b, hipStream_t st) {
-    const size_t lds = sw_walker_lds<CC>(b);
-    int rc = allow_lds(cr::k_sw_walk_service<CC>, lds);
-    if (rc) return rc;
-    const unsigned waves = (unsigned)std::min<int64_t>(b->count, kWalkServiceWaves);
-    CR_LAUNCH(cr::k_sw_walk_service<CC>, dim3(waves), dim3(cr::kWave), lds, st, b->probs.p, b->sw_dirs_off.p, b->sw_dirs.p, b->seeds.p,
-              b->walk_queue.p, (int)b->count, b->cap_max, b->aln.p, b->trace.p);
-    CR_HIP(hipGetLastError());
-    return CR_OK;
-}
-
 template <int CC, int WAVES = (CC <= 4 ? 5 : CC == 5 ? 4 : 3)>
 int launch_sw_trace_rows(cr_explicit_batch* b) {
-    // (the walkers keep a problem's decision words in LDS: at most kWalkLdsLimit, two or three walkers per CU beside the fill)
-    const bool service = use_walk_service(b) && !g_cfg.sw_rows_nowalk && sw_walker_lds<CC>(b) <= kWalkLdsLimit;
-    b->last_walk_service = service;
-    // (with the service the fill's LDS is its two row buffers: the walkers hold the entries)
-    const size_t lds = std::max(sizeof(double) * 2 * cr::RowSweep<CC>::kBufDoubles, service ? (size_t)0 : sizeof(uint32_t) * ((size_t)b->cap_max + 2));
+    const size_t lds = std::max(sizeof(double) * 2 * cr::RowSweep<CC>::kBufDoubles, sizeof(uint32_t) * ((size_t)b->cap_max + 2));
     int rc = allow_lds(cr::k_sw_trace_rows<CC, WAVES>, lds);
     if (rc) return rc;
-    hipStream_t side = nullptr;
-    if (service && (rc = walk_service_begin(b, &side))) return rc;
     CR_LAUNCH((cr::k_sw_trace_rows<CC, WAVES>), dim3((unsigned)b->count), dim3(cr::kWave), lds, b->ctx->stream, b->probs.p, b->sw_dirs_off.p,
-              b->S.p + kSlackFront, b->seqs.p, b->hand.p, b->sw_dirs.p, b->seeds.p, b->aln.p, b->trace.p, service ? 2 : g_cfg.sw_rows_nowalk ? 0 : 1,
-              b->walk_queue.p);
+              b->S.p + kSlackFront, b->seqs.p, b->hand.p, b->sw_dirs.p, b->seeds.p, b->aln.p, b->trace.p, g_cfg.sw_rows_nowalk ? 0 : 1);
     CR_HIP(hipGetLastError());
-    if (!service) return CR_OK;
-    if ((rc = launch_sw_walkers<CC>(b, side))) return rc;
-    return join_lanes(b->ctx, 2);
+    return CR_OK;
 }
 
 int smith_waterman_rows(cr_explicit_batch* b, int64_t* aln, int64_t aln_stride, int64_t* aln_len, double* scores, int32_t* all_zero) {
@@ -1348,13 +1120,6 @@ int smith_waterman_rows(cr_explicit_batch* b, int64_t* aln, int64_t aln_stride, 
     }
     if (rc) return rc;
     CR_HIP(hipEventRecord(b->ev1, st));
-    if (b->last_walk_service) {
-        rc = walk_service_finish(b, [&](hipStream_t s2) {
-            return CC == 1 ? launch_sw_walkers<1>(b, s2) : CC == 2 ? launch_sw_walkers<2>(b, s2) : CC == 3 ? launch_sw_walkers<3>(b, s2)
-                 : CC == 4 ? launch_sw_walkers<4>(b, s2) : CC == 5 ? launch_sw_walkers<5>(b, s2) : launch_sw_walkers<8>(b, s2);
-        });
-        if (rc) return rc;
-    }
     return sw_results_to_caller(b, aln_total, aln, aln_stride, aln_len, scores, all_zero);
 }
 
@@ -1495,12 +1260,6 @@ int cr_explicit_batch_last_ms(cr_explicit_batch* b, float* ms) {
     return CR_OK;
 }
 
-int cr_explicit_batch_last_service(cr_explicit_batch* b, int* service) {
-    CR_REQUIRE(b && service, "null argument");
-    *service = b->last_walk_service ? 1 : 0;
-    return CR_OK;
-}
-
 int cr_smith_waterman_score_batch(cr_explicit_batch* b, double gap, double* scores) {
     CR_REQUIRE(b != nullptr && scores != nullptr, "null argument");
     int rc = set_device(b->ctx);
@@ -1552,7 +1311,6 @@ int cr_smith_waterman_batch(cr_explicit_batch* b, double gap, int64_t* aln, int6
     CR_REQUIRE(aln_stride >= b->cap_max, "aln needs a stride of at least the longest n + m");
     CR_REQUIRE(!b->has_minus1, "seq2: index outside the score matrix (-1 only ends a row of smith_waterman_score)");
     hipStream_t st = b->ctx->stream;
-    b->last_walk_service = false;
     if (gap == 0.0 && !g_cfg.no_sw_rows) return smith_waterman_rows(b, aln, aln_stride, aln_len, scores, all_zero);
     const bool stream = b->all_ident;                    // contiguous columns everywhere: the streaming sweep
     const int R = stream ? b->r_stream : kExplicitR;
@@ -1626,18 +1384,7 @@ int cr_dtw_align_batch(cr_explicit_batch* b, double gap_open, double gap_extend,
         CR_HIP(b->trace.ensure((size_t)b->count));
     }
     CR_HIP(hipEventRecord(b->ev0, st));
-    // (dtw_align's walkers gather from HBM under the fill's streams -- 4 bits per cell do not fit the LDS beside twelve streaming waves --
-    // and lose to the walk in the fill's own wave: 2.31 against 2.04 ms on 8 128 x 300 x 300, profiles/r06/sw_rows_probe.txt.  Kept for tests.)
-    const bool service = stream && aln && g_cfg.force_walk_service && !g_cfg.no_walk_service;
-    b->last_walk_service = service;
-    if (service) {
-        // the fill on the context's stream, the walks by persistent waves on a side stream beside it (the walk service)
-        hipStream_t side = nullptr;
-        if ((rc = walk_service_begin(b, &side))) return rc;
-        if ((rc = launch_stream_r<MODE>(R, b, b->probs.p, prm, b->bits.p, b->cap_max, true))) return rc;
-        if ((rc = launch_dtw_walkers_r(R, b, side, b->cap_max))) return rc;
-        if ((rc = join_lanes(b->ctx, 2))) return rc;
-    } else if (stream) {
+    if (stream) {
         // (with alignments: fill, decisions and the walk of every problem in ONE launch)
         if ((rc = launch_stream_r<MODE>(R, b, b->probs.p, prm, aln ? b->bits.p : nullptr, aln ? b->cap_max : 0))) return rc;
     } else {
@@ -1652,7 +1399,6 @@ int cr_dtw_align_batch(cr_explicit_batch* b, double gap_open, double gap_extend,
         if ((rc = launch_trace<kExplicitR, false>(b, b->cap_max))) return rc;
     }
     CR_HIP(hipEventRecord(b->ev1, st));
-    if (service && (rc = walk_service_finish(b, [&](hipStream_t s2) { return launch_dtw_walkers_r(R, b, s2, b->cap_max); }))) return rc;
     std::vector<cr::AlignEnd> ends((size_t)b->count);
     CR_DOWNLOAD(b->ctx, ends.data(), b->ends.p, sizeof(cr::AlignEnd) * ends.size());
     std::vector<int32_t> h_aln;

@@ -126,9 +126,7 @@ CR_D uint32_t pack_entry(int i, int j) { return ((uint32_t)i & 0xffffu) | ((uint
 // SKEW = 1: words written by the time-skewed sweeps (time step of a cell = column + fill lane); SKEW = 0: words of
 // the column sweep (time step = column).
 // ---------------------------------------------------------------------------------------------
-// AGENT: the words were written by ANOTHER workgroup of a launch that is still running (the walk service of
-// cr_explicit_batch.h): device-scope loads, past this CU's L1 and the XCD's L2.
-template <int R, int BITS, int SKEW = 1, int RB = R, bool AGENT = false>
+template <int R, int BITS, int SKEW = 1, int RB = R>
 struct Walker {
     static constexpr int kLog = BITS == 2 ? 4 : 3;                 // log2(steps per word)
     static constexpr int kStepMask = (1 << kLog) - 1;
@@ -188,11 +186,6 @@ struct Walker {
         const int qa = relc - la * rs;
         la_out = la;
         const int tb = ((c + la * SKEW) >> kLog) - wx;
-        if constexpr (AGENT) {
-            uint32_t v = 0u;
-            if (rv && tb >= 0) v = __hip_atomic_load(const_cast<uint32_t*>(words) + (((int64_t)slot0 * TB + (int64_t)tb * rs + qa) * kWave + la), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return v;
-        }
         return (rv && tb >= 0) ? words[((int64_t)slot0 * TB + (int64_t)tb * rs + qa) * kWave + la] : 0u;
     }
     // (Requesting the block above along the diagonal while the walk crosses this one was measured: 225 k -> 218 k cycles
@@ -659,13 +652,13 @@ __host__ __device__ inline size_t trace_team_lds_doubles(int max_entries) {
 // DTW traceback (dynamic_time_warping.py:90-144) on the packed decisions: leaves the alignment columns
 // as packed entries in lds[first .. cap) (cap = n + m), writes the rows to HBM (back-to-front in
 // [aln, aln + 2*cap)), returns the number of columns and of aligned pairs.  Wave-uniform.
-template <int R, int RB = R, bool AGENT = false>
+template <int R, int RB = R>
 CR_D void dtw_walk(int n0, int m0, int max_entries, const uint32_t* __restrict__ w, int start_layer,
                    double* lds, int32_t* __restrict__ aln, int& len_out, int& pairs_out, const int nA = 0) {
     const int lane = threadIdx.x;
     uint32_t* arow = reinterpret_cast<uint32_t*>(lds);           // packed alignment columns, back-to-front
     const int cap = n0 + m0;
-    Walker<R, 4, 1, RB, AGENT> wk;
+    Walker<R, 4, 1, RB> wk;
     wk.init(w, tblocks(m0, 8), lane, nA);
     // the walk is wave-uniform: pin its state to SGPRs so that it compiles to scalar code
     int n = __builtin_amdgcn_readfirstlane(n0), m = __builtin_amdgcn_readfirstlane(m0);

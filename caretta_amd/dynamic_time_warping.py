@@ -141,12 +141,6 @@ class ExplicitBatch:
         check(self._lib.cr_explicit_batch_last_ms(self._h, C.byref(ms)))
         return float(ms.value)
 
-    def last_walk_service(self) -> bool:
-        """Did the last traced call run its walks beside its fill (the walk service: lists that fill the chip)?"""
-        flag = C.c_int(0)
-        check(self._lib.cr_explicit_batch_last_service(self._h, C.byref(flag)))
-        return bool(flag.value)
-
     def close(self):
         if self._h:
             self._lib.cr_explicit_batch_destroy(self._h)

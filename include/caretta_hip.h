@@ -280,10 +280,6 @@ int cr_explicit_batch_create(cr_context *ctx, const double *S, int64_t s_elems, 
 int cr_explicit_batch_destroy(cr_explicit_batch *b);
 /* device time (ms, HIP events on the context's stream) of the kernels of the last batch call */
 int cr_explicit_batch_last_ms(cr_explicit_batch *b, float *ms);
-/* *service = 1 when the last traced call (cr_smith_waterman_batch / cr_dtw_align_batch) ran its walks by the walk service --
- * persistent walker waves on a second stream beside the fill launch (lists that fill the chip; caretta_amd/csrc/cr_explicit_batch.h) --
- * 0 when every problem's walk followed its fill in the same wave.  Diagnostic; the results are the same.  No reference counterpart. */
-int cr_explicit_batch_last_service(cr_explicit_batch *b, int *service);
 /* scores[count] = smith_waterman_score(seq1_k, seq2_k, S_k, gap)      dynamic_time_warping.py:205-222 */
 int cr_smith_waterman_score_batch(cr_explicit_batch *b, double gap, double *scores);
 /* smith_waterman WITH its traceback (dynamic_time_warping.py:226-278) of every problem: aln i64[count][2][aln_stride] = the

@@ -428,64 +428,6 @@ def test_smith_waterman_gap0_traceback_on_the_row_sweep(oracle, monkeypatch):
         engine.reload_config()
 
 
-def test_walk_service_beside_the_fill(oracle, monkeypatch):
-    """Lists that fill the chip run their walks by persistent walker waves on a second stream BESIDE the fill launch (the walk
-    service: a queue of finished problems, decision words written through and copied into the walker's LDS) -- smith_waterman
-    with gap 0 on the row sweep by default from 2 048 problems on, dtw_align only when forced (it loses there).  Against the
-    oracle: ragged problems, ties, single rows; forced for a short list; a list whose largest decision array does not fit the
-    walkers' LDS (falls back to the walk in the fill's wave); 2 600 problems (more than the 768 walkers); and switched off."""
-    from caretta_amd import dynamic_time_warping as dtw, engine
-    rng = np.random.default_rng(9601)
-    ar = np.arange
-    small = [(1, 1), (5, 64), (64, 65), (37, 128), (150, 150), (300, 300), (90, 320), (300, 17), (1, 70), (70, 1)]
-    big = small + [(33, 700), (257, 513), (12, 1100)]
-    def make(shapes):
-        out = [(ar(n), ar(m), rng.uniform(size=(n, m)) ** 3 - 0.1) for n, m in shapes]
-        return out + [(ar(n), ar(m), rng.integers(0, 2, size=(n, m)).astype(np.float64)) for n, m in shapes[2:8]]
-    def check(batch, problems, want_sw, want_dtw, sw_service, dtw_service):
-        got = batch.smith_waterman(0.0)
-        assert batch.last_walk_service() == sw_service
-        for k in list(range(len(problems))) + list(range(len(got) - len(problems), len(got))):
-            a1, a2, score = got[k]
-            r1, r2, rs, _none = want_sw[k % len(problems)]
-            assert np.array_equal(a1, r1) and np.array_equal(a2, r2) and score == rs, ("sw", k)
-        got = batch.dtw_align(1.0, 0.01)
-        assert batch.last_walk_service() == dtw_service
-        for k in list(range(len(problems))) + list(range(len(got) - len(problems), len(got))):
-            a1, a2, score = got[k]
-            r1, r2, rs = want_dtw[k % len(problems)][:3]
-            assert np.array_equal(a1, r1) and np.array_equal(a2, r2) and score == rs, ("dtw", k)
-    p_small, p_big = make(small), make(big)
-    oracle_of = lambda ps: ([oracle.smith_waterman(*p, 0.0) for p in ps], [oracle.dtw_align(*p, 1.0, 0.01) for p in ps])
-    w_small, w_big = oracle_of(p_small), oracle_of(p_big)
-    try:
-        # default: a short list walks in the fill's wave; 2 608 problems: smith_waterman on the service, dtw_align not
-        b = dtw.ExplicitBatch(p_small)
-        check(b, p_small, *w_small, False, False)
-        b.close()
-        b = dtw.ExplicitBatch(p_small * 163)
-        check(b, p_small, *w_small, True, False)
-        b.close()
-        monkeypatch.setenv("CARETTA_FORCE_WALK_SERVICE", "1")
-        engine.reload_config()
-        b = dtw.ExplicitBatch(p_small)
-        check(b, p_small, *w_small, True, True)
-        b.close()
-        b = dtw.ExplicitBatch(p_big)                   # 257 x 513: 70 KB of decision words -- no walker holds them
-        check(b, p_big, *w_big, False, True)
-        b.close()
-        monkeypatch.delenv("CARETTA_FORCE_WALK_SERVICE")
-        monkeypatch.setenv("CARETTA_NO_WALK_SERVICE", "1")
-        engine.reload_config()
-        b = dtw.ExplicitBatch(p_small * 163)
-        check(b, p_small, *w_small, False, False)
-        b.close()
-    finally:
-        monkeypatch.delenv("CARETTA_FORCE_WALK_SERVICE", raising=False)
-        monkeypatch.delenv("CARETTA_NO_WALK_SERVICE", raising=False)
-        engine.reload_config()
-
-
 @pytest.mark.parametrize("num,length,seed,limit", [(512, 300, 20243, 1.5), (64, 1200, 20244, None)])
 def test_multi_device_loopback_eight_shares(ctx, num, length, seed, limit, monkeypatch):
     """cr_multi_* with EIGHT shares on the one GPU of the box (loopback: the gather is device copies; the deal, the parked host

@@ -24,14 +24,13 @@ def main():
     idx = np.arange(n)
     batch = dtw.ExplicitBatch([(idx, idx, base[k % 64]) for k in range(count)])
     nbytes = 8.25 * batch.cells + 24.0 * count * 2 * n + 8.0 * count
-    variants = [("row sweep, walks beside the fill (product)", {}), ("row sweep + walk in the fill's wave", {"CARETTA_NO_WALK_SERVICE": "1"}),
-                ("row sweep, fill only", {"CARETTA_SW_ROWS_NOWALK": "1"}),
+    variants = [("row sweep + walk (product)", {}), ("row sweep, fill only", {"CARETTA_SW_ROWS_NOWALK": "1"}),
                 ("row sweep + walk, 5 waves/SIMD build", {"CARETTA_SW_ROWS_WAVES": "5"}), ("row sweep + walk, 3 waves/SIMD build", {"CARETTA_SW_ROWS_WAVES": "3"}),
                 ("fill only, 5 waves/SIMD build", {"CARETTA_SW_ROWS_WAVES": "5", "CARETTA_SW_ROWS_NOWALK": "1"}),
                 ("skewed sweep + walk launch (round 5)", {"CARETTA_NO_SW_ROWS": "1"})]
     for name, env in variants:
         for k in list(os.environ):
-            if k.startswith("CARETTA_SW_ROWS") or k in ("CARETTA_NO_SW_ROWS", "CARETTA_NO_WALK_SERVICE"):
+            if k.startswith("CARETTA_SW_ROWS") or k == "CARETTA_NO_SW_ROWS":
                 del os.environ[k]
         os.environ.update(env)
         engine.reload_config()
@@ -41,20 +40,13 @@ def main():
             batch.smith_waterman(0.0)
             ms.append(batch.last_kernel_ms())
         print(f"{name:45s}: {min(ms):.3f} ms (median {sorted(ms)[1]:.3f}) -> {nbytes / min(ms) / 1e6:.0f} GB/s = {nbytes / min(ms) / 1e6 / 8000:.3f} of peak", flush=True)
-    # dtw_align with its traceback: walks beside the fill / in the fill's wave
     nb = 8.5 * batch.cells + 24.0 * count * 2 * n + 8.0 * count
-    for name, env in [("dtw_align, walks beside the fill (product)", {}), ("dtw_align, walk in the fill's wave", {"CARETTA_NO_WALK_SERVICE": "1"})]:
-        os.environ.pop("CARETTA_NO_WALK_SERVICE", None)
-        os.environ.update(env)
-        engine.reload_config()
+    batch.dtw_align(1.0, 0.01, want_alignments=True)
+    ms = []
+    for _ in range(3):
         batch.dtw_align(1.0, 0.01, want_alignments=True)
-        ms = []
-        for _ in range(3):
-            batch.dtw_align(1.0, 0.01, want_alignments=True)
-            ms.append(batch.last_kernel_ms())
-        print(f"{name:45s}: {min(ms):.3f} ms (median {sorted(ms)[1]:.3f}) -> {nb / min(ms) / 1e6:.0f} GB/s = {nb / min(ms) / 1e6 / 8000:.3f} of peak", flush=True)
-    os.environ.pop("CARETTA_NO_WALK_SERVICE", None)
-    engine.reload_config()
+        ms.append(batch.last_kernel_ms())
+    print(f"{'dtw_align with its traceback':45s}: {min(ms):.3f} ms (median {sorted(ms)[1]:.3f}) -> {nb / min(ms) / 1e6:.0f} GB/s = {nb / min(ms) / 1e6 / 8000:.3f} of peak", flush=True)
     batch.close()
 
 
