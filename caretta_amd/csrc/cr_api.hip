@@ -644,7 +644,6 @@ int launch_align_team(int R, cr_batch* b, const cr_batch::Chunk& ck, const cr_pa
 }  // namespace
 
 #include "cr_staged.h"      // scores formed by their own launches: kernels and launchers
-#include "cr_tree.h"        // the whole guide tree in one persistent launch
 
 namespace {
 

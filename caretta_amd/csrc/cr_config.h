@@ -37,7 +37,6 @@ struct Calibration {
     bool no_wide = false;            // CARETTA_NO_WIDE
     bool sw_rows_nowalk = false;     // CARETTA_SW_ROWS_NOWALK: measurement only -- the fill of k_sw_trace_rows without its walk (results are then wrong)
     int sw_rows_waves = 0;           // CARETTA_SW_ROWS_WAVES=3|5: measurement only -- k_sw_trace_rows<5> built for that many waves per SIMD
-    bool tree_resident = true;       // CARETTA_TREE_RESIDENT=0: the progressive alignment level by level (five launches per level, as round 5)
     bool no_sw_rows = false;         // CARETTA_NO_SW_ROWS: smith_waterman lists with gap 0 on the skewed sweep + walk launch (the path before round 6)
     bool trio = true;                // CARETTA_TRIO=0 switches the split by function off
     bool mid = true;                 // CARETTA_MID=0 switches the mid-size row split off
@@ -92,7 +91,6 @@ struct Calibration {
         c.no_team = env_set("CARETTA_NO_TEAM");
         c.no_wide = env_set("CARETTA_NO_WIDE");
         c.no_sw_rows = env_set("CARETTA_NO_SW_ROWS");
-        c.tree_resident = env_on("CARETTA_TREE_RESIDENT");
         c.sw_rows_nowalk = env_set("CARETTA_SW_ROWS_NOWALK");
         c.trio = env_on("CARETTA_TRIO");
         c.mid = env_on("CARETTA_MID");

@@ -343,158 +343,6 @@ int run_tree_planned(cr_progressive* h, const std::vector<std::vector<int64_t>>&
     return CR_OK;
 }
 
-
-// The whole tree in ONE persistent launch (cr_tree.h): applicable where run_tree_planned's staged path is, with one or two rows
-// per lane (bound <= 1 024) and a tensor width the kernel is instantiated for.  Returns 1 when it does not apply, when a node
-// outgrew the bound or when a poll gave up: the caller then runs run_tree_planned / the level-by-level path.
-template <int D, int R>
-int launch_tree_resident(bool flexible, unsigned grid, size_t lds, hipStream_t stream, const cr::PlanNode* plan, int num_nodes, int P, int bound,
-                         cr::TreeCtl* ctl, uint32_t* done, int64_t* len, int64_t* off, int64_t arena_base, double* coords, double* tensors, int d,
-                         double* weights, const cr_params& prm, double gamma_weight, double* staged, const cr::StagedShape shape, int tc_tensor,
-                         int tc_node, uint32_t* dirs, int64_t dirs_words, uint32_t* bits, int64_t bits_words, int32_t* aln, cr::NodeOut* outs) {
-    auto go = [&](auto kernel) -> int {
-        int rc = allow_lds(kernel, lds);
-        if (rc) return rc;
-        CR_LAUNCH(kernel, dim3(grid), dim3(shape.waves * cr::kWave), lds, stream, plan, num_nodes, P, bound, ctl, done, len, off, arena_base, coords,
-                  tensors, d, weights, prm.gamma_tensor, prm.gamma_coords, gamma_weight, prm.sw_gap, prm.gap_open, prm.gap_extend, staged, shape,
-                  tc_tensor, tc_node, dirs, dirs_words, bits, bits_words, aln, outs, (int)crcfg::env_ll("CARETTA_TREE_DBG", 0));
-        CR_HIP(hipGetLastError());
-        return CR_OK;
-    };
-    return flexible ? go(cr::k_tree_resident<D, R, true>) : go(cr::k_tree_resident<D, R, false>);
-}
-
-int run_tree_resident(cr_progressive* h, const std::vector<std::vector<int64_t>>& by_level, const cr_params& prm, double gamma_weight,
-                      const char** why) {
-    cr_batch& b = h->scratch;
-    hipStream_t stream = h->ctx->stream;
-    const int64_t P = h->P, total = h->used, num_nodes = P - 1;
-    int64_t longest = 0;
-    for (int64_t s = 0; s < P; s++) longest = std::max(longest, h->len[(size_t)s]);
-    const int bound = (int)std::min<int64_t>(cr::kStagedMaxRows, (longest * 3 + 1) / 2 + 8);
-    *why = "the resident tree serves structures of at most 1 024 x 2 / 3 rows";
-    if (longest > bound || bound > 2 * cr::kStagedMaxWaves * cr::kWave) return 1;
-    *why = "CARETTA_NO_TEAM / CARETTA_STAGED=0 / CARETTA_TREE_RESIDENT=0";
-    if (g_cfg.no_team || !g_cfg.staged || !g_cfg.tree_resident) return 1;
-    *why = "a tree of more than 65 535 nodes";
-    if (num_nodes > 65535) return 1;
-    const cr::StagedShape shape = staged_shape(bound, bound);
-    // one workgroup per CU at most (all resident: a waiting workgroup waits for workgroups that run), one per node at most
-    int cus = 0;
-    CR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->ctx->device));
-    int64_t widest_level = 0;
-    for (int64_t lv = 1; lv <= h->levels; lv++) widest_level = std::max<int64_t>(widest_level, (int64_t)by_level[(size_t)lv].size());
-    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(cus, widest_level), num_nodes));
-
-    // the plan: every internal node in level order (a node's children hold smaller tickets)
-    std::vector<cr::PlanNode> plan;
-    plan.reserve((size_t)num_nodes);
-    for (int64_t lv = 1; lv <= h->levels; lv++)
-        for (int64_t id : by_level[(size_t)lv]) {
-            const int64_t c1 = h->child1[(size_t)id], c2 = h->child2[(size_t)id];
-            const double tot = (double)(h->members[(size_t)c1] + h->members[(size_t)c2]);
-            plan.push_back(cr::PlanNode{(int32_t)c1, (int32_t)c2, (int32_t)id, 0, (double)h->members[(size_t)c2] / (2.0 * tot),
-                                        (double)h->members[(size_t)c1] / (2.0 * tot)});
-        }
-    int rc = arena_reserve(h, total + num_nodes * 2 * (int64_t)bound);
-    if (rc) return rc;
-    const int R = shape.r;
-    const int64_t dirs_words = (int64_t)cr::strips_of(bound, R) * cr::tblocks(bound, 16) * R * cr::kWave;
-    const int64_t bits_words = (int64_t)cr::strips_of(bound, R) * cr::tblocks(bound, 8) * R * cr::kWave;
-    const int64_t aln_total = num_nodes * 4 * (int64_t)bound;
-    // steps per staging pass: the window of columns (width + 63) of the widest provider in at most 48 KB of LDS
-    auto steps_for = [&](int col_doubles) {
-        const int fit = (int)(48 * 1024 / sizeof(double) / (size_t)col_doubles) - (cr::kWave - 1);
-        return std::max(cr::kStagedBlock, std::min(fit, bound + cr::kWave) / cr::kStagedBlock * cr::kStagedBlock);
-    };
-    const int tc_tensor = steps_for(b.d_pad + (h->flexible ? 1 : 0)), tc_node = steps_for(cr::RbfNode<1>::kColDoubles);
-    size_t lds_doubles = std::max(cr::stage_lds_doubles(b.d_pad + (h->flexible ? 1 : 0), tc_tensor), cr::stage_lds_doubles(cr::RbfNode<1>::kColDoubles, tc_node));
-    lds_doubles = std::max(lds_doubles, cr::sweep_staged_lds_doubles<cr::kDtw>(shape.waves));
-    lds_doubles = std::max(lds_doubles, cr::sweep_staged_lds_doubles<cr::kSwTrace>(shape.waves));
-    lds_doubles = std::max(lds_doubles, (size_t)cr::kExpDoubles + cr::trace_team_lds_doubles(2 * bound));
-    *why = "the node kernel's LDS";
-    if (sizeof(double) * lds_doubles > 150 * 1024) return 1;
-
-    // ctl | done[2P-1] | plan | len | off in ONE device block and ONE upload
-    const size_t nids = (size_t)(2 * P - 1);
-    const size_t o_done = 16, o_plan = (o_done + sizeof(uint32_t) * nids + 15) / 16 * 16, o_len = o_plan + (sizeof(cr::PlanNode) * plan.size() + 15) / 16 * 16;
-    const size_t o_off = o_len + sizeof(int64_t) * nids, meta_bytes = o_off + sizeof(int64_t) * nids;
-    DevBuf<char> d_meta;
-    CR_HIP(d_meta.ensure(meta_bytes));
-    CR_HIP(h->d_outs.ensure((size_t)num_nodes));
-    CR_HIP(b.dirs.ensure((size_t)(grid * dirs_words)));
-    CR_HIP(b.bits.ensure((size_t)(grid * bits_words)));
-    CR_HIP(b.aln.ensure((size_t)aln_total));
-    CR_HIP(h->staged.ensure((size_t)((int64_t)grid * shape.pair_doubles())));
-    {
-        std::vector<char> meta(meta_bytes, 0);
-        uint32_t* done = reinterpret_cast<uint32_t*>(meta.data() + o_done);
-        for (int64_t s = 0; s < P; s++) done[s] = 1u;                  // the leaves are there
-        std::memcpy(meta.data() + o_plan, plan.data(), sizeof(cr::PlanNode) * plan.size());
-        std::memcpy(meta.data() + o_len, h->len.data(), sizeof(int64_t) * nids);
-        std::memcpy(meta.data() + o_off, h->off.data(), sizeof(int64_t) * nids);
-        CR_UPLOAD(h->ctx, d_meta.p, meta.data(), meta_bytes);
-        CR_HIP(hipStreamSynchronize(stream));
-    }
-    cr::TreeCtl* d_ctl = reinterpret_cast<cr::TreeCtl*>(d_meta.p);
-    uint32_t* d_done = reinterpret_cast<uint32_t*>(d_meta.p + o_done);
-    const cr::PlanNode* d_plan = reinterpret_cast<const cr::PlanNode*>(d_meta.p + o_plan);
-    int64_t* d_len = reinterpret_cast<int64_t*>(d_meta.p + o_len);
-    int64_t* d_off = reinterpret_cast<int64_t*>(d_meta.p + o_off);
-    const size_t lds = sizeof(double) * lds_doubles;
-    auto launch = [&](auto dt, auto rt) -> int {
-        return launch_tree_resident<decltype(dt)::value, decltype(rt)::value>(
-            h->flexible, grid, lds, stream, d_plan, (int)num_nodes, (int)P, bound, d_ctl, d_done, d_len, d_off, total, b.coords.p, b.tensors.p, (int)h->d,
-            h->weights.p, prm, gamma_weight, h->staged.p, shape, tc_tensor, tc_node, b.dirs.p, dirs_words, b.bits.p, bits_words, b.aln.p, h->d_outs.p);
-    };
-    auto by_r = [&](auto dt) -> int { return R == 1 ? launch(dt, std::integral_constant<int, 1>{}) : launch(dt, std::integral_constant<int, 2>{}); };
-    *why = "no resident-tree kernel for this tensor width";
-    switch (b.d_pad) {
-        case 4: rc = by_r(std::integral_constant<int, 4>{}); break;
-        case 8: rc = by_r(std::integral_constant<int, 8>{}); break;
-        case 10: rc = by_r(std::integral_constant<int, 10>{}); break;
-        case 16: rc = by_r(std::integral_constant<int, 16>{}); break;
-        default: return 1;
-    }
-    if (rc) return rc;
-    // one read-back for the whole tree
-    std::vector<cr::NodeOut> outs((size_t)num_nodes);
-    std::vector<int32_t> rows_host((size_t)aln_total);
-    cr::TreeCtl ctl{};
-    {
-        const size_t b_outs = sizeof(cr::NodeOut) * (size_t)num_nodes, b_rows = sizeof(int32_t) * (size_t)aln_total;
-        const size_t a_ctl = (b_outs + 15) / 16 * 16, a_rows = a_ctl + 16;
-        void* land_v = nullptr;
-        if ((rc = host_landing(h->ctx, a_rows + b_rows, &land_v))) return rc;
-        char* land = static_cast<char*>(land_v);
-        CR_HIP(hipMemcpyAsync(land, h->d_outs.p, b_outs, hipMemcpyDeviceToHost, stream));
-        CR_HIP(hipMemcpyAsync(land + a_ctl, d_meta.p, sizeof(cr::TreeCtl), hipMemcpyDeviceToHost, stream));
-        CR_HIP(hipMemcpyAsync(land + a_rows, b.aln.p, b_rows, hipMemcpyDeviceToHost, stream));
-        CR_HIP(hipStreamSynchronize(stream));
-        std::memcpy(outs.data(), land, b_outs);
-        std::memcpy(&ctl, land + a_ctl, sizeof(ctl));
-        std::memcpy(rows_host.data(), land + a_rows, b_rows);
-    }
-    *why = ctl.abort ? "a workgroup of the resident tree gave up waiting for a child node" : "a tree node outgrew the launch bound (1.5 x the longest structure)";
-    if (ctl.abort || ctl.overflow) return 1;
-    for (size_t x = 0; x < plan.size(); x++) {
-        const cr::PlanNode& pn = plan[x];
-        const int64_t k = pn.id - P, cap = h->len[(size_t)pn.c1] + h->len[(size_t)pn.c2];
-        const cr::NodeOut& no = outs[x];
-        h->len[(size_t)pn.id] = no.len;
-        h->off[(size_t)pn.id] = total + (int64_t)x * 2 * bound + no.first;
-        h->flags[(size_t)k] = no.flags;
-        h->any_flags |= no.flags;
-        std::vector<int32_t>& a = h->aln[(size_t)k];
-        a.resize((size_t)(2 * no.len));
-        const int32_t* src = rows_host.data() + (int64_t)x * 4 * bound;
-        std::copy(src + no.first, src + no.first + no.len, a.begin());
-        std::copy(src + cap + no.first, src + cap + no.first + no.len, a.begin() + no.len);
-    }
-    h->used = total + num_nodes * 2 * (int64_t)bound;
-    return CR_OK;
-}
-
 }  // namespace
 
 extern "C" {
@@ -615,13 +463,7 @@ static int progressive_align_impl(cr_context* ctx, const double* coords, const d
     std::vector<std::vector<int64_t>> by_level((size_t)h->levels + 1);
     for (int64_t id = P; id < num_ids; id++) by_level[(size_t)h->level[(size_t)id]].push_back(id);
     const char* why = "CARETTA_SYNC_LEVELS is set";
-    rc = g_cfg.sync_levels ? 1 : run_tree_resident(h, by_level, prm, gamma_weight, &why);
-    if (rc == 1 && !g_cfg.sync_levels) {                 // the persistent launch does not apply (or gave up): level by level, still without host round trips
-        h->used = total;
-        h->any_flags = 0;
-        for (int64_t s = 0; s < P; s++) h->len[(size_t)s] = offsets[s + 1] - offsets[s];
-        rc = run_tree_planned(h, by_level, prm, gamma_weight, &why);
-    }
+    rc = g_cfg.sync_levels ? 1 : run_tree_planned(h, by_level, prm, gamma_weight, &why);
     if (rc < 0) return rc;
     if (rc == 1 && flexible)                         // (CR_ERR_STATE = "not served by the device path": the host module then walks the tree itself)
         return fail(CR_ERR_STATE, std::string("flexible progressive alignment is not served by the resident-tree path here: ") + why);

@@ -69,48 +69,6 @@ CR_D void stage_block(Src& src, const int n, const int m, const int tc, double* 
     }
 }
 
-// The same lines for ALL steps of the pair by ONE workgroup, `tc` steps per pass (the resident tree of cr_tree.h: a node's own
-// workgroup forms its scores between its sweeps).  The exp table and the rows are loaded once; every pass brings its window
-// of columns through LDS.  Same provider code, same values, same zeros outside [0, m) as stage_block.
-template <int R, class Src>
-CR_D void stage_whole(Src& src, const int n, const int m, const int tc, double* __restrict__ pair_base, const StagedShape shape,
-                      double* lds) {
-    constexpr int kBack = kWave - 1;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int t_end = (m + kBack + kStagedBlock - 1) / kStagedBlock * kStagedBlock;
-    const int stride = tc + kBack;
-    const ExpEntry* tab = reinterpret_cast<const ExpEntry*>(lds);
-    double* res = lds + kExpDoubles;
-    load_exp_table(lds, threadIdx.x);
-    const bool mine = w * kWave * R < n;
-    if (mine) src.load_rows((w * kWave + lane) * R, n);    // rows past n: the far-away features whose score is exactly 0
-    double* __restrict__ out = pair_base + (int64_t)w * shape.strip_doubles() + lane;
-    for (int t0 = 0; t0 < t_end; t0 += tc) {
-        const int c_lo = t0 - kBack > 0 ? t0 - kBack : 0;
-        const int c_hi = t0 + tc < m ? t0 + tc : m;
-        __syncthreads();                                   // (the previous pass's window has been read; first pass: the exp table)
-        src.load_resident_range(res, stride, c_lo, c_hi, (int)threadIdx.x, (int)blockDim.x);
-        __syncthreads();
-        if (mine) {
-            const int t1 = t0 + tc < t_end ? t0 + tc : t_end;
-            for (int t = t0; t < t1; t++) {
-                const int c = t - lane;
-                if ((unsigned)c < (unsigned)m) {
-                    src.fetch_resident(res, stride, c - c_lo);
-#pragma unroll
-                    for (int q = 0; q < R; q++) out[((int64_t)t * R + q) * kWave] = src.score(q, tab);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < R; q++) out[((int64_t)t * R + q) * kWave] = 0.0;
-                }
-            }
-        }
-    }
-    __threadfence_block();
-    __syncthreads();                                       // the lines are there for every wave of the workgroup; the LDS is free
-}
-
 __host__ __device__ inline size_t stage_lds_doubles(int col_doubles, int tc) {
     return kExpDoubles + (size_t)col_doubles * (tc + kWave - 1);
 }
@@ -199,13 +157,21 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_stage_coords(const P
 
 // Seed stage on staged scores: SW fill with one wave per strip, then
 // traceback (wave 0) + seed Kabsch (the ordered sums by the whole workgroup), as the first half of k_pair_wide.
-// (the body of k_seed_staged; `strip`: this WAVE's strip of the pair's staged scores; every thread returns the transform)
 template <bool ZG, int R>
-CR_D void seed_staged_body(const PairDesc& pd, const double* __restrict__ coords, const double sw_gap, const int max_entries,
-                           const double* __restrict__ strip, uint32_t* __restrict__ dirs, double* lds, SeedMax& sm, Transform& tr) {
+__global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_seed_staged(const PairDesc* __restrict__ pairs,
+                                                                     const double* __restrict__ coords, double sw_gap,
+                                                                     int max_entries, const double* __restrict__ staged,
+                                                                     const StagedShape shape, uint32_t* __restrict__ dirs,
+                                                                     Transform* __restrict__ xf,
+                                                                     double* __restrict__ seed_score) {
+    extern __shared__ double lds[];
+    CR_STAMP(0);
+    const PairDesc pd = pairs[blockIdx.x];
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    SeedMax sm;
     AlignEnd unused;
     {
+        const double* strip = staged + (int64_t)blockIdx.x * shape.pair_doubles() + (int64_t)w * shape.strip_doubles();
         const StripGeom geom = WidePlan<R>{0}.geom(w, pd.n);
         SweepParams prm{sw_gap, 0.0, 0.0};
         // (until round 5 the gap-0 seed of one or two rows per lane was a column sweep on an unskewed layout; the skewed sweep
@@ -231,6 +197,7 @@ CR_D void seed_staged_body(const PairDesc& pd, const double* __restrict__ coords
     }
     __syncthreads();
     const int k = s_walk[0];
+    Transform tr;
 #pragma unroll
     for (int x = 0; x < 3; x++) tr.c1[x] = tr.c2[x] = 0.0;
 #pragma unroll
@@ -245,25 +212,6 @@ CR_D void seed_staged_body(const PairDesc& pd, const double* __restrict__ coords
         kabsch_team(coords + pd.off_i * 3, coords + pd.off_j * 3, seed_list + (cap - k), k, k, terms, terms + kSumTile * kMaxAcc + kSumSlack,
                     tr.c1, tr.c2, tr.R, t);
     }
-}
-
-// Seed stage on staged scores: SW fill with one wave per strip, then
-// traceback (wave 0) + seed Kabsch (the ordered sums by the whole workgroup), as the first half of k_pair_wide.
-template <bool ZG, int R>
-__global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_seed_staged(const PairDesc* __restrict__ pairs,
-                                                                     const double* __restrict__ coords, double sw_gap,
-                                                                     int max_entries, const double* __restrict__ staged,
-                                                                     const StagedShape shape, uint32_t* __restrict__ dirs,
-                                                                     Transform* __restrict__ xf,
-                                                                     double* __restrict__ seed_score) {
-    extern __shared__ double lds[];
-    CR_STAMP(0);
-    const PairDesc pd = pairs[blockIdx.x];
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    SeedMax sm;
-    Transform tr;
-    seed_staged_body<ZG, R>(pd, coords, sw_gap, max_entries, staged + (int64_t)blockIdx.x * shape.pair_doubles() + (int64_t)w * shape.strip_doubles(),
-                            dirs, lds, sm, tr);
     if (threadIdx.x == 0) {
         xf[blockIdx.x] = tr;
         seed_score[blockIdx.x] = sm.score;
@@ -275,20 +223,29 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_seed_staged(const Pa
 // workgroup, what node_finish does behind it: the superposition on the aligned positions and the merged node.
 // FLEX: flexible=True in score and mean function -- no seed, no superposition, no coordinates: the node is its mean tensors and
 // consensus weights (multiple_alignment.py:351-362); `coords`, `xfs` and `Xn_base` are not touched.
-// (the body of k_node_staged; `strip`: this WAVE's strip of the node's staged scores; `seed_flags`: the flags of the seed
-// superposition; thread 0's `no` is the node's record)
-template <int R, bool FLEX>
-CR_D void node_staged_body(const PairDesc& pd, const NodeDesc& nd, const double* coords, const double* tensors, const int d,
-                           const double* weights, const uint32_t seed_flags, const double gap_open, const double gap_extend,
-                           const int max_entries, const double* __restrict__ strip, uint32_t* __restrict__ bits_base,
-                           int32_t* __restrict__ aln_base, double* Xn_base, double* Tn_base, double* Wn_base, double* lds, NodeOut& no) {
+template <int R, bool FLEX = false>
+__global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_node_staged(const PairDesc* __restrict__ pairs, const double* coords,
+                                                                     const double* tensors, int d, const double* weights,
+                                                                     const NodeDesc* __restrict__ nodes,
+                                                                     const Transform* __restrict__ xfs, double gap_open,
+                                                                     double gap_extend, int max_entries,
+                                                                     const double* __restrict__ staged, const StagedShape shape,
+                                                                     uint32_t* __restrict__ bits_base,
+                                                                     int32_t* __restrict__ aln_base, double* Xn_base,
+                                                                     double* Tn_base, double* Wn_base,
+                                                                     NodeOut* __restrict__ outs) {
+    extern __shared__ double lds[];
+    CR_STAMP(4);
+    const PairDesc pd = pairs[blockIdx.x];
+    const NodeDesc nd = nodes[blockIdx.x];
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t* bits = bits_base + pd.bt_off;
     SeedMax unused;
     AlignEnd e;
     {
         SweepParams prm{0.0, gap_open, gap_extend};
-        sweep_staged<R, kDtw>(strip, pd.n, pd.m, prm, lds, nullptr, bits, unused, e, WidePlan<R>{0}.geom(w, pd.n));
+        sweep_staged<R, kDtw>(staged + (int64_t)blockIdx.x * shape.pair_doubles() + (int64_t)w * shape.strip_doubles(), pd.n, pd.m,
+                              prm, lds, nullptr, bits, unused, e, WidePlan<R>{0}.geom(w, pd.n));
     }
     // wave 0 walks; superposition sums and the merged node by the whole workgroup (node_finish with all hands)
     __shared__ int s_walk[4];
@@ -317,7 +274,7 @@ CR_D void node_staged_body(const PairDesc& pd, const NodeDesc& nd, const double*
     double* Xn = Xn_base + nd.out_off * 3;
     double* Tn = Tn_base + nd.out_off * d;
     double* Wn = Wn_base + nd.out_off;
-    uint32_t flags = FLEX ? 0u : seed_flags;
+    uint32_t flags = FLEX ? 0u : xfs[blockIdx.x].flags;
     double c1[3] = {0, 0, 0}, c2[3] = {0, 0, 0}, Rm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3];
     const bool superpose = !FLEX && k > 3;               // multiple_alignment.py:364
     if constexpr (!FLEX) {
@@ -353,33 +310,14 @@ CR_D void node_staged_body(const PairDesc& pd, const NodeDesc& nd, const double*
         if (has2) wsum += W2[j];
         Wn[o] = wsum;
     }
-    no.len = idx;
-    no.first = first;
-    no.flags = flags;
-    no.pad = 0;
-}
-
-template <int R, bool FLEX = false>
-__global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_node_staged(const PairDesc* __restrict__ pairs, const double* coords,
-                                                                     const double* tensors, int d, const double* weights,
-                                                                     const NodeDesc* __restrict__ nodes,
-                                                                     const Transform* __restrict__ xfs, double gap_open,
-                                                                     double gap_extend, int max_entries,
-                                                                     const double* __restrict__ staged, const StagedShape shape,
-                                                                     uint32_t* __restrict__ bits_base,
-                                                                     int32_t* __restrict__ aln_base, double* Xn_base,
-                                                                     double* Tn_base, double* Wn_base,
-                                                                     NodeOut* __restrict__ outs) {
-    extern __shared__ double lds[];
-    CR_STAMP(4);
-    const PairDesc pd = pairs[blockIdx.x];
-    const NodeDesc nd = nodes[blockIdx.x];
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    NodeOut no;
-    node_staged_body<R, FLEX>(pd, nd, coords, tensors, d, weights, FLEX ? 0u : xfs[blockIdx.x].flags, gap_open, gap_extend, max_entries,
-                              staged + (int64_t)blockIdx.x * shape.pair_doubles() + (int64_t)w * shape.strip_doubles(), bits_base, aln_base,
-                              Xn_base, Tn_base, Wn_base, lds, no);
-    if (threadIdx.x == 0) outs[blockIdx.x] = no;
+    if (threadIdx.x == 0) {
+        NodeOut no;
+        no.len = idx;
+        no.first = first;
+        no.flags = flags;
+        no.pad = 0;
+        outs[blockIdx.x] = no;
+    }
     CR_STAMP(7);
 }
 

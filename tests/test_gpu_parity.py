@@ -950,53 +950,6 @@ def test_progressive_staged_scores_equal_fused(oracle, monkeypatch, num, length,
     assert np.array_equal(wn, a.final_consensus_weights[2 * num - 2])
 
 
-@pytest.mark.parametrize("num,length,ragged,seed,dim,flexible", [(24, 150, False, 5101, 10, False), (33, 335, False, 5102, 10, False),
-                                                                  (19, 140, True, 5103, 7, False), (12, 600, False, 5104, 16, False),
-                                                                  (5, 40, True, 5105, 4, False), (3, 90, False, 5106, 10, False),
-                                                                  (21, 200, True, 5107, 10, True), (9, 520, False, 5108, 8, True)])
-def test_resident_tree_equals_level_by_level(oracle, monkeypatch, num, length, ragged, seed, dim, flexible):
-    """The whole guide tree in ONE persistent launch (cr_tree.h: a workgroup per node, done words instead of level barriers, the
-    node's own workgroup forms its scores) against the level-by-level launches (CARETTA_TREE_RESIDENT=0): the alignment, every
-    node's coordinates / tensors / consensus weights, lengths and flags bit for bit -- one and two rows per lane, ragged
-    leaves, a two-leaf tree, padded and wide tensors, flexible=True -- and the root join against the oracle."""
-    from caretta_amd import multiple_alignment as ma, neighbor_joining as nj
-    fam = synthetic.make_family(num, length, dim=dim, seed=seed, ragged=ragged, clades=2)
-    prm = dict(flexible=flexible, gamma_tensor=7.0 if dim == 10 else 2.0, gamma_coords=0.03, verbose=False)
-    runs = []
-    tree = None
-    for resident in ("1", "0"):
-        monkeypatch.setenv("CARETTA_TREE_RESIDENT", resident)
-        prots = [ma.Protein(s.name, s.tensors, None if flexible else s.coordinates, "") for s in fam]
-        msa = ma.MultipleAlignment(prots)
-        if tree is None:
-            m = msa.make_pairwise_matrix(prm)
-            tree, _ = nj.neighbor_joining(m.max() - m)
-        aln = msa.progressive_align(tree, 1.0, 0.01, 1.0, 1.0, prm, dict(flexible=flexible, verbose=False))
-        runs.append((msa, aln))
-    (a, aln_a), (b, aln_b) = runs
-    assert np.array_equal(a.node_table, b.node_table)
-    for q in aln_a:
-        assert np.array_equal(aln_a[q], aln_b[q])
-    for k in range(num, 2 * num - 1):
-        if not flexible:
-            assert np.array_equal(a.final_sequences[k].coordinates, b.final_sequences[k].coordinates)
-        assert np.array_equal(a.final_sequences[k].tensors, b.final_sequences[k].tensors)
-        assert np.array_equal(a.final_consensus_weights[k], b.final_consensus_weights[k])
-    if not flexible and num > 2:
-        n1, n2 = _replay_tree(a, tree, num)[-1]
-        members = a.node_table[:, 5]
-        size = lambda x: 1 if x < num else int(members[x - num])
-        tot = size(n1) + size(n2)
-        s1, s2 = a.final_sequences[n1], a.final_sequences[n2]
-        from oracle.pyoracle import default_params
-        _, _, xn, tn, wn, _ = oracle.progressive_node(s1.coordinates, s1.tensors, a.final_consensus_weights[n1], s2.coordinates, s2.tensors,
-                                                      a.final_consensus_weights[n2], size(n2) / (2 * tot), size(n1) / (2 * tot),
-                                                      params=default_params(gamma_tensor=prm["gamma_tensor"], gamma_coords=0.03))
-        root = a.final_sequences[2 * num - 2]
-        assert np.array_equal(xn, root.coordinates) and np.array_equal(tn, root.tensors)
-        assert np.array_equal(wn, a.final_consensus_weights[2 * num - 2])
-
-
 def test_gamma_too_small_is_rejected(ctx):
     """gamma = 0 would make the scores of the padding rows 1.0 instead of 0.0: the fused kernels refuse it."""
     from caretta_amd import engine, synthetic as syn
