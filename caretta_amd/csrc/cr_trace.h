@@ -664,8 +664,9 @@ CR_D void dtw_walk(int n0, int m0, int max_entries, const uint32_t* __restrict__
     int n = __builtin_amdgcn_readfirstlane(n0), m = __builtin_amdgcn_readfirstlane(m0);
     int dir = __builtin_amdgcn_readfirstlane(start_layer), idx = 0, k = 0;
     wk.set_row(n - 1);
+    int guard = cap + 8;      // every iteration consumes a cell: damaged decision words can never hang the device (the rows are then wrong, not endless)
 #pragma unroll 1
-    while (n > 0 && m > 0) {
+    while (n > 0 && m > 0 && --guard >= 0) {
         const uint32_t nib = wk.get(n - 1, m - 1);
         // dynamic_time_warping.py:118-143.  In layer 1 the stored decision either keeps the walk on
         // the diagonal or switches layer at the SAME cell; the switch and the move it then makes in
