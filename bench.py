@@ -234,6 +234,10 @@ def main():
         try:
             import explicit_batch_rate
             extras["explicit_batch"] = explicit_batch_rate.explicit_record(8128, 300)
+            fam_rec = explicit_batch_rate.explicit_record(8128, 300, matrices="family")
+            extras["explicit_batch"]["family_matrices"] = {k: v for k, v in fam_rec["functions"].items() if "WITH" in k}
+            extras["explicit_batch"]["family_matrices"]["what"] = ("the same list with score matrices as the reference forms them (tensor RBF of two related "
+                                                                   "structures): a walk through random scores with free gaps is the worst case (runs of 1-2 cells)")
             tfile = bl.latest_profile("explicit_batch_pmc.json")
             if tfile is not None:
                 extras["explicit_batch"]["traffic_over_algorithmic"] = json.loads(tfile.read_text()).get("traffic_over_algorithmic")
