@@ -19,7 +19,9 @@ opt gpurun_out/${R}_pmc_c3share/summary.json $P/pmc_c3share.json
 opt gpurun_out/${R}_pmc_c5share/summary.json $P/pmc_c5share.json
 opt $O/explicit_batch_pmc.json $P/explicit_batch_pmc.json
 cp $O/multi_gpu_check_1device.json $P/multi_gpu_check_1device.json
-for f in msa_128.txt msa_512.txt ragged.txt c3_share.txt c3_stages.txt long_share_layouts.txt dropin_latency.txt explicit_batch_rate.txt stamps.txt stamps_c3share.txt; do strip $O/$f $P/$f; done
+for f in msa_128.txt msa_512.txt ragged.txt c3_share.txt c3_stages.txt long_share_layouts.txt dropin_latency.txt explicit_batch_rate.txt stamps.txt stamps_c3share.txt sw_rows_probe.txt; do strip $O/$f $P/$f; done
+opt $O/sstore_rate.txt $P/sstore_rate.txt
+if [ -f $O/bench_forced_dist.json ]; then tail -n 1 $O/bench_forced_dist.json > $P/bench_forced_dist.json; fi
 if [ -f $O/staged_vs_trio.txt ]; then strip $O/staged_vs_trio.txt $P/staged_vs_trio.txt; fi
 mkdir -p $FINAL
 cp $P/* $FINAL/

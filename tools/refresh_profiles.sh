@@ -27,6 +27,10 @@ python tools/long_share_layouts.py 64,900,77 2 4 8 >> $O/long_share_layouts.txt 
 python tools/multi_gpu_check.py 512 300 2>/dev/null | grep '^{' > $O/multi_gpu_check_1device.json
 python tools/dropin_latency.py > $O/dropin_latency.txt 2>&1
 python tools/explicit_batch_rate.py > $O/explicit_batch_rate.txt 2>&1
+python tools/sw_rows_probe.py > $O/sw_rows_probe.txt 2>&1
+if [ -x tools/sstore_rate.bin ]; then ./tools/sstore_rate.bin > $O/sstore_rate.txt 2>&1; fi
+# every branch of an N-rank bench line on this one GPU (RCCL process group with one rank, the N-ranks-against-one-GPU gates)
+CARETTA_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29555 bench.py --gpus 1 --steps 10 --repeats 3 > $O/bench_forced_dist.json 2> $O/bench_forced_dist.log
 # HBM counters of the batched explicit-matrix kernels (separate --pmc passes, --kernel-trace only)
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/explicit_$C -- python3 tools/explicit_batch_rate.py 8128 300 > $O/explicit_$C.log 2>&1
