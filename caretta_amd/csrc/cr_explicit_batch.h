@@ -381,6 +381,9 @@ __global__ __launch_bounds__(kWave, WAVES) void k_sw_trace_rows(const ExplicitPr
     sm.i = best_v > 0.0 ? best_i + 1 : 0;
     sm.j = best_v > 0.0 ? best_j + 1 : 0;
     if (lane == 0) seeds[blockIdx.x] = sm;
+    // (the walk is a chain of dependent scalar instructions on a SIMD it shares with three waves that wait for HBM most of the
+    // time: asking the arbiter for priority shortens the chain and costs the streams nothing)
+    __builtin_amdgcn_s_setprio(3);
     if (walk) sw_walk_transposed<CC>(words, n, m, sm, lds, aln + pb.aln_off, out + blockIdx.x);   // (walk == 0: calibration only)
 }
 
@@ -827,6 +830,7 @@ __global__ __launch_bounds__(kWave) void k_explicit_stream(const ExplicitProblem
     if constexpr (STORE && (MODE & kDtw) != 0) {
         if (aln) {                                        // (uniform) the walk on this wave's own decision words
             drain_stores();
+            __builtin_amdgcn_s_setprio(3);                // (a scalar chain beside waves that stream: see k_sw_trace_rows; medians 1.89-1.92 -> 1.84-1.85 ms)
             int len, pairs;
             dtw_walk<R>(pb.n, pb.m, max_entries, bits + pb.bits_off_s, ae.start_layer, lds, aln + pb.aln_off, len, pairs);
             if (threadIdx.x == 0) {
