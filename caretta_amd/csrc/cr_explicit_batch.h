@@ -40,6 +40,9 @@ struct __attribute__((packed, aligned(8))) Pair8 {
 // Problems whose columns are not contiguous (alphabet mode: seq2 arbitrary) gather their cells with per-lane loads.
 // Wider matrices take column strips one after the other; the last column of a strip goes to the next one through
 // `hand` (n doubles per problem).
+// Round 6: the row loads are range-checked BUFFER loads (zeros past the row's last column) and the transpose writes all 128 NV
+// loaded elements into a buffer that holds them -- no EXEC-masked branch is left in a row (a third of the scalar instructions and
+// their hazard nops went with them): 8 128 x 300 x 300 1.00 -> 0.95 ms (6.15 TB/s = 0.77 of peak, 0.98 of what a copy reaches).
 // ---------------------------------------------------------------------------------------------
 constexpr int kRowsInFlight = 4;
 
@@ -49,6 +52,7 @@ struct RowSweep {
     static constexpr int NV = (CC + 1) / 2;              // 16-byte loads per lane and row
     static constexpr int kStride = (CC % 2 == 0) ? CC + 1 : CC;   // LDS doubles per lane: odd, conflict-free reads
     static constexpr int kBufDoubles = kWave * kStride + 2;
+    static constexpr int kTraceBufDoubles = ((2 * NV * kWave + CC - 1) / CC) * kStride + 2;   // k_sw_trace_rows: room for all 128 NV loaded elements
 
     double hprev[CC];
     double left_prev;        // H[i-1][c0-1]: the strip's left neighbour column, previous row
@@ -121,6 +125,7 @@ __global__ __launch_bounds__(kWave) void k_sw_score_rows(const ExplicitProblem* 
                                                         const int32_t* __restrict__ seqs, double* __restrict__ hand,
                                                         double* __restrict__ scores) {
     using RS = RowSweep<CC>;
+    constexpr int kTraceBuf = RowSweep<CC>::kTraceBufDoubles;
     extern __shared__ double lds[];                      // two row buffers
     const ExplicitProblem pb = probs[blockIdx.x];
     const int lane = threadIdx.x;
@@ -146,14 +151,14 @@ __global__ __launch_bounds__(kWave) void k_sw_score_rows(const ExplicitProblem* 
                 Pair8 buf[kRowsInFlight][RS::NV];
                 auto issue = [&](int row, Pair8* dst) {
                     const double* rp = Sp + (int64_t)seq1[row] * pb.s_cols + pb.col0 + c0;
+                    // (buffer loads: the row's range check returns zeros past its last column -- no EXEC-masked branches around the
+                    // loads; the descriptor is built from wave-uniform values)
+                    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)rp);
+                    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uintptr_t)rp >> 32));
+                    auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uintptr_t)hi << 32) | lo), 0, cols * 8, 0x00020000);
 #pragma unroll
-                    for (int y = 0; y < RS::NV; y++) {
-                        const int k = 2 * (y * kWave + lane);
-                        Pair8 v{0.0, 0.0};
-                        if (k + 1 < cols) v = *reinterpret_cast<const Pair8*>(rp + k);
-                        else if (k < cols) v.a = rp[k];
-                        dst[y] = v;
-                    }
+                    for (int y = 0; y < RS::NV; y++)
+                        dst[y] = __builtin_bit_cast(Pair8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (y * kWave + lane) * 16, 0, 0));
                 };
 #pragma unroll
                 for (int u = 0; u < kRowsInFlight; u++)
@@ -165,15 +170,14 @@ __global__ __launch_bounds__(kWave) void k_sw_score_rows(const ExplicitProblem* 
                         const int i = i0 + u;
                         if (i < n) {
                             if (LEFT && (i & (kWave - 1)) == 0) left_vec = (i + lane < n) ? hcol[i + lane] : 0.0;
-                            double* rb = lds + (u & 1) * RS::kBufDoubles;
-                            // transpose: loaded element k (column c0 + k) belongs to lane k / CC, slot k % CC
+                            double* rb = lds + (u & 1) * kTraceBuf;
+                            // transpose: loaded element k (column c0 + k) belongs to lane k / CC, slot k % CC (the buffer holds all
+                            // 128 NV loaded elements: no lane is left out, no branch)
 #pragma unroll
                             for (int y = 0; y < RS::NV; y++) {
                                 const int k = 2 * (y * kWave + lane);
-                                if (k < RS::W) {
-                                    rb[(k / CC) * RS::kStride + k % CC] = buf[u][y].a;
-                                    rb[((k + 1) / CC) * RS::kStride + (k + 1) % CC] = buf[u][y].b;
-                                }
+                                rb[(k / CC) * RS::kStride + k % CC] = buf[u][y].a;
+                                rb[((k + 1) / CC) * RS::kStride + (k + 1) % CC] = buf[u][y].b;
                             }
                             if (i + kRowsInFlight < n) issue(i + kRowsInFlight, buf[u]);
                             wave_sync();
@@ -247,6 +251,7 @@ __global__ __launch_bounds__(kWave, WAVES) void k_sw_trace_rows(const ExplicitPr
                                                         SeedMax* __restrict__ seeds, int32_t* __restrict__ aln,
                                                         BatchTrace* __restrict__ out, const int walk) {
     using RS = RowSweep<CC>;
+    constexpr int kTraceBuf = RowSweep<CC>::kTraceBufDoubles;
     extern __shared__ double lds[];                      // two row buffers; then the walk's packed entries
     const ExplicitProblem pb = probs[blockIdx.x];
     const int lane = threadIdx.x;
@@ -302,17 +307,17 @@ __global__ __launch_bounds__(kWave, WAVES) void k_sw_trace_rows(const ExplicitPr
             };
             if (pb.ident) {
                 // ---- contiguous columns: stream whole row segments, kRowsInFlight rows ahead ------------------
+                // (buffer loads: the row's range check returns zeros past its last column -- no EXEC-masked branches around the
+                // loads, no selects; the descriptor is built from wave-uniform values)
                 Pair8 buf[kRowsInFlight][RS::NV];
                 auto issue = [&](int row, Pair8* dst) {
                     const double* rp = Sp + (int64_t)seq1[row] * pb.s_cols + pb.col0 + c0;
+                    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)rp);
+                    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uintptr_t)rp >> 32));
+                    auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uintptr_t)hi << 32) | lo), 0, cols * 8, 0x00020000);
 #pragma unroll
-                    for (int y = 0; y < RS::NV; y++) {
-                        const int k = 2 * (y * kWave + lane);
-                        Pair8 v{0.0, 0.0};
-                        if (k + 1 < cols) v = *reinterpret_cast<const Pair8*>(rp + k);
-                        else if (k < cols) v.a = rp[k];
-                        dst[y] = v;
-                    }
+                    for (int y = 0; y < RS::NV; y++)
+                        dst[y] = __builtin_bit_cast(Pair8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (y * kWave + lane) * 16, 0, 0));
                 };
 #pragma unroll
                 for (int u = 0; u < kRowsInFlight; u++)
@@ -327,14 +332,12 @@ __global__ __launch_bounds__(kWave, WAVES) void k_sw_trace_rows(const ExplicitPr
                                 left_vec = (i + lane < n) ? hcol[i + lane] : 0.0;
                                 first_vec = (i + lane < n) ? rowfirst[i + lane] : 0;
                             }
-                            double* rb = lds + (u & 1) * RS::kBufDoubles;
+                            double* rb = lds + (u & 1) * kTraceBuf;
 #pragma unroll
-                            for (int y = 0; y < RS::NV; y++) {
+                            for (int y = 0; y < RS::NV; y++) {           // (the buffer holds all 128 NV loaded elements: no lane is left out)
                                 const int k = 2 * (y * kWave + lane);
-                                if (k < RS::W) {
-                                    rb[(k / CC) * RS::kStride + k % CC] = buf[u][y].a;
-                                    rb[((k + 1) / CC) * RS::kStride + (k + 1) % CC] = buf[u][y].b;
-                                }
+                                rb[(k / CC) * RS::kStride + k % CC] = buf[u][y].a;
+                                rb[((k + 1) / CC) * RS::kStride + (k + 1) % CC] = buf[u][y].b;
                             }
                             if (i + kRowsInFlight < n) issue(i + kRowsInFlight, buf[u]);
                             wave_sync();
@@ -995,7 +998,7 @@ constexpr size_t kSlackFront = 128, kSlackBack = 32;     // doubles; the front k
 
 template <int CC>
 int launch_sw_rows(cr_explicit_batch* b) {
-    const size_t lds = sizeof(double) * 2 * cr::RowSweep<CC>::kBufDoubles;
+    const size_t lds = sizeof(double) * 2 * cr::RowSweep<CC>::kTraceBufDoubles;
     CR_LAUNCH(cr::k_sw_score_rows<CC>, dim3((unsigned)b->count), dim3(cr::kWave), lds, b->ctx->stream,
               b->has_minus1 ? b->probs_sw.p : b->probs.p, b->S.p + kSlackFront, b->seqs.p, b->hand.p, b->scores.p);
     CR_HIP(hipGetLastError());
@@ -1082,7 +1085,7 @@ int columns_per_lane(int m_max) {
 // smith_waterman with gap 0 over the list: fill with decisions, first maximum and the walk in ONE launch of the row sweep
 template <int CC, int WAVES = (CC <= 4 ? 5 : CC == 5 ? 4 : 3)>
 int launch_sw_trace_rows(cr_explicit_batch* b) {
-    const size_t lds = std::max(sizeof(double) * 2 * cr::RowSweep<CC>::kBufDoubles, sizeof(uint32_t) * ((size_t)b->cap_max + 2));
+    const size_t lds = std::max(sizeof(double) * 2 * cr::RowSweep<CC>::kTraceBufDoubles, sizeof(uint32_t) * ((size_t)b->cap_max + 2));
     int rc = allow_lds(cr::k_sw_trace_rows<CC, WAVES>, lds);
     if (rc) return rc;
     CR_LAUNCH((cr::k_sw_trace_rows<CC, WAVES>), dim3((unsigned)b->count), dim3(cr::kWave), lds, b->ctx->stream, b->probs.p, b->sw_dirs_off.p,

@@ -61,7 +61,7 @@ def explicit_record(count=8128, n=300, reps=5, with_tracebacks=True, matrices="r
         heavy = "WITH" in name
         fn()
         ms = []
-        for _ in range(2 if heavy else reps):
+        for _ in range(4 if heavy else reps):
             res = fn()
             ms.append(batch.last_kernel_ms())
         best = min(ms)
