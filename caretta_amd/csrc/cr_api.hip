@@ -848,6 +848,8 @@ bool all_finite(const double* v, size_t count) {
     return !std::isnan(s);
 }
 
+constexpr int64_t kMaxTensorWidth = 192;
+
 // widths the seed-fill kernel is instantiated for; narrower tensors are zero-padded in registers
 int padded_width(int64_t d) {
     if (d <= 4) return 4;
@@ -856,6 +858,9 @@ int padded_width(int64_t d) {
     if (d <= 16) return 16;
     if (d <= 24) return 24;
     if (d <= 32) return 32;
+    // wider tensors (multiple_alignment.py:312-331 takes any width): no register-resident provider -- the staged family only, whose
+    // tensor scores come from the run-time-width staging kernel (k_stage_tensor_any); the LDS holds d planes of 79 columns
+    if (d <= kMaxTensorWidth) return (int)d;
     return 0;
 }
 
@@ -1050,7 +1055,7 @@ static int batch_create(cr_context* ctx, const double* coords, const double* ten
     CR_REQUIRE(coords && tensors && offsets, "null input array");
     CR_REQUIRE(num_structures >= 1, "need at least one structure");
     CR_REQUIRE(d >= 1, "tensor width must be >= 1");
-    CR_REQUIRE(padded_width(d) != 0, "tensor width > 32 is not supported by this build");
+    CR_REQUIRE(padded_width(d) != 0, "tensor width > 192 is not supported by this build (the Python package runs such tensors through the per-function drop-ins)");
     CR_REQUIRE(offsets[0] == 0, "offsets[0] must be 0");
     for (int64_t s = 0; s < num_structures; s++) {
         CR_REQUIRE(offsets[s + 1] > offsets[s], "every structure needs at least one residue");
@@ -1123,7 +1128,13 @@ int set_pairs_one(cr_batch* b, const int32_t* pairs, int64_t npairs, const int32
         b->n_max = std::max(b->n_max, n);
         b->m_max = std::max(b->m_max, m);
     }
-    apply_layout(b, choose_layout(b->n_max, b->m_max, b->d_pad, npairs, mask));
+    {
+        const Layout lay = choose_layout(b->n_max, b->m_max, b->d_pad, npairs, mask);
+        if (!lay.ok)
+            return fail(CR_ERR_ARGUMENT, "tensor width > 32 runs on staged scores only: at most 1 024 strips of 64 rows, 2 048 rows and 2 GiB of scores per "
+                                         "pair list -- hand the list over in pieces");
+        apply_layout(b, lay);
+    }
     // (a duo or few-pair trio list is laid out again when a run comes with a Smith-Waterman gap: keep the list)
     b->duo_ij.clear();
     if (b->duo || b->trio_few) b->duo_ij.assign(pairs, pairs + 2 * npairs);
@@ -1359,10 +1370,13 @@ int cr_plan_layout(const int64_t* offsets, int64_t num_structures, int64_t d, co
                    int32_t* parts, int* nparts) {
     CR_REQUIRE(offsets != nullptr && parts != nullptr && nparts != nullptr, "null argument");
     CR_REQUIRE(num_structures >= 1 && npairs >= 0 && (npairs == 0 || pairs != nullptr), "bad pair list");
-    CR_REQUIRE(d >= 1 && padded_width(d) != 0, "tensor width > 32 is not supported by this build");
+    CR_REQUIRE(d >= 1 && padded_width(d) != 0, "tensor width > 192 is not supported by this build (the Python package runs such tensors through the per-function drop-ins)");
     ListPlan plan;
     const int rc = plan_list(offsets, num_structures, padded_width(d), pairs, npairs, LayoutMask{}, true, plan);
     if (rc) return rc;
+    if (!plan.whole.ok)
+        return fail(CR_ERR_ARGUMENT, "tensor width > 32 runs on staged scores only: at most 1 024 strips of 64 rows, 2 048 rows and 2 GiB of scores per pair "
+                                     "list -- hand the list over in pieces");
     int count = 0;
     auto put = [&](const Layout& l, int64_t n) {
         int32_t* row = parts + 5 * count++;

@@ -28,6 +28,7 @@ struct LayoutRule {
 
 constexpr int64_t kAnyPairs = std::numeric_limits<int64_t>::max();
 constexpr int kAnyLength = cr::kMaxLength;
+constexpr int kAnyWidth = 1 << 20;
 constexpr int64_t kTeamPairLimit = 256;
 // Pair lists of at most this many 64-row strips run on staged scores: one wave per SIMD of the chip.
 constexpr int64_t kStagedWaveLimit = 1024;
@@ -48,7 +49,8 @@ constexpr LayoutRule kLayoutTable[] = {
     {kFamTrio, 193, 256, 161, kTrioPairLimit, kMidMaxColumns, 16, "profiles/r05/staged_vs_trio.txt"},
     {kFamTrio, 257, 320, 161, kTrioPairLimit, kMidMaxColumns, 16, "profiles/r04/trio_few.txt, c3_share.txt, c3_share_limit.txt"},
     // staged scores (cr_staged.h): at most one wave per SIMD of the chip (pairs x strips <= 1 024: checked by fits)
-    {kFamStaged, 1, cr::kStagedMaxRows, 1, kStagedWaveLimit, kAnyLength, 32, "profiles/r03/calibrate_staged.txt"},
+    // (the only family for tensors wider than 32: its tensor scores then come from the run-time-width staging kernel)
+    {kFamStaged, 1, cr::kStagedMaxRows, 1, kStagedWaveLimit, kAnyLength, kAnyWidth, "profiles/r03/calibrate_staged.txt"},
     // one pair per CU, up to 16 waves, barrier every 8 steps (k_pair_wide)
     {kFamWide, 193, 3072, 1, kTeamPairLimit, kAnyLength, 16, "profiles/r03/calibrate_wide.txt"},
     // four-wave teams: what the wide layout cannot take (tensor widths above 16)
@@ -63,6 +65,7 @@ struct Layout {
     Family family = kFamSingle;
     int r_seed = 5, r_b = 5, wide_na = 0, wide_sync = 0;
     bool trio_few = false;
+    bool ok = true;          // false: no family serves the list (tensors wider than 32 on a list the staged family cannot take)
 };
 
 // what the caller of cr_batch_set_pairs rules out (thread-local flags of the re-layouts)
@@ -272,6 +275,7 @@ Layout choose_layout(int n_max, int m_max, int d_pad, int64_t npairs, const Layo
             case kFamSingle: return out;
         }
     }
+    out.ok = d_pad <= 32;        // (every rule but the staged one ends at width 32)
     return out;
 }
 
@@ -315,7 +319,7 @@ int plan_list(const int64_t* offsets, int64_t P, int d_pad, const int32_t* pairs
     }
     out.whole = choose_layout(out.n_max, out.m_max, d_pad, npairs, mask);
     const int nclasses = (out.in_class[0] > 0) + (out.in_class[1] > 0) + (out.in_class[2] > 0);
-    if (g_cfg.classes && nclasses >= 2 && npairs <= kClassSplitPairs && may_split) {
+    if (g_cfg.classes && nclasses >= 2 && npairs <= kClassSplitPairs && may_split && d_pad <= 32) {
         bool all_same = true, any_special = false;
         for (int c = 0; c < 3; c++) {
             if (!out.in_class[c]) continue;

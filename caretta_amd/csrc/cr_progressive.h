@@ -373,7 +373,7 @@ static int progressive_align_impl(cr_context* ctx, const double* coords, const d
     if (rc) return rc;
     CR_REQUIRE((coords || flexible) && tensors && offsets && tree && params, "null input");
     CR_REQUIRE(P >= 2 && tree_rows == 2 * P - 3, "tree must have 2P-3 rows");
-    CR_REQUIRE(d >= 1 && padded_width(d) != 0, "tensor width > 32 is not supported by this build");
+    CR_REQUIRE(d >= 1 && padded_width(d) != 0, "tensor width > 192 is not supported by this build");
     CR_REQUIRE(offsets[0] == 0, "offsets[0] must be 0");
     for (int64_t s = 0; s < P; s++)
         CR_REQUIRE(offsets[s + 1] > offsets[s] && offsets[s + 1] - offsets[s] <= cr::kMaxLength,

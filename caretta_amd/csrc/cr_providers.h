@@ -82,6 +82,51 @@ struct RbfTensor {
     CR_D double score(int q, const ExpEntry* tab) const { return exp_tab<true>(neg_gamma * dist2(q), tab); }
 };
 
+// The same score for ANY stored width (the reference takes any (L, d) tensor array, multiple_alignment.py:312-331; the kernels
+// above keep a lane's row features in registers and are instantiated for widths padded to at most 32): the staging kernel of
+// cr_staged.h only -- columns resident in LDS as d feature planes, a lane's row features read from L1 / L2 per cell, the sum in
+// the same order k = 0, 1, ... (no padding: nothing is added).  Rows past n score exactly 0, as the far-away features make them.
+template <int R>
+struct RbfTensorAny {
+    static constexpr bool kNonNegative = true;
+    static constexpr bool kMaskRows = false;
+    const double* __restrict__ rows_g;   // (n, d)
+    const double* __restrict__ cols_g;   // (m, d)
+    int d;
+    double neg_gamma;
+    const double* rowp[R];               // this lane's rows (nullptr: past n)
+    const double* colp;                  // this lane's column inside the resident planes
+    int stride_;
+
+    CR_D void load_rows(int rowbase, int n) {
+#pragma unroll
+        for (int q = 0; q < R; q++) rowp[q] = rowbase + q < n ? rows_g + (int64_t)(rowbase + q) * d : nullptr;
+    }
+    CR_D void load_resident_range(double* res, int stride, int c0, int c1, int tid, int nth) {
+        const int total = (c1 - c0) * d;
+        const double* __restrict__ from = cols_g + (int64_t)c0 * d;
+        for (int e = tid; e < total; e += nth) {
+            const int c = e / d, k = e - c * d;
+            res[k * stride + c] = from[e];
+        }
+    }
+    CR_D void fetch_resident(const double* res, int stride, int c) {
+        colp = res + c;
+        stride_ = stride;
+    }
+    CR_D double score(int q, const ExpEntry* tab) const {
+        const double* __restrict__ r = rowp[q];
+        if (!r) return 0.0;
+        double df = r[0] - colp[0];
+        double acc = df * df;
+        for (int k = 1; k < d; k++) {
+            df = r[k] - colp[(int64_t)k * stride_];
+            acc = acc + df * df;
+        }
+        return exp_tab<true>(neg_gamma * acc, tab);
+    }
+};
+
 // Coordinate RBF on the seed-superposed frames: rows X_i - c1, columns (X_j - c2) @ R
 // (superposition_functions.py:57-58), or the raw coordinates when the seed was skipped.
 template <int R>

@@ -89,6 +89,22 @@ __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_stage_tensor(const P
     stage_block<R>(src, pd.n, pd.m, tc, staged + (int64_t)blockIdx.y * shape.pair_doubles(), shape, lds);
 }
 
+// the same for tensors wider than 32 (RbfTensorAny: any stored width; dynamic LDS = exp table + d planes of the column window)
+template <int R>
+__global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_stage_tensor_any(const PairDesc* __restrict__ pairs,
+                                                                          const double* __restrict__ tensors, int d,
+                                                                          double gamma, int tc, double* __restrict__ staged,
+                                                                          const StagedShape shape) {
+    extern __shared__ double lds[];
+    const PairDesc pd = pairs[blockIdx.y];
+    RbfTensorAny<R> src;
+    src.rows_g = tensors + pd.off_i * d;
+    src.cols_g = tensors + pd.off_j * d;
+    src.d = d;
+    src.neg_gamma = -gamma;
+    stage_block<R>(src, pd.n, pd.m, tc, staged + (int64_t)blockIdx.y * shape.pair_doubles(), shape, lds);
+}
+
 // node score of the progressive alignment (multiple_alignment.py:204-210) in the frame of the node's seed superposition
 template <int R>
 __global__ __launch_bounds__(kStagedMaxWaves* kWave) void k_stage_node(const PairDesc* __restrict__ pairs,
@@ -527,8 +543,23 @@ int launch_stage_tensor(cr_batch* b, const cr_batch::Chunk& ck, const cr_params&
         case 16: return launch_stage_tensor_d<16>(b, ck, prm, staged, shape);
         case 24: return launch_stage_tensor_d<24>(b, ck, prm, staged, shape);
         case 32: return launch_stage_tensor_d<32>(b, ck, prm, staged, shape);
-        default: return fail(CR_ERR_ARGUMENT, "unsupported tensor width");
+        default: break;
     }
+    if (b->d_pad <= 32) return fail(CR_ERR_ARGUMENT, "unsupported tensor width");
+    // wider than the register-resident providers: the run-time-width staging kernel, 16 steps per workgroup (the LDS holds d planes
+    // of 16 + 63 columns)
+    const int steps = ck.m_max + cr::kWave - 1, tc = kStageSteps;
+    const size_t lds = sizeof(double) * cr::stage_lds_doubles((int)b->d, tc);
+    const unsigned chunks = (unsigned)((steps + tc - 1) / tc);
+    auto go = [&](auto kernel) -> int {
+        int rc = allow_lds(kernel, lds);
+        if (rc) return rc;
+        CR_LAUNCH(kernel, dim3(chunks, (unsigned)ck.count), dim3(shape.waves * cr::kWave), lds, b->launch_stream ? b->launch_stream : b->ctx->stream,
+                  b->pairs.p + ck.first, b->tensors.p, (int)b->d, prm.gamma_tensor, tc, staged, shape);
+        CR_HIP(hipGetLastError());
+        return CR_OK;
+    };
+    return by_rows(shape.r, [&](auto rt) { return go(cr::k_stage_tensor_any<decltype(rt)::value>); });
 }
 
 int launch_seed_staged(cr_batch* b, const cr_batch::Chunk& ck, const cr_params& prm, const double* staged, const cr::StagedShape shape) {

@@ -90,7 +90,7 @@ class Protein(SequenceBase):
         xi, ti, xj, tj = f64(self.coordinates), f64(self.tensors), f64(other.coordinates), f64(other.tensors)
         if ti.shape[1] != tj.shape[1]:
             raise ValueError("tensor widths differ")
-        if ti.shape[1] > MAX_FUSED_TENSOR_WIDTH:
+        if ti.shape[1] > MAX_FUSED_TENSOR_WIDTH and (ti.shape[1] > MAX_STAGED_TENSOR_WIDTH or max(ti.shape[0], tj.shape[0]) > _STAGED_MAX_ROWS):
             return self._score_function_wide(xi, ti, xj, tj, other, gamma_tensor, gamma_coords, verbose)
         s = np.empty((xi.shape[0], xj.shape[0]))
         flags = C.c_uint32(0)
@@ -234,10 +234,15 @@ class _NodeAttribute:
         obj.__dict__[self.slot] = value
 
 
-# Tensor widths the fused pipeline kernels are instantiated for (csrc/cr_api.hip padded_width).  The reference takes any (L, d)
-# array (multiple_alignment.py:312-319): wider tensors run the same steps through the per-function drop-ins (the plugin route of
-# make_pairwise_matrix / the host walk of progressive_align with Protein._score_function_wide), never an error.
+# Tensor widths (csrc/cr_api.hip padded_width).  The reference takes any (L, d) array (multiple_alignment.py:312-319).
+#   d <= 32 : every kernel family (row features in registers, padded to 4 ... 32);
+#   d <= 192: the staged family only -- tensor scores by the run-time-width staging kernel, lists of at most 1 024 strips of 64 rows
+#             and structures of at most 2 048 residues: `pairwise` hands longer lists over in pieces;
+#   wider, or longer structures with d > 32: the same steps through the per-function drop-ins (the plugin route of
+#             make_pairwise_matrix / the host walk of progressive_align with Protein._score_function_wide).  Never an error.
 MAX_FUSED_TENSOR_WIDTH = 32
+MAX_STAGED_TENSOR_WIDTH = 192
+_STAGED_MAX_ROWS = 2048
 
 _PLUGIN_BATCH_BYTES = 1 << 30      # score matrices of plugin sequences gathered on the host per batched launch
 
@@ -295,10 +300,16 @@ class MultipleAlignment:
     def _all_proteins(self, need_coordinates: bool = True) -> bool:
         return all(type(s) is Protein and (s.coordinates is not None or not need_coordinates) for s in self.sequences)
 
-    def _fused_width(self) -> bool:
-        """One tensor width for all sequences, and one the fused kernels are instantiated for."""
+    def _fused_width(self, staged_ok: bool = True) -> bool:
+        """One tensor width for all sequences, and one the batched engine takes: up to 32 everywhere; up to 192 on staged scores
+        (structures of at most 2 048 residues; `staged_ok=False`: callers whose kernels keep the row features in registers)."""
         widths = {np.shape(s.tensors)[1] for s in self.sequences}
-        return len(widths) == 1 and next(iter(widths)) <= MAX_FUSED_TENSOR_WIDTH
+        if len(widths) != 1:
+            return False
+        d = next(iter(widths))
+        if d <= MAX_FUSED_TENSOR_WIDTH:
+            return True
+        return staged_ok and d <= MAX_STAGED_TENSOR_WIDTH and max(len(s) for s in self.sequences) <= _STAGED_MAX_ROWS
 
     def pairwise(self, score_function_params=None, gap_open_penalty=1.0, gap_extend_penalty=0.01, pairs=None,
                  want_alignments=True, context: typing.Optional[Context] = None,
@@ -318,9 +329,11 @@ class MultipleAlignment:
             raise TypeError(f"unknown score_function parameters {sorted(prm)}")
         ctx = context or default_context()
         coords, tensors, offsets = pack_proteins(self.sequences, staging=True)
+        pairs = all_pairs(len(self.sequences)) if pairs is None else np.asarray(pairs, np.int32).reshape(-1, 2)
+        if tensors.shape[1] > MAX_FUSED_TENSOR_WIDTH and len(pairs):
+            return self._pairwise_in_pieces(ctx, coords, tensors, offsets, pairs, params, want_alignments, scores_only)
         batch = PairBatch(ctx, coords, tensors, offsets)
         try:
-            pairs = all_pairs(len(self.sequences)) if pairs is None else np.asarray(pairs, np.int32).reshape(-1, 2)
             batch.set_pairs(pairs)
             batch.run(params, scores_only=scores_only, flexible=flexible)
             if scores_only:                       # the matrix entries only: 12 bytes per pair come back
@@ -334,6 +347,51 @@ class MultipleAlignment:
                 res, aln = batch.fetch(want_alignments)
         finally:
             batch.close()
+        if np.any(res["flags"] & _capi.FLAG_SEED_ALL_ZERO):
+            bad = pairs[np.nonzero(res["flags"] & _capi.FLAG_SEED_ALL_ZERO)[0][0]]
+            raise TypeError(f"tensor score matrix of pair {tuple(bad)} has no positive local alignment "
+                            "(reference: max_pos is None)")
+        return PairwiseResults(pairs, res, aln)
+
+    def _pairwise_in_pieces(self, ctx, coords, tensors, offsets, pairs, params, want_alignments, scores_only):
+        """`pairwise` for tensors wider than 32: the staged family takes at most 1 024 strips of 64 rows (and 2 GiB of staged
+        scores) per pair list, so the list goes over in pieces on ONE batch (structures uploaded once); results in pair order."""
+        lengths = np.diff(offsets)
+        n_max = int(lengths[pairs[:, 0]].max())
+        m_max = int(lengths[pairs[:, 1]].max())
+        rows_per_lane = max(1, -(-n_max // 512))
+        strips = -(-n_max // (64 * rows_per_lane))
+        steps = (m_max + 63 + 15) // 16 * 16 + 32
+        per_piece = max(1, min(1024 // strips, int((1 << 31) // (8 * strips * steps * rows_per_lane * 64))))
+        sw_parts, flag_parts, res_parts, aln_parts = [], [], [], []
+        batch = PairBatch(ctx, coords, tensors, offsets)
+        try:
+            for lo in range(0, len(pairs), per_piece):
+                batch.set_pairs(pairs[lo:lo + per_piece])
+                batch.run(params, scores_only=scores_only)
+                if scores_only:
+                    sw, flags = batch.fetch_scores()
+                    sw_parts.append(sw.copy())
+                    flag_parts.append(flags.copy())
+                else:
+                    r, a = batch.fetch(want_alignments)
+                    res_parts.append(r.copy())
+                    aln_parts.append(None if a is None else a.copy())
+        finally:
+            batch.close()
+        if scores_only:
+            res, aln = np.zeros(len(pairs), dtype=[("sw", np.float64), ("flags", np.uint32)]), None
+            res["sw"], res["flags"] = np.concatenate(sw_parts), np.concatenate(flag_parts)
+        else:
+            res = np.concatenate(res_parts)
+            aln = None
+            if want_alignments:
+                stride = max(a.shape[2] for a in aln_parts)
+                aln = np.full((len(pairs), 2, stride), -2, dtype=aln_parts[0].dtype)
+                at = 0
+                for a in aln_parts:
+                    aln[at:at + len(a), :, :a.shape[2]] = a
+                    at += len(a)
         if np.any(res["flags"] & _capi.FLAG_SEED_ALL_ZERO):
             bad = pairs[np.nonzero(res["flags"] & _capi.FLAG_SEED_ALL_ZERO)[0][0]]
             raise TypeError(f"tensor score matrix of pair {tuple(bad)} has no positive local alignment "
@@ -369,7 +427,7 @@ class MultipleAlignment:
         if self._all_proteins() and self._fused_width() and not score_function_params.get("flexible", False):
             from . import engine
             npairs = num * (num - 1) // 2
-            if npairs >= engine.MULTI_DEVICE_MIN_PAIRS:
+            if npairs >= engine.MULTI_DEVICE_MIN_PAIRS and self._fused_width(staged_ok=False):
                 # several GPUs visible to (and owned by) this process: the pair set dealt over all of them, one RCCL
                 # all-gather.  A fault of the multi-device machinery (communicator set-up, a device that cannot be opened)
                 # is not a fault of the input: say so ONCE, remember it, and compute the same matrix on one device.
@@ -384,7 +442,7 @@ class MultipleAlignment:
             out = self.pairwise(score_function_params, want_alignments=False, scores_only=True)
             return assemble_matrix(out.pairs, out.results["sw"], num)
         if (score_function_params.get("flexible", False) and self._all_proteins(need_coordinates=False)
-                and self._fused_width()):      # (wider tensors: the plugin route below)
+                and self._fused_width(staged_ok=False)):      # (wider tensors: the plugin route below)
             # flexible=True: smith_waterman_score of the tensor score matrix of every pair (multiple_alignment.py:323-326,
             # :164), one launch over the pair list (cr_batch_run_tensor_scores)
             out = self.pairwise(score_function_params, want_alignments=False, scores_only=True)
@@ -426,10 +484,16 @@ class MultipleAlignment:
                 and all(type(s) is Protein and s.coordinates is not None for s in self.sequences)
                 and self._fused_width() and not flex_score and not flex_mean):
             # every node of the tree on the device, one launch pair per tree level (cr_progressive_align)
-            return self._progressive_align_resident(tree, gap_open_penalty, gap_extend_penalty, consensus_weight,
-                                                    gamma_weight, score_function_params, mean_function_params)
+            wide = np.shape(self.sequences[0].tensors)[1] > MAX_FUSED_TENSOR_WIDTH
+            try:
+                return self._progressive_align_resident(tree, gap_open_penalty, gap_extend_penalty, consensus_weight,
+                                                        gamma_weight, score_function_params, mean_function_params)
+            except (_capi.CarettaHipError, ValueError):
+                if not wide:
+                    raise
+                # (tensors wider than 32 run on staged scores only: a tree whose nodes outgrow them takes the host walk below)
         if (len(self.sequences) >= 2 and tree.shape == (2 * len(self.sequences) - 3, 2) and flex_score and flex_mean
-                and self._all_proteins(need_coordinates=False) and self._fused_width()):
+                and self._all_proteins(need_coordinates=False) and self._fused_width(staged_ok=False)):
             # flexible=True in score AND mean function (multiple_alignment.py:323-326, :351-362): nodes are tensors and consensus
             # weights only -- the same resident tree without the seed stage (cr_progressive_align_flexible).  A node that outgrows
             # the launch bound sends the tree to the host walk below.
@@ -448,7 +512,7 @@ class MultipleAlignment:
             size_1, size_2 = len(walk.members[s1.name]), len(walk.members[s2.name])
             mult_1, mult_2 = size_2 / (2 * (size_1 + size_2)), size_1 / (2 * (size_1 + size_2))       # :199-202
             if (fusable and type(s1) is Protein and type(s2) is Protein and s1.coordinates is not None
-                    and s2.coordinates is not None and np.shape(s1.tensors)[1] <= MAX_FUSED_TENSOR_WIDTH):
+                    and s2.coordinates is not None and np.shape(s1.tensors)[1] <= MAX_FUSED_TENSOR_WIDTH):      # (cr_progressive_node: registers)
                 # the whole node (score matrices, dtw_align, mean_function, get_mean_weights) in two launches
                 return _progressive_node(s1, s2, w1, w2, mult_1, mult_2, name_int, gap_open_penalty, gap_extend_penalty,
                                          gamma_weight, score_function_params, mean_function_params)

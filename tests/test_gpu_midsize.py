@@ -496,12 +496,13 @@ def test_by_function_layout_serves_tensor_widths_up_to_16(ctx, oracle, dim):
     run_all_ways(ctx, oracle, coords, tensors, offsets, engine.all_pairs(16), ("trio", "staged", "single"))
 
 
-@pytest.mark.parametrize("dim", [33, 48])
-def test_tensors_wider_than_the_fused_kernels_take_the_dropin_route(oracle, dim):
-    """d > 32 (multiple_alignment.py:312-331 takes any width): the pairwise matrix, the score function, the two-structure
-    alignment and the progressive alignment run through the per-function drop-ins instead of raising -- make_score_matrix
-    (any width) -> smith_waterman -> Kabsch on the seed -> make_score_matrix -> smith_waterman_score over the list / dtw_align --
-    with the oracle's values bit for bit."""
+@pytest.mark.parametrize("dim", [33, 48, 200])
+def test_tensors_wider_than_the_fused_kernels(oracle, dim):
+    """d > 32 (multiple_alignment.py:312-331 takes any width): up to 192 the pairwise matrix, the score function, the
+    two-structure alignment and the progressive alignment run on STAGED scores (the run-time-width staging kernel
+    k_stage_tensor_any; the whole tree resident), beyond that through the per-function drop-ins -- make_score_matrix (any
+    width) -> smith_waterman -> Kabsch on the seed -> make_score_matrix -> smith_waterman_score over the list / dtw_align --, never
+    an error; the oracle's values bit for bit either way."""
     from caretta_amd import engine
     from caretta_amd import multiple_alignment as ma
     from oracle.pyoracle import default_params
@@ -539,5 +540,46 @@ def test_tensors_wider_than_the_fused_kernels_take_the_dropin_route(oracle, dim)
                                                           sizes[n2] / (2 * tot), sizes[n1] / (2 * tot), params=oprm)
         node = msa.final_sequences[num + k]
         assert np.array_equal(tn, node.tensors) and np.array_equal(np.ravel(wn), np.ravel(msa.final_consensus_weights[num + k]))
-        assert np.allclose(xn, node.coordinates, rtol=0, atol=1e-9)          # (host mean_function: numpy's matmul in the frame change)
+        if dim <= 192:
+            assert np.array_equal(xn, node.coordinates)                      # (the resident tree: the device's own merge)
+        else:
+            assert np.allclose(xn, node.coordinates, rtol=0, atol=1e-9)      # (host mean_function: numpy's matmul in the frame change)
         sizes.append(tot)
+
+
+@pytest.mark.parametrize("dim,num,length,gap", [(40, 30, 300, 0.0), (64, 9, 700, 0.0), (33, 14, 150, 0.05), (192, 5, 120, 0.0)])
+def test_wide_tensor_lists_in_pieces_vs_oracle(ctx, oracle, dim, num, length, gap):
+    """Tensors of 33 ... 192 features on the batched engine: the staged family with the run-time-width staging kernel, a list
+    longer than its 1 024 strips handed over in pieces by `MultipleAlignment.pairwise` (30 x 300: 435 pairs x 5 strips = three
+    pieces; 9 x 700: two rows per lane), every output of pipeline H against the oracle bit for bit; a Smith-Waterman gap; the
+    C ABI itself refuses the list that is too long for one piece with an argument error."""
+    from caretta_amd import engine
+    from caretta_amd import multiple_alignment as ma
+    from caretta_amd._capi import CarettaHipError
+    from oracle.pyoracle import default_params
+    fam = synthetic.make_family(num, length, dim=dim, seed=7300 + dim, ragged=(num % 2 == 1), clades=3)
+    coords, tensors, offsets = synthetic.pack(fam)
+    pairs = engine.all_pairs(num)
+    gt = 70.0 / dim
+    ref, ref_aln = oracle.pairwise_batch(coords, tensors, offsets, pairs, params=default_params(gamma_tensor=gt, sw_gap=gap), nthreads=8)
+    if gap == 0.0:
+        msa = ma.MultipleAlignment([ma.Protein(s.name, s.tensors, s.coordinates, s.sequence) for s in fam])
+        out = msa.pairwise(dict(gamma_tensor=gt, gamma_coords=0.03, verbose=False))
+        assert_bit_identical(out.results, out.alignments, ref, ref_aln)
+        sc = msa.pairwise(dict(gamma_tensor=gt, gamma_coords=0.03, verbose=False), scores_only=True, want_alignments=False)
+        assert np.array_equal(sc.results["sw"], ref["sw"])
+    # one piece through the engine directly (layout "staged"), with the gap
+    piece = pairs[:min(len(pairs), 1024 // (-(-length // 64)) if length <= 512 else 40)]
+    batch = engine.PairBatch(ctx, coords, tensors, offsets).set_pairs(piece)
+    assert layout_of(batch)[0] == "staged"
+    batch.run(engine.make_params(gamma_tensor=gt, sw_gap=gap))
+    res, aln = batch.fetch()
+    for p in range(len(piece)):
+        ln = int(ref["aln_len"][p])
+        assert int(res["aln_len"][p]) == ln and np.array_equal(aln[p, :, :ln], ref_aln[p, :, :ln])
+    for key in ("sw", "dtw_score", "seed_score", "rmsd", "coverage", "tm"):
+        assert np.array_equal(res[key], ref[key][:len(piece)]), key
+    if len(pairs) * (-(-length // 64)) > 1024:
+        with pytest.raises((CarettaHipError, ValueError)):
+            batch.set_pairs(pairs)
+    batch.close()
