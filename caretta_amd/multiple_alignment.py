@@ -94,9 +94,14 @@ class Protein(SequenceBase):
             return self._score_function_wide(xi, ti, xj, tj, other, gamma_tensor, gamma_coords, verbose)
         s = np.empty((xi.shape[0], xj.shape[0]))
         flags = C.c_uint32(0)
-        check(_capi.load().cr_protein_score_function(default_context()._h, ptr(xi), ptr(ti), xi.shape[0], ptr(xj),
-                                                     ptr(tj), xj.shape[0], ti.shape[1], float(gamma_tensor),
-                                                     float(gamma_coords), ptr(s), C.byref(flags)))
+        try:
+            check(_capi.load().cr_protein_score_function(default_context()._h, ptr(xi), ptr(ti), xi.shape[0], ptr(xj),
+                                                         ptr(tj), xj.shape[0], ti.shape[1], float(gamma_tensor),
+                                                         float(gamma_coords), ptr(s), C.byref(flags)))
+        except ValueError:
+            if ti.shape[1] <= MAX_FUSED_TENSOR_WIDTH:
+                raise
+            return self._score_function_wide(xi, ti, xj, tj, other, gamma_tensor, gamma_coords, verbose)   # (a pair the staged family cannot take)
         if flags.value & _capi.FLAG_SEED_ALL_ZERO:
             raise TypeError("tensor score matrix has no positive local alignment (reference: max_pos is None)")
         if (flags.value & _capi.FLAG_SEED_SKIPPED) and verbose:
@@ -439,8 +444,14 @@ class MultipleAlignment:
                     import warnings
                     engine.multi_device_failed()
                     warnings.warn(f"multi-GPU pairwise matrix failed ({exc}); running on one device from now on", RuntimeWarning)
-            out = self.pairwise(score_function_params, want_alignments=False, scores_only=True)
-            return assemble_matrix(out.pairs, out.results["sw"], num)
+            try:
+                out = self.pairwise(score_function_params, want_alignments=False, scores_only=True)
+                return assemble_matrix(out.pairs, out.results["sw"], num)
+            except ValueError:
+                # (tensors wider than 32 run on staged scores only: a list even one pair of which does not fit them -- alignment
+                # columns beyond the LDS -- takes the plugin route below)
+                if np.shape(self.sequences[0].tensors)[1] <= MAX_FUSED_TENSOR_WIDTH:
+                    raise
         if (score_function_params.get("flexible", False) and self._all_proteins(need_coordinates=False)
                 and self._fused_width(staged_ok=False)):      # (wider tensors: the plugin route below)
             # flexible=True: smith_waterman_score of the tensor score matrix of every pair (multiple_alignment.py:323-326,

@@ -227,6 +227,20 @@ def check_explicit_batch(oracle, rng):
     want = np.array([oracle.smith_waterman_score(a, b, s, gap) for a, b, s in problems])
     if not np.array_equal(got, want):
         raise AssertionError(f"smith_waterman_score_batch differs: gap {gap}, shapes {[(len(a), len(b)) for a, b, _ in problems]}")
+    if rng.integers(0, 2) == 0:
+        # smith_waterman WITH its traceback over the list (gap 0: the row sweep with decisions, first maximum and walk in one
+        # launch, round 6; else the skewed sweep + walk launch); an all-zero matrix raises, as the reference does
+        want_sw = [oracle.smith_waterman(a, b, s, gap) for a, b, s in problems]
+        if any(w[3] for w in want_sw):
+            try:
+                dtw.smith_waterman_batch(problems, gap)
+                raise AssertionError("smith_waterman_batch did not raise on a matrix without a positive cell")
+            except TypeError:
+                pass
+        else:
+            for (a, b, s), (a1, a2, sc), (o1, o2, osc, _none) in zip(problems, dtw.smith_waterman_batch(problems, gap), want_sw):
+                if not (np.array_equal(a1, o1) and np.array_equal(a2, o2) and sc == osc):
+                    raise AssertionError(f"smith_waterman_batch differs: n {len(a)} m {len(b)} gap {gap}")
     if rng.integers(0, 3) == 0:
         go, ge = float(rng.choice([0.0, 1.0, 0.5])), float(rng.choice([0.0, 0.01, 0.5]))
         for (a, b, s), (a1, a2, sc) in zip(problems, dtw.dtw_align_batch(problems, go, ge)):
@@ -234,6 +248,33 @@ def check_explicit_batch(oracle, rng):
             if not (np.array_equal(a1, o1) and np.array_equal(a2, o2) and sc == osc):
                 raise AssertionError(f"dtw_align_batch differs: n {len(a)} m {len(b)} gaps {go} {ge}")
     return len(problems)
+
+
+def check_wide_tensors(oracle, rng):
+    """Tensors of 33 ... 192 features (round 6): MultipleAlignment.pairwise on the staged family with the run-time-width staging
+    kernel, the list in pieces when it is longer than 1 024 strips; every output against the oracle."""
+    dim = int(rng.choice([33, 40, 48, 64, 100, 192]))
+    num, length = int(rng.integers(2, 14)), int(rng.choice([20, 64, 65, 150, 300, 520]))
+    fam = synthetic.make_family(num, length, dim=dim, seed=int(rng.integers(1 << 30)), ragged=bool(rng.integers(0, 2)), clades=int(rng.integers(1, 4)))
+    coords, tensors, offsets = synthetic.pack(fam)
+    pairs = engine.all_pairs(num)
+    gt = float(rng.choice([70.0, 10.0])) / dim
+    msa = ma.MultipleAlignment([ma.Protein(s.name, s.tensors, s.coordinates, s.sequence) for s in fam])
+    ref, ref_aln = oracle.pairwise_batch(coords, tensors, offsets, pairs, pyoracle.default_params(gamma_tensor=gt), nthreads=8)
+    try:
+        out = msa.pairwise(dict(gamma_tensor=gt, gamma_coords=0.03, verbose=False))
+    except TypeError:
+        if np.any(ref["flags"] & 4):
+            return 0                                   # (a pair without a positive local alignment: the reference raises too)
+        raise
+    for key in ("flags", "aln_len", "seed_len", "sw", "dtw_score", "seed_score", "rmsd", "coverage", "tm", "R", "t"):
+        if not np.array_equal(out.results[key], ref[key]):
+            raise AssertionError(f"wide tensors: {key} differs: d {dim}, lengths {np.diff(offsets)}")
+    for p in range(len(pairs)):
+        ln = int(ref["aln_len"][p])
+        if not np.array_equal(out.alignments[p, :, :ln], ref_aln[p, :, :ln]):
+            raise AssertionError(f"wide tensors: alignment of pair {pairs[p]} differs: d {dim}, lengths {np.diff(offsets)}")
+    return len(pairs)
 
 
 def check_neighbor_joining(ctx, oracle, rng):
@@ -270,7 +311,7 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
     ctx, oracle = engine.Context(0), pyoracle.Oracle()
-    t0, batches, pairs, nodes, flagged, dropins, batched, trees, flex_nodes = time.time(), 0, 0, 0, 0, 0, 0, 0, 0
+    t0, batches, pairs, nodes, flagged, dropins, batched, trees, flex_nodes, wide = time.time(), 0, 0, 0, 0, 0, 0, 0, 0, 0
     while time.time() - t0 < seconds:
         fam, _ = random_family(rng)
         n, res = check_batch(ctx, oracle, fam, rng)
@@ -285,10 +326,12 @@ def main():
             batched += check_explicit_batch(oracle, rng)
         if rng.integers(0, 4) == 0:
             trees += check_neighbor_joining(ctx, oracle, rng)
+        if rng.integers(0, 8) == 0:
+            wide += check_wide_tensors(oracle, rng)
         batches += 1
     print(f"fuzz_parity: seed {seed}, {batches} batches, {pairs} pairs ({flagged} with a soft-condition flag), "
           f"{nodes} progressive nodes, {flex_nodes} flexible progressive nodes, {dropins} explicit-matrix drop-in cases, {batched} matrices in batched explicit calls, "
-          f"{trees} device neighbor joinings: all bit-identical to the oracle")
+          f"{wide} pairs with tensors of 33 ... 192 features, {trees} device neighbor joinings: all bit-identical to the oracle")
 
 
 if __name__ == "__main__":
