@@ -865,11 +865,15 @@ __global__ __launch_bounds__(kWave) void k_dtw_trace_batch(const ExplicitProblem
 // smith_waterman WITH its traceback (dynamic_time_warping.py:226-278) over the list: the fill with 2-bit decisions and the
 // first maximum in row-major order (kSwTrace), Explicit tile or the streaming provider; `dirs_off`: word offset of every
 // problem's decisions (laid out for this launch's rows per lane).
+template <int R>
+CR_D void sw_walk_skewed(const ExplicitProblem& pb, const uint32_t* __restrict__ words, const SeedMax sm, double* lds, int32_t* __restrict__ aln,
+                         BatchTrace* __restrict__ out);
+
 template <int R, bool STREAM>
 __global__ __launch_bounds__(kWave) void k_explicit_sw_batch(const ExplicitProblem* __restrict__ probs, const int64_t* __restrict__ dirs_off,
                                                             const double* __restrict__ S, const int32_t* __restrict__ seqs,
                                                             SweepParams prm, uint32_t* __restrict__ dirs, double* __restrict__ hand,
-                                                            SeedMax* __restrict__ seeds) {
+                                                            SeedMax* __restrict__ seeds, int32_t* __restrict__ aln, BatchTrace* __restrict__ out) {
     extern __shared__ double lds[];
     const ExplicitProblem pb = probs[blockIdx.x];
     SeedMax sm;
@@ -898,25 +902,26 @@ __global__ __launch_bounds__(kWave) void k_explicit_sw_batch(const ExplicitProbl
         }
     }
     if (threadIdx.x == 0) seeds[blockIdx.x] = sm;
+    // the walk on this wave's own decision words, at priority (as k_sw_trace_rows and k_explicit_stream: until round 6 a second
+    // launch, k_sw_trace_batch, 0.42 ms for the 8 128 x 300 x 300 list)
+    drain_stores();
+    __builtin_amdgcn_s_setprio(3);
+    sw_walk_skewed<R>(pb, dirs + dirs_off[blockIdx.x], sm, lds, aln, out + blockIdx.x);
 }
 
 // The walk of smith_waterman (:249-278) WITH its gap entries, one wave per problem on the register-resident decision
 // blocks (Walker<R, 2>): whole diagonal, horizontal and vertical runs per ballot, entries packed in LDS back to front, rows
 // to HBM coalesced (as dtw_walk).  LDS: (n + m) packed entries.
 template <int R>
-__global__ __launch_bounds__(kWave) void k_sw_trace_batch(const ExplicitProblem* __restrict__ probs, const int64_t* __restrict__ dirs_off,
-                                                         const uint32_t* __restrict__ dirs, const SeedMax* __restrict__ seeds,
-                                                         int32_t* __restrict__ aln, BatchTrace* __restrict__ out) {
-    extern __shared__ double lds[];
-    const ExplicitProblem pb = probs[blockIdx.x];
-    const SeedMax sm = seeds[blockIdx.x];
+CR_D void sw_walk_skewed(const ExplicitProblem& pb, const uint32_t* __restrict__ words, const SeedMax sm, double* lds, int32_t* __restrict__ aln,
+                         BatchTrace* __restrict__ out) {
     const int lane = threadIdx.x;
     uint32_t* arow = reinterpret_cast<uint32_t*>(lds);
     const int cap = pb.n + pb.m;
     int idx = 0;
     if (sm.i > 0) {
         Walker<R, 2, 1> wk;
-        wk.init(dirs + dirs_off[blockIdx.x], tblocks(pb.m, 16), lane);
+        wk.init(words, tblocks(pb.m, 16), lane);
         int i = __builtin_amdgcn_readfirstlane(sm.i), j = __builtin_amdgcn_readfirstlane(sm.j);
         wk.set_row(i - 1);
 #pragma unroll 1
@@ -957,8 +962,8 @@ __global__ __launch_bounds__(kWave) void k_sw_trace_batch(const ExplicitProblem*
         a2[x] = j == kGap16 ? -1 : (int)j;
     }
     if (lane == 0) {
-        out[blockIdx.x].len = idx;
-        out[blockIdx.x].start = first;
+        out->len = idx;
+        out->start = first;
     }
 }
 
@@ -1344,16 +1349,12 @@ int cr_smith_waterman_batch(cr_explicit_batch* b, double gap, int64_t* aln, int6
         constexpr int RR = decltype(rt)::value;
         constexpr bool STREAM = decltype(stream_tag)::value;
         using Src = std::conditional_t<STREAM, cr::ExplicitStream<RR>, cr::Explicit<RR>>;
-        const size_t lds = cr::sweep_lds_doubles<RR, cr::kSwTrace, Src>(b->n_max, b->m_max) * sizeof(double);
+        // (fill and walk in one launch: the LDS of the larger of the two)
+        const size_t lds = std::max(cr::sweep_lds_doubles<RR, cr::kSwTrace, Src>(b->n_max, b->m_max), cr::trace_lds_doubles(RR, b->cap_max)) * sizeof(double);
         int rc2 = allow_lds(cr::k_explicit_sw_batch<RR, STREAM>, lds);
         if (rc2) return rc2;
         CR_LAUNCH((cr::k_explicit_sw_batch<RR, STREAM>), dim3((unsigned)b->count), dim3(cr::kWave), lds, st, b->probs.p, b->sw_dirs_off.p,
-                  b->S.p + kSlackFront, b->seqs.p, prm, b->sw_dirs.p, b->hand.p, b->seeds.p);
-        CR_HIP(hipGetLastError());
-        const size_t tl = sizeof(double) * cr::trace_lds_doubles(RR, b->cap_max);
-        if ((rc2 = allow_lds(cr::k_sw_trace_batch<RR>, tl))) return rc2;
-        CR_LAUNCH((cr::k_sw_trace_batch<RR>), dim3((unsigned)b->count), dim3(cr::kWave), tl, st, b->probs.p, b->sw_dirs_off.p, b->sw_dirs.p,
-                  b->seeds.p, b->aln.p, b->trace.p);
+                  b->S.p + kSlackFront, b->seqs.p, prm, b->sw_dirs.p, b->hand.p, b->seeds.p, b->aln.p, b->trace.p);
         CR_HIP(hipGetLastError());
         return CR_OK;
     };
