@@ -638,19 +638,22 @@ struct ExplicitStream {
 //     to HBM instead -- no ring, 9 KB of LDS, sixteen waves per CU -- was measured: 1.52 / 1.61 ms against 1.42 / 1.45.)
 //   * windows whose 64 lanes are all inside the matrix run without the column mask;
 //   * STORE = false (dtw_align's score alone, dynamic_time_warping.py:188-201): no decision words are formed or written.
-// MODE: kSwScore (smith_waterman_score with a gap) or kDtw.  Same arithmetic as sweep(): dp_column on the same values.
+// MODE: kSwScore (smith_waterman_score with a gap), kSwTrace (smith_waterman with a gap and its traceback: 2-bit decisions + first maximum) or
+// kDtw.  Same arithmetic as sweep(): dp_column on the same values.
 // LDS (doubles): ring R * 1088 | pad to 128 | hout NB x 128 | hin NB x 64 | dump NB.
 // ---------------------------------------------------------------------------------------------
 template <int R, int MODE>
 __host__ __device__ inline size_t stream_lds_doubles() {
-    constexpr int NB = ((MODE & kSwScore) ? 1 : 0) + ((MODE & kDtw) ? 2 : 0);
+    constexpr int NB = ((MODE & (kSwScore | kSwTrace)) ? 1 : 0) + ((MODE & kDtw) ? 2 : 0);
     return (size_t)((ExplicitStream<R>::kRingDoubles + 127) / 128 * 128) + (size_t)NB * (kRing + kWave) + 8;
 }
 
 template <int R, int MODE, bool STORE>
 CR_D void sweep_stream(ExplicitStream<R>& src, const int n, const int m, const SweepParams prm, double* lds,
-                       uint32_t* __restrict__ dtw_bits, double* __restrict__ hand_g, AlignEnd& end_out) {
-    constexpr bool SW = (MODE & kSwScore) != 0;
+                       uint32_t* __restrict__ dtw_bits, double* __restrict__ hand_g, AlignEnd& end_out,
+                       uint32_t* __restrict__ sw_dirs = nullptr, SeedMax* seed_out = nullptr) {
+    constexpr bool SW = (MODE & (kSwScore | kSwTrace)) != 0;
+    constexpr bool TRACE = (MODE & kSwTrace) != 0;       // smith_waterman with its traceback: 2-bit decisions + first maximum (sweep())
     constexpr bool DTW = (MODE & kDtw) != 0;
     constexpr int NB = (SW ? 1 : 0) + (DTW ? 2 : 0);
     constexpr int kRingPad = (ExplicitStream<R>::kRingDoubles + 127) / 128 * 128;
@@ -660,10 +663,13 @@ CR_D void sweep_stream(ExplicitStream<R>& src, const int n, const int m, const S
     double* hin = hout + NB * kRing;                   // [NB][64]: row above lane 0 (strip 0: the DP border), current 64 columns
     src.init_ring(ring, lane);
     const int nstrips = strips_of(n, R);
-    const int TB_DTW = tblocks(m, 8);
+    const int TB_DTW = tblocks(m, 8), TB_SW = tblocks(m, 16);
     const double col0_m2 = kMinF64 - prm.gap_open;
     DpState<R> st;
     st.sw_max = 0.0;
+    double best_v = 0.0;                                 // first maximum of H in row-major order (:241-247), as sweep()
+    int best_i = 0x7fffffff, best_j = 0x7fffffff;
+    int sh2hi = 0;                                       // bit position of the current 8-step window inside a 16-step word
     // byte offsets of this lane's hand-down stores: lane 63 the ring (plus the column's slot), the others the dump word
     uint32_t out_base[NB];
     const uint32_t out_mask = lane == kWave - 1 ? 0x3f8u : 0u;
@@ -711,7 +717,7 @@ CR_D void sweep_stream(ExplicitStream<R>& src, const int n, const int m, const S
             }
             auto cell = [&]() {
                 src.fetch_col(ring, 0);
-                dp_column<R, MODE>(src, st, prm, nullptr, c, rowbase, n, 0, K * 4, h_top, m0_top, m1_top, src.val);
+                dp_column<R, MODE>(src, st, prm, nullptr, c, rowbase, n, sh2hi + K * 2, K * 4, h_top, m0_top, m1_top, src.val);
             };
             if constexpr (MASKED) {
                 if ((unsigned)c < (unsigned)m) cell();
@@ -733,6 +739,10 @@ CR_D void sweep_stream(ExplicitStream<R>& src, const int n, const int m, const S
 #pragma unroll
                 for (int q = 0; q < R; q++) asm volatile("" : "+v"(st.dtbits[q]));
             }
+            if constexpr (TRACE) {
+#pragma unroll
+                for (int q = 0; q < R; q++) asm volatile("" : "+v"(st.swbits[q]));
+            }
         };
         for (int t0 = 0; t0 < T; t0 += 8) {
             if ((t0 & (kWave - 1)) == 0 && nstrips > 1) {
@@ -747,6 +757,7 @@ CR_D void sweep_stream(ExplicitStream<R>& src, const int n, const int m, const S
                 wave_sync();
             }
             src.window_advance();
+            sh2hi = (t0 & 8) * 2;
             asm volatile("" ::: "memory");                    // (LDS executes the wave's own writes and reads in order)
             if (t0 >= kWave - 1 && t0 + 7 < m && t0 + 7 < T) {            // all 64 lanes inside the matrix for all eight steps
                 static_for<0, 8>([&](auto k) { step(k, std::false_type{}, t0 + decltype(k)::value); });
@@ -763,6 +774,26 @@ CR_D void sweep_stream(ExplicitStream<R>& src, const int n, const int m, const S
                     st.dtbits[q] = 0;
                 }
             }
+            if constexpr (TRACE) {
+                if ((t0 & 8) != 0 || t0 + 8 >= T) {             // a decision word holds 16 steps
+                    const int64_t base = ((int64_t)(s * TB_SW + (t0 >> 4)) * R) * kWave + lane;
+#pragma unroll
+                    for (int q = 0; q < R; q++) {
+                        sw_dirs[base + q * kWave] = st.swbits[q];
+                        st.swbits[q] = 0;
+                    }
+                }
+            }
+        }
+        if constexpr (TRACE) {
+            // fold this strip's per-row first maxima into the lane's running best (rows ascending)
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const bool gt = st.rowmax[q] > best_v;
+                best_v = gt ? st.rowmax[q] : best_v;
+                best_i = gt ? rowbase + q : best_i;
+                best_j = gt ? st.rowarg[q] : best_j;
+            }
         }
         if (hand_out) {
             // flush the hand-off columns not yet written (at most 127) and make them visible to this wave's own loads in the
@@ -776,8 +807,21 @@ CR_D void sweep_stream(ExplicitStream<R>& src, const int n, const int m, const S
             wave_sync();
         }
     }
+    if constexpr (TRACE) {
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(best_v, off);
+            const int oi = __shfl_xor(best_i, off), oj = __shfl_xor(best_j, off);
+            const bool take = ov > best_v || (ov == best_v && (oi < best_i || (oi == best_i && oj < best_j)));
+            best_v = take ? ov : best_v;
+            best_i = take ? oi : best_i;
+            best_j = take ? oj : best_j;
+        }
+        seed_out->score = best_v;
+        seed_out->i = best_v > 0.0 ? best_i + 1 : 0;
+        seed_out->j = best_v > 0.0 ? best_j + 1 : 0;
+    }
     double sw_max = st.sw_max;
-    if constexpr (SW) {
+    if constexpr ((MODE & kSwScore) != 0) {
         for (int off = 32; off > 0; off >>= 1) sw_max = __builtin_fmax(sw_max, __shfl_xor(sw_max, off));
     }
     const int owner = ((n - 1) / R) % kWave;           // lane and register slot that own row n - 1
@@ -891,7 +935,7 @@ __global__ __launch_bounds__(kWave) void k_explicit_sw_batch(const ExplicitProbl
             src.m_ = pb.m;
             src.t_ = 0;
             src.lane_ = threadIdx.x & (kWave - 1);
-            sweep<R, kSwTrace>(src, pb.n, pb.m, prm, lds, dirs + dirs_off[blockIdx.x], nullptr, hand + pb.hand_off, sm, ae);
+            sweep_stream<R, kSwTrace, false>(src, pb.n, pb.m, prm, lds, nullptr, hand + pb.hand_off, ae, dirs + dirs_off[blockIdx.x], &sm);
         } else {
             Explicit<R> src;
             src.S = S + pb.s_off;
@@ -1350,7 +1394,8 @@ int cr_smith_waterman_batch(cr_explicit_batch* b, double gap, int64_t* aln, int6
         constexpr bool STREAM = decltype(stream_tag)::value;
         using Src = std::conditional_t<STREAM, cr::ExplicitStream<RR>, cr::Explicit<RR>>;
         // (fill and walk in one launch: the LDS of the larger of the two)
-        const size_t lds = std::max(cr::sweep_lds_doubles<RR, cr::kSwTrace, Src>(b->n_max, b->m_max), cr::trace_lds_doubles(RR, b->cap_max)) * sizeof(double);
+        const size_t fill_lds = STREAM ? cr::stream_lds_doubles<RR, cr::kSwTrace>() : cr::sweep_lds_doubles<RR, cr::kSwTrace, Src>(b->n_max, b->m_max);
+        const size_t lds = std::max(fill_lds, cr::trace_lds_doubles(RR, b->cap_max)) * sizeof(double);
         int rc2 = allow_lds(cr::k_explicit_sw_batch<RR, STREAM>, lds);
         if (rc2) return rc2;
         CR_LAUNCH((cr::k_explicit_sw_batch<RR, STREAM>), dim3((unsigned)b->count), dim3(cr::kWave), lds, st, b->probs.p, b->sw_dirs_off.p,

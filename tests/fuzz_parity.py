@@ -229,7 +229,7 @@ def check_explicit_batch(oracle, rng):
         raise AssertionError(f"smith_waterman_score_batch differs: gap {gap}, shapes {[(len(a), len(b)) for a, b, _ in problems]}")
     if rng.integers(0, 2) == 0:
         # smith_waterman WITH its traceback over the list (gap 0: the row sweep with decisions, first maximum and walk in one
-        # launch, round 6; else the skewed sweep + walk launch); an all-zero matrix raises, as the reference does
+        # launch, round 6; else the skewed sweep with its walk); an all-zero matrix raises, as the reference does
         want_sw = [oracle.smith_waterman(a, b, s, gap) for a, b, s in problems]
         if any(w[3] for w in want_sw):
             try:
@@ -248,6 +248,31 @@ def check_explicit_batch(oracle, rng):
             if not (np.array_equal(a1, o1) and np.array_equal(a2, o2) and sc == osc):
                 raise AssertionError(f"dtw_align_batch differs: n {len(a)} m {len(b)} gaps {go} {ge}")
     return len(problems)
+
+
+def check_sw_gap_stream(oracle, rng):
+    """smith_waterman with a gap and its traceback over lists with contiguous columns everywhere: the streaming sweep with 2-bit
+    decisions and the walk in one launch (sweep_stream<kSwTrace>), at every rows-per-lane the list length selects."""
+    from caretta_amd import dynamic_time_warping as dtw
+    base = []
+    for _ in range(int(rng.integers(1, 6))):
+        n = int(rng.choice([1, 2, 9, 63, 64, 65, 129, 150, 300, 321]))
+        m = int(rng.choice([1, 3, 8, 64, 65, 129, 300, 321, 513]))
+        if rng.integers(0, 2) == 0:
+            base.append((np.arange(n), np.arange(m), rng.uniform(-0.3, 1.0, size=(n, m))))
+        else:                                                                       # ties
+            base.append((np.arange(n), np.arange(m), np.round(rng.uniform(-1.0, 2.0, size=(n, m)) * 2) / 2))
+    gap = float(rng.choice([0.2, 0.5, 1.0, 0.05]))
+    want = [oracle.smith_waterman(a, b, s, gap) for a, b, s in base]
+    if any(w[3] for w in want):
+        return 0
+    reps = int(rng.choice([1, 1, 40, 700]))                                         # (list length: five ... one row per lane)
+    got = dtw.smith_waterman_batch(base * reps, gap)
+    for k, (a1, a2, sc) in enumerate(got):
+        o1, o2, osc, _none = want[k % len(base)]
+        if not (np.array_equal(a1, o1) and np.array_equal(a2, o2) and sc == osc):
+            raise AssertionError(f"smith_waterman_batch (gap {gap}, streaming) differs: problem {k} of {len(got)}, n {len(base[k % len(base)][0])} m {len(base[k % len(base)][1])}")
+    return len(got)
 
 
 def check_wide_tensors(oracle, rng):
@@ -328,6 +353,8 @@ def main():
             trees += check_neighbor_joining(ctx, oracle, rng)
         if rng.integers(0, 8) == 0:
             wide += check_wide_tensors(oracle, rng)
+        if rng.integers(0, 6) == 0:
+            batched += check_sw_gap_stream(oracle, rng)
         batches += 1
     print(f"fuzz_parity: seed {seed}, {batches} batches, {pairs} pairs ({flagged} with a soft-condition flag), "
           f"{nodes} progressive nodes, {flex_nodes} flexible progressive nodes, {dropins} explicit-matrix drop-in cases, {batched} matrices in batched explicit calls, "

@@ -387,7 +387,7 @@ def test_smith_waterman_gap0_traceback_on_the_row_sweep(oracle, monkeypatch):
     fill, decisions, first maximum and walk in ONE launch of the row sweep (k_sw_trace_rows: a lane owns columns, the walk reads
     the transposed blocks).  Tie-heavy matrices (constant, 0/1, small integers: the diag -> left -> up priority and the
     row-major FIRST maximum decide every step), column strips (m > 64 x 8), single rows / columns, zero borders, negative
-    scores -- against the oracle, and against the skewed sweep + walk launch it replaces (CARETTA_NO_SW_ROWS=1)."""
+    scores -- against the oracle, and against the skewed sweep of the gap != 0 lists (CARETTA_NO_SW_ROWS=1)."""
     from caretta_amd import dynamic_time_warping as dtw, engine
     rng = np.random.default_rng(9501)
     ar = np.arange

@@ -53,7 +53,7 @@ def main():
                  "dtw_align_score (skewed sweep, no decisions)": (["k_explicit_stream<1, 4, false>"], 8.0 * cells + small_score),
                  "dtw_align WITH traceback (4-bit decisions + walk)": (["k_explicit_stream<1, 4, true>", "k_dtw_trace_batch<"], 8.5 * cells + small),
                  "smith_waterman WITH traceback gap 0 (row sweep: 2-bit decisions + walk in one launch)": (["k_sw_trace_rows<"], 8.25 * cells + small),
-                 "smith_waterman WITH traceback gap 0.1 (skewed sweep + walk launch)": (["k_explicit_sw_batch<", "k_sw_trace_batch<"], 8.25 * cells + small)}
+                 "smith_waterman WITH traceback gap 0.1 (skewed sweep + walk, one launch)": (["k_explicit_sw_batch<"], 8.25 * cells + small)}
     ratios = {}
     for name, (prefixes, nbytes) in functions.items():
         hbm = sum(v["hbm_bytes_per_launch"] for k, v in kernels.items() if any(k.startswith(p) for p in prefixes))

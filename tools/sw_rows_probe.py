@@ -27,7 +27,7 @@ def main():
     variants = [("row sweep + walk (product)", {}), ("row sweep, fill only", {"CARETTA_SW_ROWS_NOWALK": "1"}),
                 ("row sweep + walk, 5 waves/SIMD build", {"CARETTA_SW_ROWS_WAVES": "5"}), ("row sweep + walk, 3 waves/SIMD build", {"CARETTA_SW_ROWS_WAVES": "3"}),
                 ("fill only, 5 waves/SIMD build", {"CARETTA_SW_ROWS_WAVES": "5", "CARETTA_SW_ROWS_NOWALK": "1"}),
-                ("skewed sweep + walk launch (round 5)", {"CARETTA_NO_SW_ROWS": "1"})]
+                ("skewed sweep + walk (the gap != 0 kernel)", {"CARETTA_NO_SW_ROWS": "1"})]
     for name, env in variants:
         for k in list(os.environ):
             if k.startswith("CARETTA_SW_ROWS") or k == "CARETTA_NO_SW_ROWS":
